@@ -1,0 +1,381 @@
+/* vips_hip.h -- C ABI of libvipship.so: the MI355X (gfx950) implementation of
+ * libvips' per-tile pixel pipeline (resample/, convolution/, colour/ hot loops).
+ *
+ * This header is the drop-in boundary.  Everything is plain C: pointers, ints,
+ * doubles and two POD structs.  No HIP, torch or glib type appears in a
+ * signature, so the libvips side (a C module registering `*_hip` VipsOperation
+ * classes, see host/ and INTEGRATION.md) and any FFI (ctypes, cgo, JNI...) can
+ * bind it directly.
+ *
+ * Three layers, mirroring the reference (all paths relative to the reference
+ * tree, libvips 8.19.0):
+ *
+ *   1. runtime      device / stream / memory / error buffer
+ *                   (error convention of iofuncs/error.c: 0 or -1 + message)
+ *   2. region ops   "generate" replacements: fill out->valid from an input
+ *                   region, exactly the contract of VipsGenerateFn
+ *                   (include/vips/image.h:151-154, iofuncs/region.c:1600-1624)
+ *   3. image ops    whole-image operations on device-resident images, the
+ *                   analogue of the vips_reduce()/vips_conv()/... C wrappers;
+ *                   they do what each class's build() does on the host (sizes,
+ *                   tables, embed offsets) and then run the region ops once
+ *                   over the whole output.
+ *
+ * Pixel layout everywhere: interleaved bands, row-major, `stride` bytes per line
+ * (include/vips/image.h:382-393, include/vips/region.h:198-236).
+ */
+#ifndef VIPS_HIP_H
+#define VIPS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIPS_HIP_API __attribute__((visibility("default")))
+
+/* Same values as VipsBandFormat, include/vips/image.h:120-133. */
+typedef enum {
+	VIPS_HIP_FORMAT_UCHAR = 0,
+	VIPS_HIP_FORMAT_CHAR = 1,
+	VIPS_HIP_FORMAT_USHORT = 2,
+	VIPS_HIP_FORMAT_SHORT = 3,
+	VIPS_HIP_FORMAT_UINT = 4,
+	VIPS_HIP_FORMAT_INT = 5,
+	VIPS_HIP_FORMAT_FLOAT = 6,
+	VIPS_HIP_FORMAT_COMPLEX = 7,
+	VIPS_HIP_FORMAT_DOUBLE = 8,
+	VIPS_HIP_FORMAT_DPCOMPLEX = 9
+} VipsHipFormat;
+
+/* Same values as VipsKernel, include/vips/resample.h:41-51. */
+typedef enum {
+	VIPS_HIP_KERNEL_NEAREST = 0,
+	VIPS_HIP_KERNEL_LINEAR = 1,
+	VIPS_HIP_KERNEL_CUBIC = 2,
+	VIPS_HIP_KERNEL_MITCHELL = 3,
+	VIPS_HIP_KERNEL_LANCZOS2 = 4,
+	VIPS_HIP_KERNEL_LANCZOS3 = 5,
+	VIPS_HIP_KERNEL_MKS2013 = 6,
+	VIPS_HIP_KERNEL_MKS2021 = 7
+} VipsHipKernel;
+
+/* Same values as VipsPrecision, include/vips/basic.h:106-110. */
+typedef enum {
+	VIPS_HIP_PRECISION_INTEGER = 0,
+	VIPS_HIP_PRECISION_FLOAT = 1,
+	VIPS_HIP_PRECISION_APPROXIMATE = 2
+} VipsHipPrecision;
+
+/* The subset of VipsInterpretation (include/vips/image.h:94-118) the colour
+ * path routes between; same values.
+ */
+typedef enum {
+	VIPS_HIP_INTERPRETATION_MULTIBAND = 0,
+	VIPS_HIP_INTERPRETATION_B_W = 1,
+	VIPS_HIP_INTERPRETATION_XYZ = 12,
+	VIPS_HIP_INTERPRETATION_LAB = 13,
+	VIPS_HIP_INTERPRETATION_LABS = 21,
+	VIPS_HIP_INTERPRETATION_sRGB = 22,
+	VIPS_HIP_INTERPRETATION_RGB16 = 25,
+	VIPS_HIP_INTERPRETATION_GREY16 = 26,
+	VIPS_HIP_INTERPRETATION_scRGB = 28
+} VipsHipInterpretation;
+
+/* ------------------------------------------------------------------ runtime */
+
+/* Select the device this thread's calls go to and create the library's
+ * streams/pools on it.  Safe to call repeatedly.  Fails (-1) when no gfx950
+ * device is visible: there is NO CPU fallback anywhere in this library.
+ */
+VIPS_HIP_API int vips_hip_init(int device);
+VIPS_HIP_API void vips_hip_shutdown(void);
+VIPS_HIP_API int vips_hip_device_count(void);
+
+/* Thread-local error log, same shape as vips_error_buffer()/vips_error_clear()
+ * (iofuncs/error.c): messages are "domain: text\n".
+ */
+VIPS_HIP_API const char *vips_hip_error_buffer(void);
+VIPS_HIP_API void vips_hip_error_clear(void);
+
+/* The stream all following calls of this thread are enqueued on.  NULL selects
+ * the library's own per-thread stream (one per libvips worker thread, created in
+ * start_fn and released in stop_fn by the module).  The handle is a hipStream_t
+ * passed as void*, e.g. torch.cuda.current_stream().cuda_stream.
+ */
+VIPS_HIP_API int vips_hip_set_stream(void *stream);
+VIPS_HIP_API void *vips_hip_get_stream(void);
+VIPS_HIP_API int vips_hip_synchronize(void);
+
+/* Device memory comes from a size-bucketed caching pool (hipMalloc is far too
+ * slow to sit in a per-tile path); *_host is pinned staging memory.
+ */
+VIPS_HIP_API void *vips_hip_malloc(size_t size);
+VIPS_HIP_API void vips_hip_free(void *ptr);
+VIPS_HIP_API void *vips_hip_malloc_host(size_t size);
+VIPS_HIP_API void vips_hip_free_host(void *ptr);
+VIPS_HIP_API int vips_hip_memcpy_h2d(void *dst, const void *src, size_t size);
+VIPS_HIP_API int vips_hip_memcpy_d2h(void *dst, const void *src, size_t size);
+VIPS_HIP_API int vips_hip_memcpy_d2d(void *dst, const void *src, size_t size);
+VIPS_HIP_API int vips_hip_memcpy2d_h2d(void *dst, size_t dpitch,
+	const void *src, size_t spitch, size_t width_bytes, size_t height);
+VIPS_HIP_API int vips_hip_memcpy2d_d2h(void *dst, size_t dpitch,
+	const void *src, size_t spitch, size_t width_bytes, size_t height);
+VIPS_HIP_API size_t vips_hip_pool_bytes(void);
+VIPS_HIP_API void vips_hip_pool_trim(void);
+
+/* HIP events on the current stream, for timing kernels where they run. */
+VIPS_HIP_API void *vips_hip_event_new(void);
+VIPS_HIP_API void vips_hip_event_free(void *event);
+VIPS_HIP_API int vips_hip_event_record(void *event);
+VIPS_HIP_API double vips_hip_event_elapsed_ms(void *start, void *stop); /* syncs on stop */
+
+/* Per-kernel timing (the VIPS_GATE_START/STOP analogue, include/vips/gate.h):
+ * when enabled every kernel launch is bracketed by events on its stream.
+ */
+VIPS_HIP_API void vips_hip_gate_enable(int enable);
+VIPS_HIP_API void vips_hip_gate_reset(void);
+/* Returns the number of launches of kernels whose gate name starts with @name
+ * and their total duration in ms (synchronises the device).
+ */
+VIPS_HIP_API int vips_hip_gate_query(const char *name, double *total_ms);
+/* Write "name launches total_ms\n" for every gate name seen into @buf (at most
+ * @size bytes, NUL-terminated); returns the number of distinct names.
+ */
+VIPS_HIP_API int vips_hip_gate_report(char *buf, int size);
+
+/* ---------------------------------------------------------------- regions */
+
+/* A window onto a device-resident image: the VipsRegion of this library
+ * (include/vips/region.h:96-131).  `data` points at pixel (left, top) of the
+ * full image; `stride` is VIPS_REGION_LSKIP.  im_width/im_height are the
+ * size of the whole image the window belongs to: coordinates that an operation
+ * computes outside [0, im_width) x [0, im_height) are clamped to the edge, which
+ * is what the vips_embed(VIPS_EXTEND_COPY) each reference build() inserts does
+ * (conversion/embed.c:226-341).  After clamping they must fall inside the window.
+ */
+typedef struct {
+	void *data;
+	int left, top, width, height; /* valid: the window */
+	int im_width, im_height;      /* the whole image */
+	int bands;
+	int format; /* VipsHipFormat */
+	size_t stride;
+} VipsHipRegion;
+
+/* ------------------------------------------------ resample: reduceh/reducev */
+
+/* Host-side state of one reduceh/reducev operation: what vips_reduceh_build()
+ * (resample/reduceh.cpp:396-565) / vips_reducev_build() (reducev.cpp:859-1075)
+ * compute once per call -- output size, n_point, h/v offset, the 65 x n_point
+ * coefficient tables matrixf (double) and matrixs (short, x4096, truncated) --
+ * kept resident on the device.
+ */
+typedef struct _VipsHipReduce VipsHipReduce;
+
+/* @in_size: Xsize (horizontal) or Ysize (vertical) of the input image.
+ * @shrink:  the *residual* shrink (after any integer pre-shrink the caller did).
+ * @extra_pixels: "how many pixels we are inventing", already divided by the
+ *   integer pre-shrink (reduceh.cpp:431,459); pass NAN to have it derived as
+ *   out_size * shrink - in_size.
+ * Errors (message as the reference's): "reduce factor should be >= 1.0",
+ * "reduce factor too large", "image has shrunk to nothing".
+ */
+VIPS_HIP_API VipsHipReduce *vips_hip_reduce_new(int kernel, double shrink,
+	int in_size, int out_size, double extra_pixels);
+VIPS_HIP_API void vips_hip_reduce_free(VipsHipReduce *reduce);
+VIPS_HIP_API int vips_hip_reduce_get_n_point(const VipsHipReduce *reduce);
+VIPS_HIP_API int vips_hip_reduce_get_out_size(const VipsHipReduce *reduce);
+VIPS_HIP_API double vips_hip_reduce_get_offset(const VipsHipReduce *reduce);
+/* Copy out row @phase (0..64) of matrixs / matrixf, for tests. */
+VIPS_HIP_API int vips_hip_reduce_get_matrixs(const VipsHipReduce *reduce, int phase, short *out);
+VIPS_HIP_API int vips_hip_reduce_get_matrixf(const VipsHipReduce *reduce, int phase, double *out);
+
+/* vips_reduce_get_points(), resample/reduceh.cpp:113-141. */
+VIPS_HIP_API int vips_hip_reduce_get_points(int kernel, double shrink);
+
+/* The input rectangle a generate needs for output rect (left, top, width,
+ * height): reduceh.cpp:237-240 / reducev.cpp:539-542, already translated from
+ * embedded to un-embedded input coordinates and clipped to the input image.
+ */
+VIPS_HIP_API void vips_hip_reduceh_need(const VipsHipReduce *reduce,
+	int left, int width, int *in_left, int *in_width);
+VIPS_HIP_API void vips_hip_reducev_need(const VipsHipReduce *reduce,
+	int top, int height, int *in_top, int *in_height);
+
+/* Fill out->valid.  Bit-exact replacements for vips_reduceh_gen
+ * (reduceh.cpp:216-335) and vips_reducev_gen (reducev.cpp:517-619): the double
+ * position accumulator is seeded at out->left / out->top exactly as the
+ * reference seeds it per generate call.
+ */
+VIPS_HIP_API int vips_hip_reduceh_gen(const VipsHipReduce *reduce,
+	const VipsHipRegion *in, const VipsHipRegion *out);
+VIPS_HIP_API int vips_hip_reducev_gen(const VipsHipReduce *reduce,
+	const VipsHipRegion *in, const VipsHipRegion *out);
+/* As above, but the accumulator is re-seeded every @tile rows (columns), which
+ * reproduces what the reference computes when its sink walks the output in
+ * @tile-high strips (thread.c:301-325: 16 for FATSTRIP images).  tile <= 0
+ * means one seed for the whole rect.
+ */
+VIPS_HIP_API int vips_hip_reduceh_gen_tiled(const VipsHipReduce *reduce,
+	const VipsHipRegion *in, const VipsHipRegion *out, int tile);
+VIPS_HIP_API int vips_hip_reducev_gen_tiled(const VipsHipReduce *reduce,
+	const VipsHipRegion *in, const VipsHipRegion *out, int tile);
+
+/* Fused reducev -> reduceh for uchar images (the vips_reduce() hot path,
+ * resample/reduce.c:98-121): the vertically reduced scanlines never leave the
+ * CU.  Same results as running the two gens back to back.
+ */
+VIPS_HIP_API int vips_hip_reduce_gen(const VipsHipReduce *reducev,
+	const VipsHipReduce *reduceh,
+	const VipsHipRegion *in, const VipsHipRegion *out);
+/* The vertical accumulator re-seeded every @tile output rows, as above.
+ * Both return 0 on success, -1 on error, and 1 when the geometry (format,
+ * bands, shrink) is outside what the fused kernel covers: nothing was written
+ * and the caller runs vips_hip_reducev_gen + vips_hip_reduceh_gen instead.
+ */
+VIPS_HIP_API int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev,
+	const VipsHipReduce *reduceh,
+	const VipsHipRegion *in, const VipsHipRegion *out, int tile);
+
+/* ------------------------------------------------- resample: shrinkh/shrinkv */
+
+/* vips_shrinkh_gen / vips_shrinkv_gen (resample/shrinkh.c:235-283,
+ * shrinkv.c:318-387).  Input coordinates beyond the image edge are clamped
+ * (the reference embeds, shrinkh.c:383-386, shrinkv.c:501-506).
+ */
+VIPS_HIP_API int vips_hip_shrinkh_gen(int hshrink,
+	const VipsHipRegion *in, const VipsHipRegion *out);
+VIPS_HIP_API int vips_hip_shrinkv_gen(int vshrink,
+	const VipsHipRegion *in, const VipsHipRegion *out);
+/* Output sizes: shrinkh.c:414-416, shrinkv.c:566-568. */
+VIPS_HIP_API int vips_hip_shrink_out_size(int in_size, int shrink, int ceil_mode);
+
+/* -------------------------------------------------------------- convolution */
+
+/* Host-side state of one convi/convf: vips_convi_build (convolution/convi.c:
+ * 1123-1233, C path) / vips_convf_build (convf.c:285-369): coefficients with
+ * zeros squeezed out, their mask positions, scale/offset.
+ */
+typedef struct _VipsHipConv VipsHipConv;
+
+/* @mask: mask_width x mask_height doubles, row-major (a VIPS matrix image).
+ * precision INTEGER = convi C path, FLOAT = convf.
+ */
+VIPS_HIP_API VipsHipConv *vips_hip_conv_new(const double *mask,
+	int mask_width, int mask_height, double scale, double offset, int precision);
+VIPS_HIP_API void vips_hip_conv_free(VipsHipConv *conv);
+VIPS_HIP_API int vips_hip_conv_get_nnz(const VipsHipConv *conv);
+/* Output band format for input @format: convf.c:354-355; convi keeps it. */
+VIPS_HIP_API int vips_hip_conv_out_format(const VipsHipConv *conv, int format);
+/* Fill out->valid: vips_convi_gen (convi.c:753-857) or vips_convf_gen
+ * (convf.c:185-283).  The input is the UN-embedded image; edge clamp included.
+ */
+VIPS_HIP_API int vips_hip_conv_gen(const VipsHipConv *conv,
+	const VipsHipRegion *in, const VipsHipRegion *out);
+
+/* vips_gaussmat (create/gaussmat.c:95-167).  Writes at most @max doubles,
+ * returns the mask width (height is 1 when separable, else == width), or -1.
+ */
+VIPS_HIP_API int vips_hip_gaussmat(double sigma, double min_ampl, int separable,
+	int precision, double *mask, int max, double *scale);
+
+/* ------------------------------------------------------------------- colour */
+
+/* The per-scanline process_line functions (colour/colour.c:119-156), one call
+ * per region.  in/out bands: 3 colour bands, any extra bands are copied through
+ * with the format cast vips_colour_build does (colour.c:196-296).
+ */
+typedef enum {
+	VIPS_HIP_COLOUR_sRGB2scRGB = 0, /* colour/sRGB2scRGB.c:72-106, uchar/ushort in, float out */
+	VIPS_HIP_COLOUR_scRGB2XYZ,      /* scRGB2XYZ.c:58-82 */
+	VIPS_HIP_COLOUR_XYZ2Lab,        /* XYZ2Lab.c:144-171 */
+	VIPS_HIP_COLOUR_Lab2XYZ,        /* Lab2XYZ.c:114-143 */
+	VIPS_HIP_COLOUR_XYZ2scRGB,      /* XYZ2scRGB.c:72-94 */
+	VIPS_HIP_COLOUR_scRGB2sRGB,     /* scRGB2sRGB.c:84-132, float in, uchar out */
+	VIPS_HIP_COLOUR_scRGB2sRGB16,   /* scRGB2sRGB.c, depth 16, ushort out */
+	VIPS_HIP_COLOUR_Lab2LabS,       /* Lab2LabS.c:59-73 */
+	VIPS_HIP_COLOUR_LabS2Lab,       /* LabS2Lab.c:55-69 */
+	VIPS_HIP_COLOUR_LAST
+} VipsHipColourStep;
+
+VIPS_HIP_API int vips_hip_colour_gen(int step,
+	const VipsHipRegion *in, const VipsHipRegion *out);
+
+/* vips_cast (conversion/cast.c:120-330): clip + truncate between any two
+ * non-complex band formats.
+ */
+VIPS_HIP_API int vips_hip_cast_gen(const VipsHipRegion *in, const VipsHipRegion *out);
+
+/* vips_sharpen_generate (convolution/sharpen.c:116-168): LabS in, LabS out; the
+ * blurred L band comes from a vips_hip_conv_gen pass the caller ran.
+ */
+VIPS_HIP_API int vips_hip_sharpen_gen(const int *lut_device /* 65536 ints */,
+	const VipsHipRegion *in, const VipsHipRegion *blurred_l, const VipsHipRegion *out);
+
+/* --------------------------------------------------------------- image ops */
+
+/* A whole image resident in HBM (the VipsImage of this library). */
+typedef struct _VipsHipImage VipsHipImage;
+
+VIPS_HIP_API VipsHipImage *vips_hip_image_new(int width, int height, int bands,
+	int format, int interpretation);
+/* Upload from / wrap host or device memory (vips_image_new_from_memory,
+ * iofuncs/image.c). */
+VIPS_HIP_API VipsHipImage *vips_hip_image_new_from_memory(const void *host_data,
+	int width, int height, int bands, int format, int interpretation);
+VIPS_HIP_API VipsHipImage *vips_hip_image_new_from_device(void *device_data,
+	int width, int height, int bands, int format, int interpretation);
+VIPS_HIP_API void vips_hip_image_unref(VipsHipImage *image);
+VIPS_HIP_API int vips_hip_image_write_to_memory(const VipsHipImage *image, void *host_data);
+VIPS_HIP_API void *vips_hip_image_get_data(const VipsHipImage *image);
+VIPS_HIP_API int vips_hip_image_get_width(const VipsHipImage *image);
+VIPS_HIP_API int vips_hip_image_get_height(const VipsHipImage *image);
+VIPS_HIP_API int vips_hip_image_get_bands(const VipsHipImage *image);
+VIPS_HIP_API int vips_hip_image_get_format(const VipsHipImage *image);
+VIPS_HIP_API int vips_hip_image_get_interpretation(const VipsHipImage *image);
+VIPS_HIP_API size_t vips_hip_image_get_stride(const VipsHipImage *image);
+VIPS_HIP_API void vips_hip_image_region(const VipsHipImage *image, VipsHipRegion *region);
+
+/* Emulate the reference sink's strip height when seeding the reduce position
+ * accumulators (see vips_hip_reducev_gen_tiled); default 16 = vips__fatstrip_height
+ * (include/vips/private.h:147-153). */
+VIPS_HIP_API void vips_hip_set_fatstrip_height(int lines);
+
+/* The operation wrappers: same names, argument meaning and error behaviour as
+ * vips_reduceh() .. vips_thumbnail_image(); optional arguments are explicit.
+ * On success *out is a new image the caller unrefs.
+ */
+VIPS_HIP_API int vips_hip_reduceh(VipsHipImage *in, VipsHipImage **out,
+	double hshrink, int kernel, double gap);
+VIPS_HIP_API int vips_hip_reducev(VipsHipImage *in, VipsHipImage **out,
+	double vshrink, int kernel, double gap);
+VIPS_HIP_API int vips_hip_reduce(VipsHipImage *in, VipsHipImage **out,
+	double hshrink, double vshrink, int kernel, double gap);
+VIPS_HIP_API int vips_hip_shrinkh(VipsHipImage *in, VipsHipImage **out, int hshrink, int ceil_mode);
+VIPS_HIP_API int vips_hip_shrinkv(VipsHipImage *in, VipsHipImage **out, int vshrink, int ceil_mode);
+VIPS_HIP_API int vips_hip_shrink(VipsHipImage *in, VipsHipImage **out,
+	double hshrink, double vshrink, int ceil_mode);
+/* vips_resize for scale <= 1 (resample/resize.c:135-329); vscale <= 0 means
+ * == scale; gap < 0 selects the default 2.0 (resize.c:397). */
+VIPS_HIP_API int vips_hip_resize(VipsHipImage *in, VipsHipImage **out,
+	double scale, double vscale, int kernel, double gap);
+VIPS_HIP_API int vips_hip_conv(VipsHipImage *in, VipsHipImage **out,
+	const double *mask, int mask_width, int mask_height, double scale, double offset,
+	int precision);
+VIPS_HIP_API int vips_hip_convsep(VipsHipImage *in, VipsHipImage **out,
+	const double *mask, int mask_n, double scale, double offset, int precision);
+VIPS_HIP_API int vips_hip_gaussblur(VipsHipImage *in, VipsHipImage **out,
+	double sigma, double min_ampl, int precision);
+VIPS_HIP_API int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out,
+	double sigma, double x1, double y2, double y3, double m1, double m2);
+VIPS_HIP_API int vips_hip_colourspace(VipsHipImage *in, VipsHipImage **out, int space);
+VIPS_HIP_API int vips_hip_cast(VipsHipImage *in, VipsHipImage **out, int format);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* VIPS_HIP_H */

@@ -1,0 +1,170 @@
+"""ctypes binding of include/vips_hip.h (libvips_amd/lib/libvipship.so).
+
+Plumbing only: every signature here is the C ABI's, nothing is computed in
+Python.  The library is built by ``__graft_entry__.build()`` (hipcc, gfx950).
+There is no CPU fallback: if the shared library is missing, import fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvipship.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vips_hip.h")
+
+
+class VipsHipError(RuntimeError):
+    """Mirrors libvips' error convention: -1 + a message in the error buffer."""
+
+
+class Region(ctypes.Structure):
+    """VipsHipRegion (include/vips_hip.h)."""
+
+    _fields_ = [
+        ("data", ctypes.c_void_p),
+        ("left", ctypes.c_int),
+        ("top", ctypes.c_int),
+        ("width", ctypes.c_int),
+        ("height", ctypes.c_int),
+        ("im_width", ctypes.c_int),
+        ("im_height", ctypes.c_int),
+        ("bands", ctypes.c_int),
+        ("format", ctypes.c_int),
+        ("stride", ctypes.c_size_t),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the HIP extension is the product; there is no fallback path)" % LIB_PATH
+        )
+    return ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+
+
+lib = _load()
+
+c_int, c_double, c_void_p, c_size_t, c_char_p = (
+    ctypes.c_int,
+    ctypes.c_double,
+    ctypes.c_void_p,
+    ctypes.c_size_t,
+    ctypes.c_char_p,
+)
+P = ctypes.POINTER
+RegionP = P(Region)
+
+_SIGNATURES = {
+    # runtime
+    "vips_hip_init": (c_int, [c_int]),
+    "vips_hip_shutdown": (None, []),
+    "vips_hip_device_count": (c_int, []),
+    "vips_hip_error_buffer": (c_char_p, []),
+    "vips_hip_error_clear": (None, []),
+    "vips_hip_set_stream": (c_int, [c_void_p]),
+    "vips_hip_get_stream": (c_void_p, []),
+    "vips_hip_synchronize": (c_int, []),
+    "vips_hip_malloc": (c_void_p, [c_size_t]),
+    "vips_hip_free": (None, [c_void_p]),
+    "vips_hip_malloc_host": (c_void_p, [c_size_t]),
+    "vips_hip_free_host": (None, [c_void_p]),
+    "vips_hip_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "vips_hip_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "vips_hip_memcpy_d2d": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "vips_hip_memcpy2d_h2d": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t]),
+    "vips_hip_memcpy2d_d2h": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t]),
+    "vips_hip_pool_bytes": (c_size_t, []),
+    "vips_hip_pool_trim": (None, []),
+    "vips_hip_event_new": (c_void_p, []),
+    "vips_hip_event_free": (None, [c_void_p]),
+    "vips_hip_event_record": (c_int, [c_void_p]),
+    "vips_hip_event_elapsed_ms": (c_double, [c_void_p, c_void_p]),
+    "vips_hip_gate_enable": (None, [c_int]),
+    "vips_hip_gate_reset": (None, []),
+    "vips_hip_gate_query": (c_int, [c_char_p, P(c_double)]),
+    "vips_hip_gate_report": (c_int, [c_char_p, c_int]),
+    # reduce
+    "vips_hip_reduce_new": (c_void_p, [c_int, c_double, c_int, c_int, c_double]),
+    "vips_hip_reduce_free": (None, [c_void_p]),
+    "vips_hip_reduce_get_n_point": (c_int, [c_void_p]),
+    "vips_hip_reduce_get_out_size": (c_int, [c_void_p]),
+    "vips_hip_reduce_get_offset": (c_double, [c_void_p]),
+    "vips_hip_reduce_get_matrixs": (c_int, [c_void_p, c_int, P(ctypes.c_short)]),
+    "vips_hip_reduce_get_matrixf": (c_int, [c_void_p, c_int, P(c_double)]),
+    "vips_hip_reduce_get_points": (c_int, [c_int, c_double]),
+    "vips_hip_reduceh_need": (None, [c_void_p, c_int, c_int, P(c_int), P(c_int)]),
+    "vips_hip_reducev_need": (None, [c_void_p, c_int, c_int, P(c_int), P(c_int)]),
+    "vips_hip_reduceh_gen": (c_int, [c_void_p, RegionP, RegionP]),
+    "vips_hip_reducev_gen": (c_int, [c_void_p, RegionP, RegionP]),
+    "vips_hip_reduceh_gen_tiled": (c_int, [c_void_p, RegionP, RegionP, c_int]),
+    "vips_hip_reducev_gen_tiled": (c_int, [c_void_p, RegionP, RegionP, c_int]),
+    "vips_hip_reduce_gen": (c_int, [c_void_p, c_void_p, RegionP, RegionP]),
+    "vips_hip_reduce_gen_tiled": (c_int, [c_void_p, c_void_p, RegionP, RegionP, c_int]),
+    # shrink
+    "vips_hip_shrinkh_gen": (c_int, [c_int, RegionP, RegionP]),
+    "vips_hip_shrinkv_gen": (c_int, [c_int, RegionP, RegionP]),
+    "vips_hip_shrink_out_size": (c_int, [c_int, c_int, c_int]),
+    # convolution
+    "vips_hip_conv_new": (c_void_p, [P(c_double), c_int, c_int, c_double, c_double, c_int]),
+    "vips_hip_conv_free": (None, [c_void_p]),
+    "vips_hip_conv_get_nnz": (c_int, [c_void_p]),
+    "vips_hip_conv_out_format": (c_int, [c_void_p, c_int]),
+    "vips_hip_conv_gen": (c_int, [c_void_p, RegionP, RegionP]),
+    "vips_hip_gaussmat": (c_int, [c_double, c_double, c_int, c_int, P(c_double), c_int, P(c_double)]),
+    # colour
+    "vips_hip_colour_gen": (c_int, [c_int, RegionP, RegionP]),
+    "vips_hip_cast_gen": (c_int, [RegionP, RegionP]),
+    "vips_hip_sharpen_gen": (c_int, [c_void_p, RegionP, RegionP, RegionP]),
+    # images
+    "vips_hip_image_new": (c_void_p, [c_int, c_int, c_int, c_int, c_int]),
+    "vips_hip_image_new_from_memory": (c_void_p, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "vips_hip_image_new_from_device": (c_void_p, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "vips_hip_image_unref": (None, [c_void_p]),
+    "vips_hip_image_write_to_memory": (c_int, [c_void_p, c_void_p]),
+    "vips_hip_image_get_data": (c_void_p, [c_void_p]),
+    "vips_hip_image_get_width": (c_int, [c_void_p]),
+    "vips_hip_image_get_height": (c_int, [c_void_p]),
+    "vips_hip_image_get_bands": (c_int, [c_void_p]),
+    "vips_hip_image_get_format": (c_int, [c_void_p]),
+    "vips_hip_image_get_interpretation": (c_int, [c_void_p]),
+    "vips_hip_image_get_stride": (c_size_t, [c_void_p]),
+    "vips_hip_image_region": (None, [c_void_p, RegionP]),
+    "vips_hip_set_fatstrip_height": (None, [c_int]),
+    # operations
+    "vips_hip_reduceh": (c_int, [c_void_p, P(c_void_p), c_double, c_int, c_double]),
+    "vips_hip_reducev": (c_int, [c_void_p, P(c_void_p), c_double, c_int, c_double]),
+    "vips_hip_reduce": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_int, c_double]),
+    "vips_hip_shrinkh": (c_int, [c_void_p, P(c_void_p), c_int, c_int]),
+    "vips_hip_shrinkv": (c_int, [c_void_p, P(c_void_p), c_int, c_int]),
+    "vips_hip_shrink": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_int]),
+    "vips_hip_resize": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_int, c_double]),
+    "vips_hip_conv": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_int, c_double, c_double, c_int]),
+    "vips_hip_convsep": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_double, c_double, c_int]),
+    "vips_hip_gaussblur": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_int]),
+    "vips_hip_sharpen": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_double, c_double, c_double, c_double]),
+    "vips_hip_colourspace": (c_int, [c_void_p, P(c_void_p), c_int]),
+    "vips_hip_cast": (c_int, [c_void_p, P(c_void_p), c_int]),
+}
+
+MISSING = []
+for _name, (_res, _args) in _SIGNATURES.items():
+    try:
+        _fn = getattr(lib, _name)
+    except AttributeError:
+        MISSING.append(_name)
+        continue
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def error_buffer():
+    return lib.vips_hip_error_buffer().decode("utf-8", "replace")
+
+
+def check(result, what="vips_hip"):
+    """Turn the C convention (non-zero / NULL + error buffer) into an exception."""
+    if result is None or (isinstance(result, int) and result != 0):
+        message = error_buffer().strip() or what
+        lib.vips_hip_error_clear()
+        raise VipsHipError(message)
+    return result

@@ -1,0 +1,287 @@
+// Image-level resample operations: the host side of vips_reduceh/reducev/reduce/
+// shrinkh/shrinkv/shrink/resize.  Each function does what the corresponding
+// class build() does in the reference (sizes, integer pre-shrink under `gap`,
+// table construction) and then fills the whole output with ONE region op --
+// on a 288 GB device the natural "tile" is the image.
+#include "internal.h"
+#include "resample.h"
+
+#include <cmath>
+
+using namespace vh;
+
+static int g_fatstrip_height = 16; // include/vips/private.h:147-153
+
+extern "C" void vips_hip_set_fatstrip_height(int lines)
+{
+	g_fatstrip_height = lines;
+}
+
+namespace {
+
+struct ImageRef {
+	VipsHipImage *im;
+	explicit ImageRef(VipsHipImage *i = nullptr)
+		: im(i)
+	{
+	}
+	~ImageRef() { vips_hip_image_unref(im); }
+	VipsHipImage *release()
+	{
+		VipsHipImage *t = im;
+		im = nullptr;
+		return t;
+	}
+};
+
+VipsHipImage *like(const VipsHipImage *in, int width, int height)
+{
+	return vips_hip_image_new(width, height, in->bands, in->format, in->interpretation);
+}
+
+// A new reference to the same pixels: vips_image_write()'s pointer copy
+// (iofuncs/image.c:2610-2646) for the "factor is 1" early returns.
+VipsHipImage *copy_image(const VipsHipImage *in)
+{
+	VipsHipImage *out = like(in, in->width, in->height);
+	if (!out)
+		return nullptr;
+	if (vips_hip_memcpy_d2d(out->data, in->data, in->stride * in->height)) {
+		vips_hip_image_unref(out);
+		return nullptr;
+	}
+	return out;
+}
+
+int shrink_axis(VipsHipImage *in, VipsHipImage **out, int shrink, int ceil_mode, bool vertical)
+{
+	const char *domain = vertical ? "shrinkv" : "shrinkh";
+	if (shrink < 1) {
+		error(domain, "shrink factors should be >= 1");
+		return -1;
+	}
+	if (shrink == 1) {
+		*out = copy_image(in);
+		return *out ? 0 : -1;
+	}
+	int size = vips_hip_shrink_out_size(vertical ? in->height : in->width, shrink, ceil_mode);
+	if (size <= 0) {
+		error(domain, "image has shrunk to nothing");
+		return -1;
+	}
+	ImageRef o(vertical ? like(in, in->width, size) : like(in, size, in->height));
+	if (!o.im)
+		return -1;
+	VipsHipRegion ri, ro;
+	vips_hip_image_region(in, &ri);
+	vips_hip_image_region(o.im, &ro);
+	int result = vertical ? vips_hip_shrinkv_gen(shrink, &ri, &ro)
+						  : vips_hip_shrinkh_gen(shrink, &ri, &ro);
+	if (result)
+		return -1;
+	*out = o.release();
+	return 0;
+}
+
+// vips_reduceh_build / vips_reducev_build up to the generate:
+// reduceh.cpp:396-481, reducev.cpp:859-941.
+int reduce_axis(VipsHipImage *in, VipsHipImage **out, double shrink, int kernel, double gap,
+	bool vertical)
+{
+	const char *domain = vertical ? "reducev" : "reduceh";
+	if (shrink < 1.0) {
+		error(domain, "reduce factor should be >= 1.0");
+		return -1;
+	}
+	const int in_size = vertical ? in->height : in->width;
+	// "We need to always round to nearest, so round(), not rint()."
+	const int size = (int) ((double) in_size / shrink + 0.5);
+	double extra_pixels = size * shrink - in_size;
+	double residual = shrink;
+
+	ImageRef pre;
+	VipsHipImage *cur = in;
+	if (gap > 0.0 && kernel != VIPS_HIP_KERNEL_NEAREST) {
+		if (gap < 1.0) {
+			error(domain, "reduce gap should be >= 1.0");
+			return -1;
+		}
+		if (size <= 0) {
+			error(domain, "image has shrunk to nothing");
+			return -1;
+		}
+		int int_shrink = (int) floor((double) in_size / size / gap);
+		if (int_shrink < 1)
+			int_shrink = 1;
+		if (int_shrink > 1) {
+			if (shrink_axis(in, &pre.im, int_shrink, 1, vertical))
+				return -1;
+			cur = pre.im;
+			residual /= int_shrink;
+			extra_pixels /= int_shrink;
+		}
+	}
+
+	if (residual == 1.0) {
+		*out = copy_image(cur);
+		return *out ? 0 : -1;
+	}
+
+	if (size <= 0) {
+		error(domain, "image has shrunk to nothing");
+		return -1;
+	}
+	VipsHipReduce *r = vips_hip_reduce_new(kernel, residual,
+		vertical ? cur->height : cur->width, size, extra_pixels);
+	if (!r)
+		return -1;
+	ImageRef o(vertical ? like(cur, cur->width, size) : like(cur, size, cur->height));
+	int result = -1;
+	if (o.im) {
+		VipsHipRegion ri, ro;
+		vips_hip_image_region(cur, &ri);
+		vips_hip_image_region(o.im, &ro);
+		// reducev is evaluated by the reference in fatstrip-high generate calls
+		// (each re-seeding Y, reducev.cpp:548); reduceh's X is seeded at
+		// r->left = 0 of full-width strips (thread.c:301-325).
+		result = vertical ? vips_hip_reducev_gen_tiled(r, &ri, &ro, g_fatstrip_height)
+						  : vips_hip_reduceh_gen(r, &ri, &ro);
+	}
+	vips_hip_reduce_free(r);
+	if (result)
+		return -1;
+	*out = o.release();
+	return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int vips_hip_shrinkh(VipsHipImage *in, VipsHipImage **out, int hshrink, int ceil_mode)
+{
+	return shrink_axis(in, out, hshrink, ceil_mode, false);
+}
+
+int vips_hip_shrinkv(VipsHipImage *in, VipsHipImage **out, int vshrink, int ceil_mode)
+{
+	return shrink_axis(in, out, vshrink, ceil_mode, true);
+}
+
+int vips_hip_reduceh(VipsHipImage *in, VipsHipImage **out, double hshrink, int kernel, double gap)
+{
+	return reduce_axis(in, out, hshrink, kernel, gap, false);
+}
+
+int vips_hip_reducev(VipsHipImage *in, VipsHipImage **out, double vshrink, int kernel, double gap)
+{
+	return reduce_axis(in, out, vshrink, kernel, gap, true);
+}
+
+// vips_reduce_build, resample/reduce.c:98-121: vertical first.
+int vips_hip_reduce(VipsHipImage *in, VipsHipImage **out, double hshrink, double vshrink,
+	int kernel, double gap)
+{
+	// Fused uchar path when neither axis needs an integer pre-shrink.
+	if (in->format == VIPS_HIP_FORMAT_UCHAR && gap <= 0.0 && hshrink > 1.0 && vshrink > 1.0 &&
+		kernel != VIPS_HIP_KERNEL_NEAREST) {
+		const int height = (int) ((double) in->height / vshrink + 0.5);
+		const int width = (int) ((double) in->width / hshrink + 0.5);
+		if (width > 0 && height > 0) {
+			VipsHipReduce *rv = vips_hip_reduce_new(kernel, vshrink, in->height, height, NAN);
+			VipsHipReduce *rh = rv ? vips_hip_reduce_new(kernel, hshrink, in->width, width, NAN)
+								   : nullptr;
+			if (rv && rh) {
+				ImageRef o(like(in, width, height));
+				int result = -1;
+				if (o.im) {
+					VipsHipRegion ri, ro;
+					vips_hip_image_region(in, &ri);
+					vips_hip_image_region(o.im, &ro);
+					result = vips_hip_reduce_gen_tiled(rv, rh, &ri, &ro, g_fatstrip_height);
+				}
+				vips_hip_reduce_free(rv);
+				vips_hip_reduce_free(rh);
+				if (result < 0)
+					return -1;
+				if (result == 0) {
+					*out = o.release();
+					return 0;
+				}
+				// result > 0: geometry not covered by the fused kernel
+			}
+			else {
+				vips_hip_reduce_free(rv);
+				vips_hip_reduce_free(rh);
+				return -1;
+			}
+		}
+	}
+
+	ImageRef t0;
+	if (reduce_axis(in, &t0.im, vshrink, kernel, gap, true))
+		return -1;
+	return reduce_axis(t0.im, out, hshrink, kernel, gap, false);
+}
+
+// vips_shrink_build, resample/shrink.c:77-119
+int vips_hip_shrink(VipsHipImage *in, VipsHipImage **out, double hshrink, double vshrink,
+	int ceil_mode)
+{
+	const int hshrink_int = (int) hshrink;
+	const int vshrink_int = (int) vshrink;
+	ImageRef t0;
+	if (hshrink_int != hshrink || vshrink_int != vshrink) {
+		if (reduce_axis(in, &t0.im, vshrink, VIPS_HIP_KERNEL_LANCZOS3, 1.0, true))
+			return -1;
+		return reduce_axis(t0.im, out, hshrink, VIPS_HIP_KERNEL_LANCZOS3, 1.0, false);
+	}
+	if (shrink_axis(in, &t0.im, vshrink_int, ceil_mode, true))
+		return -1;
+	return shrink_axis(t0.im, out, hshrink_int, ceil_mode, false);
+}
+
+// vips_resize_build, resample/resize.c:135-329, downsizing half.
+int vips_hip_resize(VipsHipImage *in, VipsHipImage **out, double scale, double vscale_arg,
+	int kernel, double gap)
+{
+	double hscale = scale;
+	double vscale = vscale_arg > 0.0 ? vscale_arg : scale;
+	if (gap < 0.0)
+		gap = 2.0; // resize.c:397
+	if (kernel == VIPS_HIP_KERNEL_NEAREST) {
+		error("resize", "nearest-neighbour resize is outside the HIP path (vips_subsample)");
+		return -1;
+	}
+	if (hscale <= 0.0 || vscale <= 0.0) {
+		error("resize", "scale must be > 0");
+		return -1;
+	}
+	// "Don't let either axis drop below 1 px."
+	if (hscale < 1.0 / in->width)
+		hscale = 1.0 / in->width;
+	if (vscale < 1.0 / in->height)
+		vscale = 1.0 / in->height;
+	if (hscale > 1.0 || vscale > 1.0) {
+		error("resize", "upsizing (vips_affine) is outside the HIP path");
+		return -1;
+	}
+
+	ImageRef t2;
+	VipsHipImage *cur = in;
+	if (vscale < 1.0) {
+		if (reduce_axis(cur, &t2.im, 1.0 / vscale, kernel, gap, true))
+			return -1;
+		cur = t2.im;
+	}
+	if (hscale < 1.0)
+		return reduce_axis(cur, out, 1.0 / hscale, kernel, gap, false);
+	if (cur == in) {
+		*out = copy_image(in);
+		return *out ? 0 : -1;
+	}
+	*out = t2.release();
+	return 0;
+}
+
+} // extern "C"

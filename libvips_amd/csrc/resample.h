@@ -1,0 +1,51 @@
+// Internal: state of one reduceh/reducev operation.
+#pragma once
+
+#include "internal.h"
+
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+namespace vh {
+
+// include/vips/interpolate.h:109-118, resample/presample.h:70
+constexpr int TRANSFORM_SHIFT = 6;
+constexpr int TRANSFORM_SCALE = 1 << TRANSFORM_SHIFT;
+constexpr int INTERPOLATE_SHIFT = 12;
+constexpr int INTERPOLATE_SCALE = 1 << INTERPOLATE_SHIFT;
+constexpr int MAX_POINT = 2000;
+
+// Where output sample k reads from: first tap in UN-embedded input coordinates
+// (may be negative / beyond the edge: taps are clamped) and coefficient phase.
+struct ReducePos {
+	int first;
+	int phase;
+};
+
+} // namespace vh
+
+struct _VipsHipReduce {
+	int kernel;
+	double shrink; // residual shrink
+	int in_size, out_size;
+	int n_point;
+	double offset; // hoffset / voffset
+	int embed;     // ceil(n_point / 2) - 1
+	std::vector<double> matrixf;
+	std::vector<short> matrixs;
+	double *d_matrixf;
+	short *d_matrixs;
+	// device copies of position arrays keyed by (start, count, tile)
+	std::map<std::tuple<int, int, int>, vh::ReducePos *> pos_cache;
+	std::mutex mutex;
+};
+
+namespace vh {
+
+void reduce_make_mask(double *c, int kernel, int n_points, double shrink, double x);
+void reduce_positions(const _VipsHipReduce *r, int start, int count, int tile,
+	std::vector<ReducePos> &pos);
+
+} // namespace vh

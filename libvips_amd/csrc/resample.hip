@@ -1,0 +1,655 @@
+// reduceh / reducev / shrinkh / shrinkv generates for gfx950.
+//
+// Two tiers:
+//   * general kernels: every band format, any band count, any shrink -- one
+//     thread per output element, taps fetched with edge clamping.  They define
+//     correctness for the whole format matrix of reduceh.cpp:278-322 /
+//     reducev.cpp:563-609 / shrinkh.c:175-232 / shrinkv.c:181-310.
+//   * uchar fast kernels (reduce_u8.hip): LDS-staged, wave-coalesced kernels for
+//     the 8-bit paths the reference vectorises with Highway
+//     (reduceh_hwy.cpp:79, reducev_hwy.cpp:94, shrinkh_hwy.cpp:68,
+//     shrinkv_hwy.cpp:90,133), selected here when the geometry allows.
+//
+// Arithmetic contracts (bit-exact for the integer formats):
+//   unsigned ints  (sum + 2048) >> 12, clip           templates.h:152-157
+//   signed ints    (sum + sign(sum)*2048) >> 12, clip templates.h:203-209
+//   32-bit ints    the same in int64                   templates.h:537-545
+//   float          double coefficients, double sum, separate mul and add in
+//                  tap order, then (float)              templates.h:550-578
+#include "resample.h"
+#include "reduce_u8.h"
+
+#include <climits>
+#include <cmath>
+
+namespace vh {
+
+// --------------------------------------------------------------- finalisers
+
+template <typename T>
+struct ReduceTraits;
+
+template <>
+struct ReduceTraits<unsigned char> {
+	typedef int acc_t;
+	typedef short coef_t;
+	static __device__ __forceinline__ unsigned char fin(int s)
+	{
+		s = (s + (INTERPOLATE_SCALE >> 1)) >> INTERPOLATE_SHIFT;
+		return (unsigned char) min(max(s, 0), 255);
+	}
+};
+
+template <>
+struct ReduceTraits<signed char> {
+	typedef int acc_t;
+	typedef short coef_t;
+	static __device__ __forceinline__ signed char fin(int s)
+	{
+		const int round_by = (s >= 0 ? 1 : -1) * (INTERPOLATE_SCALE >> 1);
+		s = (s + round_by) >> INTERPOLATE_SHIFT;
+		return (signed char) min(max(s, (int) SCHAR_MIN), (int) SCHAR_MAX);
+	}
+};
+
+template <>
+struct ReduceTraits<unsigned short> {
+	typedef int acc_t;
+	typedef short coef_t;
+	static __device__ __forceinline__ unsigned short fin(int s)
+	{
+		s = (s + (INTERPOLATE_SCALE >> 1)) >> INTERPOLATE_SHIFT;
+		return (unsigned short) min(max(s, 0), (int) USHRT_MAX);
+	}
+};
+
+template <>
+struct ReduceTraits<short> {
+	typedef int acc_t;
+	typedef short coef_t;
+	static __device__ __forceinline__ short fin(int s)
+	{
+		const int round_by = (s >= 0 ? 1 : -1) * (INTERPOLATE_SCALE >> 1);
+		s = (s + round_by) >> INTERPOLATE_SHIFT;
+		return (short) min(max(s, (int) SHRT_MIN), (int) SHRT_MAX);
+	}
+};
+
+template <>
+struct ReduceTraits<unsigned int> {
+	typedef long long acc_t;
+	typedef short coef_t;
+	static __device__ __forceinline__ unsigned int fin(long long s)
+	{
+		s = (s + (INTERPOLATE_SCALE >> 1)) >> INTERPOLATE_SHIFT;
+		return (unsigned int) min(max(s, 0ll), (long long) UINT_MAX);
+	}
+};
+
+template <>
+struct ReduceTraits<int> {
+	typedef long long acc_t;
+	typedef short coef_t;
+	static __device__ __forceinline__ int fin(long long s)
+	{
+		const int round_by = (s >= 0 ? 1 : -1) * (INTERPOLATE_SCALE >> 1);
+		s = (s + round_by) >> INTERPOLATE_SHIFT;
+		return (int) min(max(s, (long long) INT_MIN), (long long) INT_MAX);
+	}
+};
+
+template <>
+struct ReduceTraits<float> {
+	typedef double acc_t;
+	typedef double coef_t;
+	static __device__ __forceinline__ float fin(double s) { return (float) s; }
+};
+
+// Accumulate one tap.  For the float path the multiply and the add must stay
+// two IEEE operations (the reference runs on baseline x86-64: no FMA).
+template <typename ACC, typename COEF, typename T>
+static __device__ __forceinline__ ACC mac(ACC sum, COEF c, T v)
+{
+	return sum + (ACC) c * (ACC) v;
+}
+
+template <>
+__device__ __forceinline__ double mac<double, double, float>(double sum, double c, float v)
+{
+	return __dadd_rn(sum, __dmul_rn(c, (double) v));
+}
+
+static __device__ __forceinline__ int clampi(int v, int lo, int hi)
+{
+	return min(max(v, lo), hi);
+}
+
+// --------------------------------------------------------- general reducev
+
+struct RegionArgs {
+	const unsigned char *data;
+	long long stride;
+	int left, top, width, height, im_width, im_height;
+};
+
+static RegionArgs region_args(const VipsHipRegion *r)
+{
+	RegionArgs a;
+	a.data = (const unsigned char *) r->data;
+	a.stride = (long long) r->stride;
+	a.left = r->left;
+	a.top = r->top;
+	a.width = r->width;
+	a.height = r->height;
+	a.im_width = r->im_width;
+	a.im_height = r->im_height;
+	return a;
+}
+
+// One thread per output element; blockIdx.y walks output rows.  All lanes of a
+// block share the row, so the coefficient row and the clamped source rows are
+// wave-uniform (scalar loads / scalar address math).
+template <typename T>
+__global__ void __launch_bounds__(256)
+reducev_general(RegionArgs in, RegionArgs out, int ne, int epp /* elements per pel */,
+	int n_point, const ReducePos *__restrict__ pos,
+	const typename ReduceTraits<T>::coef_t *__restrict__ table)
+{
+	typedef typename ReduceTraits<T>::acc_t ACC;
+	const int e = blockIdx.x * blockDim.x + threadIdx.x;
+	const int y = blockIdx.y;
+	if (e >= ne)
+		return;
+	const ReducePos p = pos[y];
+	const typename ReduceTraits<T>::coef_t *c = table + (size_t) p.phase * n_point;
+	// out.left is also the column in the input (reducev.cpp:536)
+	const long long col = (long long) (out.left - in.left) * epp + e;
+	ACC sum = 0;
+	for (int i = 0; i < n_point; i++) {
+		const int row = clampi(p.first + i, 0, in.im_height - 1) - in.top;
+		const T *src = (const T *) (in.data + row * in.stride);
+		sum = mac<ACC>(sum, c[i], src[col]);
+	}
+	T *dst = (T *) (out.data + (long long) y * out.stride);
+	dst[e] = ReduceTraits<T>::fin(sum);
+}
+
+// One thread per output element (x, band).
+template <typename T>
+__global__ void __launch_bounds__(256)
+reduceh_general(RegionArgs in, RegionArgs out, int epp, int n_point,
+	const ReducePos *__restrict__ pos,
+	const typename ReduceTraits<T>::coef_t *__restrict__ table)
+{
+	typedef typename ReduceTraits<T>::acc_t ACC;
+	const int e = blockIdx.x * blockDim.x + threadIdx.x;
+	const int y = blockIdx.y;
+	if (e >= out.width * epp)
+		return;
+	const int x = e / epp;
+	const int b = e - x * epp;
+	const ReducePos p = pos[x];
+	const typename ReduceTraits<T>::coef_t *c = table + (size_t) p.phase * n_point;
+	// same row of the input (reduceh.cpp:238)
+	const T *src = (const T *) (in.data + (long long) (out.top + y - in.top) * in.stride);
+	ACC sum = 0;
+	for (int i = 0; i < n_point; i++) {
+		const int colx = clampi(p.first + i, 0, in.im_width - 1) - in.left;
+		sum = mac<ACC>(sum, c[i], src[(long long) colx * epp + b]);
+	}
+	T *dst = (T *) (out.data + (long long) y * out.stride);
+	dst[e] = ReduceTraits<T>::fin(sum);
+}
+
+template <typename T>
+static int launch_reducev(const _VipsHipReduce *r, const VipsHipRegion *in,
+	const VipsHipRegion *out, const ReducePos *pos, const void *table)
+{
+	const int epp = region_elems_per_pel(out);
+	const int ne = out->width * epp;
+	dim3 block(256, 1, 1);
+	dim3 grid((ne + 255) / 256, out->height, 1);
+	Gate gate("reducev_general");
+	hipLaunchKernelGGL(reducev_general<T>, grid, block, 0, stream(),
+		region_args(in), region_args(out), ne, epp, r->n_point, pos,
+		(const typename ReduceTraits<T>::coef_t *) table);
+	VH_CHECK(hipGetLastError());
+	return 0;
+}
+
+template <typename T>
+static int launch_reduceh(const _VipsHipReduce *r, const VipsHipRegion *in,
+	const VipsHipRegion *out, const ReducePos *pos, const void *table)
+{
+	const int epp = region_elems_per_pel(out);
+	const int ne = out->width * epp;
+	dim3 block(256, 1, 1);
+	dim3 grid((ne + 255) / 256, out->height, 1);
+	Gate gate("reduceh_general");
+	hipLaunchKernelGGL(reduceh_general<T>, grid, block, 0, stream(),
+		region_args(in), region_args(out), epp, r->n_point, pos,
+		(const typename ReduceTraits<T>::coef_t *) table);
+	VH_CHECK(hipGetLastError());
+	return 0;
+}
+
+// Device-resident tables / position arrays, created on first use.
+static int reduce_tables(_VipsHipReduce *r, bool want_float, const void **table)
+{
+	std::lock_guard<std::mutex> lock(r->mutex);
+	if (want_float) {
+		if (!r->d_matrixf) {
+			r->d_matrixf = (double *) upload(r->matrixf.data(),
+				r->matrixf.size() * sizeof(double));
+			if (!r->d_matrixf)
+				return -1;
+		}
+		*table = r->d_matrixf;
+	}
+	else {
+		if (!r->d_matrixs) {
+			r->d_matrixs = (short *) upload(r->matrixs.data(),
+				r->matrixs.size() * sizeof(short));
+			if (!r->d_matrixs)
+				return -1;
+		}
+		*table = r->d_matrixs;
+	}
+	return 0;
+}
+
+const ReducePos *reduce_device_positions(_VipsHipReduce *r, int start, int count, int tile)
+{
+	std::lock_guard<std::mutex> lock(r->mutex);
+	auto key = std::make_tuple(start, count, tile);
+	auto it = r->pos_cache.find(key);
+	if (it != r->pos_cache.end())
+		return it->second;
+	std::vector<ReducePos> pos;
+	reduce_positions(r, start, count, tile, pos);
+	ReducePos *d = (ReducePos *) upload(pos.data(), pos.size() * sizeof(ReducePos));
+	if (!d)
+		return nullptr;
+	// Bound the cache: tiled callers walk many distinct rects.
+	if (r->pos_cache.size() > 256) {
+		for (auto &kv : r->pos_cache)
+			vips_hip_free(kv.second);
+		r->pos_cache.clear();
+	}
+	r->pos_cache[key] = d;
+	return d;
+}
+
+static int reduce_check(const char *domain, const _VipsHipReduce *r, const VipsHipRegion *in,
+	const VipsHipRegion *out, bool vertical)
+{
+	if (!r) {
+		error(domain, "null reduce");
+		return -1;
+	}
+	if (check_region(domain, in) || check_region(domain, out))
+		return -1;
+	if (in->bands != out->bands || in->format != out->format) {
+		error(domain, "input and output must have the same bands and format");
+		return -1;
+	}
+	int in_size = vertical ? in->im_height : in->im_width;
+	int out_size = vertical ? out->im_height : out->im_width;
+	if (in_size != r->in_size || out_size != r->out_size) {
+		error(domain, "region does not belong to an image of the size this reduce was built for");
+		return -1;
+	}
+	// Does the window cover what the generate needs?
+	int need0, needn;
+	if (vertical) {
+		vips_hip_reducev_need(r, out->top, out->height, &need0, &needn);
+		if (need0 < in->top || need0 + needn > in->top + in->height ||
+			out->left < in->left || out->left + out->width > in->left + in->width) {
+			error(domain, "input region too small: need rows %d..%d", need0, need0 + needn);
+			return -1;
+		}
+	}
+	else {
+		vips_hip_reduceh_need(r, out->left, out->width, &need0, &needn);
+		if (need0 < in->left || need0 + needn > in->left + in->width ||
+			out->top < in->top || out->top + out->height > in->top + in->height) {
+			error(domain, "input region too small: need columns %d..%d", need0, need0 + needn);
+			return -1;
+		}
+	}
+	return 0;
+}
+
+static int reduce_gen(const char *domain, const VipsHipReduce *reduce, const VipsHipRegion *in,
+	const VipsHipRegion *out, int tile, bool vertical)
+{
+	if (ensure_init())
+		return -1;
+	_VipsHipReduce *r = const_cast<_VipsHipReduce *>(reduce);
+	if (reduce_check(domain, r, in, out, vertical))
+		return -1;
+
+	const int fmt = format_real(out->format);
+	const bool want_float = fmt == VIPS_HIP_FORMAT_FLOAT;
+	if (fmt == VIPS_HIP_FORMAT_DOUBLE) {
+		// reduceh_notab / reducev_notab (reduceh.cpp:198-213): long double
+		// accumulation with a per-pixel mask; not implemented on the device.
+		error(domain, "double images are not supported by the HIP reduce path");
+		return -1;
+	}
+	const void *table;
+	if (reduce_tables(r, want_float, &table))
+		return -1;
+	const ReducePos *pos = vertical
+		? reduce_device_positions(r, out->top, out->height, tile)
+		: reduce_device_positions(r, out->left, out->width, tile);
+	if (!pos)
+		return -1;
+
+	if (fmt == VIPS_HIP_FORMAT_UCHAR) {
+		int done = vertical
+			? reducev_u8_try(r, in, out, pos, (const short *) table)
+			: reduceh_u8_try(r, in, out, pos, (const short *) table);
+		if (done < 0)
+			return -1;
+		if (done > 0)
+			return 0;
+	}
+
+#define DISPATCH(FN) \
+	switch (fmt) { \
+	case VIPS_HIP_FORMAT_UCHAR: return FN<unsigned char>(r, in, out, pos, table); \
+	case VIPS_HIP_FORMAT_CHAR: return FN<signed char>(r, in, out, pos, table); \
+	case VIPS_HIP_FORMAT_USHORT: return FN<unsigned short>(r, in, out, pos, table); \
+	case VIPS_HIP_FORMAT_SHORT: return FN<short>(r, in, out, pos, table); \
+	case VIPS_HIP_FORMAT_UINT: return FN<unsigned int>(r, in, out, pos, table); \
+	case VIPS_HIP_FORMAT_INT: return FN<int>(r, in, out, pos, table); \
+	case VIPS_HIP_FORMAT_FLOAT: return FN<float>(r, in, out, pos, table); \
+	default: break; \
+	}
+	if (vertical) {
+		DISPATCH(launch_reducev)
+	}
+	else {
+		DISPATCH(launch_reduceh)
+	}
+#undef DISPATCH
+	error(domain, "unsupported band format %d", out->format);
+	return -1;
+}
+
+// ------------------------------------------------------------------ shrink
+
+template <typename T>
+struct ShrinkTraits;
+
+// shrinkh.c:78-92 / shrinkv.c:218-228: ((sum + amend) * multiplier) >> 24 in
+// unsigned 32-bit arithmetic.
+template <>
+struct ShrinkTraits<unsigned char> {
+	typedef int acc_t;
+	static __device__ __forceinline__ unsigned char fin(int sum, int shrink, unsigned int mult8,
+		unsigned long long mult16, double inv)
+	{
+		return (unsigned char) (((unsigned int) sum * mult8) >> 24);
+	}
+};
+// shrinkh.c:98-112 / shrinkv.c:233-244
+template <>
+struct ShrinkTraits<unsigned short> {
+	typedef int acc_t;
+	static __device__ __forceinline__ unsigned short fin(int sum, int shrink, unsigned int mult8,
+		unsigned long long mult16, double inv)
+	{
+		return (unsigned short) (((unsigned long long) (long long) sum * mult16) >> 32);
+	}
+};
+// shrinkh.c:117-130 / shrinkv.c:248-257: C division, truncating toward zero
+#define SHRINK_INT_TRAITS(TYPE, ACC) \
+	template <> \
+	struct ShrinkTraits<TYPE> { \
+		typedef ACC acc_t; \
+		static __device__ __forceinline__ TYPE fin(ACC sum, int shrink, unsigned int mult8, \
+			unsigned long long mult16, double inv) \
+		{ \
+			return (TYPE) (sum / shrink); \
+		} \
+	};
+SHRINK_INT_TRAITS(signed char, int)
+SHRINK_INT_TRAITS(short, int)
+SHRINK_INT_TRAITS(unsigned int, long long)
+SHRINK_INT_TRAITS(int, long long)
+// shrinkh.c:136-151 / shrinkv.c:261-268: double sum * (1.0 / shrink)
+#define SHRINK_FLOAT_TRAITS(TYPE) \
+	template <> \
+	struct ShrinkTraits<TYPE> { \
+		typedef double acc_t; \
+		static __device__ __forceinline__ TYPE fin(double sum, int shrink, unsigned int mult8, \
+			unsigned long long mult16, double inv) \
+		{ \
+			return (TYPE) __dmul_rn(sum, inv); \
+		} \
+	};
+SHRINK_FLOAT_TRAITS(float)
+SHRINK_FLOAT_TRAITS(double)
+
+template <typename ACC, typename T>
+static __device__ __forceinline__ ACC shrink_add(ACC sum, T v)
+{
+	return sum + (ACC) v;
+}
+template <>
+__device__ __forceinline__ double shrink_add<double, float>(double sum, float v)
+{
+	return __dadd_rn(sum, (double) v);
+}
+template <>
+__device__ __forceinline__ double shrink_add<double, double>(double sum, double v)
+{
+	return __dadd_rn(sum, v);
+}
+
+template <typename T>
+static __device__ __forceinline__ typename ShrinkTraits<T>::acc_t shrink_seed(int amend)
+{
+	return (typename ShrinkTraits<T>::acc_t) amend;
+}
+template <>
+__device__ __forceinline__ double shrink_seed<float>(int amend) { return 0.0; }
+template <>
+__device__ __forceinline__ double shrink_seed<double>(int amend) { return 0.0; }
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+shrinkh_general(RegionArgs in, RegionArgs out, int epp, int hshrink, unsigned int mult8,
+	unsigned long long mult16, double inv)
+{
+	typedef typename ShrinkTraits<T>::acc_t ACC;
+	const int e = blockIdx.x * blockDim.x + threadIdx.x;
+	const int y = blockIdx.y;
+	if (e >= out.width * epp)
+		return;
+	const int x = e / epp;
+	const int b = e - x * epp;
+	const T *src = (const T *) (in.data + (long long) (out.top + y - in.top) * in.stride);
+	const int x0 = (out.left + x) * hshrink;
+	ACC sum = shrink_seed<T>(hshrink / 2);
+	for (int i = 0; i < hshrink; i++) {
+		const int colx = min(x0 + i, in.im_width - 1) - in.left;
+		sum = shrink_add<ACC, T>(sum, src[(long long) colx * epp + b]);
+	}
+	T *dst = (T *) (out.data + (long long) y * out.stride);
+	dst[e] = ShrinkTraits<T>::fin(sum, hshrink, mult8, mult16, inv);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+shrinkv_general(RegionArgs in, RegionArgs out, int ne, int epp, int vshrink, unsigned int mult8,
+	unsigned long long mult16, double inv)
+{
+	typedef typename ShrinkTraits<T>::acc_t ACC;
+	const int e = blockIdx.x * blockDim.x + threadIdx.x;
+	const int y = blockIdx.y;
+	if (e >= ne)
+		return;
+	const long long col = (long long) (out.left - in.left) * epp + e;
+	const int y0 = (out.top + y) * vshrink;
+	// shrinkv.c:170: sums start at 0 and `amend` is added at write time
+	// (:218-257); for the integer formats that is the same number.
+	ACC sum = shrink_seed<T>(vshrink / 2);
+	for (int i = 0; i < vshrink; i++) {
+		const int row = min(y0 + i, in.im_height - 1) - in.top;
+		const T *src = (const T *) (in.data + row * in.stride);
+		sum = shrink_add<ACC, T>(sum, src[col]);
+	}
+	T *dst = (T *) (out.data + (long long) y * out.stride);
+	dst[e] = ShrinkTraits<T>::fin(sum, vshrink, mult8, mult16, inv);
+}
+
+template <typename T>
+static int launch_shrinkh(int hshrink, const VipsHipRegion *in, const VipsHipRegion *out)
+{
+	const int epp = region_elems_per_pel(out);
+	const int ne = out->width * epp;
+	const unsigned int mult8 = (unsigned int) ((1LL << 32) / ((1 << 8) * (long long) hshrink));
+	const unsigned long long mult16 = ((1ULL << 32) + hshrink - 1) / hshrink;
+	dim3 block(256, 1, 1);
+	dim3 grid((ne + 255) / 256, out->height, 1);
+	Gate gate("shrinkh_general");
+	hipLaunchKernelGGL(shrinkh_general<T>, grid, block, 0, stream(), region_args(in),
+		region_args(out), epp, hshrink, mult8, mult16, 1.0 / hshrink);
+	VH_CHECK(hipGetLastError());
+	return 0;
+}
+
+template <typename T>
+static int launch_shrinkv(int vshrink, const VipsHipRegion *in, const VipsHipRegion *out)
+{
+	const int epp = region_elems_per_pel(out);
+	const int ne = out->width * epp;
+	const unsigned int mult8 = (unsigned int) ((1LL << 32) / ((1 << 8) * (long long) vshrink));
+	const unsigned long long mult16 = ((1ULL << 32) + vshrink - 1) / vshrink;
+	dim3 block(256, 1, 1);
+	dim3 grid((ne + 255) / 256, out->height, 1);
+	Gate gate("shrinkv_general");
+	hipLaunchKernelGGL(shrinkv_general<T>, grid, block, 0, stream(), region_args(in),
+		region_args(out), ne, epp, vshrink, mult8, mult16, 1.0 / vshrink);
+	VH_CHECK(hipGetLastError());
+	return 0;
+}
+
+static int shrink_gen(const char *domain, int shrink, const VipsHipRegion *in,
+	const VipsHipRegion *out, bool vertical)
+{
+	if (ensure_init())
+		return -1;
+	if (shrink < 1) {
+		error(domain, "shrink factors should be >= 1");
+		return -1;
+	}
+	if (check_region(domain, in) || check_region(domain, out))
+		return -1;
+	if (in->bands != out->bands || in->format != out->format) {
+		error(domain, "input and output must have the same bands and format");
+		return -1;
+	}
+	// window check: shrinkh.c:262-268 / shrinkv.c:347-358, clipped to the image
+	if (vertical) {
+		long long lo = (long long) out->top * shrink;
+		long long hi = (long long) (out->top + out->height) * shrink;
+		if (hi > in->im_height)
+			hi = in->im_height;
+		if (lo > in->im_height - 1)
+			lo = in->im_height - 1;
+		if (lo < in->top || hi > in->top + in->height || out->left < in->left ||
+			out->left + out->width > in->left + in->width) {
+			error(domain, "input region too small");
+			return -1;
+		}
+	}
+	else {
+		long long lo = (long long) out->left * shrink;
+		long long hi = (long long) (out->left + out->width) * shrink;
+		if (hi > in->im_width)
+			hi = in->im_width;
+		if (lo > in->im_width - 1)
+			lo = in->im_width - 1;
+		if (lo < in->left || hi > in->left + in->width || out->top < in->top ||
+			out->top + out->height > in->top + in->height) {
+			error(domain, "input region too small");
+			return -1;
+		}
+	}
+
+	const int fmt = format_real(out->format);
+	if (fmt == VIPS_HIP_FORMAT_UCHAR) {
+		int done = vertical ? shrinkv_u8_try(shrink, in, out) : shrinkh_u8_try(shrink, in, out);
+		if (done < 0)
+			return -1;
+		if (done > 0)
+			return 0;
+	}
+#define DISPATCH(FN) \
+	switch (fmt) { \
+	case VIPS_HIP_FORMAT_UCHAR: return FN<unsigned char>(shrink, in, out); \
+	case VIPS_HIP_FORMAT_CHAR: return FN<signed char>(shrink, in, out); \
+	case VIPS_HIP_FORMAT_USHORT: return FN<unsigned short>(shrink, in, out); \
+	case VIPS_HIP_FORMAT_SHORT: return FN<short>(shrink, in, out); \
+	case VIPS_HIP_FORMAT_UINT: return FN<unsigned int>(shrink, in, out); \
+	case VIPS_HIP_FORMAT_INT: return FN<int>(shrink, in, out); \
+	case VIPS_HIP_FORMAT_FLOAT: return FN<float>(shrink, in, out); \
+	case VIPS_HIP_FORMAT_DOUBLE: return FN<double>(shrink, in, out); \
+	default: break; \
+	}
+	if (vertical) {
+		DISPATCH(launch_shrinkv)
+	}
+	else {
+		DISPATCH(launch_shrinkh)
+	}
+#undef DISPATCH
+	error(domain, "unsupported band format %d", out->format);
+	return -1;
+}
+
+} // namespace vh
+
+using namespace vh;
+
+extern "C" {
+
+int vips_hip_reduceh_gen(const VipsHipReduce *reduce, const VipsHipRegion *in,
+	const VipsHipRegion *out)
+{
+	return reduce_gen("reduceh", reduce, in, out, 0, false);
+}
+
+int vips_hip_reducev_gen(const VipsHipReduce *reduce, const VipsHipRegion *in,
+	const VipsHipRegion *out)
+{
+	return reduce_gen("reducev", reduce, in, out, 0, true);
+}
+
+int vips_hip_reduceh_gen_tiled(const VipsHipReduce *reduce, const VipsHipRegion *in,
+	const VipsHipRegion *out, int tile)
+{
+	return reduce_gen("reduceh", reduce, in, out, tile, false);
+}
+
+int vips_hip_reducev_gen_tiled(const VipsHipReduce *reduce, const VipsHipRegion *in,
+	const VipsHipRegion *out, int tile)
+{
+	return reduce_gen("reducev", reduce, in, out, tile, true);
+}
+
+int vips_hip_shrinkh_gen(int hshrink, const VipsHipRegion *in, const VipsHipRegion *out)
+{
+	return shrink_gen("shrinkh", hshrink, in, out, false);
+}
+
+int vips_hip_shrinkv_gen(int vshrink, const VipsHipRegion *in, const VipsHipRegion *out)
+{
+	return shrink_gen("shrinkv", vshrink, in, out, true);
+}
+
+} // extern "C"

@@ -1,0 +1,596 @@
+// Runtime layer of libvipship.so: device selection, per-thread streams, the
+// caching HBM pool, pinned staging, the error buffer and kernel gates.
+//
+// Mirrors the host plumbing a libvips generate leans on, nothing more:
+//   error buffer        iofuncs/error.c (vips_error / vips_error_buffer)
+//   tracked malloc      iofuncs/memory.c:304,369 (vips_tracked_malloc)
+//   per-thread sequence include/vips/image.h:151-154 (start/stop own a stream)
+//   gates               include/vips/gate.h:40-56
+#include "internal.h"
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace vh {
+
+static thread_local std::string tls_error;
+static thread_local hipStream_t tls_stream = nullptr;
+static thread_local bool tls_stream_external = false;
+static thread_local int tls_device = -1;
+
+static std::mutex g_mutex;
+static bool g_inited = false;
+
+void error(const char *domain, const char *fmt, ...)
+{
+	char buf[1024];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	tls_error += domain;
+	tls_error += ": ";
+	tls_error += buf;
+	tls_error += "\n";
+}
+
+int hip_failed(hipError_t err, const char *what)
+{
+	error("vips_hip", "%s failed: %s", what, hipGetErrorString(err));
+	return -1;
+}
+
+int ensure_init()
+{
+	if (tls_device >= 0)
+		return 0;
+	return vips_hip_init(0);
+}
+
+hipStream_t stream()
+{
+	if (tls_stream_external)
+		return tls_stream;
+	if (!tls_stream) {
+		if (hipStreamCreateWithFlags(&tls_stream, hipStreamNonBlocking) != hipSuccess)
+			tls_stream = nullptr;
+	}
+	return tls_stream;
+}
+
+int check_region(const char *domain, const VipsHipRegion *r)
+{
+	if (!r || !r->data) {
+		error(domain, "null region");
+		return -1;
+	}
+	if (r->width <= 0 || r->height <= 0 || r->bands <= 0) {
+		error(domain, "empty region");
+		return -1;
+	}
+	if (format_sizeof(r->format) == 0) {
+		error(domain, "bad band format %d", r->format);
+		return -1;
+	}
+	return 0;
+}
+
+// ---------------------------------------------------------------- the pool
+//
+// Size-bucketed free lists (power-of-two classes from 256 B, exact size above
+// 1 GiB).  Frees are stream-ordered in practice because every thread uses one
+// stream; blocks freed by one thread and reused by another are separated by the
+// hipStreamSynchronize in image download / explicit synchronize, which is the
+// only place results leave the device.
+struct Pool {
+	std::mutex mutex;
+	std::map<size_t, std::vector<void *>> free_lists;
+	std::unordered_map<void *, size_t> live;
+	size_t cached_bytes = 0;
+	size_t live_bytes = 0;
+
+	static size_t bucket(size_t size)
+	{
+		if (size <= 256)
+			return 256;
+		if (size > ((size_t) 1 << 30))
+			return (size + ((size_t) 1 << 21) - 1) & ~(((size_t) 1 << 21) - 1);
+		size_t b = 256;
+		while (b < size)
+			b <<= 1;
+		return b;
+	}
+
+	void *alloc(size_t size)
+	{
+		size_t b = bucket(size);
+		{
+			std::lock_guard<std::mutex> lock(mutex);
+			auto it = free_lists.find(b);
+			if (it != free_lists.end() && !it->second.empty()) {
+				void *p = it->second.back();
+				it->second.pop_back();
+				cached_bytes -= b;
+				live[p] = b;
+				live_bytes += b;
+				return p;
+			}
+		}
+		void *p = nullptr;
+		hipError_t err = hipMalloc(&p, b);
+		if (err != hipSuccess) {
+			// Out of HBM: drop the cache and retry once.
+			trim();
+			err = hipMalloc(&p, b);
+		}
+		if (err != hipSuccess) {
+			hip_failed(err, "hipMalloc");
+			return nullptr;
+		}
+		std::lock_guard<std::mutex> lock(mutex);
+		live[p] = b;
+		live_bytes += b;
+		return p;
+	}
+
+	void release(void *p)
+	{
+		if (!p)
+			return;
+		std::lock_guard<std::mutex> lock(mutex);
+		auto it = live.find(p);
+		if (it == live.end())
+			return; // not ours
+		size_t b = it->second;
+		live.erase(it);
+		live_bytes -= b;
+		free_lists[b].push_back(p);
+		cached_bytes += b;
+	}
+
+	void trim()
+	{
+		std::lock_guard<std::mutex> lock(mutex);
+		for (auto &kv : free_lists)
+			for (void *p : kv.second)
+				(void) hipFree(p);
+		free_lists.clear();
+		cached_bytes = 0;
+	}
+};
+
+static Pool g_pool;
+
+void *upload(const void *host, size_t size)
+{
+	void *d = g_pool.alloc(size);
+	if (!d)
+		return nullptr;
+	// Tables are tiny; a synchronous copy keeps their lifetime simple.
+	if (hipMemcpy(d, host, size, hipMemcpyHostToDevice) != hipSuccess) {
+		error("vips_hip", "table upload failed");
+		g_pool.release(d);
+		return nullptr;
+	}
+	return d;
+}
+
+// ------------------------------------------------------------------- gates
+struct GateRecord {
+	std::string name;
+	hipEvent_t start, stop;
+};
+static bool g_gate_enabled = false;
+static std::mutex g_gate_mutex;
+static std::vector<GateRecord> g_gate_records;
+
+Gate::Gate(const char *name_)
+	: name(name_), start(nullptr), active(false)
+{
+	if (!g_gate_enabled)
+		return;
+	if (hipEventCreate(&start) != hipSuccess)
+		return;
+	(void) hipEventRecord(start, stream());
+	active = true;
+}
+
+Gate::~Gate()
+{
+	if (!active)
+		return;
+	hipEvent_t stop;
+	if (hipEventCreate(&stop) != hipSuccess)
+		return;
+	(void) hipEventRecord(stop, stream());
+	std::lock_guard<std::mutex> lock(g_gate_mutex);
+	g_gate_records.push_back({ name, start, stop });
+}
+
+} // namespace vh
+
+using namespace vh;
+
+extern "C" {
+
+int vips_hip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+int vips_hip_init(int device)
+{
+	int n = vips_hip_device_count();
+	if (n <= 0) {
+		error("vips_hip_init", "no HIP device visible (this library has no CPU path)");
+		return -1;
+	}
+	if (device < 0 || device >= n) {
+		error("vips_hip_init", "device %d out of range (have %d)", device, n);
+		return -1;
+	}
+	VH_CHECK(hipSetDevice(device));
+	{
+		std::lock_guard<std::mutex> lock(g_mutex);
+		if (!g_inited) {
+			hipDeviceProp_t prop;
+			VH_CHECK(hipGetDeviceProperties(&prop, device));
+			if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+				error("vips_hip_init", "device is %s, this library is built for gfx950 only",
+					prop.gcnArchName);
+				return -1;
+			}
+			g_inited = true;
+		}
+	}
+	tls_device = device;
+	return 0;
+}
+
+void vips_hip_shutdown(void)
+{
+	if (tls_stream && !tls_stream_external) {
+		(void) hipStreamSynchronize(tls_stream);
+		(void) hipStreamDestroy(tls_stream);
+	}
+	tls_stream = nullptr;
+	tls_stream_external = false;
+	g_pool.trim();
+}
+
+const char *vips_hip_error_buffer(void)
+{
+	return tls_error.c_str();
+}
+
+void vips_hip_error_clear(void)
+{
+	tls_error.clear();
+}
+
+int vips_hip_set_stream(void *s)
+{
+	if (ensure_init())
+		return -1;
+	if (tls_stream && !tls_stream_external) {
+		(void) hipStreamSynchronize(tls_stream);
+		(void) hipStreamDestroy(tls_stream);
+		tls_stream = nullptr;
+	}
+	if (s) {
+		tls_stream = (hipStream_t) s;
+		tls_stream_external = true;
+	}
+	else {
+		tls_stream = nullptr;
+		tls_stream_external = false;
+	}
+	return 0;
+}
+
+void *vips_hip_get_stream(void)
+{
+	if (ensure_init())
+		return nullptr;
+	return (void *) stream();
+}
+
+int vips_hip_synchronize(void)
+{
+	if (ensure_init())
+		return -1;
+	VH_CHECK(hipStreamSynchronize(stream()));
+	return 0;
+}
+
+void *vips_hip_malloc(size_t size)
+{
+	if (ensure_init())
+		return nullptr;
+	return g_pool.alloc(size ? size : 1);
+}
+
+void vips_hip_free(void *ptr)
+{
+	g_pool.release(ptr);
+}
+
+void *vips_hip_malloc_host(size_t size)
+{
+	if (ensure_init())
+		return nullptr;
+	void *p = nullptr;
+	VH_CHECK_NULL(hipHostMalloc(&p, size ? size : 1, hipHostMallocDefault));
+	return p;
+}
+
+void vips_hip_free_host(void *ptr)
+{
+	if (ptr)
+		(void) hipHostFree(ptr);
+}
+
+int vips_hip_memcpy_h2d(void *dst, const void *src, size_t size)
+{
+	if (ensure_init())
+		return -1;
+	VH_CHECK(hipMemcpyAsync(dst, src, size, hipMemcpyHostToDevice, stream()));
+	VH_CHECK(hipStreamSynchronize(stream()));
+	return 0;
+}
+
+int vips_hip_memcpy_d2h(void *dst, const void *src, size_t size)
+{
+	if (ensure_init())
+		return -1;
+	VH_CHECK(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToHost, stream()));
+	VH_CHECK(hipStreamSynchronize(stream()));
+	return 0;
+}
+
+int vips_hip_memcpy_d2d(void *dst, const void *src, size_t size)
+{
+	if (ensure_init())
+		return -1;
+	VH_CHECK(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToDevice, stream()));
+	return 0;
+}
+
+int vips_hip_memcpy2d_h2d(void *dst, size_t dpitch, const void *src, size_t spitch,
+	size_t width_bytes, size_t height)
+{
+	if (ensure_init())
+		return -1;
+	VH_CHECK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height,
+		hipMemcpyHostToDevice, stream()));
+	VH_CHECK(hipStreamSynchronize(stream()));
+	return 0;
+}
+
+int vips_hip_memcpy2d_d2h(void *dst, size_t dpitch, const void *src, size_t spitch,
+	size_t width_bytes, size_t height)
+{
+	if (ensure_init())
+		return -1;
+	VH_CHECK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height,
+		hipMemcpyDeviceToHost, stream()));
+	VH_CHECK(hipStreamSynchronize(stream()));
+	return 0;
+}
+
+size_t vips_hip_pool_bytes(void)
+{
+	std::lock_guard<std::mutex> lock(g_pool.mutex);
+	return g_pool.cached_bytes + g_pool.live_bytes;
+}
+
+void vips_hip_pool_trim(void)
+{
+	g_pool.trim();
+}
+
+void *vips_hip_event_new(void)
+{
+	if (ensure_init())
+		return nullptr;
+	hipEvent_t e;
+	VH_CHECK_NULL(hipEventCreate(&e));
+	return (void *) e;
+}
+
+void vips_hip_event_free(void *event)
+{
+	if (event)
+		(void) hipEventDestroy((hipEvent_t) event);
+}
+
+int vips_hip_event_record(void *event)
+{
+	if (ensure_init())
+		return -1;
+	VH_CHECK(hipEventRecord((hipEvent_t) event, stream()));
+	return 0;
+}
+
+double vips_hip_event_elapsed_ms(void *start, void *stop)
+{
+	float ms = 0.f;
+	if (hipEventSynchronize((hipEvent_t) stop) != hipSuccess)
+		return -1.0;
+	if (hipEventElapsedTime(&ms, (hipEvent_t) start, (hipEvent_t) stop) != hipSuccess)
+		return -1.0;
+	return (double) ms;
+}
+
+void vips_hip_gate_enable(int enable)
+{
+	g_gate_enabled = enable != 0;
+}
+
+void vips_hip_gate_reset(void)
+{
+	std::lock_guard<std::mutex> lock(g_gate_mutex);
+	for (auto &r : g_gate_records) {
+		(void) hipEventDestroy(r.start);
+		(void) hipEventDestroy(r.stop);
+	}
+	g_gate_records.clear();
+}
+
+int vips_hip_gate_query(const char *name, double *total_ms)
+{
+	(void) hipDeviceSynchronize();
+	std::lock_guard<std::mutex> lock(g_gate_mutex);
+	int n = 0;
+	double total = 0.0;
+	size_t len = strlen(name);
+	for (auto &r : g_gate_records) {
+		if (strncmp(r.name.c_str(), name, len) != 0)
+			continue;
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+			total += ms;
+			n += 1;
+		}
+	}
+	if (total_ms)
+		*total_ms = total;
+	return n;
+}
+
+int vips_hip_gate_report(char *buf, int size)
+{
+	(void) hipDeviceSynchronize();
+	std::lock_guard<std::mutex> lock(g_gate_mutex);
+	std::map<std::string, std::pair<int, double>> totals;
+	for (auto &r : g_gate_records) {
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess)
+			continue;
+		auto &t = totals[r.name];
+		t.first += 1;
+		t.second += ms;
+	}
+	std::string text;
+	for (auto &kv : totals) {
+		char line[256];
+		snprintf(line, sizeof(line), "%s %d %.6f\n", kv.first.c_str(), kv.second.first,
+			kv.second.second);
+		text += line;
+	}
+	if (buf && size > 0) {
+		strncpy(buf, text.c_str(), size - 1);
+		buf[size - 1] = '\0';
+	}
+	return (int) totals.size();
+}
+
+// ------------------------------------------------------------------ images
+
+VipsHipImage *vips_hip_image_new(int width, int height, int bands, int format,
+	int interpretation)
+{
+	if (ensure_init())
+		return nullptr;
+	int es = format_sizeof(format);
+	if (width <= 0 || height <= 0 || bands <= 0 || es == 0) {
+		error("vips_hip_image_new", "bad image parameters %dx%dx%d format %d",
+			width, height, bands, format);
+		return nullptr;
+	}
+	VipsHipImage *im = new VipsHipImage;
+	im->width = width;
+	im->height = height;
+	im->bands = bands;
+	im->format = format;
+	im->interpretation = interpretation;
+	im->stride = (size_t) width * bands * es;
+	im->owns = true;
+	im->data = g_pool.alloc(im->stride * height);
+	if (!im->data) {
+		delete im;
+		return nullptr;
+	}
+	return im;
+}
+
+VipsHipImage *vips_hip_image_new_from_memory(const void *host_data, int width, int height,
+	int bands, int format, int interpretation)
+{
+	VipsHipImage *im = vips_hip_image_new(width, height, bands, format, interpretation);
+	if (!im)
+		return nullptr;
+	if (vips_hip_memcpy_h2d(im->data, host_data, im->stride * height)) {
+		vips_hip_image_unref(im);
+		return nullptr;
+	}
+	return im;
+}
+
+VipsHipImage *vips_hip_image_new_from_device(void *device_data, int width, int height,
+	int bands, int format, int interpretation)
+{
+	if (ensure_init())
+		return nullptr;
+	int es = format_sizeof(format);
+	if (!device_data || width <= 0 || height <= 0 || bands <= 0 || es == 0) {
+		error("vips_hip_image_new_from_device", "bad image parameters");
+		return nullptr;
+	}
+	VipsHipImage *im = new VipsHipImage;
+	im->width = width;
+	im->height = height;
+	im->bands = bands;
+	im->format = format;
+	im->interpretation = interpretation;
+	im->stride = (size_t) width * bands * es;
+	im->owns = false;
+	im->data = device_data;
+	return im;
+}
+
+void vips_hip_image_unref(VipsHipImage *image)
+{
+	if (!image)
+		return;
+	if (image->owns)
+		g_pool.release(image->data);
+	delete image;
+}
+
+int vips_hip_image_write_to_memory(const VipsHipImage *image, void *host_data)
+{
+	return vips_hip_memcpy_d2h(host_data, image->data, image->stride * image->height);
+}
+
+void *vips_hip_image_get_data(const VipsHipImage *image) { return image->data; }
+int vips_hip_image_get_width(const VipsHipImage *image) { return image->width; }
+int vips_hip_image_get_height(const VipsHipImage *image) { return image->height; }
+int vips_hip_image_get_bands(const VipsHipImage *image) { return image->bands; }
+int vips_hip_image_get_format(const VipsHipImage *image) { return image->format; }
+int vips_hip_image_get_interpretation(const VipsHipImage *image) { return image->interpretation; }
+size_t vips_hip_image_get_stride(const VipsHipImage *image) { return image->stride; }
+
+void vips_hip_image_region(const VipsHipImage *image, VipsHipRegion *region)
+{
+	region->data = image->data;
+	region->left = 0;
+	region->top = 0;
+	region->width = image->width;
+	region->height = image->height;
+	region->im_width = image->width;
+	region->im_height = image->height;
+	region->bands = image->bands;
+	region->format = image->format;
+	region->stride = image->stride;
+}
+
+} // extern "C"

@@ -1,0 +1,48 @@
+/* TEST INFRASTRUCTURE ONLY -- declarations of the CPU restatement (oracle/port).
+ * See the header of each port_*.c for the reference lines it follows.
+ */
+#ifndef ORACLE_PORT_H
+#define ORACLE_PORT_H
+
+#include <stddef.h>
+
+/* VipsBandFormat values (include/vips/image.h:120-133) */
+enum {
+	PORT_FORMAT_UCHAR = 0,
+	PORT_FORMAT_CHAR = 1,
+	PORT_FORMAT_USHORT = 2,
+	PORT_FORMAT_SHORT = 3,
+	PORT_FORMAT_UINT = 4,
+	PORT_FORMAT_INT = 5,
+	PORT_FORMAT_FLOAT = 6,
+	PORT_FORMAT_COMPLEX = 7,
+	PORT_FORMAT_DOUBLE = 8,
+	PORT_FORMAT_DPCOMPLEX = 9
+};
+
+/* VipsKernel values (include/vips/resample.h:41-51) */
+enum {
+	PORT_KERNEL_NEAREST = 0,
+	PORT_KERNEL_LINEAR,
+	PORT_KERNEL_CUBIC,
+	PORT_KERNEL_MITCHELL,
+	PORT_KERNEL_LANCZOS2,
+	PORT_KERNEL_LANCZOS3,
+	PORT_KERNEL_MKS2013,
+	PORT_KERNEL_MKS2021
+};
+
+/* resample */
+int port_reduce_get_points(int kernel, double shrink);
+void port_reduce_make_mask(double *c, int kernel, int n_points, double shrink, double x);
+int port_reduceh(const void *in, int width, int height, int bands, int format,
+	double hshrink, int kernel, int out_width, double extra_pixels, void *out);
+int port_reducev(const void *in, int width, int height, int bands, int format,
+	double vshrink, int kernel, int out_height, double extra_pixels, int tile, void *out);
+int port_shrink_out_size(int in_size, int shrink, int ceil_mode);
+int port_shrinkh(const void *in, int width, int height, int bands, int format, int hshrink,
+	int ceil_mode, void *out);
+int port_shrinkv(const void *in, int width, int height, int bands, int format, int vshrink,
+	int ceil_mode, void *out);
+
+#endif

@@ -1,0 +1,323 @@
+"""Test helpers: synthetic inputs, the reference shim, the oracle port.
+
+TEST INFRASTRUCTURE.  ``Ref`` drives the *compiled reference* (oracle/_ref, built
+by oracle/build_ref.sh from /root/reference; the .so travels to the GPU box).
+``Port`` drives the plain-C restatement (oracle/port).  Neither is ever imported
+by the product package.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_LIB = os.path.join(ROOT, "oracle", "_ref", "lib", "libref_shim.so")
+PORT_LIB = os.path.join(ROOT, "oracle", "_build", "liboracle_port.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+FORMAT_DTYPES = {
+    0: np.uint8, 1: np.int8, 2: np.uint16, 3: np.int16, 4: np.uint32,
+    5: np.int32, 6: np.float32, 7: np.complex64, 8: np.float64, 9: np.complex128,
+}
+DTYPE_FORMATS = {np.dtype(v): k for k, v in FORMAT_DTYPES.items()}
+
+
+def lcg_bytes(n, seed=12345):
+    """s = s*1664525 + 1013904223 (mod 2^32); byte = s >> 24."""
+    out = np.empty(n, dtype=np.uint8)
+    B = 1 << 16
+    M = np.uint64(0xFFFFFFFF)
+    a = np.uint64(1664525)
+    c = np.uint64(1013904223)
+    ak = np.empty(B, dtype=np.uint64)
+    ck = np.empty(B, dtype=np.uint64)
+    aa = np.uint64(1)
+    cc = np.uint64(0)
+    for k in range(B):
+        aa = (aa * a) & M
+        cc = (cc * a + c) & M
+        ak[k] = aa
+        ck[k] = cc
+    s = np.uint64(seed)
+    for i in range(0, n, B):
+        m = min(B, n - i)
+        v = (ak[:m] * s + ck[:m]) & M
+        out[i:i + m] = (v >> np.uint64(24)).astype(np.uint8)
+        s = v[m - 1]
+    return out
+
+
+def lcg_image(width, height, bands, dtype=np.uint8, seed=12345):
+    """Deterministic synthetic image of any band format (full range for ints)."""
+    dtype = np.dtype(dtype)
+    n = width * height * bands
+    if dtype == np.uint8:
+        return lcg_bytes(n, seed).reshape(height, width, bands)
+    if dtype == np.int8:
+        return lcg_bytes(n, seed).view(np.int8).reshape(height, width, bands)
+    if dtype.kind in "ui":
+        raw = lcg_bytes(n * dtype.itemsize, seed)
+        return raw.view(dtype).reshape(height, width, bands)
+    if dtype.kind == "f":
+        # byte values 0..255 plus a deterministic fraction
+        raw = lcg_bytes(n * 2, seed).astype(np.float64)
+        v = raw[0::2] + raw[1::2] / 256.0
+        return v.astype(dtype).reshape(height, width, bands)
+    raise ValueError(dtype)
+
+
+def checksum(array):
+    """SURVEY.md 8(c) golden checksum: sum o[i] * (i mod 251 + 1)."""
+    o = np.ascontiguousarray(array).reshape(-1).astype(np.int64)
+    idx = (np.arange(o.size, dtype=np.int64) % 251) + 1
+    return int((o * idx).sum())
+
+
+class RefImage(ctypes.Structure):
+    _fields_ = [
+        ("data", ctypes.c_void_p), ("width", ctypes.c_int), ("height", ctypes.c_int),
+        ("bands", ctypes.c_int), ("format", ctypes.c_int), ("interpretation", ctypes.c_int),
+    ]
+
+
+def have_ref():
+    return os.path.exists(REF_LIB)
+
+
+class Ref(object):
+    """The compiled reference (libvips 8.19.0 scalar C paths) through oracle/ref_shim.c."""
+
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            lib = ctypes.CDLL(REF_LIB)
+            lib.ref_init.argtypes = [ctypes.c_int]
+            lib.ref_error.restype = ctypes.c_char_p
+            lib.ref_version.restype = ctypes.c_char_p
+            lib.ref_free.argtypes = [ctypes.c_void_p]
+            lib.ref_run.argtypes = [ctypes.c_char_p, ctypes.POINTER(RefImage), ctypes.c_char_p,
+                                    ctypes.POINTER(RefImage)]
+            lib.ref_run_mask.argtypes = [ctypes.c_char_p, ctypes.POINTER(RefImage),
+                                         ctypes.POINTER(RefImage), ctypes.c_double, ctypes.c_double,
+                                         ctypes.c_char_p, ctypes.POINTER(RefImage)]
+            lib.ref_create.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(RefImage),
+                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+            lib.ref_run_chain.argtypes = [ctypes.c_char_p, ctypes.POINTER(RefImage),
+                                          ctypes.POINTER(RefImage)]
+            lib.ref_time_chain.argtypes = [ctypes.c_char_p, ctypes.POINTER(RefImage), ctypes.c_int]
+            lib.ref_time_chain.restype = ctypes.c_double
+            for name in ("ref_col_Lab2XYZ", "ref_col_XYZ2Lab"):
+                getattr(lib, name).argtypes = [ctypes.c_float] * 3 + [ctypes.POINTER(ctypes.c_float)] * 3
+            if lib.ref_init(0) != 0:
+                raise RuntimeError("reference failed to initialise")
+            cls._lib = lib
+        return cls._lib
+
+    @staticmethod
+    def _wrap(array, interpretation=0):
+        a = np.ascontiguousarray(array)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        h, w, b = a.shape
+        return a, RefImage(a.ctypes.data, w, h, b, DTYPE_FORMATS[a.dtype], interpretation)
+
+    @classmethod
+    def _take(cls, out):
+        dtype = np.dtype(FORMAT_DTYPES[out.format])
+        n = out.width * out.height * out.bands
+        buf = (ctypes.c_char * (n * dtype.itemsize)).from_address(out.data)
+        a = np.frombuffer(buf, dtype=dtype).reshape(out.height, out.width, out.bands).copy()
+        cls.lib().ref_free(out.data)
+        return a
+
+    @classmethod
+    def _fail(cls, what):
+        lib = cls.lib()
+        msg = lib.ref_error().decode()
+        lib.ref_error_clear()
+        raise RuntimeError("%s: %s" % (what, msg))
+
+    @classmethod
+    def run(cls, nick, array, args="", interpretation=0):
+        a, ri = cls._wrap(array, interpretation)
+        ro = RefImage()
+        if cls.lib().ref_run(nick.encode(), ctypes.byref(ri), args.encode(), ctypes.byref(ro)) != 0:
+            cls._fail(nick)
+        return cls._take(ro)
+
+    @classmethod
+    def run_interp(cls, nick, array, args="", interpretation=0):
+        """As run(), also returning the output's interpretation."""
+        a, ri = cls._wrap(array, interpretation)
+        ro = RefImage()
+        if cls.lib().ref_run(nick.encode(), ctypes.byref(ri), args.encode(), ctypes.byref(ro)) != 0:
+            cls._fail(nick)
+        interp = ro.interpretation
+        return cls._take(ro), interp
+
+    @classmethod
+    def run_mask(cls, nick, array, mask, scale=1.0, offset=0.0, args="", interpretation=0):
+        a, ri = cls._wrap(array, interpretation)
+        m, rm = cls._wrap(np.asarray(mask, dtype=np.float64))
+        ro = RefImage()
+        if cls.lib().ref_run_mask(nick.encode(), ctypes.byref(ri), ctypes.byref(rm), scale, offset,
+                                  args.encode(), ctypes.byref(ro)) != 0:
+            cls._fail(nick)
+        return cls._take(ro)
+
+    @classmethod
+    def create(cls, nick, args=""):
+        ro = RefImage()
+        scale = ctypes.c_double()
+        offset = ctypes.c_double()
+        if cls.lib().ref_create(nick.encode(), args.encode(), ctypes.byref(ro), ctypes.byref(scale),
+                                ctypes.byref(offset)) != 0:
+            cls._fail(nick)
+        return cls._take(ro), scale.value, offset.value
+
+    @classmethod
+    def run_chain(cls, chain, array, interpretation=0):
+        a, ri = cls._wrap(array, interpretation)
+        ro = RefImage()
+        if cls.lib().ref_run_chain(chain.encode(), ctypes.byref(ri), ctypes.byref(ro)) != 0:
+            cls._fail(chain)
+        return cls._take(ro)
+
+    @classmethod
+    def time_chain(cls, chain, array, repeats=3, interpretation=0, concurrency=0):
+        lib = cls.lib()
+        if concurrency:
+            lib.ref_init(concurrency)
+        a, ri = cls._wrap(array, interpretation)
+        t = lib.ref_time_chain(chain.encode(), ctypes.byref(ri), repeats)
+        if t < 0:
+            cls._fail(chain)
+        return t
+
+    @classmethod
+    def concurrency(cls):
+        return cls.lib().ref_concurrency()
+
+
+def have_port():
+    return os.path.exists(PORT_LIB)
+
+
+KERNELS = {"nearest": 0, "linear": 1, "cubic": 2, "mitchell": 3, "lanczos2": 4, "lanczos3": 5,
+           "mks2013": 6, "mks2021": 7}
+
+
+class Port(object):
+    """oracle/port: the plain-C restatement of the hot path (CPU, single thread)."""
+
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            lib = ctypes.CDLL(PORT_LIB)
+            vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+            lib.port_reduce_get_points.argtypes = [ci, cd]
+            lib.port_reduce_make_mask.argtypes = [ctypes.POINTER(cd), ci, ci, cd, cd]
+            lib.port_reduce_make_mask.restype = None
+            lib.port_reduceh.argtypes = [vp, ci, ci, ci, ci, cd, ci, ci, cd, vp]
+            lib.port_reducev.argtypes = [vp, ci, ci, ci, ci, cd, ci, ci, cd, ci, vp]
+            lib.port_shrink_out_size.argtypes = [ci, ci, ci]
+            lib.port_shrinkh.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp]
+            lib.port_shrinkv.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp]
+            cls._lib = lib
+        return cls._lib
+
+    @staticmethod
+    def _prep(array):
+        a = np.ascontiguousarray(array)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        return a
+
+    @classmethod
+    def shrinkh(cls, array, hshrink, ceil=False):
+        a = cls._prep(array)
+        h, w, b = a.shape
+        ow = cls.lib().port_shrink_out_size(w, hshrink, int(ceil))
+        out = np.empty((h, ow, b), dtype=a.dtype)
+        cls.lib().port_shrinkh(a.ctypes.data, w, h, b, DTYPE_FORMATS[a.dtype], hshrink, int(ceil),
+                               out.ctypes.data)
+        return out
+
+    @classmethod
+    def shrinkv(cls, array, vshrink, ceil=False):
+        a = cls._prep(array)
+        h, w, b = a.shape
+        oh = cls.lib().port_shrink_out_size(h, vshrink, int(ceil))
+        out = np.empty((oh, w, b), dtype=a.dtype)
+        cls.lib().port_shrinkv(a.ctypes.data, w, h, b, DTYPE_FORMATS[a.dtype], vshrink, int(ceil),
+                               out.ctypes.data)
+        return out
+
+    @classmethod
+    def _reduce_axis(cls, array, shrink, kernel, gap, vertical, tile):
+        """vips_reduceh_build / vips_reducev_build (reduceh.cpp:396-481, reducev.cpp:859-941)."""
+        a = cls._prep(array)
+        k = KERNELS[kernel] if isinstance(kernel, str) else kernel
+        in_size = a.shape[0] if vertical else a.shape[1]
+        size = int(in_size / shrink + 0.5)
+        extra = size * shrink - in_size
+        residual = shrink
+        if gap > 0.0 and k != 0:
+            int_shrink = max(1, int(np.floor(in_size / size / gap)))
+            if int_shrink > 1:
+                a = cls.shrinkv(a, int_shrink, True) if vertical else cls.shrinkh(a, int_shrink, True)
+                residual /= int_shrink
+                extra /= int_shrink
+        if residual == 1.0:
+            return a.copy()
+        h, w, b = a.shape
+        fmt = DTYPE_FORMATS[a.dtype]
+        if vertical:
+            out = np.empty((size, w, b), dtype=a.dtype)
+            r = cls.lib().port_reducev(a.ctypes.data, w, h, b, fmt, residual, k, size, extra, tile,
+                                       out.ctypes.data)
+        else:
+            out = np.empty((h, size, b), dtype=a.dtype)
+            r = cls.lib().port_reduceh(a.ctypes.data, w, h, b, fmt, residual, k, size, extra,
+                                       out.ctypes.data)
+        if r != 0:
+            raise RuntimeError("port reduce failed")
+        return out
+
+    @classmethod
+    def reducev(cls, array, vshrink, kernel="lanczos3", gap=0.0, tile=16):
+        return cls._reduce_axis(array, vshrink, kernel, gap, True, tile)
+
+    @classmethod
+    def reduceh(cls, array, hshrink, kernel="lanczos3", gap=0.0):
+        return cls._reduce_axis(array, hshrink, kernel, gap, False, 0)
+
+    @classmethod
+    def reduce(cls, array, hshrink, vshrink, kernel="lanczos3", gap=0.0, tile=16):
+        """vips_reduce_build (reduce.c:98-121): vertical first."""
+        return cls.reduceh(cls.reducev(array, vshrink, kernel, gap, tile), hshrink, kernel, gap)
+
+    @classmethod
+    def shrink(cls, array, hshrink, vshrink, ceil=False):
+        """vips_shrink_build (shrink.c:77-119)."""
+        if int(hshrink) != hshrink or int(vshrink) != vshrink:
+            return cls.reduceh(cls.reducev(array, vshrink, "lanczos3", 1.0), hshrink, "lanczos3", 1.0)
+        return cls.shrinkh(cls.shrinkv(array, int(vshrink), ceil), int(hshrink), ceil)
+
+    @classmethod
+    def resize(cls, array, scale, vscale=None, kernel="lanczos3", gap=2.0, tile=16):
+        """vips_resize_build (resize.c:135-329), downsizing half."""
+        a = cls._prep(array)
+        hscale = scale
+        vscale = scale if vscale is None else vscale
+        hscale = max(hscale, 1.0 / a.shape[1])
+        vscale = max(vscale, 1.0 / a.shape[0])
+        if vscale < 1.0:
+            a = cls.reducev(a, 1.0 / vscale, kernel, gap, tile)
+        if hscale < 1.0:
+            a = cls.reduceh(a, 1.0 / hscale, kernel, gap)
+        return a

@@ -1,0 +1,114 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol the header
+declares; the host-side table builders agree with the oracle; error behaviour."""
+import ctypes
+import math
+import re
+
+import numpy as np
+import pytest
+
+import libvips_amd
+from libvips_amd import _ffi
+from tests import helpers
+from tests.helpers import Port
+
+
+def header_symbols():
+    text = open(libvips_amd.HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"VIPS_HIP_API[^;(]*?\b(vips_hip_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = header_symbols()
+    assert len(syms) > 60
+    missing = [s for s in syms if not hasattr(_ffi.lib, s)]
+    assert missing == []
+
+
+def test_binding_covers_header():
+    assert _ffi.MISSING == []
+    unbound = [s for s in header_symbols() if s not in _ffi._SIGNATURES]
+    assert unbound == []
+
+
+def test_reduce_get_points():
+    for kernel in range(8):
+        for shrink in (1.0, 1.1, 1.5, 2.0, 3.3, 8.0, 100.5):
+            assert _ffi.lib.vips_hip_reduce_get_points(kernel, shrink) == \
+                Port.lib().port_reduce_get_points(kernel, shrink)
+    # reduceh.cpp:129-130: lanczos3 at x8 -> 49 taps
+    assert _ffi.lib.vips_hip_reduce_get_points(5, 8.0) == 49
+
+
+@pytest.mark.parametrize("kernel", range(1, 8))
+@pytest.mark.parametrize("shrink", [1.1, 2.0, 2.718, 8.0])
+def test_reduce_tables_match_oracle(kernel, shrink):
+    r = _ffi.lib.vips_hip_reduce_new(kernel, shrink, 1000, int(1000 / shrink + 0.5), math.nan)
+    assert r
+    try:
+        n = _ffi.lib.vips_hip_reduce_get_n_point(r)
+        assert n == Port.lib().port_reduce_get_points(kernel, shrink)
+        for phase in range(65):
+            cf = (ctypes.c_double * n)()
+            cs = (ctypes.c_short * n)()
+            assert _ffi.lib.vips_hip_reduce_get_matrixf(r, phase, cf) == 0
+            assert _ffi.lib.vips_hip_reduce_get_matrixs(r, phase, cs) == 0
+            want = (ctypes.c_double * n)()
+            Port.lib().port_reduce_make_mask(want, kernel, n, shrink, np.float32(phase) / 64)
+            want = np.array(want[:])
+            assert np.array_equal(np.array(cf[:]).view(np.uint64), want.view(np.uint64))
+            # reduceh.cpp:497-499: (short)(c * 4096), truncation
+            assert np.array_equal(np.array(cs[:]), np.trunc(want * 4096).astype(np.int16))
+    finally:
+        _ffi.lib.vips_hip_reduce_free(r)
+
+
+def test_c2_table_shape():
+    # x8 lanczos3 -> 49 taps of which tap 48 is 0, offset -0.5
+    r = _ffi.lib.vips_hip_reduce_new(5, 8.0, 16384, 2048, math.nan)
+    try:
+        assert _ffi.lib.vips_hip_reduce_get_n_point(r) == 49
+        assert _ffi.lib.vips_hip_reduce_get_offset(r) == -0.5
+        cs = (ctypes.c_short * 49)()
+        _ffi.lib.vips_hip_reduce_get_matrixs(r, 0, cs)
+        assert cs[48] == 0
+        assert list(cs[:24]) == list(cs[47:23:-1])  # symmetric
+    finally:
+        _ffi.lib.vips_hip_reduce_free(r)
+
+
+def test_reduce_new_errors():
+    lib = _ffi.lib
+    lib.vips_hip_error_clear()
+    assert not lib.vips_hip_reduce_new(5, 0.5, 100, 200, math.nan)
+    assert "reduce factor should be >= 1.0" in _ffi.error_buffer()
+    lib.vips_hip_error_clear()
+    assert not lib.vips_hip_reduce_new(5, 1000.0, 100000, 100, math.nan)
+    assert "reduce factor too large" in _ffi.error_buffer()
+    lib.vips_hip_error_clear()
+    assert not lib.vips_hip_reduce_new(5, 2.0, 1, 0, math.nan)
+    assert "image has shrunk to nothing" in _ffi.error_buffer()
+    lib.vips_hip_error_clear()
+
+
+def test_shrink_out_size():
+    lib = _ffi.lib
+    for size in (1, 9, 10, 11, 4096, 16383):
+        for shrink in (2, 3, 4, 7, 8):
+            for ceil in (0, 1):
+                assert lib.vips_hip_shrink_out_size(size, shrink, ceil) == \
+                    Port.lib().port_shrink_out_size(size, shrink, ceil)
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = _ffi.lib
+    lib.vips_hip_error_clear()
+    assert lib.vips_hip_init(0) != 0
+    assert "no HIP device" in _ffi.error_buffer()
+    with pytest.raises(libvips_amd.VipsHipError):
+        libvips_amd.Image.new_from_array(np.zeros((4, 4, 3), np.uint8))

@@ -1,0 +1,196 @@
+"""GPU parity: HIP reduce/shrink through the C ABI vs the oracle.
+
+Checker order: committed golden vectors (from the compiled reference), the plain-C
+port on fresh seeded inputs, the compiled reference itself (oracle/_ref travels to
+the GPU box) at BASELINE sizes.  Integer formats bit-exact; float bitwise too (the
+device keeps the reference's double mul/add order), asserted as <= 1 ULP, the
+tolerance north_star states.
+"""
+import ctypes
+import math
+import os
+
+import numpy as np
+import pytest
+
+import libvips_amd
+from libvips_amd import Image, _ffi
+from tests import helpers
+from tests.golden import cases
+from tests.helpers import Port, Ref
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(helpers.GOLDEN, "resample.npz"))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    libvips_amd.init(0)
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, dtype=np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return np.abs(a - b).max()
+
+
+def assert_same(got, want, what=""):
+    assert got.shape == want.shape, what
+    assert got.dtype == want.dtype, what
+    if got.dtype.kind == "f" and got.dtype.itemsize == 4:
+        assert ulp_diff(got, want) <= 1, what  # tolerance: 1 ULP (north_star)
+    elif got.dtype.kind == "f":
+        np.testing.assert_allclose(got, want, rtol=2e-16, atol=0, err_msg=what)
+    else:
+        assert np.array_equal(got, want), what
+
+
+def hip_call(case, src):
+    fn, kw = case["call"]
+    return getattr(Image.new_from_array(src), fn)(**kw).numpy()
+
+
+@pytest.mark.parametrize("case", cases.RESAMPLE_CASES, ids=[c["name"] for c in cases.RESAMPLE_CASES])
+def test_hip_matches_golden(case):
+    src = helpers.lcg_image(case["width"], case["height"], case["bands"], case["dtype"], case["seed"])
+    assert_same(hip_call(case, src), GOLD[case["name"]], case["name"])
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.float32])
+@pytest.mark.parametrize("bands", [1, 2, 3, 4, 5])
+def test_reduce_formats_vs_port(dtype, bands):
+    src = helpers.lcg_image(157, 121, bands, dtype, 41)
+    im = Image.new_from_array(src)
+    for kernel, h, v in (("lanczos3", 2.3, 3.1), ("cubic", 1.1, 1.999), ("linear", 4.0, 2.0),
+                         ("mks2021", 1.5, 1.5), ("nearest", 2.0, 3.0)):
+        assert_same(im.reduce(h, v, kernel=kernel).numpy(), Port.reduce(src, h, v, kernel),
+                    "%s %s %s" % (kernel, h, v))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32,
+                                   np.float32, np.float64])
+def test_shrink_formats_vs_port(dtype):
+    for bands in (1, 3, 4):
+        src = helpers.lcg_image(203, 157, bands, dtype, 42)
+        im = Image.new_from_array(src)
+        for h, v, ceil in ((2, 2, False), (3, 5, True), (4, 4, False), (7, 9, True), (8, 1, False)):
+            assert_same(im.shrink(h, v, ceil=ceil).numpy(), Port.shrink(src, h, v, ceil),
+                        "%s %s %s" % (h, v, ceil))
+
+
+def test_reduce_ragged_and_tiny():
+    # edge cases: 1-pixel outputs, widths not a multiple of anything, heavy clamping
+    for (w, h, hs, vs) in ((1, 1, 1.0, 1.0), (3, 2, 2.0, 2.0), (17, 5, 16.9, 4.9), (1000, 3, 37.3, 1.2),
+                           (5, 700, 1.0, 49.5)):
+        src = helpers.lcg_image(w, h, 3, np.uint8, 43)
+        assert_same(Image.new_from_array(src).reduce(hs, vs).numpy(), Port.reduce(src, hs, vs),
+                    str((w, h, hs, vs)))
+
+
+def test_tile_seeding_matches_reference_tiles():
+    src = helpers.lcg_image(33, 1500, 1, np.uint8, 32)
+    got = Image.new_from_array(src).reducev(2.7182818).numpy()
+    assert_same(got, Port.reducev(src, 2.7182818, "lanczos3", tile=16))
+    if helpers.have_ref():
+        assert_same(got, Ref.run("reducev", src, "vshrink=2.7182818,kernel=lanczos3"))
+
+
+def test_region_generate_contract():
+    """Drive the region-level gens the way a libvips generate would: arbitrary output
+    rects, input windows that only just cover the needed rows/columns."""
+    lib = _ffi.lib
+    src = helpers.lcg_image(300, 260, 4, np.uint8, 44)
+    h, w, b = src.shape
+    vshrink = 3.3
+    oh = int(h / vshrink + 0.5)
+    want = Port.reducev(src, vshrink, "lanczos3", tile=0)  # seeded once at row 0
+    r = lib.vips_hip_reduce_new(5, vshrink, h, oh, math.nan)
+    assert r
+    full = Image.new_from_array(src)
+    try:
+        # (1) whole image, one seed
+        out = Image.new_from_array(np.zeros((oh, w, b), np.uint8))
+        ri, ro = full.region(), out.region()
+        _ffi.check(lib.vips_hip_reducev_gen(r, ctypes.byref(ri), ctypes.byref(ro)))
+        assert np.array_equal(out.numpy(), want)
+        # (2) a sub-rect, seeded at its own top: equals the port seeded the same way
+        top, height, left, width = 17, 23, 40, 100
+        t0, tn = ctypes.c_int(), ctypes.c_int()
+        lib.vips_hip_reducev_need(r, top, height, ctypes.byref(t0), ctypes.byref(tn))
+        win = np.ascontiguousarray(src[t0.value:t0.value + tn.value, left:left + width])
+        dwin = Image.new_from_array(win)
+        rin = dwin.region()
+        rin.left, rin.top, rin.im_width, rin.im_height = left, t0.value, w, h
+        dout = Image.new_from_array(np.zeros((height, width, b), np.uint8))
+        rout = dout.region()
+        rout.left, rout.top, rout.im_width, rout.im_height = left, top, w, oh
+        _ffi.check(lib.vips_hip_reducev_gen(r, ctypes.byref(rin), ctypes.byref(rout)))
+        # reference semantics: Y seeded at r->top (reducev.cpp:548)
+        ref_rows = Port.lib()
+        full_seeded = np.empty((oh, w, b), np.uint8)
+        # emulate: tile boundaries at `top` -> seed there: run port with tile = top, then
+        # rows [top, top+height) of a run whose strips start at multiples of `top`... simpler:
+        # exact-arithmetic check: seeded-at-top positions differ from seeded-at-0 only by fp
+        # rounding of repeated addition; compare against a port run on the shifted problem.
+        exp = Port.reducev(src, vshrink, "lanczos3", tile=top)[top:top + height, left:left + width]
+        # rows top..2*top-1 come from the strip seeded at `top`
+        n = min(height, top)
+        assert np.array_equal(dout.numpy()[:n], exp[:n])
+        # (3) a window that is too small is rejected loudly
+        rin.height -= 1
+        lib.vips_hip_error_clear()
+        assert lib.vips_hip_reducev_gen(r, ctypes.byref(rin), ctypes.byref(rout)) == -1
+        assert "input region too small" in _ffi.error_buffer()
+        lib.vips_hip_error_clear()
+    finally:
+        lib.vips_hip_reduce_free(r)
+
+
+def test_error_behaviour():
+    im = Image.new_from_array(helpers.lcg_image(20, 20, 3, np.uint8, 45))
+    with pytest.raises(libvips_amd.VipsHipError, match="reduce factor should be >= 1.0"):
+        im.reduceh(0.5)
+    with pytest.raises(libvips_amd.VipsHipError, match="shrink factors should be >= 1"):
+        im.shrinkh(0)
+    with pytest.raises(libvips_amd.VipsHipError, match="reduce gap should be >= 1.0"):
+        im.reducev(2.0, gap=0.5)
+    with pytest.raises(libvips_amd.VipsHipError, match="upsizing"):
+        im.resize(2.0)
+
+
+def test_c2_quarter_size_vs_reference_checksum():
+    # SURVEY.md 8(c) golden: 4096^2 x4 LCG -> 512^2, checksum 16793779256
+    src = helpers.lcg_image(4096, 4096, 4, np.uint8, 12345)
+    got = Image.new_from_array(src).reduce(8, 8, kernel="lanczos3").numpy()
+    assert got.shape == (512, 512, 4)
+    assert helpers.checksum(got) == 16793779256
+
+
+def test_c2_full_size():
+    """BASELINE config 2: 16384^2 RGBA -> 2048^2.  Bit-exact against the compiled
+    reference when it travelled with the snapshot, plus size-independent properties."""
+    import torch
+
+    n = 16384
+    src = helpers.lcg_image(n, n, 4, np.uint8, 12345)
+    t = torch.from_numpy(src).cuda()
+    got = Image.new_from_tensor(t).reduce(8, 8, kernel="lanczos3").numpy()
+    assert got.shape == (2048, 2048, 4)
+    # property: the top-left 512^2 block depends only on the top-left 4096+ pixels; the
+    # image rows of the LCG stream differ from the 4096^2 case, so check against a port
+    # run on a crop instead (interior rows only: away from the crop's clamped edges)
+    crop = np.ascontiguousarray(src[:1024, :1024])
+    want = Port.reduce(crop, 8, 8, "lanczos3")
+    assert np.array_equal(got[:120, :120], want[:120, :120])
+    # property: average preserved (test_resample.py:83-92)
+    assert abs(got.mean() - src[::64, ::64].mean()) < 2
+    if helpers.have_ref():
+        want_full = Ref.run("reduce", src, "hshrink=8,vshrink=8,kernel=lanczos3")
+        assert np.array_equal(got, want_full)
+    # constant image stays constant (test_resample.py:94-103), full size
+    t.fill_(201)
+    const = Image.new_from_tensor(t).reduce(8, 8, kernel="lanczos3").numpy()
+    assert const.min() == 201 and const.max() == 201
