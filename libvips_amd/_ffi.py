@@ -161,10 +161,21 @@ def error_buffer():
     return lib.vips_hip_error_buffer().decode("utf-8", "replace")
 
 
+def _raise(what):
+    message = error_buffer().strip() or what
+    lib.vips_hip_error_clear()
+    raise VipsHipError(message)
+
+
 def check(result, what="vips_hip"):
-    """Turn the C convention (non-zero / NULL + error buffer) into an exception."""
-    if result is None or (isinstance(result, int) and result != 0):
-        message = error_buffer().strip() or what
-        lib.vips_hip_error_clear()
-        raise VipsHipError(message)
+    """Turn the C convention (non-zero return + error buffer) into an exception."""
+    if result != 0:
+        _raise(what)
     return result
+
+
+def check_handle(handle, what="vips_hip"):
+    """NULL handle + error buffer -> exception."""
+    if not handle:
+        _raise(what)
+    return handle

@@ -7,6 +7,10 @@
 #include "resample.h"
 
 #include <cmath>
+#include <cstring>
+#include <list>
+#include <memory>
+#include <mutex>
 
 using namespace vh;
 
@@ -18,6 +22,52 @@ extern "C" void vips_hip_set_fatstrip_height(int lines)
 }
 
 namespace {
+
+// The operation cache (iofuncs/cache.c:990, vips_cache_max = 100): building a
+// reduce means 65 x n_point sin() evaluations and two table uploads, so built
+// operations are kept and shared, exactly as the reference caches built
+// VipsOperations.  Entries are handed out as shared_ptr so an eviction cannot
+// pull tables out from under a running call.
+struct ReduceKey {
+	int kernel, in_size, out_size;
+	double shrink, extra;
+	bool operator==(const ReduceKey &o) const
+	{
+		return kernel == o.kernel && in_size == o.in_size && out_size == o.out_size &&
+			memcmp(&shrink, &o.shrink, sizeof(double)) == 0 &&
+			memcmp(&extra, &o.extra, sizeof(double)) == 0;
+	}
+};
+
+typedef std::shared_ptr<VipsHipReduce> ReducePtr;
+
+std::mutex g_cache_mutex;
+std::list<std::pair<ReduceKey, ReducePtr>> g_cache; // most recently used first
+const size_t CACHE_MAX = 100;
+
+ReducePtr reduce_cached(int kernel, double shrink, int in_size, int out_size, double extra)
+{
+	if (std::isnan(extra))
+		extra = out_size * shrink - in_size;
+	ReduceKey key = { kernel, in_size, out_size, shrink, extra };
+	{
+		std::lock_guard<std::mutex> lock(g_cache_mutex);
+		for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
+			if (it->first == key) {
+				g_cache.splice(g_cache.begin(), g_cache, it);
+				return g_cache.front().second;
+			}
+	}
+	VipsHipReduce *raw = vips_hip_reduce_new(kernel, shrink, in_size, out_size, extra);
+	if (!raw)
+		return ReducePtr();
+	ReducePtr r(raw, vips_hip_reduce_free);
+	std::lock_guard<std::mutex> lock(g_cache_mutex);
+	g_cache.emplace_front(key, r);
+	while (g_cache.size() > CACHE_MAX)
+		g_cache.pop_back();
+	return r;
+}
 
 struct ImageRef {
 	VipsHipImage *im;
@@ -131,10 +181,11 @@ int reduce_axis(VipsHipImage *in, VipsHipImage **out, double shrink, int kernel,
 		error(domain, "image has shrunk to nothing");
 		return -1;
 	}
-	VipsHipReduce *r = vips_hip_reduce_new(kernel, residual,
-		vertical ? cur->height : cur->width, size, extra_pixels);
-	if (!r)
+	ReducePtr rp = reduce_cached(kernel, residual, vertical ? cur->height : cur->width, size,
+		extra_pixels);
+	if (!rp)
 		return -1;
+	VipsHipReduce *r = rp.get();
 	ImageRef o(vertical ? like(cur, cur->width, size) : like(cur, size, cur->height));
 	int result = -1;
 	if (o.im) {
@@ -147,7 +198,6 @@ int reduce_axis(VipsHipImage *in, VipsHipImage **out, double shrink, int kernel,
 		result = vertical ? vips_hip_reducev_gen_tiled(r, &ri, &ro, g_fatstrip_height)
 						  : vips_hip_reduceh_gen(r, &ri, &ro);
 	}
-	vips_hip_reduce_free(r);
 	if (result)
 		return -1;
 	*out = o.release();
@@ -188,9 +238,9 @@ int vips_hip_reduce(VipsHipImage *in, VipsHipImage **out, double hshrink, double
 		const int height = (int) ((double) in->height / vshrink + 0.5);
 		const int width = (int) ((double) in->width / hshrink + 0.5);
 		if (width > 0 && height > 0) {
-			VipsHipReduce *rv = vips_hip_reduce_new(kernel, vshrink, in->height, height, NAN);
-			VipsHipReduce *rh = rv ? vips_hip_reduce_new(kernel, hshrink, in->width, width, NAN)
-								   : nullptr;
+			ReducePtr rvp = reduce_cached(kernel, vshrink, in->height, height, NAN);
+			ReducePtr rhp = rvp ? reduce_cached(kernel, hshrink, in->width, width, NAN) : ReducePtr();
+			VipsHipReduce *rv = rvp.get(), *rh = rhp.get();
 			if (rv && rh) {
 				ImageRef o(like(in, width, height));
 				int result = -1;
@@ -200,8 +250,6 @@ int vips_hip_reduce(VipsHipImage *in, VipsHipImage **out, double hshrink, double
 					vips_hip_image_region(o.im, &ro);
 					result = vips_hip_reduce_gen_tiled(rv, rh, &ri, &ro, g_fatstrip_height);
 				}
-				vips_hip_reduce_free(rv);
-				vips_hip_reduce_free(rh);
 				if (result < 0)
 					return -1;
 				if (result == 0) {
@@ -210,11 +258,8 @@ int vips_hip_reduce(VipsHipImage *in, VipsHipImage **out, double hshrink, double
 				}
 				// result > 0: geometry not covered by the fused kernel
 			}
-			else {
-				vips_hip_reduce_free(rv);
-				vips_hip_reduce_free(rh);
+			else
 				return -1;
-			}
 		}
 	}
 

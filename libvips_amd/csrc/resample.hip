@@ -157,21 +157,22 @@ reducev_general(RegionArgs in, RegionArgs out, int ne, int epp /* elements per p
 {
 	typedef typename ReduceTraits<T>::acc_t ACC;
 	const int e = blockIdx.x * blockDim.x + threadIdx.x;
-	const int y = blockIdx.y;
 	if (e >= ne)
 		return;
-	const ReducePos p = pos[y];
-	const typename ReduceTraits<T>::coef_t *c = table + (size_t) p.phase * n_point;
 	// out.left is also the column in the input (reducev.cpp:536)
 	const long long col = (long long) (out.left - in.left) * epp + e;
-	ACC sum = 0;
-	for (int i = 0; i < n_point; i++) {
-		const int row = clampi(p.first + i, 0, in.im_height - 1) - in.top;
-		const T *src = (const T *) (in.data + row * in.stride);
-		sum = mac<ACC>(sum, c[i], src[col]);
+	for (int y = blockIdx.y; y < out.height; y += gridDim.y) {
+		const ReducePos p = pos[y];
+		const typename ReduceTraits<T>::coef_t *c = table + (size_t) p.phase * n_point;
+		ACC sum = 0;
+		for (int i = 0; i < n_point; i++) {
+			const int row = clampi(p.first + i, 0, in.im_height - 1) - in.top;
+			const T *src = (const T *) (in.data + row * in.stride);
+			sum = mac<ACC>(sum, c[i], src[col]);
+		}
+		T *dst = (T *) (out.data + (long long) y * out.stride);
+		dst[e] = ReduceTraits<T>::fin(sum);
 	}
-	T *dst = (T *) (out.data + (long long) y * out.stride);
-	dst[e] = ReduceTraits<T>::fin(sum);
 }
 
 // One thread per output element (x, band).
@@ -183,22 +184,23 @@ reduceh_general(RegionArgs in, RegionArgs out, int epp, int n_point,
 {
 	typedef typename ReduceTraits<T>::acc_t ACC;
 	const int e = blockIdx.x * blockDim.x + threadIdx.x;
-	const int y = blockIdx.y;
 	if (e >= out.width * epp)
 		return;
 	const int x = e / epp;
 	const int b = e - x * epp;
 	const ReducePos p = pos[x];
 	const typename ReduceTraits<T>::coef_t *c = table + (size_t) p.phase * n_point;
-	// same row of the input (reduceh.cpp:238)
-	const T *src = (const T *) (in.data + (long long) (out.top + y - in.top) * in.stride);
-	ACC sum = 0;
-	for (int i = 0; i < n_point; i++) {
-		const int colx = clampi(p.first + i, 0, in.im_width - 1) - in.left;
-		sum = mac<ACC>(sum, c[i], src[(long long) colx * epp + b]);
+	for (int y = blockIdx.y; y < out.height; y += gridDim.y) {
+		// same row of the input (reduceh.cpp:238)
+		const T *src = (const T *) (in.data + (long long) (out.top + y - in.top) * in.stride);
+		ACC sum = 0;
+		for (int i = 0; i < n_point; i++) {
+			const int colx = clampi(p.first + i, 0, in.im_width - 1) - in.left;
+			sum = mac<ACC>(sum, c[i], src[(long long) colx * epp + b]);
+		}
+		T *dst = (T *) (out.data + (long long) y * out.stride);
+		dst[e] = ReduceTraits<T>::fin(sum);
 	}
-	T *dst = (T *) (out.data + (long long) y * out.stride);
-	dst[e] = ReduceTraits<T>::fin(sum);
 }
 
 template <typename T>
@@ -208,7 +210,7 @@ static int launch_reducev(const _VipsHipReduce *r, const VipsHipRegion *in,
 	const int epp = region_elems_per_pel(out);
 	const int ne = out->width * epp;
 	dim3 block(256, 1, 1);
-	dim3 grid((ne + 255) / 256, out->height, 1);
+	dim3 grid((ne + 255) / 256, out->height < 32768 ? out->height : 32768, 1);
 	Gate gate("reducev_general");
 	hipLaunchKernelGGL(reducev_general<T>, grid, block, 0, stream(),
 		region_args(in), region_args(out), ne, epp, r->n_point, pos,
@@ -224,7 +226,7 @@ static int launch_reduceh(const _VipsHipReduce *r, const VipsHipRegion *in,
 	const int epp = region_elems_per_pel(out);
 	const int ne = out->width * epp;
 	dim3 block(256, 1, 1);
-	dim3 grid((ne + 255) / 256, out->height, 1);
+	dim3 grid((ne + 255) / 256, out->height < 32768 ? out->height : 32768, 1);
 	Gate gate("reduceh_general");
 	hipLaunchKernelGGL(reduceh_general<T>, grid, block, 0, stream(),
 		region_args(in), region_args(out), epp, r->n_point, pos,
@@ -466,20 +468,21 @@ shrinkh_general(RegionArgs in, RegionArgs out, int epp, int hshrink, unsigned in
 {
 	typedef typename ShrinkTraits<T>::acc_t ACC;
 	const int e = blockIdx.x * blockDim.x + threadIdx.x;
-	const int y = blockIdx.y;
 	if (e >= out.width * epp)
 		return;
 	const int x = e / epp;
 	const int b = e - x * epp;
-	const T *src = (const T *) (in.data + (long long) (out.top + y - in.top) * in.stride);
 	const int x0 = (out.left + x) * hshrink;
-	ACC sum = shrink_seed<T>(hshrink / 2);
-	for (int i = 0; i < hshrink; i++) {
-		const int colx = min(x0 + i, in.im_width - 1) - in.left;
-		sum = shrink_add<ACC, T>(sum, src[(long long) colx * epp + b]);
+	for (int y = blockIdx.y; y < out.height; y += gridDim.y) {
+		const T *src = (const T *) (in.data + (long long) (out.top + y - in.top) * in.stride);
+		ACC sum = shrink_seed<T>(hshrink / 2);
+		for (int i = 0; i < hshrink; i++) {
+			const int colx = min(x0 + i, in.im_width - 1) - in.left;
+			sum = shrink_add<ACC, T>(sum, src[(long long) colx * epp + b]);
+		}
+		T *dst = (T *) (out.data + (long long) y * out.stride);
+		dst[e] = ShrinkTraits<T>::fin(sum, hshrink, mult8, mult16, inv);
 	}
-	T *dst = (T *) (out.data + (long long) y * out.stride);
-	dst[e] = ShrinkTraits<T>::fin(sum, hshrink, mult8, mult16, inv);
 }
 
 template <typename T>
@@ -489,21 +492,22 @@ shrinkv_general(RegionArgs in, RegionArgs out, int ne, int epp, int vshrink, uns
 {
 	typedef typename ShrinkTraits<T>::acc_t ACC;
 	const int e = blockIdx.x * blockDim.x + threadIdx.x;
-	const int y = blockIdx.y;
 	if (e >= ne)
 		return;
 	const long long col = (long long) (out.left - in.left) * epp + e;
-	const int y0 = (out.top + y) * vshrink;
-	// shrinkv.c:170: sums start at 0 and `amend` is added at write time
-	// (:218-257); for the integer formats that is the same number.
-	ACC sum = shrink_seed<T>(vshrink / 2);
-	for (int i = 0; i < vshrink; i++) {
-		const int row = min(y0 + i, in.im_height - 1) - in.top;
-		const T *src = (const T *) (in.data + row * in.stride);
-		sum = shrink_add<ACC, T>(sum, src[col]);
+	for (int y = blockIdx.y; y < out.height; y += gridDim.y) {
+		const int y0 = (out.top + y) * vshrink;
+		// shrinkv.c:170: sums start at 0 and `amend` is added at write time
+		// (:218-257); for the integer formats that is the same number.
+		ACC sum = shrink_seed<T>(vshrink / 2);
+		for (int i = 0; i < vshrink; i++) {
+			const int row = min(y0 + i, in.im_height - 1) - in.top;
+			const T *src = (const T *) (in.data + row * in.stride);
+			sum = shrink_add<ACC, T>(sum, src[col]);
+		}
+		T *dst = (T *) (out.data + (long long) y * out.stride);
+		dst[e] = ShrinkTraits<T>::fin(sum, vshrink, mult8, mult16, inv);
 	}
-	T *dst = (T *) (out.data + (long long) y * out.stride);
-	dst[e] = ShrinkTraits<T>::fin(sum, vshrink, mult8, mult16, inv);
 }
 
 template <typename T>
@@ -514,7 +518,7 @@ static int launch_shrinkh(int hshrink, const VipsHipRegion *in, const VipsHipReg
 	const unsigned int mult8 = (unsigned int) ((1LL << 32) / ((1 << 8) * (long long) hshrink));
 	const unsigned long long mult16 = ((1ULL << 32) + hshrink - 1) / hshrink;
 	dim3 block(256, 1, 1);
-	dim3 grid((ne + 255) / 256, out->height, 1);
+	dim3 grid((ne + 255) / 256, out->height < 32768 ? out->height : 32768, 1);
 	Gate gate("shrinkh_general");
 	hipLaunchKernelGGL(shrinkh_general<T>, grid, block, 0, stream(), region_args(in),
 		region_args(out), epp, hshrink, mult8, mult16, 1.0 / hshrink);
@@ -530,7 +534,7 @@ static int launch_shrinkv(int vshrink, const VipsHipRegion *in, const VipsHipReg
 	const unsigned int mult8 = (unsigned int) ((1LL << 32) / ((1 << 8) * (long long) vshrink));
 	const unsigned long long mult16 = ((1ULL << 32) + vshrink - 1) / vshrink;
 	dim3 block(256, 1, 1);
-	dim3 grid((ne + 255) / 256, out->height, 1);
+	dim3 grid((ne + 255) / 256, out->height < 32768 ? out->height : 32768, 1);
 	Gate gate("shrinkv_general");
 	hipLaunchKernelGGL(shrinkv_general<T>, grid, block, 0, stream(), region_args(in),
 		region_args(out), ne, epp, vshrink, mult8, mult16, 1.0 / vshrink);

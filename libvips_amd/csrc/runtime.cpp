@@ -171,8 +171,13 @@ void *upload(const void *host, size_t size)
 	void *d = g_pool.alloc(size);
 	if (!d)
 		return nullptr;
-	// Tables are tiny; a synchronous copy keeps their lifetime simple.
-	if (hipMemcpy(d, host, size, hipMemcpyHostToDevice) != hipSuccess) {
+	// Stream-ordered: the block may have been released to the pool by a plan
+	// whose last kernel is still in flight on this stream, so the copy must
+	// queue behind it.  The wait keeps the (pageable) host source alive; uploads
+	// only happen when an operation is first built, never in steady state.
+	hipStream_t s = stream();
+	if (hipMemcpyAsync(d, host, size, hipMemcpyHostToDevice, s) != hipSuccess ||
+		hipStreamSynchronize(s) != hipSuccess) {
 		error("vips_hip", "table upload failed");
 		g_pool.release(d);
 		return nullptr;

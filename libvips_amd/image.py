@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 
 from . import _ffi
-from ._ffi import lib, check
+from ._ffi import lib, check, check_handle
 
 # VipsBandFormat (include/vips/image.h:120-133)
 FORMATS = {
@@ -89,8 +89,7 @@ class Image(object):
     """A device-resident image (VipsHipImage)."""
 
     def __init__(self, handle, keepalive=None):
-        if not handle:
-            check(None, "image")
+        check_handle(handle, "image")
         self._h = ctypes.c_void_p(handle)
         self._keepalive = keepalive
 
@@ -114,7 +113,7 @@ class Image(object):
         handle = lib.vips_hip_image_new_from_memory(
             a.ctypes.data, w, h, b, fmt, _enum(INTERPRETATIONS, interpretation, "interpretation")
         )
-        return cls(check(handle))
+        return cls(check_handle(handle))
 
     @classmethod
     def new_from_tensor(cls, tensor, interpretation="multiband"):
@@ -130,7 +129,7 @@ class Image(object):
         handle = lib.vips_hip_image_new_from_device(
             t.data_ptr(), w, h, b, fmt, _enum(INTERPRETATIONS, interpretation, "interpretation")
         )
-        return cls(check(handle), keepalive=tensor)
+        return cls(check_handle(handle), keepalive=tensor)
 
     @classmethod
     def new_from_device(cls, ptr, width, height, bands, format, interpretation="multiband", keepalive=None):
@@ -138,7 +137,7 @@ class Image(object):
             ptr, width, height, bands, _enum(FORMATS, format, "format"),
             _enum(INTERPRETATIONS, interpretation, "interpretation"),
         )
-        return cls(check(handle), keepalive=keepalive)
+        return cls(check_handle(handle), keepalive=keepalive)
 
     # ---------------------------------------------------------- properties
     @property

@@ -128,13 +128,8 @@ def test_region_generate_contract():
         rout = dout.region()
         rout.left, rout.top, rout.im_width, rout.im_height = left, top, w, oh
         _ffi.check(lib.vips_hip_reducev_gen(r, ctypes.byref(rin), ctypes.byref(rout)))
-        # reference semantics: Y seeded at r->top (reducev.cpp:548)
-        ref_rows = Port.lib()
-        full_seeded = np.empty((oh, w, b), np.uint8)
-        # emulate: tile boundaries at `top` -> seed there: run port with tile = top, then
-        # rows [top, top+height) of a run whose strips start at multiples of `top`... simpler:
-        # exact-arithmetic check: seeded-at-top positions differ from seeded-at-0 only by fp
-        # rounding of repeated addition; compare against a port run on the shifted problem.
+        # reference semantics: Y is seeded at r->top (reducev.cpp:548).  A port run whose
+        # strips are `top` rows high seeds its second strip at exactly that row.
         exp = Port.reducev(src, vshrink, "lanczos3", tile=top)[top:top + height, left:left + width]
         # rows top..2*top-1 come from the strip seeded at `top`
         n = min(height, top)
