@@ -34,6 +34,13 @@ class Region(ctypes.Structure):
 
 
 def _load():
+    # PyTorch-ROCm carries its own HIP runtime (soname libamdhip64.so).  Import it first so
+    # libvipship.so, which needs that soname, binds to the SAME runtime: device pointers,
+    # streams and events can then be shared with torch, and there is one runtime at exit.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "

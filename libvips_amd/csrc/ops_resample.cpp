@@ -41,8 +41,10 @@ struct ReduceKey {
 
 typedef std::shared_ptr<VipsHipReduce> ReducePtr;
 
-std::mutex g_cache_mutex;
-std::list<std::pair<ReduceKey, ReducePtr>> g_cache; // most recently used first
+// leaked on purpose (no device frees from static destructors at exit)
+std::mutex &g_cache_mutex = *new std::mutex;
+std::list<std::pair<ReduceKey, ReducePtr>> &g_cache =
+	*new std::list<std::pair<ReduceKey, ReducePtr>>; // most recently used first
 const size_t CACHE_MAX = 100;
 
 ReducePtr reduce_cached(int kernel, double shrink, int in_size, int out_size, double extra)

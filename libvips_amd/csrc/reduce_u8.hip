@@ -1,7 +1,280 @@
-// uchar fast paths -- see reduce_u8.h.  (first cut: general kernels only)
+// uchar fast paths for gfx950 -- see reduce_u8.h.
+//
+// reduce_fused_u8x4<S, D>: vips_reduce() on uchar RGBA with an even integer
+// shrink S on both axes and a constant coefficient phase (input size a
+// multiple of S gives phase 0: SURVEY.md appendix "C2 phase arithmetic").
+// One launch does reducev (reducev.cpp:418-459) AND reduceh
+// (reduceh.cpp:269-328); the vertically reduced scanlines live only in LDS.
+//
+//   workgroup = 256 threads = one output tile (OWT x OHT pixels)
+//   thread t  = input columns col0 + 2t, col0 + 2t + 1 (8 contiguous bytes per
+//               row: a wave reads 512 contiguous bytes per scanline)
+//   vertical  : the thread walks down the tile's input rows in groups of S.
+//               Row S*g + i is tap k = S*d + i of output row g - d, d < D, so D
+//               accumulator sets are live and one output row completes per
+//               group -- every input byte is loaded from HBM once per tile and
+//               used D times from registers.  Rows are paired so one
+//               v_dot2_i32_i16 does two taps: v_perm_b32 builds (row r, row r+1)
+//               i16 pairs of one channel, the coefficient pair is a scalar.
+//   LDS       : a finished row is stored as u16 pairs, planar per channel
+//               (plane[row][channel][column]); after R rows a barrier, then
+//   horizontal: every thread takes output pixels of the R x OWT strip; its 4
+//               channels are D*S/2 dot2 over consecutive LDS dwords
+//               (ds_read_b128, 16-byte aligned for S = 8, conflict-free across
+//               a wave), rounds, packs RGBA and stores one dword.
+//
+// Integer arithmetic is exact, so the i32 sums equal the reference's whatever
+// the summation order; rounding/clipping is templates.h:152-157.
 #include "reduce_u8.h"
 
 namespace vh {
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+static __device__ __forceinline__ int dot2(unsigned int pix, unsigned int coef, int acc)
+{
+	return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, pix),
+		__builtin_bit_cast(short2v, coef), acc, false);
+}
+
+// (sum + 2048) >> 12, clipped to 0..255 (templates.h:152-157).
+//
+// The empty asm keeps the shift and the clamp apart on purpose: when hipcc
+// (ROCm 7.2) sees shift+clamp of two values being packed into bytes it selects
+// gfx950's v_ashr_pk_u8_i32 and then treats bits 31:16 of the result as zero,
+// but the hardware leaves the old register contents there -- OR-ing a third
+// channel in at bit 16 picked up garbage (found as +1..+9 errors in the blue
+// channel only, see DESIGN.md "toolchain findings").
+static __device__ __forceinline__ int fin_u8(int s)
+{
+	s = (s + (INTERPOLATE_SCALE >> 1)) >> INTERPOLATE_SHIFT;
+	asm volatile("" : "+v"(s));
+	return min(max(s, 0), 255);
+}
+
+constexpr int FUSED_THREADS = 256;
+constexpr int FUSED_SPAN = 2 * FUSED_THREADS; // input columns per tile
+constexpr int FUSED_R = 8;                    // T rows buffered in LDS per H pass
+
+struct FusedArgs {
+	const unsigned char *in;
+	long long in_stride;
+	int in_left, in_top;   // origin of the input window
+	int im_width, im_height;
+	unsigned char *out;
+	long long out_stride;
+	int out_width, out_height; // region being generated
+	int fx0, fy0;              // first tap (un-embedded input coords) of output (0, 0) of the region
+	int owt, oht;              // tile size in output pixels
+	int tiles_x;
+	int aligned8;           // input base and stride are multiples of 8 bytes
+	const unsigned int *cv; // D*S/2 packed coefficient pairs (lo = even tap)
+	const unsigned int *ch;
+};
+
+template <int S, int D>
+__global__ void __launch_bounds__(FUSED_THREADS)
+reduce_fused_u8x4(FusedArgs a)
+{
+	constexpr int NP = S * D / 2; // coefficient pairs
+	constexpr int PLANE = FUSED_SPAN / 2; // dwords per (row, channel) plane
+	__shared__ __attribute__((aligned(16))) unsigned int lds[FUSED_R * 4 * PLANE];
+
+	const int t = threadIdx.x;
+	const int bx = blockIdx.x % a.tiles_x;
+	const int by = blockIdx.x / a.tiles_x;
+	const int x0 = bx * a.owt;
+	const int y0 = by * a.oht;
+	const int ow = min(a.owt, a.out_width - x0);
+	const int oh = min(a.oht, a.out_height - y0);
+
+	// this thread's two input columns, clamped to the image (vips_embed COPY)
+	const int tile_col0 = a.fx0 + S * x0;
+	const int col0 = tile_col0 + 2 * t;
+	const int ca = min(max(col0, 0), a.im_width - 1) - a.in_left;
+	const int cb = min(max(col0 + 1, 0), a.im_width - 1) - a.in_left;
+	// block-uniform: no column of this tile touches the left/right edge, so every
+	// thread reads 8 aligned contiguous bytes per row
+	const bool interior = a.aligned8 && tile_col0 >= 0 && tile_col0 + FUSED_SPAN <= a.im_width &&
+		(((tile_col0 - a.in_left) & 1) == 0);
+	const int row0 = a.fy0 + S * y0;
+
+	// scalar coefficient pairs (uniform loads -> SGPRs)
+	unsigned int cv[NP], chp[NP];
+#pragma unroll
+	for (int i = 0; i < NP; i++) {
+		cv[i] = a.cv[i];
+		chp[i] = a.ch[i];
+	}
+
+	int acc[D][8];
+#pragma unroll
+	for (int d = 0; d < D; d++)
+#pragma unroll
+		for (int c = 0; c < 8; c++)
+			acc[d][c] = 0;
+
+	const int ngroups = oh + D - 1;
+	for (int g = 0; g < ngroups; g++) {
+		// ---- load the S rows of this group
+		uint2 px[S];
+		if (interior) {
+#pragma unroll
+			for (int i = 0; i < S; i++) {
+				const int row = min(max(row0 + S * g + i, 0), a.im_height - 1) - a.in_top;
+				px[i] = *reinterpret_cast<const uint2 *>(a.in + row * a.in_stride + 4 * ca);
+			}
+		}
+		else {
+#pragma unroll
+			for (int i = 0; i < S; i++) {
+				const int row = min(max(row0 + S * g + i, 0), a.im_height - 1) - a.in_top;
+				const unsigned char *line = a.in + row * a.in_stride;
+				px[i].x = *reinterpret_cast<const unsigned int *>(line + 4 * ca);
+				px[i].y = *reinterpret_cast<const unsigned int *>(line + 4 * cb);
+			}
+		}
+
+		// ---- vertical taps: row pair (i, i+1) feeds accumulator d with pair d*S/2 + i/2
+#pragma unroll
+		for (int i = 0; i < S; i += 2) {
+#pragma unroll
+			for (int p = 0; p < 2; p++) {
+				const unsigned int ra = p ? px[i].y : px[i].x;
+				const unsigned int rb = p ? px[i + 1].y : px[i + 1].x;
+#pragma unroll
+				for (int c = 0; c < 4; c++) {
+					// bytes: [ra.c, 0, rb.c, 0]
+					const unsigned int pair =
+						__builtin_amdgcn_perm(rb, ra, 0x0c000c00u | (unsigned) c | ((4u + c) << 16));
+#pragma unroll
+					for (int d = 0; d < D; d++)
+						acc[d][p * 4 + c] = dot2(pair, cv[d * (S / 2) + i / 2], acc[d][p * 4 + c]);
+				}
+			}
+		}
+
+		// ---- output row j = g - (D - 1) is complete: round, park in LDS
+		const int j = g - (D - 1);
+		if (j >= 0) {
+			const int slot = j % FUSED_R;
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				const unsigned int v = (unsigned) fin_u8(acc[D - 1][c]) |
+					((unsigned) fin_u8(acc[D - 1][4 + c]) << 16);
+				lds[(slot * 4 + c) * PLANE + t] = v;
+			}
+		}
+		// rotate the accumulator sets
+#pragma unroll
+		for (int d = D - 1; d > 0; d--)
+#pragma unroll
+			for (int c = 0; c < 8; c++)
+				acc[d][c] = acc[d - 1][c];
+#pragma unroll
+		for (int c = 0; c < 8; c++)
+			acc[0][c] = 0;
+
+		// ---- horizontal pass over the buffered rows
+		if (j >= 0 && ((j % FUSED_R) == FUSED_R - 1 || j == oh - 1)) {
+			__syncthreads();
+			const int jbase = j - (j % FUSED_R);
+			const int nrows = j - jbase + 1;
+			const int items = nrows * ow;
+			for (int it = t; it < items; it += FUSED_THREADS) {
+				const int rr = it / ow;
+				const int xo = it - rr * ow;
+				unsigned int rgba = 0;
+#pragma unroll
+				for (int c = 0; c < 4; c++) {
+					const unsigned int *src = &lds[(rr * 4 + c) * PLANE + xo * (S / 2)];
+					int sum = 0;
+					if (S % 8 == 0) {
+#pragma unroll
+						for (int q = 0; q < NP; q += 4) {
+							const uint4 v = *reinterpret_cast<const uint4 *>(src + q);
+							sum = dot2(v.x, chp[q], sum);
+							sum = dot2(v.y, chp[q + 1], sum);
+							sum = dot2(v.z, chp[q + 2], sum);
+							sum = dot2(v.w, chp[q + 3], sum);
+						}
+					}
+					else if (S % 4 == 0) {
+#pragma unroll
+						for (int q = 0; q < NP; q += 2) {
+							const uint2 v = *reinterpret_cast<const uint2 *>(src + q);
+							sum = dot2(v.x, chp[q], sum);
+							sum = dot2(v.y, chp[q + 1], sum);
+						}
+					}
+					else {
+#pragma unroll
+						for (int q = 0; q < NP; q++)
+							sum = dot2(src[q], chp[q], sum);
+					}
+					rgba |= (unsigned) fin_u8(sum) << (8 * c);
+				}
+				unsigned int *dst = reinterpret_cast<unsigned int *>(
+					a.out + (long long) (y0 + jbase + rr) * a.out_stride);
+				dst[x0 + xo] = rgba;
+			}
+			__syncthreads();
+		}
+	}
+}
+
+// Is pos[] an arithmetic progression first0 + S*k with one phase?  (What an
+// integer shrink of a size-divisible image produces.)
+static bool positions_regular(const std::vector<ReducePos> &pos, int *first0, int *step, int *phase)
+{
+	if (pos.empty())
+		return false;
+	*first0 = pos[0].first;
+	*phase = pos[0].phase;
+	*step = pos.size() > 1 ? pos[1].first - pos[0].first : 0;
+	for (size_t k = 0; k < pos.size(); k++)
+		if (pos[k].first != *first0 + (int) k * *step || pos[k].phase != *phase)
+			return false;
+	return true;
+}
+
+// Pack taps [0, n) of matrixs row `phase`, zero-padded to `total`, as i16 pairs.
+static void pack_pairs(const _VipsHipReduce *r, int phase, int total, std::vector<unsigned int> &out)
+{
+	const short *c = &r->matrixs[(size_t) phase * r->n_point];
+	out.resize(total / 2);
+	for (int q = 0; q < total / 2; q++) {
+		const int k0 = 2 * q, k1 = 2 * q + 1;
+		const unsigned short lo = k0 < r->n_point ? (unsigned short) c[k0] : 0;
+		const unsigned short hi = k1 < r->n_point ? (unsigned short) c[k1] : 0;
+		out[q] = (unsigned int) lo | ((unsigned int) hi << 16);
+	}
+}
+
+// number of leading taps that matter: trailing zero coefficients are dropped
+static int effective_taps(const _VipsHipReduce *r, int phase)
+{
+	const short *c = &r->matrixs[(size_t) phase * r->n_point];
+	int n = r->n_point;
+	while (n > 1 && c[n - 1] == 0)
+		n--;
+	return n;
+}
+
+struct FusedPlan {
+	unsigned int *d_cv;
+	unsigned int *d_ch;
+	int fx0, fy0, step, d;
+};
+
+template <int S, int D>
+static int launch_fused(const FusedArgs &args, int tiles)
+{
+	Gate gate("reduce_fused_u8");
+	hipLaunchKernelGGL((reduce_fused_u8x4<S, D>), dim3(tiles), dim3(FUSED_THREADS), 0, stream(), args);
+	VH_CHECK(hipGetLastError());
+	return 0;
+}
 
 int reducev_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out,
 	const ReducePos *pos, const short *table)
@@ -27,11 +300,150 @@ int shrinkh_u8_try(int hshrink, const VipsHipRegion *in, const VipsHipRegion *ou
 
 } // namespace vh
 
+using namespace vh;
+
 extern "C" {
 
 int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce *reduceh,
 	const VipsHipRegion *in, const VipsHipRegion *out, int tile)
 {
+	const char *domain = "reduce";
+	if (ensure_init())
+		return -1;
+	if (!reducev || !reduceh) {
+		error(domain, "null reduce");
+		return -1;
+	}
+	if (check_region(domain, in) || check_region(domain, out))
+		return -1;
+	if (in->format != VIPS_HIP_FORMAT_UCHAR || out->format != VIPS_HIP_FORMAT_UCHAR ||
+		in->bands != 4 || out->bands != 4)
+		return 1;
+	if (in->im_height != reducev->in_size || out->im_height != reducev->out_size ||
+		in->im_width != reduceh->in_size || out->im_width != reduceh->out_size) {
+		error(domain, "region does not belong to an image of the size these reduces were built for");
+		return -1;
+	}
+	if (((uintptr_t) in->data & 3) || (in->stride & 3) || ((uintptr_t) out->data & 3) ||
+		(out->stride & 3))
+		return 1;
+
+	// Geometry: both axes must step by the same even integer with one phase.
+	std::vector<ReducePos> pv, ph;
+	reduce_positions(reducev, out->top, out->height, tile, pv);
+	reduce_positions(reduceh, out->left, out->width, 0, ph);
+	int fy0, sy, phase_y, fx0, sx, phase_x;
+	if (!positions_regular(pv, &fy0, &sy, &phase_y) || !positions_regular(ph, &fx0, &sx, &phase_x))
+		return 1;
+	if (out->height == 1)
+		sy = sx;
+	if (out->width == 1)
+		sx = sy;
+	if (sx != sy || sx < 2 || (sx & 1))
+		return 1;
+	const int S = sx;
+	const int nv = effective_taps(reducev, phase_y);
+	const int nh = effective_taps(reduceh, phase_x);
+	const int nmax = nv > nh ? nv : nh;
+	const int D = (nmax + S - 1) / S;
+	if (!((S == 8 && (D == 6 || D == 7)) || (S == 4 && (D == 6 || D == 7)) ||
+			(S == 2 && (D == 6 || D == 7))))
+		return 1;
+
+	// the input window must cover what the two gens need
+	int need0, needn;
+	vips_hip_reducev_need(reducev, out->top, out->height, &need0, &needn);
+	if (need0 < in->top || need0 + needn > in->top + in->height) {
+		error(domain, "input region too small: need rows %d..%d", need0, need0 + needn);
+		return -1;
+	}
+	vips_hip_reduceh_need(reduceh, out->left, out->width, &need0, &needn);
+	if (need0 < in->left || need0 + needn > in->left + in->width) {
+		error(domain, "input region too small: need columns %d..%d", need0, need0 + needn);
+		return -1;
+	}
+
+	// packed coefficient pairs, cached on the vertical reduce object keyed by phases
+	_VipsHipReduce *rv = const_cast<_VipsHipReduce *>(reducev);
+	_VipsHipReduce *rh = const_cast<_VipsHipReduce *>(reduceh);
+	const unsigned int *d_cv, *d_ch;
+	{
+		std::vector<unsigned int> pairs;
+		std::lock_guard<std::mutex> lock(rv->mutex);
+		auto key = std::make_tuple(-1, phase_y, S * D);
+		auto it = rv->pos_cache.find(key);
+		if (it == rv->pos_cache.end()) {
+			pack_pairs(rv, phase_y, S * D, pairs);
+			void *d = upload(pairs.data(), pairs.size() * sizeof(unsigned int));
+			if (!d)
+				return -1;
+			rv->pos_cache[key] = (ReducePos *) d;
+			d_cv = (const unsigned int *) d;
+		}
+		else
+			d_cv = (const unsigned int *) it->second;
+	}
+	{
+		std::vector<unsigned int> pairs;
+		std::lock_guard<std::mutex> lock(rh->mutex);
+		auto key = std::make_tuple(-1, phase_x, S * D);
+		auto it = rh->pos_cache.find(key);
+		if (it == rh->pos_cache.end()) {
+			pack_pairs(rh, phase_x, S * D, pairs);
+			void *d = upload(pairs.data(), pairs.size() * sizeof(unsigned int));
+			if (!d)
+				return -1;
+			rh->pos_cache[key] = (ReducePos *) d;
+			d_ch = (const unsigned int *) d;
+		}
+		else
+			d_ch = (const unsigned int *) it->second;
+	}
+
+	FusedArgs args;
+	args.in = (const unsigned char *) in->data;
+	args.in_stride = (long long) in->stride;
+	args.in_left = in->left;
+	args.in_top = in->top;
+	args.im_width = in->im_width;
+	args.im_height = in->im_height;
+	args.out = (unsigned char *) out->data;
+	args.out_stride = (long long) out->stride;
+	args.out_width = out->width;
+	args.out_height = out->height;
+	args.aligned8 = !(((uintptr_t) in->data & 7) || (in->stride & 7));
+	args.fx0 = fx0;
+	args.fy0 = fy0;
+	args.owt = FUSED_SPAN / S - D + 1;
+	args.tiles_x = (out->width + args.owt - 1) / args.owt;
+	// Tile height: tall tiles amortise the (D-1)*S-row vertical halo, but all
+	// workgroups should be resident at once (256 CUs x 4 blocks at ~108 VGPRs),
+	// so pick the shortest tile that keeps the grid within one residency wave.
+	{
+		const int capacity = 256 * 4;
+		int rows_of_tiles = capacity / args.tiles_x;
+		if (rows_of_tiles < 1)
+			rows_of_tiles = 1;
+		int oht = (out->height + rows_of_tiles - 1) / rows_of_tiles;
+		if (oht < 32)
+			oht = 32;
+		args.oht = oht;
+	}
+	args.cv = d_cv;
+	args.ch = d_ch;
+	const int tiles_y = (out->height + args.oht - 1) / args.oht;
+	const int tiles = args.tiles_x * tiles_y;
+
+#define FUSED_CASE(SS, DD) \
+	if (S == SS && D == DD) \
+		return launch_fused<SS, DD>(args, tiles);
+	FUSED_CASE(8, 6)
+	FUSED_CASE(8, 7)
+	FUSED_CASE(4, 6)
+	FUSED_CASE(4, 7)
+	FUSED_CASE(2, 6)
+	FUSED_CASE(2, 7)
+#undef FUSED_CASE
 	return 1;
 }
 

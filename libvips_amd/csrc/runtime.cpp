@@ -164,7 +164,9 @@ struct Pool {
 	}
 };
 
-static Pool g_pool;
+// Leaked on purpose: other translation units release blocks from their own static
+// destructors, and static destruction order across units is unspecified.
+static Pool &g_pool = *new Pool;
 
 void *upload(const void *host, size_t size)
 {
@@ -191,8 +193,8 @@ struct GateRecord {
 	hipEvent_t start, stop;
 };
 static bool g_gate_enabled = false;
-static std::mutex g_gate_mutex;
-static std::vector<GateRecord> g_gate_records;
+static std::mutex &g_gate_mutex = *new std::mutex;
+static std::vector<GateRecord> &g_gate_records = *new std::vector<GateRecord>;
 
 Gate::Gate(const char *name_)
 	: name(name_), start(nullptr), active(false)

@@ -189,3 +189,26 @@ def test_c2_full_size():
     t.fill_(201)
     const = Image.new_from_tensor(t).reduce(8, 8, kernel="lanczos3").numpy()
     assert const.min() == 201 and const.max() == 201
+
+
+@pytest.mark.parametrize("shrink", [2, 4, 8])
+@pytest.mark.parametrize("size", [(1203, 917), (2048, 1024), (640, 8), (96, 2000)])
+def test_fused_reduce_rgba(shrink, size):
+    """The fused reducev+reduceh kernel (reduce_u8.hip): even integer shrink, RGBA uchar;
+    sizes that are / are not multiples of the shrink (phase 0 and constant non-zero
+    phase), several tiles wide and tall, all four edges clamped."""
+    from libvips_amd import lib
+
+    w, h = size
+    src = helpers.lcg_image(w, h, 4, np.uint8, 46)
+    im = Image.new_from_array(src)
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    try:
+        got = im.reduce(shrink, shrink, kernel="lanczos3").numpy()
+        report = libvips_amd.gate_report()
+    finally:
+        lib.vips_hip_gate_enable(0)
+        lib.vips_hip_gate_reset()
+    assert any(k.startswith("reduce_fused_u8") for k in report), report
+    assert_same(got, Port.reduce(src, shrink, shrink, "lanczos3"), str((shrink, size)))
