@@ -69,6 +69,19 @@ def lcg_image_device(torch, width, height, bands, seed, device):
     return out[:n].reshape(height, width, bands).contiguous()
 
 
+def traffic_for(kernel_name):
+    """HBM bytes per launch for the dominant kernel, from the committed rocprofv3 PMC
+    summary (profiles/traffic.json; PMC passes cannot run inside the timed bench)."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except (IOError, ValueError):
+        return None
+    for key, entry in table.items():
+        if not key.startswith("_") and kernel_name.startswith(key):
+            return entry.get("traffic_bytes")
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,7 +190,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic_for(name),
                 "kernel_ms": round(mean_ms, 4),
                 "algorithmic_bytes": alg_bytes[key],
                 "kernels": {k: {"launches": v[0], "mean_ms": round(v[1] / v[0], 4)} for k, v in report.items()},
