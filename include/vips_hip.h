@@ -298,10 +298,21 @@ typedef enum {
 	VIPS_HIP_COLOUR_scRGB2sRGB16,   /* scRGB2sRGB.c, depth 16, ushort out */
 	VIPS_HIP_COLOUR_Lab2LabS,       /* Lab2LabS.c:59-73 */
 	VIPS_HIP_COLOUR_LabS2Lab,       /* LabS2Lab.c:55-69 */
+	VIPS_HIP_COLOUR_sRGB2scRGB16,   /* sRGB2scRGB.c:91-105, RGB16 (ushort) in */
 	VIPS_HIP_COLOUR_LAST
 } VipsHipColourStep;
 
 VIPS_HIP_API int vips_hip_colour_gen(int step,
+	const VipsHipRegion *in, const VipsHipRegion *out);
+/* A whole colourspace route (colourspace.c:223-520) in one pass: the steps are
+ * evaluated per pixel in registers with the reference's intermediate types, so the
+ * result is bit-identical to running them as separate images.  Decoding steps
+ * (sRGB2scRGB*, LabS2Lab) may only come first and encoding steps (scRGB2sRGB*,
+ * Lab2LabS) only last.  The stored input may be uchar, ushort, short or float: it is
+ * vips_cast to what the first step wants (colour.c:343-348,428-434).  @alpha_scale is
+ * max_alpha_after / max_alpha_before for the extra bands (colour.c:257-273).
+ */
+VIPS_HIP_API int vips_hip_colour_route_gen(const int *steps, int n_steps, double alpha_scale,
 	const VipsHipRegion *in, const VipsHipRegion *out);
 
 /* vips_cast (conversion/cast.c:120-330): clip + truncate between any two

@@ -120,6 +120,7 @@ _SIGNATURES = {
     "vips_hip_gaussmat": (c_int, [c_double, c_double, c_int, c_int, P(c_double), c_int, P(c_double)]),
     # colour
     "vips_hip_colour_gen": (c_int, [c_int, RegionP, RegionP]),
+    "vips_hip_colour_route_gen": (c_int, [P(c_int), c_int, c_double, RegionP, RegionP]),
     "vips_hip_cast_gen": (c_int, [RegionP, RegionP]),
     "vips_hip_sharpen_gen": (c_int, [c_void_p, RegionP, RegionP, RegionP]),
     # images

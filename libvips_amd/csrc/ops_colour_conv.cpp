@@ -1,0 +1,506 @@
+// Image-level convolution and colour operations: the host side of vips_conv /
+// vips_convsep / vips_gaussblur / vips_sharpen / vips_colourspace / vips_cast.
+// Each mirrors the build() of the corresponding reference class and then runs the
+// region ops once over the whole (device-resident) image.
+#include "colour.h"
+#include "conv.h"
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+using namespace vh;
+
+namespace {
+
+struct ImageRef {
+	VipsHipImage *im;
+	explicit ImageRef(VipsHipImage *i = nullptr)
+		: im(i)
+	{
+	}
+	~ImageRef() { vips_hip_image_unref(im); }
+	VipsHipImage *release()
+	{
+		VipsHipImage *t = im;
+		im = nullptr;
+		return t;
+	}
+};
+
+struct ConvDeleter {
+	void operator()(VipsHipConv *c) const { vips_hip_conv_free(c); }
+};
+typedef std::unique_ptr<VipsHipConv, ConvDeleter> ConvPtr;
+
+int conv_image(VipsHipImage *in, VipsHipImage **out, const double *mask, int mw, int mh,
+	double scale, double offset, int precision)
+{
+	ConvPtr c(vips_hip_conv_new(mask, mw, mh, scale, offset, precision));
+	if (!c)
+		return -1;
+	const int fmt = vips_hip_conv_out_format(c.get(), in->format);
+	ImageRef o(vips_hip_image_new(in->width, in->height, in->bands, fmt, in->interpretation));
+	if (!o.im)
+		return -1;
+	VipsHipRegion ri, ro;
+	vips_hip_image_region(in, &ri);
+	vips_hip_image_region(o.im, &ro);
+	if (vips_hip_conv_gen(c.get(), &ri, &ro))
+		return -1;
+	// the plan's tables go back to the pool behind the kernel on this stream
+	*out = o.release();
+	return 0;
+}
+
+// vips_image_guess_interpretation (iofuncs/header.c:666-759) for the formats and tags
+// this library carries; vips_image_default_interpretation :590-652.
+int guess_interpretation(const VipsHipImage *im)
+{
+	bool sane = true;
+	const int fmt = im->format;
+	const bool is8 = fmt == VIPS_HIP_FORMAT_UCHAR || fmt == VIPS_HIP_FORMAT_CHAR;
+	const bool isuint = fmt == VIPS_HIP_FORMAT_UCHAR || fmt == VIPS_HIP_FORMAT_USHORT ||
+		fmt == VIPS_HIP_FORMAT_UINT;
+	const bool isfloat = fmt == VIPS_HIP_FORMAT_FLOAT || fmt == VIPS_HIP_FORMAT_DOUBLE;
+	int want_bands = 0;
+	switch (im->interpretation) {
+	case VIPS_HIP_INTERPRETATION_B_W:
+	case VIPS_HIP_INTERPRETATION_GREY16:
+		want_bands = 1;
+		break;
+	case VIPS_HIP_INTERPRETATION_XYZ:
+	case VIPS_HIP_INTERPRETATION_LAB:
+	case VIPS_HIP_INTERPRETATION_LABS:
+	case VIPS_HIP_INTERPRETATION_sRGB:
+	case VIPS_HIP_INTERPRETATION_RGB16:
+	case VIPS_HIP_INTERPRETATION_scRGB:
+		want_bands = 3;
+		break;
+	default:
+		break;
+	}
+	if (im->bands < want_bands)
+		sane = false;
+	switch (im->interpretation) {
+	case VIPS_HIP_INTERPRETATION_MULTIBAND:
+		sane = false;
+		break;
+	case VIPS_HIP_INTERPRETATION_scRGB:
+		if (!isfloat)
+			sane = false;
+		break;
+	case VIPS_HIP_INTERPRETATION_LABS:
+		if (isuint || is8)
+			sane = false;
+		break;
+	case VIPS_HIP_INTERPRETATION_RGB16:
+	case VIPS_HIP_INTERPRETATION_GREY16:
+		if (is8)
+			sane = false;
+		break;
+	default:
+		break;
+	}
+	if (sane)
+		return im->interpretation;
+	switch (fmt) {
+	case VIPS_HIP_FORMAT_UCHAR:
+	case VIPS_HIP_FORMAT_SHORT:
+	case VIPS_HIP_FORMAT_UINT:
+	case VIPS_HIP_FORMAT_INT:
+	case VIPS_HIP_FORMAT_FLOAT:
+	case VIPS_HIP_FORMAT_DOUBLE:
+		if (im->bands <= 2)
+			return VIPS_HIP_INTERPRETATION_B_W;
+		if (im->bands <= 4)
+			return VIPS_HIP_INTERPRETATION_sRGB;
+		return VIPS_HIP_INTERPRETATION_MULTIBAND;
+	case VIPS_HIP_FORMAT_USHORT:
+		if (im->bands <= 2)
+			return VIPS_HIP_INTERPRETATION_GREY16;
+		if (im->bands <= 4)
+			return VIPS_HIP_INTERPRETATION_RGB16;
+		return VIPS_HIP_INTERPRETATION_MULTIBAND;
+	default:
+		return VIPS_HIP_INTERPRETATION_MULTIBAND;
+	}
+}
+
+// vips_interpretation_max_alpha, iofuncs/header.c:194-206
+double max_alpha(int interpretation)
+{
+	switch (interpretation) {
+	case VIPS_HIP_INTERPRETATION_GREY16:
+	case VIPS_HIP_INTERPRETATION_RGB16:
+		return 65535.0;
+	case VIPS_HIP_INTERPRETATION_scRGB:
+		return 1.0;
+	default:
+		return 255.0;
+	}
+}
+
+const char *interpretation_nick(int v)
+{
+	switch (v) {
+	case VIPS_HIP_INTERPRETATION_MULTIBAND: return "multiband";
+	case VIPS_HIP_INTERPRETATION_B_W: return "b-w";
+	case VIPS_HIP_INTERPRETATION_XYZ: return "xyz";
+	case VIPS_HIP_INTERPRETATION_LAB: return "lab";
+	case VIPS_HIP_INTERPRETATION_LABS: return "labs";
+	case VIPS_HIP_INTERPRETATION_sRGB: return "srgb";
+	case VIPS_HIP_INTERPRETATION_RGB16: return "rgb16";
+	case VIPS_HIP_INTERPRETATION_GREY16: return "grey16";
+	case VIPS_HIP_INTERPRETATION_scRGB: return "scrgb";
+	default: return "unknown";
+	}
+}
+
+// One entry of vips_colour_routes[] (colourspace.c:223-520), restricted to the spaces
+// of this library: the colour steps, or a plain vips_cast_* (route == cast only).
+struct Route {
+	int from, to;
+	int n;
+	int steps[5];
+	int cast_format; // for the x -> x identity routes
+};
+
+enum {
+	S_sRGB2scRGB = VIPS_HIP_COLOUR_sRGB2scRGB,
+	S_scRGB2XYZ = VIPS_HIP_COLOUR_scRGB2XYZ,
+	S_XYZ2Lab = VIPS_HIP_COLOUR_XYZ2Lab,
+	S_Lab2XYZ = VIPS_HIP_COLOUR_Lab2XYZ,
+	S_XYZ2scRGB = VIPS_HIP_COLOUR_XYZ2scRGB,
+	S_scRGB2sRGB = VIPS_HIP_COLOUR_scRGB2sRGB,
+	S_Lab2LabS = VIPS_HIP_COLOUR_Lab2LabS,
+	S_LabS2Lab = VIPS_HIP_COLOUR_LabS2Lab
+};
+
+#define XYZ VIPS_HIP_INTERPRETATION_XYZ
+#define LAB VIPS_HIP_INTERPRETATION_LAB
+#define LABS VIPS_HIP_INTERPRETATION_LABS
+#define scRGB VIPS_HIP_INTERPRETATION_scRGB
+#define sRGB VIPS_HIP_INTERPRETATION_sRGB
+
+const Route routes[] = {
+	{ XYZ, XYZ, 0, {}, VIPS_HIP_FORMAT_FLOAT },
+	{ XYZ, LAB, 1, { S_XYZ2Lab }, -1 },
+	{ XYZ, LABS, 2, { S_XYZ2Lab, S_Lab2LabS }, -1 },
+	{ XYZ, scRGB, 1, { S_XYZ2scRGB }, -1 },
+	{ XYZ, sRGB, 2, { S_XYZ2scRGB, S_scRGB2sRGB }, -1 },
+
+	{ LAB, XYZ, 1, { S_Lab2XYZ }, -1 },
+	{ LAB, LAB, 0, {}, VIPS_HIP_FORMAT_FLOAT },
+	{ LAB, LABS, 1, { S_Lab2LabS }, -1 },
+	{ LAB, scRGB, 2, { S_Lab2XYZ, S_XYZ2scRGB }, -1 },
+	{ LAB, sRGB, 3, { S_Lab2XYZ, S_XYZ2scRGB, S_scRGB2sRGB }, -1 },
+
+	{ LABS, XYZ, 2, { S_LabS2Lab, S_Lab2XYZ }, -1 },
+	{ LABS, LAB, 1, { S_LabS2Lab }, -1 },
+	{ LABS, LABS, 0, {}, VIPS_HIP_FORMAT_SHORT },
+	{ LABS, scRGB, 3, { S_LabS2Lab, S_Lab2XYZ, S_XYZ2scRGB }, -1 },
+	{ LABS, sRGB, 4, { S_LabS2Lab, S_Lab2XYZ, S_XYZ2scRGB, S_scRGB2sRGB }, -1 },
+
+	{ scRGB, XYZ, 1, { S_scRGB2XYZ }, -1 },
+	{ scRGB, LAB, 2, { S_scRGB2XYZ, S_XYZ2Lab }, -1 },
+	{ scRGB, LABS, 3, { S_scRGB2XYZ, S_XYZ2Lab, S_Lab2LabS }, -1 },
+	{ scRGB, scRGB, 0, {}, VIPS_HIP_FORMAT_FLOAT },
+	{ scRGB, sRGB, 1, { S_scRGB2sRGB }, -1 },
+
+	{ sRGB, XYZ, 2, { S_sRGB2scRGB, S_scRGB2XYZ }, -1 },
+	{ sRGB, LAB, 3, { S_sRGB2scRGB, S_scRGB2XYZ, S_XYZ2Lab }, -1 },
+	{ sRGB, LABS, 4, { S_sRGB2scRGB, S_scRGB2XYZ, S_XYZ2Lab, S_Lab2LabS }, -1 },
+	{ sRGB, scRGB, 1, { S_sRGB2scRGB }, -1 },
+	{ sRGB, sRGB, 0, {}, VIPS_HIP_FORMAT_UCHAR },
+};
+
+#undef XYZ
+#undef LAB
+#undef LABS
+#undef scRGB
+#undef sRGB
+
+int step_out_interpretation(int step)
+{
+	switch (step) {
+	case VIPS_HIP_COLOUR_sRGB2scRGB:
+	case VIPS_HIP_COLOUR_sRGB2scRGB16:
+	case VIPS_HIP_COLOUR_XYZ2scRGB:
+		return VIPS_HIP_INTERPRETATION_scRGB;
+	case VIPS_HIP_COLOUR_scRGB2XYZ:
+	case VIPS_HIP_COLOUR_Lab2XYZ:
+		return VIPS_HIP_INTERPRETATION_XYZ;
+	case VIPS_HIP_COLOUR_XYZ2Lab:
+	case VIPS_HIP_COLOUR_LabS2Lab:
+		return VIPS_HIP_INTERPRETATION_LAB;
+	case VIPS_HIP_COLOUR_scRGB2sRGB:
+		return VIPS_HIP_INTERPRETATION_sRGB;
+	case VIPS_HIP_COLOUR_scRGB2sRGB16:
+		return VIPS_HIP_INTERPRETATION_RGB16;
+	case VIPS_HIP_COLOUR_Lab2LabS:
+		return VIPS_HIP_INTERPRETATION_LABS;
+	default:
+		return VIPS_HIP_INTERPRETATION_MULTIBAND;
+	}
+}
+
+int step_out_format(int step)
+{
+	switch (step) {
+	case VIPS_HIP_COLOUR_scRGB2sRGB: return VIPS_HIP_FORMAT_UCHAR;
+	case VIPS_HIP_COLOUR_scRGB2sRGB16: return VIPS_HIP_FORMAT_USHORT;
+	case VIPS_HIP_COLOUR_Lab2LabS: return VIPS_HIP_FORMAT_SHORT;
+	default: return VIPS_HIP_FORMAT_FLOAT;
+	}
+}
+
+int cast_image(VipsHipImage *in, VipsHipImage **out, int format)
+{
+	ImageRef o(vips_hip_image_new(in->width, in->height, in->bands, format, in->interpretation));
+	if (!o.im)
+		return -1;
+	VipsHipRegion ri, ro;
+	vips_hip_image_region(in, &ri);
+	vips_hip_image_region(o.im, &ro);
+	if (vips_hip_cast_gen(&ri, &ro))
+		return -1;
+	*out = o.release();
+	return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+// vips_conv_build, convolution/conv.c:62-118
+int vips_hip_conv(VipsHipImage *in, VipsHipImage **out, const double *mask, int mask_width,
+	int mask_height, double scale, double offset, int precision)
+{
+	if (precision == VIPS_HIP_PRECISION_APPROXIMATE) {
+		error("conv", "precision 'approximate' (vips_conva) is outside the HIP path");
+		return -1;
+	}
+	return conv_image(in, out, mask, mask_width, mask_height, scale, offset, precision);
+}
+
+// vips_convsep_build, convolution/convsep.c:61-118: conv(M) then conv(rot90(M), offset 0)
+int vips_hip_convsep(VipsHipImage *in, VipsHipImage **out, const double *mask, int mask_n,
+	double scale, double offset, int precision)
+{
+	if (precision == VIPS_HIP_PRECISION_APPROXIMATE) {
+		error("convsep", "precision 'approximate' (vips_convasep) is outside the HIP path");
+		return -1;
+	}
+	if (mask_n <= 0) {
+		error("convsep", "separable matrix images must have width or height 1");
+		return -1;
+	}
+	ImageRef t1;
+	// first pass: the mask as given (1 row of mask_n)
+	if (conv_image(in, &t1.im, mask, mask_n, 1, scale, offset, precision))
+		return -1;
+	// second pass: vips_rot(D90) turns the row into a column (same element order
+	// top to bottom), same scale, offset forced to 0
+	return conv_image(t1.im, out, mask, 1, mask_n, scale, 0.0, precision);
+}
+
+// vips_gaussblur_build, convolution/gaussblur.c:71-116
+int vips_hip_gaussblur(VipsHipImage *in, VipsHipImage **out, double sigma, double min_ampl,
+	int precision)
+{
+	if (sigma < 0.2) {
+		ImageRef o(vips_hip_image_new(in->width, in->height, in->bands, in->format,
+			in->interpretation));
+		if (!o.im || vips_hip_memcpy_d2d(o.im->data, in->data, in->stride * in->height))
+			return -1;
+		*out = o.release();
+		return 0;
+	}
+	int width = vips_hip_gaussmat(sigma, min_ampl, 1, precision, nullptr, 0, nullptr);
+	if (width < 0)
+		return -1;
+	std::vector<double> mask(width);
+	double scale = 1.0;
+	if (vips_hip_gaussmat(sigma, min_ampl, 1, precision, mask.data(), width, &scale) < 0)
+		return -1;
+	return vips_hip_convsep(in, out, mask.data(), width, scale, 0.0, precision);
+}
+
+int vips_hip_cast(VipsHipImage *in, VipsHipImage **out, int format)
+{
+	return cast_image(in, out, format);
+}
+
+// vips_colourspace_build, colour/colourspace.c:551-612
+int vips_hip_colourspace(VipsHipImage *in, VipsHipImage **out, int space)
+{
+	int interpretation = guess_interpretation(in);
+	const Route *route = nullptr;
+	for (const Route &r : routes)
+		if (r.from == interpretation && r.to == space) {
+			route = &r;
+			break;
+		}
+	if (!route) {
+		error("vips_colourspace", "no known route from '%s' to '%s'",
+			interpretation_nick(interpretation), interpretation_nick(space));
+		return -1;
+	}
+	if (route->n == 0) {
+		// vips_cast_float / vips_cast_uchar / vips_cast_short; interpretation unchanged
+		return cast_image(in, out, route->cast_format);
+	}
+	if (in->bands < 3) {
+		error("colourspace", "image must have at least 3 bands");
+		return -1;
+	}
+
+	// The stored input: the fused route kernel reads uchar / ushort / short / float and
+	// applies the cast the first step's build() would insert; other formats get that
+	// vips_cast as a pass of its own first.
+	ImageRef pre;
+	VipsHipImage *cur = in;
+	const int first = route->steps[0];
+	const bool readable = cur->format == VIPS_HIP_FORMAT_UCHAR || cur->format == VIPS_HIP_FORMAT_USHORT ||
+		cur->format == VIPS_HIP_FORMAT_SHORT || cur->format == VIPS_HIP_FORMAT_FLOAT;
+	if (!readable) {
+		int want = VIPS_HIP_FORMAT_FLOAT;
+		if (first == VIPS_HIP_COLOUR_sRGB2scRGB)
+			want = VIPS_HIP_FORMAT_UCHAR;
+		else if (first == VIPS_HIP_COLOUR_LabS2Lab)
+			want = VIPS_HIP_FORMAT_SHORT;
+		if (cast_image(cur, &pre.im, want))
+			return -1;
+		cur = pre.im;
+	}
+
+	// Extra bands: every step rescales them in float when the alpha range changes
+	// (vips_linear1) and casts them to its output format (colour.c:249-296).  Those
+	// roundings do not compose, so images with extra bands run the chain one step per
+	// pass like the reference; 3-band images take the fused route.
+	const double alpha_scale = 1.0;
+	const int last = route->steps[route->n - 1];
+	const bool stepwise = cur->bands > 3 && route->n > 1;
+
+	if (!stepwise) {
+		ImageRef o(vips_hip_image_new(cur->width, cur->height, cur->bands, step_out_format(last),
+			step_out_interpretation(last)));
+		if (!o.im)
+			return -1;
+		VipsHipRegion ri, ro;
+		vips_hip_image_region(cur, &ri);
+		vips_hip_image_region(o.im, &ro);
+		if (vips_hip_colour_route_gen(route->steps, route->n, alpha_scale, &ri, &ro))
+			return -1;
+		*out = o.release();
+		return 0;
+	}
+
+	// images with extra bands: one pass per step, exactly the reference's chain
+	ImageRef hold;
+	int before = interpretation;
+	for (int s = 0; s < route->n; s++) {
+		const int st = route->steps[s];
+		const int after = step_out_interpretation(st);
+		ImageRef o(vips_hip_image_new(cur->width, cur->height, cur->bands, step_out_format(st), after));
+		if (!o.im)
+			return -1;
+		VipsHipRegion ri, ro;
+		vips_hip_image_region(cur, &ri);
+		vips_hip_image_region(o.im, &ro);
+		if (vips_hip_colour_route_gen(&st, 1, max_alpha(after) / max_alpha(before), &ri, &ro))
+			return -1;
+		vips_hip_image_unref(hold.im);
+		hold.im = o.release();
+		cur = hold.im;
+		before = after;
+	}
+	*out = hold.release();
+	return 0;
+}
+
+// vips_sharpen_build, convolution/sharpen.c:171-302
+int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out, double sigma, double x1, double y2,
+	double y3, double m1, double m2)
+{
+	const int old_interpretation = in->interpretation;
+	ImageRef labs;
+	if (vips_hip_colourspace(in, &labs.im, VIPS_HIP_INTERPRETATION_LABS))
+		return -1;
+	if (labs.im->bands < 3) {
+		error("sharpen", "image must have at least 3 bands");
+		return -1;
+	}
+
+	// "Stop at 10% of max ... We always sharpen a short, so there's no point using a
+	// float mask."
+	int width = vips_hip_gaussmat(sigma, 0.1, 1, VIPS_HIP_PRECISION_INTEGER, nullptr, 0, nullptr);
+	if (width < 0)
+		return -1;
+	std::vector<double> mask(width);
+	double scale = 1.0;
+	if (vips_hip_gaussmat(sigma, 0.1, 1, VIPS_HIP_PRECISION_INTEGER, mask.data(), width, &scale) < 0)
+		return -1;
+
+	// vips_cast_short: colourspace(LABS) already produced short
+	ImageRef shorts;
+	VipsHipImage *cur = labs.im;
+	if (cur->format != VIPS_HIP_FORMAT_SHORT) {
+		if (cast_image(cur, &shorts.im, VIPS_HIP_FORMAT_SHORT))
+			return -1;
+		cur = shorts.im;
+	}
+
+	// the LUT, sharpen.c:230-257
+	std::vector<int> lut(65536);
+	for (int i = 0; i < 65536; i++) {
+		double v = (i - 32767) / 327.67;
+		double y;
+
+		if (v < -x1)
+			y = (v + x1) * m2 + -x1 * m1;
+		else if (v < x1)
+			y = v * m1;
+		else
+			y = (v - x1) * m2 + x1 * m1;
+
+		if (y < -y3)
+			y = -y3;
+		if (y > y2)
+			y = y2;
+
+		lut[i] = rint(y * 327.67);
+	}
+	int *d_lut = (int *) upload(lut.data(), lut.size() * sizeof(int));
+	if (!d_lut)
+		return -1;
+
+	// extract L, blur it with the integer separable mask (sharpen.c:274-278)
+	ImageRef L(vips_hip_image_new(cur->width, cur->height, 1, VIPS_HIP_FORMAT_SHORT,
+		cur->interpretation));
+	ImageRef blurred, sharp(vips_hip_image_new(cur->width, cur->height, cur->bands,
+							   VIPS_HIP_FORMAT_SHORT, VIPS_HIP_INTERPRETATION_LABS));
+	int result = -1;
+	if (L.im && sharp.im) {
+		VipsHipRegion rc, rl;
+		vips_hip_image_region(cur, &rc);
+		vips_hip_image_region(L.im, &rl);
+		if (!band_cast(&rc, 0, &rl, 0, 1) &&
+			!vips_hip_convsep(L.im, &blurred.im, mask.data(), width, scale, 0.0,
+				VIPS_HIP_PRECISION_INTEGER)) {
+			VipsHipRegion rb, rs;
+			vips_hip_image_region(blurred.im, &rb);
+			vips_hip_image_region(sharp.im, &rs);
+			result = vips_hip_sharpen_gen(d_lut, &rc, &rb, &rs);
+		}
+	}
+	vips_hip_free(d_lut);
+	if (result)
+		return -1;
+
+	// back to where we came from (sharpen.c:295-297)
+	return vips_hip_colourspace(sharp.im, out, old_interpretation);
+}
+
+} // extern "C"

@@ -45,4 +45,28 @@ int port_shrinkh(const void *in, int width, int height, int bands, int format, i
 int port_shrinkv(const void *in, int width, int height, int bands, int format, int vshrink,
 	int ceil_mode, void *out);
 
+/* convolution (port_conv.c) */
+int port_convi(const void *in, int width, int height, int bands, int format,
+	const double *mask, int mw, int mh, double scale, double offset, void *out);
+int port_convf(const void *in, int width, int height, int bands, int format,
+	const double *mask, int mw, int mh, double scale, double offset, void *out);
+int port_gaussmat(double sigma, double min_ampl, int separable, int integer, double *mask,
+	double *scale);
+void port_sharpen_lut(double x1, double y2, double y3, double m1, double m2, int *lut);
+void port_sharpen_apply(const short *in, const short *blur, int n_pixels, int bands,
+	const int *lut, short *out);
+
+/* colour (port_colour.c): n pixels of 3 bands */
+void port_sRGB2scRGB_8(const unsigned char *p, int n, float *q);
+void port_sRGB2scRGB_16(const unsigned short *p, int n, float *q);
+void port_scRGB2XYZ(const float *p, int n, float *q);
+void port_XYZ2Lab(const float *p, int n, float *q);
+void port_Lab2XYZ(const float *p, int n, float *q);
+void port_XYZ2scRGB(const float *p, int n, float *q);
+void port_scRGB2sRGB_8(const float *p, int n, unsigned char *q);
+void port_scRGB2sRGB_16(const float *p, int n, unsigned short *q);
+void port_Lab2LabS(const float *p, int n, short *q);
+void port_LabS2Lab(const short *p, int n, float *q);
+int port_cast(const void *in, size_t n, int in_format, int out_format, void *out);
+
 #endif

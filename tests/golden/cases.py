@@ -57,3 +57,125 @@ for _bands in (3, 4):
                                 call=("resize", dict(scale=0.125))))
 RESAMPLE_CASES.append(_case("resize", "scale=0.3,vscale=0.21,kernel=mitchell", 300, 260, 3, np.uint16, 21,
                             call=("resize", dict(scale=0.3, vscale=0.21, kernel="mitchell"))))
+
+
+# ----------------------------------------------------------------- conv / colour cases
+# kind: "mask" (conv/convsep with an explicit mask), "op" (one-input op), each with the
+# reference nickname + args and the equivalent Image / PortCC method + kwargs.
+
+_rng = np.random.RandomState(1234)
+MASKS = {
+    "blur3": (np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]], dtype=np.float64), 16.0, 0.0),
+    "rand5x7": (np.round(_rng.randn(5, 7) * 3, 3), 2.5, 1.7),
+    "sobel": (np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], dtype=np.float64), 1.0, 128.0),
+    "zeros": (np.zeros((3, 3)), 1.0, 5.0),
+    "row5": (np.array([[1.0, 2, 3, 4, 10]]), 20.0, 3.0),
+}
+
+INTERP = {"multiband": 0, "b-w": 1, "xyz": 12, "lab": 13, "labs": 21, "srgb": 22, "rgb16": 25,
+          "grey16": 26, "scrgb": 28}
+
+CC_CASES = []
+
+
+def _cc(name, **kw):
+    kw["name"] = name
+    CC_CASES.append(kw)
+
+
+for _dtype in (np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.float32, np.float64):
+    for _m in ("blur3", "rand5x7", "sobel"):
+        for _prec in ("integer", "float"):
+            _cc("conv|%s|%s|%s" % (np.dtype(_dtype).name, _m, _prec), kind="mask", op="conv", mask=_m,
+                args="precision=%s" % _prec, method="conv", kwargs=dict(precision=_prec),
+                width=53, height=41, bands=3, dtype=np.dtype(_dtype), seed=31, interp="multiband")
+_cc("conv|zeros|integer", kind="mask", op="conv", mask="zeros", args="precision=integer", method="conv",
+    kwargs=dict(precision="integer"), width=20, height=10, bands=1, dtype=np.dtype(np.uint8), seed=32,
+    interp="multiband")
+for _prec in ("integer", "float"):
+    _cc("convsep|row5|%s" % _prec, kind="mask", op="convsep", mask="row5", args="precision=%s" % _prec,
+        method="convsep", kwargs=dict(precision=_prec), width=50, height=40, bands=2,
+        dtype=np.dtype(np.uint8), seed=33, interp="multiband")
+for _dtype in (np.uint8, np.uint16, np.float32):
+    for _prec in ("integer", "float"):
+        _cc("gaussblur|%s|%s" % (np.dtype(_dtype).name, _prec), kind="op", op="gaussblur",
+            args="sigma=2.5,precision=%s" % _prec, method="gaussblur",
+            kwargs=dict(sigma=2.5, precision=_prec), width=80, height=60, bands=3, dtype=np.dtype(_dtype),
+            seed=34, interp="multiband")
+# the BASELINE config 3 mask: sigma 8 -> 29 taps
+_cc("gaussblur|sigma8|float32", kind="op", op="gaussblur", args="sigma=8", method="gaussblur",
+    kwargs=dict(sigma=8.0), width=96, height=64, bands=3, dtype=np.dtype(np.float32), seed=35,
+    interp="srgb")
+
+_SPACE_INPUT = {"srgb": np.uint8, "scrgb": np.float32, "xyz": np.float32, "lab": np.float32,
+                "labs": np.int16}
+for _fr in ("srgb", "scrgb", "xyz", "lab", "labs"):
+    for _to in ("srgb", "scrgb", "xyz", "lab", "labs"):
+        for _bands in (3, 4):
+            _cc("colourspace|%s|%s|%d" % (_fr, _to, _bands), kind="op", op="colourspace",
+                args="space=%s" % _to, method="colourspace", kwargs=dict(space=_to), width=37, height=29,
+                bands=_bands, dtype=np.dtype(_SPACE_INPUT[_fr]), seed=36, interp=_fr, space_input=_fr)
+# BASELINE config 3 colour half: float pixels 0..255 tagged sRGB -> Lab
+_cc("colourspace|float-srgb|lab", kind="op", op="colourspace", args="space=lab", method="colourspace",
+    kwargs=dict(space="lab"), width=64, height=48, bands=3, dtype=np.dtype(np.float32), seed=37,
+    interp="srgb")
+_cc("colourspace|ushort-srgb|xyz", kind="op", op="colourspace", args="space=xyz", method="colourspace",
+    kwargs=dict(space="xyz"), width=64, height=48, bands=3, dtype=np.dtype(np.uint16), seed=38,
+    interp="srgb")
+for _bands in (3, 4):
+    _cc("sharpen|default|%d" % _bands, kind="op", op="sharpen", args="", method="sharpen", kwargs={},
+        width=97, height=71, bands=_bands, dtype=np.dtype(np.uint8), seed=39, interp="srgb")
+_cc("sharpen|params", kind="op", op="sharpen", args="sigma=1.5,m1=1,m2=2,x1=3", method="sharpen",
+    kwargs=dict(sigma=1.5, m1=1.0, m2=2.0, x1=3.0), width=97, height=71, bands=3,
+    dtype=np.dtype(np.uint8), seed=40, interp="srgb")
+_FMT = {"uint8": "uchar", "int8": "char", "uint16": "ushort", "int16": "short", "uint32": "uint",
+        "int32": "int", "float32": "float", "float64": "double"}
+for _a in (np.uint8, np.int16, np.uint32, np.float32, np.float64):
+    for _b in (np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.float32, np.float64):
+        _cc("cast|%s|%s" % (np.dtype(_a).name, np.dtype(_b).name), kind="op", op="cast",
+            args="format=%s" % _FMT[np.dtype(_b).name], method="cast",
+            kwargs=dict(format=_FMT[np.dtype(_b).name]), width=40, height=30, bands=2, dtype=np.dtype(_a),
+            seed=41, interp="multiband", spread=True)
+
+
+def cc_input(case):
+    """The synthetic input of a CC case (needs tests.helpers)."""
+    from tests import helpers
+
+    a = helpers.lcg_image(case["width"], case["height"], case["bands"], np.uint8, case["seed"])
+    space = case.get("space_input")
+    if space == "scrgb":
+        return (a.astype(np.float32) / 200.0 - 0.1).astype(np.float32)
+    if space == "xyz":
+        return (a.astype(np.float32) / 2.3).astype(np.float32)
+    if space == "lab":
+        f = a.astype(np.float32)
+        f[:, :, 0] = f[:, :, 0] / 2.55
+        f[:, :, 1:3] -= 128
+        return f
+    if space == "labs":
+        s = helpers.lcg_image(case["width"], case["height"], case["bands"], np.int16, case["seed"])
+        s[:, :, 0] = np.abs(s[:, :, 0])
+        return s
+    src = helpers.lcg_image(case["width"], case["height"], case["bands"], case["dtype"], case["seed"])
+    if case.get("spread") and src.dtype.kind == "f":
+        src = (src - 100) * 300  # exercise the clipping of float -> int casts
+    return src
+
+
+def cc_reference(case):
+    from tests import helpers
+
+    src = cc_input(case)
+    interp = INTERP[case["interp"]]
+    if case["kind"] == "mask":
+        mask, scale, offset = MASKS[case["mask"]]
+        return helpers.Ref.run_mask(case["op"], src, mask, scale, offset, case["args"], interp)
+    return helpers.Ref.run(case["op"], src, case["args"], interp)
+
+
+def extra_groups():
+    def make():
+        return {c["name"]: cc_reference(c) for c in CC_CASES}
+
+    return [("conv_colour.npz", make)]

@@ -321,3 +321,177 @@ class Port(object):
         if hscale < 1.0:
             a = cls.reduceh(a, 1.0 / hscale, kernel, gap)
         return a
+
+
+# ------------------------------------------------------------------ conv / colour port
+
+INTERP = {"multiband": 0, "b-w": 1, "xyz": 12, "lab": 13, "labs": 21, "srgb": 22, "rgb16": 25,
+          "grey16": 26, "scrgb": 28}
+
+
+def _port_conv_setup(lib):
+    if getattr(lib, "_conv_ready", False):
+        return
+    vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    pd = ctypes.POINTER(cd)
+    for name in ("port_convi", "port_convf"):
+        getattr(lib, name).argtypes = [vp, ci, ci, ci, ci, pd, ci, ci, cd, cd, vp]
+    lib.port_gaussmat.argtypes = [cd, cd, ci, ci, pd, pd]
+    lib.port_sharpen_lut.argtypes = [cd, cd, cd, cd, cd, vp]
+    lib.port_sharpen_lut.restype = None
+    lib.port_sharpen_apply.argtypes = [vp, vp, ci, ci, vp, vp]
+    lib.port_sharpen_apply.restype = None
+    for name in ("port_sRGB2scRGB_8", "port_sRGB2scRGB_16", "port_scRGB2XYZ", "port_XYZ2Lab",
+                 "port_Lab2XYZ", "port_XYZ2scRGB", "port_scRGB2sRGB_8", "port_scRGB2sRGB_16",
+                 "port_Lab2LabS", "port_LabS2Lab"):
+        getattr(lib, name).argtypes = [vp, ci, vp]
+        getattr(lib, name).restype = None
+    lib.port_cast.argtypes = [vp, ctypes.c_size_t, ci, ci, vp]
+    lib._conv_ready = True
+
+
+class PortCC(object):
+    """oracle/port conv + colour, composed the way the reference composes images."""
+
+    @staticmethod
+    def lib():
+        lib = Port.lib()
+        _port_conv_setup(lib)
+        return lib
+
+    @staticmethod
+    def _mask(mask):
+        m = np.ascontiguousarray(np.asarray(mask, dtype=np.float64))
+        if m.ndim == 1:
+            m = m[None, :]
+        return m
+
+    @classmethod
+    def conv(cls, array, mask, scale=1.0, offset=0.0, precision="float"):
+        """vips_conv (conv.c:62-118)."""
+        a = Port._prep(array)
+        m = cls._mask(mask)
+        h, w, b = a.shape
+        fmt = DTYPE_FORMATS[a.dtype]
+        pm = m.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        if precision == "integer":
+            out = np.empty_like(a)
+            r = cls.lib().port_convi(a.ctypes.data, w, h, b, fmt, pm, m.shape[1], m.shape[0], scale, offset,
+                                     out.ctypes.data)
+        else:
+            out = np.empty(a.shape, dtype=np.float64 if a.dtype == np.float64 else np.float32)
+            r = cls.lib().port_convf(a.ctypes.data, w, h, b, fmt, pm, m.shape[1], m.shape[0], scale, offset,
+                                     out.ctypes.data)
+        if r != 0:
+            raise RuntimeError("port conv failed")
+        return out
+
+    @classmethod
+    def convsep(cls, array, mask, scale=1.0, offset=0.0, precision="float"):
+        """vips_convsep (convsep.c:61-118): conv(M) then conv(rot90(M), offset 0)."""
+        m = cls._mask(mask).reshape(1, -1)
+        t = cls.conv(array, m, scale, offset, precision)
+        return cls.conv(t, m.reshape(-1, 1), scale, 0.0, precision)
+
+    @classmethod
+    def gaussmat(cls, sigma, min_ampl, separable=False, precision="integer"):
+        integer = 0 if precision == "float" else 1
+        scale = ctypes.c_double()
+        n = cls.lib().port_gaussmat(sigma, min_ampl, int(separable), integer, None, ctypes.byref(scale))
+        m = np.empty((1 if separable else n, n), dtype=np.float64)
+        cls.lib().port_gaussmat(sigma, min_ampl, int(separable), integer,
+                                m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.byref(scale))
+        return m, scale.value
+
+    @classmethod
+    def gaussblur(cls, array, sigma, min_ampl=0.2, precision="integer"):
+        """vips_gaussblur (gaussblur.c:71-116)."""
+        if sigma < 0.2:
+            return Port._prep(array).copy()
+        m, scale = cls.gaussmat(sigma, min_ampl, True, precision)
+        return cls.convsep(array, m, scale, 0.0, precision)
+
+    @classmethod
+    def cast(cls, array, dtype):
+        a = Port._prep(array)
+        out = np.empty(a.shape, dtype=dtype)
+        if cls.lib().port_cast(a.ctypes.data, a.size, DTYPE_FORMATS[a.dtype], DTYPE_FORMATS[np.dtype(dtype)],
+                               out.ctypes.data) != 0:
+            raise RuntimeError("port cast failed")
+        return out
+
+    # one colour step on the first 3 bands; extra bands carried like colour.c:249-296
+    _STEPS = {
+        "sRGB2scRGB": ("port_sRGB2scRGB_8", np.uint8, np.float32, "scrgb"),
+        "sRGB2scRGB16": ("port_sRGB2scRGB_16", np.uint16, np.float32, "scrgb"),
+        "scRGB2XYZ": ("port_scRGB2XYZ", np.float32, np.float32, "xyz"),
+        "XYZ2Lab": ("port_XYZ2Lab", np.float32, np.float32, "lab"),
+        "Lab2XYZ": ("port_Lab2XYZ", np.float32, np.float32, "xyz"),
+        "XYZ2scRGB": ("port_XYZ2scRGB", np.float32, np.float32, "scrgb"),
+        "scRGB2sRGB": ("port_scRGB2sRGB_8", np.float32, np.uint8, "srgb"),
+        "Lab2LabS": ("port_Lab2LabS", np.float32, np.int16, "labs"),
+        "LabS2Lab": ("port_LabS2Lab", np.int16, np.float32, "lab"),
+    }
+    _ROUTES = {
+        ("xyz", "lab"): ["XYZ2Lab"], ("xyz", "labs"): ["XYZ2Lab", "Lab2LabS"],
+        ("xyz", "scrgb"): ["XYZ2scRGB"], ("xyz", "srgb"): ["XYZ2scRGB", "scRGB2sRGB"],
+        ("lab", "xyz"): ["Lab2XYZ"], ("lab", "labs"): ["Lab2LabS"],
+        ("lab", "scrgb"): ["Lab2XYZ", "XYZ2scRGB"], ("lab", "srgb"): ["Lab2XYZ", "XYZ2scRGB", "scRGB2sRGB"],
+        ("labs", "xyz"): ["LabS2Lab", "Lab2XYZ"], ("labs", "lab"): ["LabS2Lab"],
+        ("labs", "scrgb"): ["LabS2Lab", "Lab2XYZ", "XYZ2scRGB"],
+        ("labs", "srgb"): ["LabS2Lab", "Lab2XYZ", "XYZ2scRGB", "scRGB2sRGB"],
+        ("scrgb", "xyz"): ["scRGB2XYZ"], ("scrgb", "lab"): ["scRGB2XYZ", "XYZ2Lab"],
+        ("scrgb", "labs"): ["scRGB2XYZ", "XYZ2Lab", "Lab2LabS"], ("scrgb", "srgb"): ["scRGB2sRGB"],
+        ("srgb", "xyz"): ["sRGB2scRGB", "scRGB2XYZ"], ("srgb", "lab"): ["sRGB2scRGB", "scRGB2XYZ", "XYZ2Lab"],
+        ("srgb", "labs"): ["sRGB2scRGB", "scRGB2XYZ", "XYZ2Lab", "Lab2LabS"],
+        ("srgb", "scrgb"): ["sRGB2scRGB"],
+    }
+    _IDENTITY = {"xyz": np.float32, "lab": np.float32, "scrgb": np.float32, "srgb": np.uint8,
+                 "labs": np.int16}
+    _MAX_ALPHA = {"rgb16": 65535.0, "grey16": 65535.0, "scrgb": 1.0}
+
+    @classmethod
+    def colour_step(cls, array, step, interp_in):
+        fn, tin, tout, interp_out = cls._STEPS[step]
+        a = Port._prep(array)
+        main = np.ascontiguousarray(cls.cast(a[:, :, :3], tin))  # code/transform build casts
+        h, w, _ = main.shape
+        out3 = np.empty((h, w, 3), dtype=tout)
+        getattr(cls.lib(), fn)(main.ctypes.data, h * w, out3.ctypes.data)
+        if a.shape[2] == 3:
+            return out3, interp_out
+        extra = a[:, :, 3:]
+        before = cls._MAX_ALPHA.get(interp_in, 255.0)
+        after = cls._MAX_ALPHA.get(interp_out, 255.0)
+        if before != after:
+            # vips_linear1, LOOP1 (arithmetic/linear.c:213-223): float a1 * (float) p + b1
+            extra = np.float32(after / before) * extra.astype(np.float32) + np.float32(0.0)
+        extra = cls.cast(np.ascontiguousarray(extra), tout)
+        return np.concatenate([out3, extra], axis=2), interp_out
+
+    @classmethod
+    def colourspace(cls, array, space, interpretation):
+        """vips_colourspace (colourspace.c:551-612) between the spaces of this library."""
+        a = Port._prep(array)
+        if interpretation == space:
+            return cls.cast(a, cls._IDENTITY[space])
+        interp = interpretation
+        for step in cls._ROUTES[(interpretation, space)]:
+            a, interp = cls.colour_step(a, step, interp)
+        return a
+
+    @classmethod
+    def sharpen(cls, array, interpretation="srgb", sigma=0.5, x1=2.0, y2=10.0, y3=20.0, m1=0.0, m2=3.0):
+        """vips_sharpen (sharpen.c:171-302)."""
+        labs = cls.colourspace(array, "labs", interpretation)
+        labs = np.ascontiguousarray(cls.cast(labs, np.int16))
+        m, scale = cls.gaussmat(sigma, 0.1, True, "integer")
+        lut = np.empty(65536, dtype=np.int32)
+        cls.lib().port_sharpen_lut(x1, y2, y3, m1, m2, lut.ctypes.data)
+        L = np.ascontiguousarray(labs[:, :, :1])
+        blur = np.ascontiguousarray(cls.convsep(L, m, scale, 0.0, "integer"))
+        out = np.empty_like(labs)
+        h, w, b = labs.shape
+        cls.lib().port_sharpen_apply(labs.ctypes.data, blur.ctypes.data, h * w, b, lut.ctypes.data,
+                                     out.ctypes.data)
+        return cls.colourspace(out, interpretation, "labs")
