@@ -381,7 +381,7 @@ int vips_hip_colourspace(VipsHipImage *in, VipsHipImage **out, int space)
 	// pass like the reference; 3-band images take the fused route.
 	const double alpha_scale = 1.0;
 	const int last = route->steps[route->n - 1];
-	const bool stepwise = cur->bands > 3 && route->n > 1;
+	const bool stepwise = cur->bands > 3;
 
 	if (!stepwise) {
 		ImageRef o(vips_hip_image_new(cur->width, cur->height, cur->bands, step_out_format(last),
