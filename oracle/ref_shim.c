@@ -18,6 +18,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vips/vips.h>
+#include <vips/vector.h>
+#include <gmodule.h>
 
 typedef struct {
 	void *data; /* interleaved pixels, no line padding */
@@ -325,6 +327,25 @@ void
 ref_col_XYZ2Lab(float X, float Y, float Z, float *L, float *a, float *b)
 {
 	vips_col_XYZ2Lab(X, Y, Z, L, a, b);
+}
+
+/* Open a libvips module (a .so exporting g_module_check_init, libvips/module/heif.c:53-78)
+ * the way vips_init() does for everything in $libdir/vips-modules-8.19
+ * (iofuncs/init.c:288-330).  Used to load host/_build/vips-hip.so into the reference.
+ */
+int
+ref_load_module(const char *path)
+{
+	GModule *module;
+
+	if (ref_init(0))
+		return -1;
+	if (!(module = g_module_open(path, G_MODULE_BIND_LAZY))) {
+		vips_error("ref_load_module", "unable to load \"%s\" -- %s", path, g_module_error());
+		return -1;
+	}
+
+	return 0;
 }
 
 int

@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_LIB = os.path.join(ROOT, "oracle", "_ref", "lib", "libref_shim.so")
 PORT_LIB = os.path.join(ROOT, "oracle", "_build", "liboracle_port.so")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+MODULE_LIB = os.path.join(ROOT, "host", "_build", "vips-hip.so")
 
 FORMAT_DTYPES = {
     0: np.uint8, 1: np.int8, 2: np.uint16, 3: np.int16, 4: np.uint32,
@@ -82,6 +83,10 @@ class RefImage(ctypes.Structure):
 
 def have_ref():
     return os.path.exists(REF_LIB)
+
+
+def have_module():
+    return os.path.exists(REF_LIB) and os.path.exists(MODULE_LIB)
 
 
 class Ref(object):
@@ -199,6 +204,19 @@ class Ref(object):
     @classmethod
     def concurrency(cls):
         return cls.lib().ref_concurrency()
+
+    _module_loaded = False
+
+    @classmethod
+    def load_module(cls):
+        """Open host/_build/vips-hip.so in the reference libvips (registers the *_hip ops)."""
+        if cls._module_loaded:
+            return
+        lib = cls.lib()
+        lib.ref_load_module.argtypes = [ctypes.c_char_p]
+        if lib.ref_load_module(MODULE_LIB.encode()) != 0:
+            cls._fail("load_module")
+        cls._module_loaded = True
 
 
 def have_port():

@@ -1,0 +1,111 @@
+"""The libvips-side module (host/vips_hip_module.c): it loads into the compiled reference,
+registers the *_hip operations with the originals' arguments, and -- on a GPU -- produces
+the same pixels as the built-in operations through libvips' own operation API
+(vips_operation_new / set_from_string / cache_operation_buildp / write_to_memory)."""
+import numpy as np
+import pytest
+
+from tests import helpers
+from tests.golden import cases
+from tests.helpers import Ref
+
+needs_module = pytest.mark.skipif(not helpers.have_module(), reason="oracle/_ref or host/_build missing")
+
+HIP_OPS = ["reduce_hip", "reduceh_hip", "reducev_hip", "shrink_hip", "shrinkh_hip", "shrinkv_hip",
+           "resize_hip", "conv_hip", "convsep_hip", "gaussblur_hip", "sharpen_hip", "colourspace_hip",
+           "cast_hip"]
+
+
+@needs_module
+def test_module_registers_operations():
+    import ctypes
+
+    Ref.load_module()
+    lib = Ref.lib()
+    lib.vips_operation_new = ctypes.CDLL(helpers.REF_LIB.replace("libref_shim", "libvips")).vips_operation_new
+    lib.vips_operation_new.restype = ctypes.c_void_p
+    lib.vips_operation_new.argtypes = [ctypes.c_char_p]
+    for nick in HIP_OPS:
+        assert lib.vips_operation_new(nick.encode()), nick
+
+
+@needs_module
+def test_module_without_gpu_reports_vips_error():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    Ref.load_module()
+    src = helpers.lcg_image(64, 48, 4, np.uint8, 71)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        Ref.run("reduce_hip", src, "hshrink=2,vshrink=2")
+
+
+@pytest.mark.gpu
+@needs_module
+class TestModuleOnGpu(object):
+    def setup_class(cls):
+        Ref.load_module()
+
+    def same(self, hip_op, ref_op, src, args, interp=0):
+        got = Ref.run(hip_op, src, args, interp)
+        want = Ref.run(ref_op, src, args, interp)
+        assert got.shape == want.shape and got.dtype == want.dtype
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (hip_op, args)
+
+    def test_reduce(self):
+        src = helpers.lcg_image(1024, 768, 4, np.uint8, 72)
+        self.same("reduce_hip", "reduce", src, "hshrink=8,vshrink=8,kernel=lanczos3")
+        self.same("reduce_hip", "reduce", src, "hshrink=2.5,vshrink=3.3,kernel=cubic")
+        self.same("reduceh_hip", "reduceh", src, "hshrink=3.1")
+        self.same("reducev_hip", "reducev", src, "vshrink=3.1,gap=2")
+
+    def test_shrink_resize(self):
+        for dtype in (np.uint8, np.uint16, np.float32):
+            src = helpers.lcg_image(515, 389, 3, dtype, 73)
+            self.same("shrink_hip", "shrink", src, "hshrink=3,vshrink=4")
+            self.same("shrinkh_hip", "shrinkh", src, "hshrink=5,ceil=true")
+            self.same("shrinkv_hip", "shrinkv", src, "vshrink=5")
+            self.same("resize_hip", "resize", src, "scale=0.125")
+            self.same("resize_hip", "resize", src, "scale=0.3,vscale=0.21,kernel=mitchell")
+
+    def test_conv_family(self):
+        src = helpers.lcg_image(200, 150, 3, np.uint8, 74)
+        for name in ("blur3", "rand5x7", "sobel"):
+            mask, scale, offset = cases.MASKS[name]
+            for prec in ("integer", "float"):
+                got = Ref.run_mask("conv_hip", src, mask, scale, offset, "precision=%s" % prec)
+                want = Ref.run_mask("conv", src, mask, scale, offset, "precision=%s" % prec)
+                assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (name, prec)
+        mask, scale, offset = cases.MASKS["row5"]
+        got = Ref.run_mask("convsep_hip", src, mask, scale, offset, "precision=integer")
+        want = Ref.run_mask("convsep", src, mask, scale, offset, "precision=integer")
+        assert np.array_equal(got, want)
+        self.same("gaussblur_hip", "gaussblur", src, "sigma=2.5")
+        self.same("gaussblur_hip", "gaussblur", src.astype(np.float32), "sigma=8,precision=float")
+
+    def test_colour_and_sharpen(self):
+        srgb = cases.INTERP["srgb"]
+        src = helpers.lcg_image(200, 150, 3, np.uint8, 75)
+        for space in ("lab", "xyz", "scrgb", "labs"):
+            self.same("colourspace_hip", "colourspace", src, "space=%s" % space, srgb)
+        self.same("sharpen_hip", "sharpen", src, "", srgb)
+        self.same("cast_hip", "cast", src, "format=float")
+
+    def test_chained_ops_stay_on_device(self):
+        """resize_hip -> sharpen_hip: the second op must pick up the first op's device image
+        (metadata link) and the result must equal the reference chain."""
+        src = helpers.lcg_image(1024, 768, 3, np.uint8, 76)
+        srgb = cases.INTERP["srgb"]
+        got = Ref.run_chain("resize_hip:scale=0.125;sharpen_hip:", src, srgb)
+        want = Ref.run_chain("resize:scale=0.125;sharpen:", src, srgb)
+        assert np.array_equal(got, want)
+        # mixed: a CPU op between two device ops must not see a stale device image
+        got = Ref.run_chain("resize_hip:scale=0.5;invert:;gaussblur_hip:sigma=1.5", src, srgb)
+        want = Ref.run_chain("resize:scale=0.5;invert:;gaussblur:sigma=1.5", src, srgb)
+        assert np.array_equal(got, want)
+
+    def test_error_propagates_as_vips_error(self):
+        src = helpers.lcg_image(64, 48, 3, np.uint8, 77)
+        with pytest.raises(RuntimeError, match="upsizing"):
+            Ref.run("resize_hip", src, "scale=2")
