@@ -1,0 +1,160 @@
+"""Multi-GPU partitioning of the hot path.
+
+One process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI on the GPUs,
+"gloo" in the CPU tests).  Two partitions, neither with a data-path collective:
+
+* **batch** (BASELINE config 4): independent images are dealt round-robin to ranks,
+  ``batch_indices``; ``bench.py --gpus N`` times this shape.
+* **row strips of one image** (config 5, also 2/3): rank r owns a contiguous strip of output
+  rows.  An op with a vertical footprint (conv: mask_height // 2 rows above, the rest below;
+  reducev: ``vips_hip_reducev_need``) needs a few input rows owned by its neighbours: ONE
+  nearest-neighbour exchange of halo rows (send/recv pairs, ~2 MB per side for C5) before
+  the kernel, then every rank runs the ordinary region op on its window.  Image edges need
+  no halo: the kernels clamp (vips_embed COPY semantics).
+
+The arithmetic of who-needs-what is the C ABI's (``vips_hip_*_need``); this module only
+moves rows.  Everything here works on CPU tensors too, which is how the gloo tests cover it.
+"""
+import ctypes
+
+import numpy as np
+
+
+def batch_indices(n_images, world, rank):
+    """Images rank ``rank`` processes: round-robin, as libvips' thread pool deals tiles."""
+    return list(range(rank, n_images, world))
+
+
+def strip_bounds(total_rows, world, rank):
+    """Contiguous, near-equal split of ``total_rows`` rows: [row0, row1)."""
+    base, extra = divmod(total_rows, world)
+    row0 = rank * base + min(rank, extra)
+    return row0, row0 + base + (1 if rank < extra else 0)
+
+
+def conv_need(mask_height, in_height):
+    """need(out_top, out_height) -> (in_top, in_height) for a conv with this mask
+    (convi.c:778-782: out rect grown by the mask, after the embed by mask/2), clipped."""
+    above = mask_height // 2
+    below = mask_height - 1 - above
+
+    def need(out_top, out_height):
+        lo = max(out_top - above, 0)
+        hi = min(out_top + out_height + below, in_height)
+        return lo, hi - lo
+
+    return need
+
+
+def reducev_need(reduce_handle):
+    """need() for a VipsHipReduce built for the vertical axis (vips_hip_reducev_need)."""
+    from ._ffi import lib
+
+    def need(out_top, out_height):
+        t0, tn = ctypes.c_int(), ctypes.c_int()
+        lib.vips_hip_reducev_need(reduce_handle, out_top, out_height, ctypes.byref(t0), ctypes.byref(tn))
+        return t0.value, tn.value
+
+    return need
+
+
+class StripPlan(object):
+    """Who owns which input rows, and which rows each rank must fetch from which neighbour."""
+
+    def __init__(self, in_height, out_height, world, need):
+        self.world = world
+        self.in_height = in_height
+        self.out_height = out_height
+        self.in_bounds = [strip_bounds(in_height, world, r) for r in range(world)]
+        self.out_bounds = [strip_bounds(out_height, world, r) for r in range(world)]
+        self.windows = []
+        for r in range(world):
+            o0, o1 = self.out_bounds[r]
+            if o1 > o0:
+                top, n = need(o0, o1 - o0)
+            else:
+                top, n = self.in_bounds[r][0], 0
+            # a rank always keeps its own rows in the window
+            i0, i1 = self.in_bounds[r]
+            lo = min(top, i0) if n else i0
+            hi = max(top + n, i1) if n else i1
+            self.windows.append((lo, hi))
+
+    def transfers(self):
+        """[(src_rank, dst_rank, row0, row1)]: rows of src's strip that dst's window needs."""
+        out = []
+        for dst in range(self.world):
+            w0, w1 = self.windows[dst]
+            for src in range(self.world):
+                if src == dst:
+                    continue
+                s0, s1 = self.in_bounds[src]
+                lo, hi = max(w0, s0), min(w1, s1)
+                if hi > lo:
+                    out.append((src, dst, lo, hi))
+        return out
+
+
+def exchange_halos(strip, plan, rank, dist=None, group=None):
+    """Return this rank's window (its strip plus the halo rows the plan says it needs).
+
+    ``strip``: tensor [rows, width, bands] holding rows plan.in_bounds[rank].  Uses one
+    batch of point-to-point sends/receives (RCCL ncclSend/ncclRecv pairs on GPUs).
+    """
+    import torch
+
+    if dist is None:
+        import torch.distributed as dist
+    i0, i1 = plan.in_bounds[rank]
+    w0, w1 = plan.windows[rank]
+    assert strip.shape[0] == i1 - i0
+    window = torch.empty((w1 - w0,) + tuple(strip.shape[1:]), dtype=strip.dtype, device=strip.device)
+    window[i0 - w0:i1 - w0] = strip
+    ops = []
+    recv_slots = []
+    for src, dst, lo, hi in plan.transfers():
+        if src == rank:
+            ops.append(dist.P2POp(dist.isend, strip[lo - i0:hi - i0].contiguous(), dst, group))
+        elif dst == rank:
+            buf = torch.empty((hi - lo,) + tuple(strip.shape[1:]), dtype=strip.dtype, device=strip.device)
+            recv_slots.append((buf, lo, hi))
+            ops.append(dist.P2POp(dist.irecv, buf, src, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for buf, lo, hi in recv_slots:
+        window[lo - w0:hi - w0] = buf
+    return window, w0
+
+
+def conv_strip(window, window_top, plan, rank, mask, scale=1.0, offset=0.0, precision="float"):
+    """Run vips_hip_conv_gen on this rank's window: returns its strip of output rows
+    (a torch CUDA tensor).  ``window`` is what exchange_halos returned."""
+    import torch
+
+    from . import PRECISIONS
+    from ._ffi import Region, check, check_handle, lib
+    from .image import DTYPE_FORMATS, FORMAT_DTYPES
+
+    m = np.ascontiguousarray(np.asarray(mask, dtype=np.float64))
+    if m.ndim == 1:
+        m = m[None, :]
+    conv = check_handle(lib.vips_hip_conv_new(
+        m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), m.shape[1], m.shape[0], float(scale),
+        float(offset), PRECISIONS[precision]))
+    try:
+        rows, width, bands = window.shape
+        in_fmt = DTYPE_FORMATS[np.dtype(str(window.dtype).replace("torch.", ""))]
+        out_fmt = lib.vips_hip_conv_out_format(conv, in_fmt)
+        o0, o1 = plan.out_bounds[rank]
+        out = torch.empty((o1 - o0, width, bands), device=window.device,
+                          dtype=getattr(torch, np.dtype(FORMAT_DTYPES[out_fmt]).name))
+        rin = Region(window.data_ptr(), 0, window_top, width, rows, width, plan.in_height, bands, in_fmt,
+                     width * bands * window.element_size())
+        rout = Region(out.data_ptr(), 0, o0, width, o1 - o0, width, plan.out_height, bands, out_fmt,
+                      width * bands * out.element_size())
+        check(lib.vips_hip_conv_gen(conv, ctypes.byref(rin), ctypes.byref(rout)))
+        check(lib.vips_hip_synchronize())
+        return out
+    finally:
+        lib.vips_hip_conv_free(conv)
