@@ -4,6 +4,7 @@
  * iofuncs/init.c:288-330): g_module_check_init() registers VipsOperation subclasses
  *
  *     reduce_hip reduceh_hip reducev_hip shrink_hip shrinkh_hip shrinkv_hip resize_hip
+ *     thumbnail_image_hip
  *     conv_hip convsep_hip gaussblur_hip sharpen_hip colourspace_hip cast_hip
  *
  * with the argument names / meaning / defaults of the originals (resample/reduce.c,
@@ -521,6 +522,49 @@ vips_resize_hip_init(VipsResizeHip *resize)
 	resize->kernel = VIPS_KERNEL_LANCZOS3;
 }
 
+/* thumbnail_image_hip: resample/thumbnail.c:1690-1760 (vips_thumbnail_image) */
+typedef struct _VipsThumbnailHip {
+	VipsHipOp parent_instance;
+	int width, height;
+	VipsSize size;
+	gboolean linear;
+} VipsThumbnailHip;
+
+static int
+vips_thumbnail_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
+{
+	VipsThumbnailHip *thumbnail = (VipsThumbnailHip *) op;
+	int height = vips_object_argument_isset(VIPS_OBJECT(op), "height") ? thumbnail->height : 0;
+
+	return vips_hip_thumbnail_image(in, out, thumbnail->width, height, thumbnail->size,
+		thumbnail->linear);
+}
+
+HIP_SUBCLASS(VipsThumbnailHip, vips_thumbnail_hip, "thumbnail_image_hip",
+	"generate thumbnail from image (MI355X)")
+
+static void
+vips_thumbnail_hip_args(VipsThumbnailHipClass *class)
+{
+	VIPS_ARG_INT(class, "width", 3, "Target width", "Size to this width",
+		VIPS_ARGUMENT_REQUIRED_INPUT, G_STRUCT_OFFSET(VipsThumbnailHip, width), 1, VIPS_MAX_COORD, 1);
+	VIPS_ARG_INT(class, "height", 113, "Target height", "Size to this height",
+		VIPS_ARGUMENT_OPTIONAL_INPUT, G_STRUCT_OFFSET(VipsThumbnailHip, height), 1, VIPS_MAX_COORD, 1);
+	VIPS_ARG_ENUM(class, "size", 114, "Size", "Only upsize, only downsize, or both",
+		VIPS_ARGUMENT_OPTIONAL_INPUT, G_STRUCT_OFFSET(VipsThumbnailHip, size),
+		VIPS_TYPE_SIZE, VIPS_SIZE_BOTH);
+	VIPS_ARG_BOOL(class, "linear", 118, "Linear", "Reduce in linear light",
+		VIPS_ARGUMENT_OPTIONAL_INPUT, G_STRUCT_OFFSET(VipsThumbnailHip, linear), FALSE);
+}
+
+static void
+vips_thumbnail_hip_init(VipsThumbnailHip *thumbnail)
+{
+	thumbnail->width = 1;
+	thumbnail->height = 1;
+	thumbnail->size = VIPS_SIZE_BOTH;
+}
+
 /* conv_hip / convsep_hip: convolution/conv.c:120-175, convsep.c:120-170 */
 typedef struct _VipsConvHip {
 	VipsHipOp parent_instance;
@@ -761,6 +805,7 @@ g_module_check_init(GModule *module)
 	vips_shrinkh_hip_get_type();
 	vips_shrinkv_hip_get_type();
 	vips_resize_hip_get_type();
+	vips_thumbnail_hip_get_type();
 	vips_conv_hip_get_type();
 	vips_convsep_hip_get_type();
 	vips_gaussblur_hip_get_type();

@@ -373,6 +373,15 @@ VIPS_HIP_API int vips_hip_shrink(VipsHipImage *in, VipsHipImage **out,
  * == scale; gap < 0 selects the default 2.0 (resize.c:397). */
 VIPS_HIP_API int vips_hip_resize(VipsHipImage *in, VipsHipImage **out,
 	double scale, double vscale, int kernel, double gap);
+/* vips_thumbnail_image (resample/thumbnail.c:678-1067 with vips_thumbnail_calculate_shrink
+ * :413-467): processing-space conversion, the shrink for the target box and fit mode,
+ * vips_resize, conversion back.  @height <= 0 means == @width; @size is a VipsSize
+ * (include/vips/resample.h: 0 both, 1 up, 2 down, 3 force); @linear shrinks in scRGB.
+ * Alpha (premultiply, thumbnail.c:848-904), crop, auto-rotate and ICC are outside the
+ * path this round: images that need them are refused.
+ */
+VIPS_HIP_API int vips_hip_thumbnail_image(VipsHipImage *in, VipsHipImage **out,
+	int width, int height, int size, int linear);
 VIPS_HIP_API int vips_hip_conv(VipsHipImage *in, VipsHipImage **out,
 	const double *mask, int mask_width, int mask_height, double scale, double offset,
 	int precision);

@@ -146,6 +146,7 @@ _SIGNATURES = {
     "vips_hip_shrinkv": (c_int, [c_void_p, P(c_void_p), c_int, c_int]),
     "vips_hip_shrink": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_int]),
     "vips_hip_resize": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_int, c_double]),
+    "vips_hip_thumbnail_image": (c_int, [c_void_p, P(c_void_p), c_int, c_int, c_int, c_int]),
     "vips_hip_conv": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_int, c_double, c_double, c_int]),
     "vips_hip_convsep": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_double, c_double, c_int]),
     "vips_hip_gaussblur": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_int]),

@@ -420,6 +420,72 @@ int vips_hip_colourspace(VipsHipImage *in, VipsHipImage **out, int space)
 	return 0;
 }
 
+// vips_thumbnail_build, resample/thumbnail.c:678-1067, for in-memory images
+// (vips_thumbnail_image: no pre-shrink on load, no pages).
+int vips_hip_thumbnail_image(VipsHipImage *in, VipsHipImage **out, int width, int height, int size,
+	int linear)
+{
+	const char *domain = "thumbnail";
+	if (width <= 0) {
+		error(domain, "parameter width not set");
+		return -1;
+	}
+	if (height <= 0)
+		height = width; // thumbnail.c:720-721
+	if (size < 0 || size > 3) {
+		error(domain, "bad size mode %d", size);
+		return -1;
+	}
+
+	// processing space (thumbnail.c:763-823)
+	if (in->bands < 3) {
+		error(domain, "images with fewer than 3 bands (B_W / GREY16 processing space) are "
+					  "outside the HIP path");
+		return -1;
+	}
+	ImageRef space;
+	if (vips_hip_colourspace(in, &space.im,
+			linear ? VIPS_HIP_INTERPRETATION_scRGB : VIPS_HIP_INTERPRETATION_sRGB))
+		return -1;
+	VipsHipImage *cur = space.im;
+
+	// vips_thumbnail_calculate_shrink, thumbnail.c:413-467 (crop NONE, no rotate)
+	double hshrink = (double) cur->width / width;
+	double vshrink = (double) cur->height / height;
+	const bool horizontal = !(hshrink < vshrink);
+	if (size != 3) { // != VIPS_SIZE_FORCE
+		if (horizontal)
+			vshrink = hshrink;
+		else
+			hshrink = vshrink;
+	}
+	if (size == 1) { // VIPS_SIZE_UP
+		hshrink = hshrink < 1 ? hshrink : 1;
+		vshrink = vshrink < 1 ? vshrink : 1;
+	}
+	else if (size == 2) { // VIPS_SIZE_DOWN
+		hshrink = hshrink > 1 ? hshrink : 1;
+		vshrink = vshrink > 1 ? vshrink : 1;
+	}
+	hshrink = hshrink < cur->width ? hshrink : cur->width;
+	vshrink = vshrink < cur->height ? vshrink : cur->height;
+
+	// vips_image_hasalpha: premultiply before shrinking (thumbnail.c:848-860)
+	if (cur->bands > 3 && hshrink != 1.0 && vshrink != 1.0) {
+		error(domain, "images with alpha need vips_premultiply, which is outside the HIP path");
+		return -1;
+	}
+
+	ImageRef resized;
+	if (vips_hip_resize(cur, &resized.im, 1.0 / hshrink, 1.0 / vshrink, VIPS_HIP_KERNEL_LANCZOS3, 2.0))
+		return -1;
+
+	if (linear) // thumbnail.c:973-987: back to sRGB
+		return vips_hip_colourspace(resized.im, out, VIPS_HIP_INTERPRETATION_sRGB);
+	*out = resized.release();
+	return 0;
+}
+
 // vips_sharpen_build, convolution/sharpen.c:171-302
 int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out, double sigma, double x1, double y2,
 	double y3, double m1, double m2)

@@ -212,6 +212,11 @@ class Image(object):
             float(gap),
         )
 
+    def thumbnail_image(self, width, height=None, size="both", linear=False):
+        sizes = {"both": 0, "up": 1, "down": 2, "force": 3}
+        return self._unary(lib.vips_hip_thumbnail_image, int(width), int(height) if height else 0,
+                           sizes[size] if isinstance(size, str) else int(size), int(bool(linear)))
+
     @staticmethod
     def _mask(mask):
         m = np.ascontiguousarray(np.asarray(mask, dtype=np.float64))

@@ -128,6 +128,19 @@ for _bands in (3, 4):
 _cc("sharpen|params", kind="op", op="sharpen", args="sigma=1.5,m1=1,m2=2,x1=3", method="sharpen",
     kwargs=dict(sigma=1.5, m1=1.0, m2=2.0, x1=3.0), width=97, height=71, bands=3,
     dtype=np.dtype(np.uint8), seed=40, interp="srgb")
+# BASELINE config 1 shape (vipsthumbnail 4096^2 -> 512^2: shrink 4 + reduce 2 per axis), scaled
+_cc("thumbnail|c1", kind="op", op="thumbnail_image", args="width=64,height=64", method="thumbnail_image",
+    kwargs=dict(width=64, height=64), width=512, height=512, bands=3, dtype=np.dtype(np.uint8), seed=42,
+    interp="srgb")
+_cc("thumbnail|fit", kind="op", op="thumbnail_image", args="width=100,height=40", method="thumbnail_image",
+    kwargs=dict(width=100, height=40), width=517, height=389, bands=3, dtype=np.dtype(np.uint8), seed=43,
+    interp="srgb")
+_cc("thumbnail|force", kind="op", op="thumbnail_image", args="width=100,height=40,size=force",
+    method="thumbnail_image", kwargs=dict(width=100, height=40, size="force"), width=517, height=389,
+    bands=3, dtype=np.dtype(np.uint8), seed=44, interp="srgb")
+_cc("thumbnail|linear", kind="op", op="thumbnail_image", args="width=90,linear=true",
+    method="thumbnail_image", kwargs=dict(width=90, linear=True), width=517, height=389, bands=3,
+    dtype=np.dtype(np.uint8), seed=45, interp="srgb")
 _FMT = {"uint8": "uchar", "int8": "char", "uint16": "ushort", "int16": "short", "uint32": "uint",
         "int32": "int", "float32": "float", "float64": "double"}
 for _a in (np.uint8, np.int16, np.uint32, np.float32, np.float64):

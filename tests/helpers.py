@@ -499,6 +499,28 @@ class PortCC(object):
         return a
 
     @classmethod
+    def thumbnail_image(cls, array, interpretation, width, height=None, size="both", linear=False):
+        """vips_thumbnail_image (thumbnail.c:678-1067, shrink :413-467), no alpha / crop / ICC."""
+        a = cls.colourspace(array, "scrgb" if linear else "srgb", interpretation)
+        h, w, _ = a.shape
+        height = height or width
+        hshrink, vshrink = w / width, h / height
+        if size != "force":
+            if not (hshrink < vshrink):
+                vshrink = hshrink
+            else:
+                hshrink = vshrink
+        if size == "up":
+            hshrink, vshrink = min(1, hshrink), min(1, vshrink)
+        elif size == "down":
+            hshrink, vshrink = max(1, hshrink), max(1, vshrink)
+        hshrink, vshrink = min(hshrink, w), min(vshrink, h)
+        out = Port.resize(a, 1.0 / hshrink, 1.0 / vshrink)
+        if linear:
+            out = cls.colourspace(out, "srgb", "scrgb")
+        return out
+
+    @classmethod
     def sharpen(cls, array, interpretation="srgb", sigma=0.5, x1=2.0, y2=10.0, y3=20.0, m1=0.0, m2=3.0):
         """vips_sharpen (sharpen.c:171-302)."""
         labs = cls.colourspace(array, "labs", interpretation)
@@ -513,3 +535,30 @@ class PortCC(object):
         cls.lib().port_sharpen_apply(labs.ctypes.data, blur.ctypes.data, h * w, b, lut.ctypes.data,
                                      out.ctypes.data)
         return cls.colourspace(out, interpretation, "labs")
+
+
+# ------------------------------------------------------------------ the .v native format
+
+def write_v(path, array, interpretation=22):
+    """Write a libvips native .v file (doc/file-format.md:42-57: 64-byte header + pixels)."""
+    import struct
+
+    a = np.ascontiguousarray(array)
+    h, w, b = a.shape
+    magic = bytes([0xB6, 0xA6, 0xF2, 0x08])  # VIPS_MAGIC_INTEL, always written MSB first (iofuncs/vips.c:427)
+    header = magic + struct.pack("<iiiiiiiffiiii", w, h, b, 0, DTYPE_FORMATS[a.dtype], 0, interpretation,
+                                 1.0, 1.0, 0, 0, 0, 0)
+    header = header.ljust(64, b"\0")
+    with open(path, "wb") as f:
+        f.write(header)
+        f.write(a.tobytes())
+
+
+def read_v(path):
+    import struct
+
+    raw = open(path, "rb").read()
+    w, h, b, _, fmt, coding, interp = struct.unpack("<iiiiiii", raw[4:32])
+    dtype = np.dtype(FORMAT_DTYPES[fmt])
+    n = w * h * b * dtype.itemsize
+    return np.frombuffer(raw[64:64 + n], dtype=dtype).reshape(h, w, b).copy(), interp

@@ -12,7 +12,7 @@ from tests.helpers import Ref
 needs_module = pytest.mark.skipif(not helpers.have_module(), reason="oracle/_ref or host/_build missing")
 
 HIP_OPS = ["reduce_hip", "reduceh_hip", "reducev_hip", "shrink_hip", "shrinkh_hip", "shrinkv_hip",
-           "resize_hip", "conv_hip", "convsep_hip", "gaussblur_hip", "sharpen_hip", "colourspace_hip",
+           "resize_hip", "thumbnail_image_hip", "conv_hip", "convsep_hip", "gaussblur_hip", "sharpen_hip", "colourspace_hip",
            "cast_hip"]
 
 
@@ -68,6 +68,13 @@ class TestModuleOnGpu(object):
             self.same("shrinkv_hip", "shrinkv", src, "vshrink=5")
             self.same("resize_hip", "resize", src, "scale=0.125")
             self.same("resize_hip", "resize", src, "scale=0.3,vscale=0.21,kernel=mitchell")
+
+    def test_thumbnail(self):
+        srgb = cases.INTERP["srgb"]
+        src = helpers.lcg_image(1024, 768, 3, np.uint8, 78)
+        self.same("thumbnail_image_hip", "thumbnail_image", src, "width=128", srgb)
+        self.same("thumbnail_image_hip", "thumbnail_image", src, "width=100,height=40,size=force", srgb)
+        self.same("thumbnail_image_hip", "thumbnail_image", src, "width=90,linear=true", srgb)
 
     def test_conv_family(self):
         src = helpers.lcg_image(200, 150, 3, np.uint8, 74)

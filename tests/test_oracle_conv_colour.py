@@ -23,6 +23,8 @@ def port_call(case, src):
         return PortCC.colourspace(src, kw["space"], case["interp"])
     if case["method"] == "sharpen":
         return PortCC.sharpen(src, case["interp"], **kw)
+    if case["method"] == "thumbnail_image":
+        return PortCC.thumbnail_image(src, case["interp"], **kw)
     if case["method"] == "cast":
         inv = {v: k for k, v in cases._FMT.items()}
         return PortCC.cast(src, np.dtype(inv[kw["format"]]))
