@@ -30,6 +30,7 @@ struct _VipsHipConv {
 	// device tables
 	void *d_coeff; // int[nnz] or double[nnz]
 	short *d_dx, *d_dy;
+	void *d_dense; // int / double [mask_width * mask_height], zeros kept (tiled kernels)
 	std::mutex mutex;
 };
 
@@ -45,6 +46,8 @@ struct ConvArgs {
 	int nnz;
 	int half_w, half_h;
 	const void *coeff;
+	const void *dense;
+	int mask_width, mask_height;
 	const short *dx, *dy;
 	int scale_i, rounding, offset_i;
 	double offset;
@@ -141,6 +144,189 @@ static int launch_conv(const ConvArgs &a, const char *gate_name)
 	return 0;
 }
 
+
+// ---------------------------------------------------------- register-tiled kernels
+//
+// conv_general re-reads every tap from memory for every output.  Here a thread makes
+// TILE outputs that are neighbours along the mask's long axis (same band), so one load
+// feeds TILE multiply-adds: a sliding window of TILE inputs lives in registers and the tap
+// loop slides it one pixel per tap.  The window's slots rotate with the tap index, so
+// the loop is unrolled TILE-fold with static register names (no moves).
+//   ALONG_Y = false: any mask, tile along x (each mask row restarts the window)
+//   ALONG_Y = true:  n x 1 masks (the second pass of convsep / gaussblur), tile along y,
+//                    perfectly coalesced: adjacent threads are adjacent elements of a row
+// Every output still sums its non-zero taps in row-major mask order, so results are
+// bit-identical to conv_general (and to the reference).
+constexpr int CONV_TILE = 8;
+
+template <typename TIN, int MODE>
+struct ConvAcc;
+template <typename TIN>
+struct ConvAcc<TIN, 0> {
+	typedef long long acc_t;
+	typedef int coef_t;
+	typedef long long win_t;
+	static __device__ __forceinline__ acc_t seed(const ConvArgs &) { return 0; }
+	static __device__ __forceinline__ win_t widen(TIN v) { return (long long) v; }
+	static __device__ __forceinline__ acc_t mac(acc_t s, int c, long long v) { return s + (long long) c * v; }
+	static __device__ __forceinline__ TIN fin(acc_t s, const ConvArgs &a)
+	{
+		s = ((s + a.rounding) / a.scale_i) + a.offset_i;
+		return ConvClip<TIN>::run(s);
+	}
+};
+template <typename TIN>
+struct ConvAcc<TIN, 1> {
+	typedef double acc_t;
+	typedef int coef_t;
+	typedef double win_t;
+	static __device__ __forceinline__ acc_t seed(const ConvArgs &) { return 0.0; }
+	static __device__ __forceinline__ win_t widen(TIN v) { return (double) v; }
+	static __device__ __forceinline__ acc_t mac(acc_t s, int c, double v)
+	{
+		return __dadd_rn(s, __dmul_rn((double) c, v));
+	}
+	static __device__ __forceinline__ TIN fin(acc_t s, const ConvArgs &a)
+	{
+		return (TIN) __dadd_rn(__ddiv_rn(s, (double) a.scale_i), (double) a.offset_i);
+	}
+};
+template <typename TIN>
+struct ConvAcc<TIN, 2> {
+	typedef double acc_t;
+	typedef double coef_t;
+	typedef double win_t;
+	static __device__ __forceinline__ acc_t seed(const ConvArgs &a) { return a.offset; }
+	static __device__ __forceinline__ win_t widen(TIN v) { return (double) v; }
+	static __device__ __forceinline__ acc_t mac(acc_t s, double c, double v)
+	{
+		return __dadd_rn(s, __dmul_rn(c, v));
+	}
+	static __device__ __forceinline__ double fin(acc_t s, const ConvArgs &) { return s; }
+};
+
+template <typename TIN, typename TOUT, int MODE, bool ALONG_Y>
+__global__ void __launch_bounds__(256)
+conv_tiled(ConvArgs a)
+{
+	typedef ConvAcc<TIN, MODE> A;
+	typedef typename A::acc_t acc_t;
+	typedef typename A::coef_t coef_t;
+	typedef typename A::win_t win_t;
+	constexpr int T = CONV_TILE;
+	const coef_t *__restrict__ dense = (const coef_t *) a.dense;
+
+	// thread -> (tile index along the tiled axis, element across it)
+	int e, x0, y0;
+	if (ALONG_Y) {
+		e = blockIdx.x * blockDim.x + threadIdx.x; // element of the row: x * epp + b
+		if (e >= a.out_width * a.epp)
+			return;
+		x0 = e / a.epp;
+		y0 = blockIdx.y * T;
+	}
+	else {
+		const int id = blockIdx.x * blockDim.x + threadIdx.x;
+		const int tiles = (a.out_width + T - 1) / T;
+		if (id >= tiles * a.epp)
+			return;
+		const int tile = id / a.epp;
+		e = id - tile * a.epp; // band
+		x0 = tile * T;
+		y0 = blockIdx.y;
+	}
+	const int b = ALONG_Y ? e - x0 * a.epp : e;
+
+	acc_t acc[T];
+#pragma unroll
+	for (int k = 0; k < T; k++)
+		acc[k] = A::seed(a);
+
+	// input coordinates of tap (0, 0) of output (x0, y0)
+	const int gx = a.out_left + x0 - a.half_w;
+	const int gy = a.out_top + y0 - a.half_h;
+
+	auto fetch = [&](int col, int row) -> win_t {
+		const int cc = min(max(col, 0), a.im_width - 1) - a.in_left;
+		const int rr = min(max(row, 0), a.im_height - 1) - a.in_top;
+		const TIN *src = (const TIN *) (a.in + rr * a.in_stride);
+		return A::widen(src[(long long) cc * a.epp + b]);
+	};
+
+	const int n_long = ALONG_Y ? a.mask_height : a.mask_width;
+	const int n_short = ALONG_Y ? 1 : a.mask_height;
+	for (int j = 0; j < n_short; j++) {
+		// window slot s holds input (tap + k) with s = (tap + k) % T
+		win_t w[T];
+#pragma unroll
+		for (int k = 0; k < T - 1; k++)
+			w[k] = ALONG_Y ? fetch(gx, gy + k) : fetch(gx + k, gy + j);
+		for (int i0 = 0; i0 < n_long; i0 += T) {
+#pragma unroll
+			for (int ii = 0; ii < T; ii++) {
+				const int i = i0 + ii;
+				if (i < n_long) {
+					// the newest element of this tap's window goes into slot (ii + T - 1) % T
+					w[(ii + T - 1) % T] =
+						ALONG_Y ? fetch(gx, gy + i + T - 1) : fetch(gx + i + T - 1, gy + j);
+					const coef_t c = ALONG_Y ? dense[i] : dense[j * a.mask_width + i];
+					if (c != 0) {
+#pragma unroll
+						for (int k = 0; k < T; k++)
+							acc[k] = A::mac(acc[k], c, w[(ii + k) % T]);
+					}
+				}
+			}
+		}
+	}
+
+#pragma unroll
+	for (int k = 0; k < T; k++) {
+		const int ox = ALONG_Y ? x0 : x0 + k;
+		const int oy = ALONG_Y ? y0 + k : y0;
+		if (ox < a.out_width && oy < a.out_height) {
+			TOUT *dst = (TOUT *) (a.out + (long long) oy * a.out_stride);
+			dst[(long long) ox * a.epp + b] = (TOUT) A::fin(acc[k], a);
+		}
+	}
+}
+
+template <typename TIN, typename TOUT, int MODE>
+static int launch_conv_tiled(const ConvArgs &a, const char *gate_name)
+{
+	dim3 block(256, 1, 1);
+	Gate gate(gate_name);
+	if (a.mask_width == 1) {
+		const int ne = a.out_width * a.epp;
+		dim3 grid((ne + 255) / 256, (a.out_height + CONV_TILE - 1) / CONV_TILE, 1);
+		if (grid.y > 65535)
+			return 1;
+		hipLaunchKernelGGL((conv_tiled<TIN, TOUT, MODE, true>), grid, block, 0, stream(), a);
+	}
+	else {
+		const int ids = ((a.out_width + CONV_TILE - 1) / CONV_TILE) * a.epp;
+		dim3 grid((ids + 255) / 256, a.out_height, 1);
+		if (grid.y > 65535)
+			return 1;
+		hipLaunchKernelGGL((conv_tiled<TIN, TOUT, MODE, false>), grid, block, 0, stream(), a);
+	}
+	VH_CHECK(hipGetLastError());
+	return 0;
+}
+
+// The tiled kernel wins whenever a thread's TILE outputs share taps; masks that are a
+// single element (or tiny images) keep the general kernel.
+template <typename TIN, typename TOUT, int MODE>
+static int launch_conv_best(const ConvArgs &a, const char *name)
+{
+	if (a.mask_width * a.mask_height >= 3 && a.out_height <= 65535 * (a.mask_width == 1 ? CONV_TILE : 1)) {
+		const int r = launch_conv_tiled<TIN, TOUT, MODE>(a, name);
+		if (r <= 0)
+			return r;
+	}
+	return launch_conv<TIN, TOUT, MODE>(a, name);
+}
+
 static int conv_tables(_VipsHipConv *c)
 {
 	std::lock_guard<std::mutex> lock(c->mutex);
@@ -157,7 +343,21 @@ static int conv_tables(_VipsHipConv *c)
 		c->d_coeff = upload(c->coeffi.data(), c->coeffi.size() * sizeof(int));
 	else
 		c->d_coeff = upload(c->coefff.data(), c->coefff.size() * sizeof(double));
-	if (!c->d_dx || !c->d_dy || !c->d_coeff)
+	// dense copy (zeros kept, they are skipped at run time) for the register-tiled kernels
+	const int ne = c->mask_width * c->mask_height;
+	if (c->precision == VIPS_HIP_PRECISION_INTEGER) {
+		std::vector<int> dense(ne, 0);
+		for (int i = 0; i < c->nnz; i++)
+			dense[c->pos[i]] = c->coeffi[i];
+		c->d_dense = upload(dense.data(), dense.size() * sizeof(int));
+	}
+	else {
+		std::vector<double> dense(ne, 0.0);
+		for (int i = 0; i < c->nnz; i++)
+			dense[c->pos[i]] = c->coefff[i];
+		c->d_dense = upload(dense.data(), dense.size() * sizeof(double));
+	}
+	if (!c->d_dx || !c->d_dy || !c->d_coeff || !c->d_dense)
 		return -1;
 	return 0;
 }
@@ -197,6 +397,7 @@ VipsHipConv *vips_hip_conv_new(const double *mask, int mask_width, int mask_heig
 	c->offset = offset;
 	c->d_coeff = nullptr;
 	c->d_dx = c->d_dy = nullptr;
+	c->d_dense = nullptr;
 	c->scale_i = c->rounding = c->offset_i = 0;
 	const int ne = mask_width * mask_height;
 	if (precision == VIPS_HIP_PRECISION_INTEGER) {
@@ -249,6 +450,7 @@ void vips_hip_conv_free(VipsHipConv *c)
 	vips_hip_free(c->d_coeff);
 	vips_hip_free(c->d_dx);
 	vips_hip_free(c->d_dy);
+	vips_hip_free(c->d_dense);
 	delete c;
 }
 
@@ -323,6 +525,9 @@ int vips_hip_conv_gen(const VipsHipConv *conv, const VipsHipRegion *in, const Vi
 	a.half_w = half_w;
 	a.half_h = half_h;
 	a.coeff = c->d_coeff;
+	a.dense = c->d_dense;
+	a.mask_width = c->mask_width;
+	a.mask_height = c->mask_height;
 	a.dx = c->d_dx;
 	a.dy = c->d_dy;
 	a.scale_i = c->scale_i;
@@ -333,27 +538,27 @@ int vips_hip_conv_gen(const VipsHipConv *conv, const VipsHipRegion *in, const Vi
 	const int fmt = format_real(in->format);
 	if (c->precision == VIPS_HIP_PRECISION_INTEGER) {
 		switch (fmt) {
-		case VIPS_HIP_FORMAT_UCHAR: return launch_conv<unsigned char, unsigned char, 0>(a, "convi");
-		case VIPS_HIP_FORMAT_CHAR: return launch_conv<signed char, signed char, 0>(a, "convi");
-		case VIPS_HIP_FORMAT_USHORT: return launch_conv<unsigned short, unsigned short, 0>(a, "convi");
-		case VIPS_HIP_FORMAT_SHORT: return launch_conv<short, short, 0>(a, "convi");
-		case VIPS_HIP_FORMAT_UINT: return launch_conv<unsigned int, unsigned int, 0>(a, "convi");
-		case VIPS_HIP_FORMAT_INT: return launch_conv<int, int, 0>(a, "convi");
-		case VIPS_HIP_FORMAT_FLOAT: return launch_conv<float, float, 1>(a, "convi");
-		case VIPS_HIP_FORMAT_DOUBLE: return launch_conv<double, double, 1>(a, "convi");
+		case VIPS_HIP_FORMAT_UCHAR: return launch_conv_best<unsigned char, unsigned char, 0>(a, "convi");
+		case VIPS_HIP_FORMAT_CHAR: return launch_conv_best<signed char, signed char, 0>(a, "convi");
+		case VIPS_HIP_FORMAT_USHORT: return launch_conv_best<unsigned short, unsigned short, 0>(a, "convi");
+		case VIPS_HIP_FORMAT_SHORT: return launch_conv_best<short, short, 0>(a, "convi");
+		case VIPS_HIP_FORMAT_UINT: return launch_conv_best<unsigned int, unsigned int, 0>(a, "convi");
+		case VIPS_HIP_FORMAT_INT: return launch_conv_best<int, int, 0>(a, "convi");
+		case VIPS_HIP_FORMAT_FLOAT: return launch_conv_best<float, float, 1>(a, "convi");
+		case VIPS_HIP_FORMAT_DOUBLE: return launch_conv_best<double, double, 1>(a, "convi");
 		default: break;
 		}
 	}
 	else {
 		switch (fmt) {
-		case VIPS_HIP_FORMAT_UCHAR: return launch_conv<unsigned char, float, 2>(a, "convf");
-		case VIPS_HIP_FORMAT_CHAR: return launch_conv<signed char, float, 2>(a, "convf");
-		case VIPS_HIP_FORMAT_USHORT: return launch_conv<unsigned short, float, 2>(a, "convf");
-		case VIPS_HIP_FORMAT_SHORT: return launch_conv<short, float, 2>(a, "convf");
-		case VIPS_HIP_FORMAT_UINT: return launch_conv<unsigned int, float, 2>(a, "convf");
-		case VIPS_HIP_FORMAT_INT: return launch_conv<int, float, 2>(a, "convf");
-		case VIPS_HIP_FORMAT_FLOAT: return launch_conv<float, float, 2>(a, "convf");
-		case VIPS_HIP_FORMAT_DOUBLE: return launch_conv<double, double, 2>(a, "convf");
+		case VIPS_HIP_FORMAT_UCHAR: return launch_conv_best<unsigned char, float, 2>(a, "convf");
+		case VIPS_HIP_FORMAT_CHAR: return launch_conv_best<signed char, float, 2>(a, "convf");
+		case VIPS_HIP_FORMAT_USHORT: return launch_conv_best<unsigned short, float, 2>(a, "convf");
+		case VIPS_HIP_FORMAT_SHORT: return launch_conv_best<short, float, 2>(a, "convf");
+		case VIPS_HIP_FORMAT_UINT: return launch_conv_best<unsigned int, float, 2>(a, "convf");
+		case VIPS_HIP_FORMAT_INT: return launch_conv_best<int, float, 2>(a, "convf");
+		case VIPS_HIP_FORMAT_FLOAT: return launch_conv_best<float, float, 2>(a, "convf");
+		case VIPS_HIP_FORMAT_DOUBLE: return launch_conv_best<double, double, 2>(a, "convf");
 		default: break;
 		}
 	}

@@ -371,10 +371,188 @@ static int launch_fused(const FusedArgs &args, int tiles, const std::vector<unsi
 	return 0;
 }
 
+// ------------------------------------------------- vertical uchar fast kernels
+//
+// reducev and shrinkv never look across a scanline, so a uchar image of any band count
+// is a byte array per row: each thread owns DW consecutive dwords of the row (16 bytes
+// when the geometry allows -> 1 KiB contiguous per wave per row) and walks the taps.
+
+struct VerticalArgs {
+	const unsigned char *in; // already offset to the first column of the rect
+	unsigned char *out;
+	long long in_stride, out_stride;
+	int in_top, im_height;
+	int out_top, out_height;
+	int ndw; // dwords per row
+};
+
+// reducev.cpp:418-459 / reducev_hwy.cpp:94-268: sum_i k[i] * in[x + i * lskip], +2048, >>12,
+// saturate.  Rows are taken in pairs so one v_dot2 does two taps of one byte lane.
+template <int DW>
+__global__ void __launch_bounds__(256)
+reducev_u8_kernel(VerticalArgs a, int n_point, const ReducePos *__restrict__ pos,
+	const short *__restrict__ table)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t * DW >= a.ndw)
+		return;
+	for (int y = blockIdx.y; y < a.out_height; y += gridDim.y) {
+		const ReducePos p = pos[y];
+		const short *c = table + (size_t) p.phase * n_point;
+		int acc[DW][4];
+#pragma unroll
+		for (int w = 0; w < DW; w++)
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				acc[w][k] = 0;
+		for (int i = 0; i < n_point; i += 2) {
+			const int ra = min(max(p.first + i, 0), a.im_height - 1) - a.in_top;
+			const int rb = min(max(p.first + i + 1, 0), a.im_height - 1) - a.in_top;
+			const unsigned int lo = (unsigned short) c[i];
+			const unsigned int hi = i + 1 < n_point ? (unsigned short) c[i + 1] : 0u;
+			const unsigned int coef = lo | (hi << 16);
+			const unsigned int *pa = (const unsigned int *) (a.in + ra * a.in_stride) + t * DW;
+			const unsigned int *pb = (const unsigned int *) (a.in + rb * a.in_stride) + t * DW;
+			unsigned int va[DW], vb[DW];
+			if (DW == 4) {
+				const uint4 xa = *reinterpret_cast<const uint4 *>(pa);
+				const uint4 xb = *reinterpret_cast<const uint4 *>(pb);
+				va[0] = xa.x, va[1 % DW] = xa.y, va[2 % DW] = xa.z, va[3 % DW] = xa.w;
+				vb[0] = xb.x, vb[1 % DW] = xb.y, vb[2 % DW] = xb.z, vb[3 % DW] = xb.w;
+			}
+			else {
+#pragma unroll
+				for (int w = 0; w < DW; w++) {
+					va[w] = pa[w];
+					vb[w] = pb[w];
+				}
+			}
+#pragma unroll
+			for (int w = 0; w < DW; w++)
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const unsigned int pair = __builtin_amdgcn_perm(vb[w], va[w],
+						0x0c000c00u | (unsigned) k | ((4u + k) << 16));
+					acc[w][k] = dot2(pair, coef, acc[w][k]);
+				}
+		}
+		unsigned int *dst = (unsigned int *) (a.out + (long long) y * a.out_stride) + t * DW;
+		unsigned int o[DW];
+#pragma unroll
+		for (int w = 0; w < DW; w++)
+			o[w] = (unsigned) fin_u8(acc[w][0]) | ((unsigned) fin_u8(acc[w][1]) << 8) |
+				((unsigned) fin_u8(acc[w][2]) << 16) | ((unsigned) fin_u8(acc[w][3]) << 24);
+		if (DW == 4)
+			*reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1 % DW], o[2 % DW], o[3 % DW]);
+		else {
+#pragma unroll
+			for (int w = 0; w < DW; w++)
+				dst[w] = o[w];
+		}
+	}
+}
+
+// shrinkv.c:158-165,218-228 / shrinkv_hwy.cpp:90-203: column sums of vshrink rows, then
+// ((sum + vshrink/2) * (2^32 / (256 * vshrink))) >> 24 in unsigned 32-bit arithmetic.
+template <int DW>
+__global__ void __launch_bounds__(256)
+shrinkv_u8_kernel(VerticalArgs a, int vshrink, unsigned int multiplier)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t * DW >= a.ndw)
+		return;
+	const unsigned int amend = vshrink / 2;
+	for (int y = blockIdx.y; y < a.out_height; y += gridDim.y) {
+		const int y0 = (a.out_top + y) * vshrink;
+		// even / odd bytes as two u16 lanes each: packed adds, no carries for vshrink <= 256
+		unsigned int even[DW], odd[DW];
+#pragma unroll
+		for (int w = 0; w < DW; w++)
+			even[w] = odd[w] = 0;
+		for (int i = 0; i < vshrink; i++) {
+			const int row = min(y0 + i, a.im_height - 1) - a.in_top;
+			const unsigned int *p = (const unsigned int *) (a.in + row * a.in_stride) + t * DW;
+			unsigned int v[DW];
+			if (DW == 4) {
+				const uint4 x = *reinterpret_cast<const uint4 *>(p);
+				v[0] = x.x, v[1 % DW] = x.y, v[2 % DW] = x.z, v[3 % DW] = x.w;
+			}
+			else {
+#pragma unroll
+				for (int w = 0; w < DW; w++)
+					v[w] = p[w];
+			}
+#pragma unroll
+			for (int w = 0; w < DW; w++) {
+				even[w] += v[w] & 0x00ff00ffu;
+				odd[w] += (v[w] >> 8) & 0x00ff00ffu;
+			}
+		}
+		unsigned int *dst = (unsigned int *) (a.out + (long long) y * a.out_stride) + t * DW;
+		unsigned int o[DW];
+#pragma unroll
+		for (int w = 0; w < DW; w++) {
+			const unsigned int b0 = (((even[w] & 0xffffu) + amend) * multiplier) >> 24;
+			const unsigned int b2 = (((even[w] >> 16) + amend) * multiplier) >> 24;
+			const unsigned int b1 = (((odd[w] & 0xffffu) + amend) * multiplier) >> 24;
+			const unsigned int b3 = (((odd[w] >> 16) + amend) * multiplier) >> 24;
+			o[w] = (b0 & 0xffu) | ((b1 & 0xffu) << 8) | ((b2 & 0xffu) << 16) | (b3 << 24);
+		}
+		if (DW == 4)
+			*reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1 % DW], o[2 % DW], o[3 % DW]);
+		else {
+#pragma unroll
+			for (int w = 0; w < DW; w++)
+				dst[w] = o[w];
+		}
+	}
+}
+
+// Common geometry of the vertical fast paths: the rect's rows as dword arrays.
+static bool vertical_args(const VipsHipRegion *in, const VipsHipRegion *out, VerticalArgs *a, int *dw)
+{
+	const int bands = in->bands;
+	const long long nbytes = (long long) out->width * bands;
+	const unsigned char *src = (const unsigned char *) in->data + (size_t) (out->left - in->left) * bands;
+	if (nbytes & 3)
+		return false;
+	if (((uintptr_t) src & 3) || (in->stride & 3) || ((uintptr_t) out->data & 3) || (out->stride & 3))
+		return false;
+	a->in = src;
+	a->out = (unsigned char *) out->data;
+	a->in_stride = (long long) in->stride;
+	a->out_stride = (long long) out->stride;
+	a->in_top = in->top;
+	a->im_height = in->im_height;
+	a->out_top = out->top;
+	a->out_height = out->height;
+	a->ndw = (int) (nbytes >> 2);
+	const bool wide = !(nbytes & 15) && !((uintptr_t) src & 15) && !(in->stride & 15) &&
+		!((uintptr_t) out->data & 15) && !(out->stride & 15);
+	*dw = wide ? 4 : 1;
+	return true;
+}
+
 int reducev_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out,
 	const ReducePos *pos, const short *table)
 {
-	return 0;
+	VerticalArgs a;
+	int dw;
+	if (!vertical_args(in, out, &a, &dw))
+		return 0;
+	const int threads = (a.ndw + dw - 1) / dw;
+	dim3 block(256, 1, 1);
+	dim3 grid((threads + 255) / 256, out->height < 32768 ? out->height : 32768, 1);
+	Gate gate("reducev_u8");
+	if (dw == 4)
+		hipLaunchKernelGGL(reducev_u8_kernel<4>, grid, block, 0, stream(), a, r->n_point, pos, table);
+	else
+		hipLaunchKernelGGL(reducev_u8_kernel<1>, grid, block, 0, stream(), a, r->n_point, pos, table);
+	if (hipGetLastError() != hipSuccess) {
+		error("reducev", "kernel launch failed");
+		return -1;
+	}
+	return 1;
 }
 
 int reduceh_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out,
@@ -385,7 +563,24 @@ int reduceh_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsH
 
 int shrinkv_u8_try(int vshrink, const VipsHipRegion *in, const VipsHipRegion *out)
 {
-	return 0;
+	VerticalArgs a;
+	int dw;
+	if (vshrink > 256 || !vertical_args(in, out, &a, &dw))
+		return 0;
+	const unsigned int multiplier = (unsigned int) ((1LL << 32) / ((1 << 8) * (long long) vshrink));
+	const int threads = (a.ndw + dw - 1) / dw;
+	dim3 block(256, 1, 1);
+	dim3 grid((threads + 255) / 256, out->height < 32768 ? out->height : 32768, 1);
+	Gate gate("shrinkv_u8");
+	if (dw == 4)
+		hipLaunchKernelGGL(shrinkv_u8_kernel<4>, grid, block, 0, stream(), a, vshrink, multiplier);
+	else
+		hipLaunchKernelGGL(shrinkv_u8_kernel<1>, grid, block, 0, stream(), a, vshrink, multiplier);
+	if (hipGetLastError() != hipSuccess) {
+		error("shrinkv", "kernel launch failed");
+		return -1;
+	}
+	return 1;
 }
 
 int shrinkh_u8_try(int hshrink, const VipsHipRegion *in, const VipsHipRegion *out)
