@@ -113,11 +113,30 @@ static __device__ __forceinline__ Px step_scRGB2XYZ(Px p)
 	return q;
 }
 
+// a / y for a compile-time constant y, correctly rounded: q0 = a * RN(1/y), one FMA
+// residual, one FMA correction (Markstein's theorem: with r = RN(1/y) and q0 within an ulp
+// of a/y, RN(q0 + (a - y*q0) * r) = RN(a/y)).  Three DP ops instead of the ~12 of the
+// generic IEEE division expansion; the FMAs are the exact-division device, not a fused
+// version of reference arithmetic.
+static __device__ __forceinline__ double div_const(double a, double y, double r)
+{
+	const double q0 = __dmul_rn(a, r);
+	const double e = __fma_rn(-y, q0, a);
+	const double q1 = __fma_rn(e, r, q0);
+	// an infinite quotient has no finite residual: keep it (the reference gets inf too)
+	return isinf(q0) ? q0 : q1;
+}
+#define DIV_CONST(A, Y) div_const((A), (Y), 1.0 / (Y))
+
 // vips_col_XYZ2Lab_helper, XYZ2Lab.c:109-138 (D65: include/vips/colour.h:58-60)
-static __device__ __forceinline__ float cbrt_lerp(const float *__restrict__ table, float v, double w0)
+template <int WHICH>
+static __device__ __forceinline__ float cbrt_lerp(const float *__restrict__ table, float v)
 {
 	// nX = QUANT_ELEMENTS * X / X0: (int * float) in float, then / double, back to float
-	const float n = (float) __ddiv_rn((double) __fmul_rn(100000.0f, v), w0);
+	const double num = (double) __fmul_rn(100000.0f, v);
+	const float n = (float) (WHICH == 0 ? DIV_CONST(num, 95.0470)
+							 : WHICH == 1 ? DIV_CONST(num, 100.0)
+										  : DIV_CONST(num, 108.8827));
 	// VIPS_CLIP(0, (int) nX, QUANT_ELEMENTS - 2); (int) of NaN / overflow is the x86
 	// "integer indefinite" INT_MIN, which the clip turns into 0
 	int i;
@@ -133,9 +152,9 @@ static __device__ __forceinline__ float cbrt_lerp(const float *__restrict__ tabl
 
 static __device__ __forceinline__ Px step_XYZ2Lab(Px p, const float *__restrict__ table)
 {
-	const float cbx = cbrt_lerp(table, p.a, 95.0470);
-	const float cby = cbrt_lerp(table, p.b, 100.0);
-	const float cbz = cbrt_lerp(table, p.c, 108.8827);
+	const float cbx = cbrt_lerp<0>(table, p.a);
+	const float cby = cbrt_lerp<1>(table, p.b);
+	const float cbz = cbrt_lerp<2>(table, p.c);
 	Px q;
 	q.a = __fsub_rn(__fmul_rn(116.0F, cby), 16.0F);
 	q.b = __fmul_rn(500.0F, __fsub_rn(cbx, cby));
@@ -178,9 +197,9 @@ static __device__ __forceinline__ Px step_Lab2XYZ(Px p)
 static __device__ __forceinline__ Px step_XYZ2scRGB(Px p)
 {
 	// X /= SCALE with SCALE = VIPS_D65_Y0 (double)
-	const float X = (float) __ddiv_rn((double) p.a, 100.0);
-	const float Y = (float) __ddiv_rn((double) p.b, 100.0);
-	const float Z = (float) __ddiv_rn((double) p.c, 100.0);
+	const float X = (float) DIV_CONST((double) p.a, 100.0);
+	const float Y = (float) DIV_CONST((double) p.b, 100.0);
+	const float Z = (float) DIV_CONST((double) p.c, 100.0);
 	Px q;
 	q.a = __fadd_rn(__fadd_rn(__fmul_rn(3.240625F, X), __fmul_rn(-1.537208F, Y)), __fmul_rn(-0.498629F, Z));
 	q.b = __fadd_rn(__fadd_rn(__fmul_rn(-0.968931F, X), __fmul_rn(1.875756F, Y)), __fmul_rn(0.041518F, Z));
@@ -373,6 +392,85 @@ CARRY_INT(short, unsigned short)
 CARRY_INT(short, short)
 #undef CARRY_INT
 
+// The chain for one pixel: stored bands in, stored bands out.
+template <typename TIN, typename TOUT>
+static __device__ __forceinline__ void route_pixel(const RouteArgs &a, TIN i0, TIN i1, TIN i2,
+	TOUT &o0, TOUT &o1, TOUT &o2)
+{
+	Px v;
+	const int first = a.steps[0];
+	int s = 0;
+	// ---- the first step fixes how the stored bands are interpreted
+	if (first == VIPS_HIP_COLOUR_sRGB2scRGB) {
+		// vips_colour_code_build casts to uchar (colour.c:428-434), sRGB2scRGB.c:72-90
+		v.a = a.tables.v2Y_8[load_as_uchar_like<TIN>(i0, 255)];
+		v.b = a.tables.v2Y_8[load_as_uchar_like<TIN>(i1, 255)];
+		v.c = a.tables.v2Y_8[load_as_uchar_like<TIN>(i2, 255)];
+		s = 1;
+	}
+	else if (first == VIPS_HIP_COLOUR_sRGB2scRGB16) {
+		v.a = a.tables.v2Y_16[load_as_uchar_like<TIN>(i0, 65535)];
+		v.b = a.tables.v2Y_16[load_as_uchar_like<TIN>(i1, 65535)];
+		v.c = a.tables.v2Y_16[load_as_uchar_like<TIN>(i2, 65535)];
+		s = 1;
+	}
+	else if (first == VIPS_HIP_COLOUR_LabS2Lab) {
+		// LabS2Lab.c:55-69 on the vips_cast_short'ed input
+		v.a = (float) __ddiv_rn((double) load_as_short<TIN>(i0), 32767.0 / 100.0);
+		v.b = (float) __ddiv_rn((double) load_as_short<TIN>(i1), 32768.0 / 128.0);
+		v.c = (float) __ddiv_rn((double) load_as_short<TIN>(i2), 32768.0 / 128.0);
+		s = 1;
+	}
+	else {
+		// colour transforms see vips_cast_float'ed input (colour.c:343-348)
+		v.a = (float) i0;
+		v.b = (float) i1;
+		v.c = (float) i2;
+	}
+
+	// ---- float -> float steps
+	int last = -1;
+	for (; s < a.n_steps; s++) {
+		const int st = a.steps[s];
+		if (st == VIPS_HIP_COLOUR_scRGB2XYZ)
+			v = step_scRGB2XYZ(v);
+		else if (st == VIPS_HIP_COLOUR_XYZ2Lab)
+			v = step_XYZ2Lab(v, a.tables.cbrt);
+		else if (st == VIPS_HIP_COLOUR_Lab2XYZ)
+			v = step_Lab2XYZ(v);
+		else if (st == VIPS_HIP_COLOUR_XYZ2scRGB)
+			v = step_XYZ2scRGB(v);
+		else
+			last = st; // a coding step: must be the final one
+	}
+
+	// ---- the last step fixes the stored format
+	if (last == VIPS_HIP_COLOUR_scRGB2sRGB || last == VIPS_HIP_COLOUR_scRGB2sRGB16) {
+		const bool wide = last == VIPS_HIP_COLOUR_scRGB2sRGB16;
+		const int *lut = wide ? a.tables.Y2v_16 : a.tables.Y2v_8;
+		const int maxval = wide ? 65535 : 255;
+		int r = 0, g = 0, b = 0;
+		if (!(isnan(v.a) || isnan(v.b) || isnan(v.c))) {
+			r = scRGB2sRGB_channel(lut, v.a, maxval);
+			g = scRGB2sRGB_channel(lut, v.b, maxval);
+			b = scRGB2sRGB_channel(lut, v.c, maxval);
+		}
+		o0 = (TOUT) r;
+		o1 = (TOUT) g;
+		o2 = (TOUT) b;
+	}
+	else if (last == VIPS_HIP_COLOUR_Lab2LabS) {
+		o0 = (TOUT) lab2labs(v.a, 32767.0 / 100.0, 0.0);
+		o1 = (TOUT) lab2labs(v.b, 32768.0 / 128.0, -32768.0);
+		o2 = (TOUT) lab2labs(v.c, 32768.0 / 128.0, -32768.0);
+	}
+	else {
+		o0 = (TOUT) v.a;
+		o1 = (TOUT) v.b;
+		o2 = (TOUT) v.c;
+	}
+}
+
 // One thread per pixel.  TIN/TOUT are the in-memory band formats.
 template <typename TIN, typename TOUT>
 __global__ void __launch_bounds__(256)
@@ -384,83 +482,32 @@ colour_route_kernel(RouteArgs a)
 	for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
 		const TIN *p = (const TIN *) (a.in + (long long) y * a.in_stride) + (long long) x * a.in_bands;
 		TOUT *q = (TOUT *) (a.out + (long long) y * a.out_stride) + (long long) x * a.out_bands;
-		const TIN i0 = p[0], i1 = p[1], i2 = p[2];
-
-		Px v;
-		int first = a.steps[0];
-		int s = 0;
-		// ---- the first step fixes how the stored bands are interpreted
-		if (first == VIPS_HIP_COLOUR_sRGB2scRGB) {
-			// vips_colour_code_build casts to uchar (colour.c:428-434), sRGB2scRGB.c:72-90
-			v.a = a.tables.v2Y_8[load_as_uchar_like<TIN>(i0, 255)];
-			v.b = a.tables.v2Y_8[load_as_uchar_like<TIN>(i1, 255)];
-			v.c = a.tables.v2Y_8[load_as_uchar_like<TIN>(i2, 255)];
-			s = 1;
-		}
-		else if (first == VIPS_HIP_COLOUR_sRGB2scRGB16) {
-			v.a = a.tables.v2Y_16[load_as_uchar_like<TIN>(i0, 65535)];
-			v.b = a.tables.v2Y_16[load_as_uchar_like<TIN>(i1, 65535)];
-			v.c = a.tables.v2Y_16[load_as_uchar_like<TIN>(i2, 65535)];
-			s = 1;
-		}
-		else if (first == VIPS_HIP_COLOUR_LabS2Lab) {
-			// LabS2Lab.c:55-69 on the vips_cast_short'ed input
-			v.a = (float) __ddiv_rn((double) load_as_short<TIN>(i0), 32767.0 / 100.0);
-			v.b = (float) __ddiv_rn((double) load_as_short<TIN>(i1), 32768.0 / 128.0);
-			v.c = (float) __ddiv_rn((double) load_as_short<TIN>(i2), 32768.0 / 128.0);
-			s = 1;
-		}
-		else {
-			// colour transforms see vips_cast_float'ed input (colour.c:343-348)
-			v.a = (float) i0;
-			v.b = (float) i1;
-			v.c = (float) i2;
-		}
-
-		// ---- float -> float steps
-		int last = -1;
-		for (; s < a.n_steps; s++) {
-			const int st = a.steps[s];
-			if (st == VIPS_HIP_COLOUR_scRGB2XYZ)
-				v = step_scRGB2XYZ(v);
-			else if (st == VIPS_HIP_COLOUR_XYZ2Lab)
-				v = step_XYZ2Lab(v, a.tables.cbrt);
-			else if (st == VIPS_HIP_COLOUR_Lab2XYZ)
-				v = step_Lab2XYZ(v);
-			else if (st == VIPS_HIP_COLOUR_XYZ2scRGB)
-				v = step_XYZ2scRGB(v);
-			else
-				last = st; // a coding step: must be the final one
-		}
-
-		// ---- the last step fixes the stored format
-		if (last == VIPS_HIP_COLOUR_scRGB2sRGB || last == VIPS_HIP_COLOUR_scRGB2sRGB16) {
-			const bool wide = last == VIPS_HIP_COLOUR_scRGB2sRGB16;
-			const int *lut = wide ? a.tables.Y2v_16 : a.tables.Y2v_8;
-			const int maxval = wide ? 65535 : 255;
-			int r = 0, g = 0, b = 0;
-			if (!(isnan(v.a) || isnan(v.b) || isnan(v.c))) {
-				r = scRGB2sRGB_channel(lut, v.a, maxval);
-				g = scRGB2sRGB_channel(lut, v.b, maxval);
-				b = scRGB2sRGB_channel(lut, v.c, maxval);
-			}
-			q[0] = (TOUT) r;
-			q[1] = (TOUT) g;
-			q[2] = (TOUT) b;
-		}
-		else if (last == VIPS_HIP_COLOUR_Lab2LabS) {
-			q[0] = (TOUT) lab2labs(v.a, 32767.0 / 100.0, 0.0);
-			q[1] = (TOUT) lab2labs(v.b, 32768.0 / 128.0, -32768.0);
-			q[2] = (TOUT) lab2labs(v.c, 32768.0 / 128.0, -32768.0);
-		}
-		else {
-			q[0] = (TOUT) v.a;
-			q[1] = (TOUT) v.b;
-			q[2] = (TOUT) v.c;
-		}
-
+		route_pixel<TIN, TOUT>(a, p[0], p[1], p[2], q[0], q[1], q[2]);
 		for (int e = 0; e < a.extra_bands; e++)
 			q[3 + e] = Carry<TIN, TOUT>::run(p[3 + e], a.alpha_scale);
+	}
+}
+
+// float RGB -> float RGB, 4 pixels (48 bytes = three 16-byte accesses) per thread: the
+// BASELINE config 3 shape (colourspace on a 3-band float image).
+__global__ void __launch_bounds__(256)
+colour_route_f32x4_kernel(RouteArgs a)
+{
+	const int x4 = blockIdx.x * blockDim.x + threadIdx.x;
+	if (x4 * 4 >= a.width)
+		return;
+	for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
+		const float4 *p = (const float4 *) (a.in + (long long) y * a.in_stride) + (long long) x4 * 3;
+		float4 *q = (float4 *) (a.out + (long long) y * a.out_stride) + (long long) x4 * 3;
+		const float4 v0 = p[0], v1 = p[1], v2 = p[2];
+		float4 r0, r1, r2;
+		route_pixel<float, float>(a, v0.x, v0.y, v0.z, r0.x, r0.y, r0.z);
+		route_pixel<float, float>(a, v0.w, v1.x, v1.y, r0.w, r1.x, r1.y);
+		route_pixel<float, float>(a, v1.z, v1.w, v2.x, r1.z, r1.w, r2.x);
+		route_pixel<float, float>(a, v2.y, v2.z, v2.w, r2.y, r2.z, r2.w);
+		q[0] = r0;
+		q[1] = r1;
+		q[2] = r2;
 	}
 }
 
@@ -761,6 +808,14 @@ int colour_route(const int *steps, int n_steps, double alpha_scale, const VipsHi
 	dim3 block(256, 1, 1);
 	dim3 grid((a.width + 255) / 256, a.height < 32768 ? a.height : 32768, 1);
 	Gate gate("colour_route");
+	if (in->format == VIPS_HIP_FORMAT_FLOAT && want_out == VIPS_HIP_FORMAT_FLOAT && in->bands == 3 &&
+		!(a.width & 3) && !((uintptr_t) a.in & 15) && !((uintptr_t) a.out & 15) &&
+		!(a.in_stride & 15) && !(a.out_stride & 15)) {
+		dim3 grid4((a.width / 4 + 255) / 256, grid.y, 1);
+		hipLaunchKernelGGL(colour_route_f32x4_kernel, grid4, block, 0, stream(), a);
+		VH_CHECK(hipGetLastError());
+		return 0;
+	}
 #define GO(TIN, TOUT) \
 	hipLaunchKernelGGL((colour_route_kernel<TIN, TOUT>), grid, block, 0, stream(), a)
 #define GO_IN(TOUT) \
