@@ -6,6 +6,7 @@
  *     reduce_hip reduceh_hip reducev_hip shrink_hip shrinkh_hip shrinkv_hip resize_hip
  *     thumbnail_image_hip
  *     conv_hip convsep_hip gaussblur_hip sharpen_hip colourspace_hip cast_hip
+ *     premultiply_hip unpremultiply_hip
  *
  * with the argument names / meaning / defaults of the originals (resample/reduce.c,
  * shrink.c, resize.c, convolution/conv.c, convsep.c, gaussblur.c, sharpen.c,
@@ -790,6 +791,56 @@ vips_cast_hip_init(VipsCastHip *c)
 	c->format = VIPS_FORMAT_UCHAR;
 }
 
+/* premultiply_hip / unpremultiply_hip: conversion/premultiply.c:273-330, unpremultiply.c:340-400 */
+typedef struct _VipsPremultiplyHip {
+	VipsHipOp parent_instance;
+	gboolean uchar;
+} VipsPremultiplyHip;
+
+typedef VipsPremultiplyHip VipsUnpremultiplyHip;
+
+static int
+vips_premultiply_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
+{
+	return vips_hip_premultiply(in, out, ((VipsPremultiplyHip *) op)->uchar);
+}
+
+static int
+vips_unpremultiply_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
+{
+	return vips_hip_unpremultiply(in, out, ((VipsPremultiplyHip *) op)->uchar);
+}
+
+HIP_SUBCLASS(VipsPremultiplyHip, vips_premultiply_hip, "premultiply_hip", "premultiply image alpha (MI355X)")
+HIP_SUBCLASS(VipsUnpremultiplyHip, vips_unpremultiply_hip, "unpremultiply_hip",
+	"unpremultiply image alpha (MI355X)")
+
+#define PREMUL_ARGS(class) \
+	VIPS_ARG_BOOL(class, "uchar", 116, "Uchar", "Use the uchar fast path", \
+		VIPS_ARGUMENT_OPTIONAL_INPUT, G_STRUCT_OFFSET(VipsPremultiplyHip, uchar), FALSE);
+
+static void
+vips_premultiply_hip_args(VipsPremultiplyHipClass *class)
+{
+	PREMUL_ARGS(class)
+}
+
+static void
+vips_unpremultiply_hip_args(VipsUnpremultiplyHipClass *class)
+{
+	PREMUL_ARGS(class)
+}
+
+static void
+vips_premultiply_hip_init(VipsPremultiplyHip *p)
+{
+}
+
+static void
+vips_unpremultiply_hip_init(VipsUnpremultiplyHip *p)
+{
+}
+
 /* ------------------------------------------------------------------ registration */
 
 /* Register every class. Called by GModule when libvips (or the test shim) opens the
@@ -812,6 +863,8 @@ g_module_check_init(GModule *module)
 	vips_sharpen_hip_get_type();
 	vips_colourspace_hip_get_type();
 	vips_cast_hip_get_type();
+	vips_premultiply_hip_get_type();
+	vips_unpremultiply_hip_get_type();
 
 	/* types registered by a module must never be unloaded */
 	g_module_make_resident(module);

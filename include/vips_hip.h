@@ -320,6 +320,14 @@ VIPS_HIP_API int vips_hip_colour_route_gen(const int *steps, int n_steps, double
  */
 VIPS_HIP_API int vips_hip_cast_gen(const VipsHipRegion *in, const VipsHipRegion *out);
 
+/* vips_premultiply_gen (conversion/premultiply.c:134-214) / vips_unpremultiply_gen
+ * (conversion/unpremultiply.c:198-262); the last band is alpha.  @uchar selects the
+ * uchar -> uchar fixed-point fast path (scale table, (in * scale + 128) >> 8) that
+ * vips_thumbnail uses (resample/thumbnail.c:848-904); otherwise the output is float.
+ */
+VIPS_HIP_API int vips_hip_premultiply_gen(const VipsHipRegion *in, const VipsHipRegion *out,
+	double max_alpha, int uchar, int inverse);
+
 /* vips_sharpen_generate (convolution/sharpen.c:116-168): LabS in, LabS out; the
  * blurred L band comes from a vips_hip_conv_gen pass the caller ran.
  */
@@ -377,8 +385,8 @@ VIPS_HIP_API int vips_hip_resize(VipsHipImage *in, VipsHipImage **out,
  * :413-467): processing-space conversion, the shrink for the target box and fit mode,
  * vips_resize, conversion back.  @height <= 0 means == @width; @size is a VipsSize
  * (include/vips/resample.h: 0 both, 1 up, 2 down, 3 force); @linear shrinks in scRGB.
- * Alpha (premultiply, thumbnail.c:848-904), crop, auto-rotate and ICC are outside the
- * path this round: images that need them are refused.
+ * Images with alpha are premultiplied around the resize (thumbnail.c:848-904).  Crop,
+ * auto-rotate and ICC are outside the path: images that need them are refused.
  */
 VIPS_HIP_API int vips_hip_thumbnail_image(VipsHipImage *in, VipsHipImage **out,
 	int width, int height, int size, int linear);
@@ -393,6 +401,10 @@ VIPS_HIP_API int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out,
 	double sigma, double x1, double y2, double y3, double m1, double m2);
 VIPS_HIP_API int vips_hip_colourspace(VipsHipImage *in, VipsHipImage **out, int space);
 VIPS_HIP_API int vips_hip_cast(VipsHipImage *in, VipsHipImage **out, int format);
+/* vips_premultiply / vips_unpremultiply with max_alpha from the interpretation
+ * (premultiply.c:246-250) and alpha = the last band. */
+VIPS_HIP_API int vips_hip_premultiply(VipsHipImage *in, VipsHipImage **out, int uchar);
+VIPS_HIP_API int vips_hip_unpremultiply(VipsHipImage *in, VipsHipImage **out, int uchar);
 
 #ifdef __cplusplus
 }

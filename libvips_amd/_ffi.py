@@ -122,6 +122,7 @@ _SIGNATURES = {
     "vips_hip_colour_gen": (c_int, [c_int, RegionP, RegionP]),
     "vips_hip_colour_route_gen": (c_int, [P(c_int), c_int, c_double, RegionP, RegionP]),
     "vips_hip_cast_gen": (c_int, [RegionP, RegionP]),
+    "vips_hip_premultiply_gen": (c_int, [RegionP, RegionP, c_double, c_int, c_int]),
     "vips_hip_sharpen_gen": (c_int, [c_void_p, RegionP, RegionP, RegionP]),
     # images
     "vips_hip_image_new": (c_void_p, [c_int, c_int, c_int, c_int, c_int]),
@@ -153,6 +154,8 @@ _SIGNATURES = {
     "vips_hip_sharpen": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_double, c_double, c_double, c_double]),
     "vips_hip_colourspace": (c_int, [c_void_p, P(c_void_p), c_int]),
     "vips_hip_cast": (c_int, [c_void_p, P(c_void_p), c_int]),
+    "vips_hip_premultiply": (c_int, [c_void_p, P(c_void_p), c_int]),
+    "vips_hip_unpremultiply": (c_int, [c_void_p, P(c_void_p), c_int]),
 }
 
 MISSING = []

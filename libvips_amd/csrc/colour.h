@@ -16,4 +16,7 @@ int band_cast(const VipsHipRegion *in, int in_first, const VipsHipRegion *out, i
 int colour_route(const int *steps, int n_steps, double alpha_scale, const VipsHipRegion *in,
 	const VipsHipRegion *out);
 
+int premultiply_region(const VipsHipRegion *in, const VipsHipRegion *out, double max_alpha, int uchar,
+	int inverse);
+
 } // namespace vh

@@ -726,6 +726,167 @@ sharpen_kernel(SharpenArgs a)
 	}
 }
 
+// ------------------------------------------------- premultiply / unpremultiply
+
+struct PremulArgs {
+	const unsigned char *in;
+	unsigned char *out;
+	long long in_stride, out_stride;
+	int width, height, bands;
+	double max_alpha;
+	int scale[256]; // the uchar fast path's table (premultiply.c:252-258, unpremultiply.c:316-323)
+};
+
+// fast uchar -> uchar path: premultiply.c:163-176, unpremultiply.c:222-235
+__global__ void __launch_bounds__(256)
+premul_u8_kernel(PremulArgs a)
+{
+	__shared__ int scale[256];
+	scale[threadIdx.x] = a.scale[threadIdx.x];
+	__syncthreads();
+	const int x = blockIdx.x * blockDim.x + threadIdx.x;
+	if (x >= a.width)
+		return;
+	for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
+		const unsigned char *p = a.in + (long long) y * a.in_stride + (long long) x * a.bands;
+		unsigned char *q = a.out + (long long) y * a.out_stride + (long long) x * a.bands;
+		if (a.bands == 4) {
+			const unsigned int v = *reinterpret_cast<const unsigned int *>(p);
+			const unsigned int alpha = v >> 24;
+			const int s = scale[alpha];
+			const unsigned int r = ((int) (v & 0xff) * s + 128) >> 8;
+			const unsigned int g = ((int) ((v >> 8) & 0xff) * s + 128) >> 8;
+			const unsigned int b = ((int) ((v >> 16) & 0xff) * s + 128) >> 8;
+			*reinterpret_cast<unsigned int *>(q) =
+				(r & 0xff) | ((g & 0xff) << 8) | ((b & 0xff) << 16) | (alpha << 24);
+		}
+		else {
+			const int alpha = p[a.bands - 1];
+			const int s = scale[alpha];
+			for (int i = 0; i < a.bands - 1; i++)
+				q[i] = (unsigned char) ((p[i] * s + 128) >> 8);
+			q[a.bands - 1] = (unsigned char) alpha;
+		}
+	}
+}
+
+// PRE_MANY / PRE_RGBA (premultiply.c:78-128) and UNPRE / FUNPRE (unpremultiply.c:85-186),
+// float output.
+template <typename TIN, bool INVERSE>
+__global__ void __launch_bounds__(256)
+premul_float_kernel(PremulArgs a)
+{
+	const int x = blockIdx.x * blockDim.x + threadIdx.x;
+	if (x >= a.width)
+		return;
+	const int ab = a.bands - 1;
+	for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
+		const TIN *p = (const TIN *) (a.in + (long long) y * a.in_stride) + (long long) x * a.bands;
+		float *q = (float *) (a.out + (long long) y * a.out_stride) + (long long) x * a.bands;
+		const TIN alpha = p[ab];
+		// VIPS_CLIP(0, alpha, max_alpha) is evaluated in double
+		double clip = (double) alpha;
+		clip = a.max_alpha < clip ? a.max_alpha : clip;
+		clip = 0.0 > clip ? 0.0 : clip;
+		if (!INVERSE) {
+			// IN clip_alpha = CLIP(...); OUT nalpha = (OUT) clip_alpha / max_alpha
+			const TIN clip_alpha = (TIN) clip;
+			const float nalpha = (float) __ddiv_rn((double) (float) clip_alpha, a.max_alpha);
+			for (int i = 0; i < ab; i++)
+				q[i] = __fmul_rn((float) p[i], nalpha);
+			q[ab] = (float) alpha;
+		}
+		else {
+			float factor;
+			if (sizeof(TIN) == 4 && ((TIN) 0.5f != (TIN) 0)) // float input: FUNPRE
+				factor = fabs((double) alpha) < 0.01 ? 0.0f : (float) __ddiv_rn(a.max_alpha, (double) alpha);
+			else
+				factor = alpha == (TIN) 0 ? 0.0f : (float) __ddiv_rn(a.max_alpha, (double) alpha);
+			for (int i = 0; i < ab; i++)
+				q[i] = __fmul_rn(factor, (float) p[i]);
+			q[ab] = (float) clip;
+		}
+	}
+}
+
+int premultiply_region(const VipsHipRegion *in, const VipsHipRegion *out, double max_alpha, int uchar,
+	int inverse)
+{
+	const char *domain = inverse ? "unpremultiply" : "premultiply";
+	if (ensure_init())
+		return -1;
+	if (check_region(domain, in) || check_region(domain, out))
+		return -1;
+	if (in->bands != out->bands || in->bands < 2) {
+		error(domain, "need the same number of bands (at least 2) in and out");
+		return -1;
+	}
+	if (out->left < in->left || out->top < in->top ||
+		out->left + out->width > in->left + in->width ||
+		out->top + out->height > in->top + in->height) {
+		error(domain, "input region too small");
+		return -1;
+	}
+	const bool fast = uchar && in->format == VIPS_HIP_FORMAT_UCHAR;
+	if (out->format != (fast ? VIPS_HIP_FORMAT_UCHAR : VIPS_HIP_FORMAT_FLOAT)) {
+		error(domain, "output region has the wrong format");
+		return -1;
+	}
+	PremulArgs a;
+	const int ies = format_sizeof(in->format);
+	a.in = (const unsigned char *) in->data + (size_t) (out->top - in->top) * in->stride +
+		(size_t) (out->left - in->left) * in->bands * ies;
+	a.out = (unsigned char *) out->data;
+	a.in_stride = (long long) in->stride;
+	a.out_stride = (long long) out->stride;
+	a.width = out->width;
+	a.height = out->height;
+	a.bands = in->bands;
+	a.max_alpha = max_alpha;
+	for (int i = 0; i < 256; i++) {
+		double clip = (double) i;
+		clip = max_alpha < clip ? max_alpha : clip;
+		clip = 0.0 > clip ? 0.0 : clip;
+		if (inverse)
+			a.scale[i] = clip == 0 ? 0 : (int) (256 * max_alpha / clip);
+		else
+			a.scale[i] = (int) (256 * clip / max_alpha);
+	}
+	dim3 block(256, 1, 1);
+	dim3 grid((a.width + 255) / 256, a.height < 32768 ? a.height : 32768, 1);
+	Gate gate(inverse ? "unpremultiply" : "premultiply");
+	if (fast) {
+		if (a.bands == 4 && (((uintptr_t) a.in | (uintptr_t) a.out | a.in_stride | a.out_stride) & 3)) {
+			error(domain, "RGBA rows must be 4-byte aligned");
+			return -1;
+		}
+		hipLaunchKernelGGL(premul_u8_kernel, grid, block, 0, stream(), a);
+	}
+	else {
+#define GO(TIN) \
+	if (inverse) \
+		hipLaunchKernelGGL((premul_float_kernel<TIN, true>), grid, block, 0, stream(), a); \
+	else \
+		hipLaunchKernelGGL((premul_float_kernel<TIN, false>), grid, block, 0, stream(), a); \
+	break;
+		switch (in->format) {
+		case VIPS_HIP_FORMAT_UCHAR: GO(unsigned char)
+		case VIPS_HIP_FORMAT_CHAR: GO(signed char)
+		case VIPS_HIP_FORMAT_USHORT: GO(unsigned short)
+		case VIPS_HIP_FORMAT_SHORT: GO(short)
+		case VIPS_HIP_FORMAT_UINT: GO(unsigned int)
+		case VIPS_HIP_FORMAT_INT: GO(int)
+		case VIPS_HIP_FORMAT_FLOAT: GO(float)
+		default:
+			error(domain, "band format %d is outside the HIP path", in->format);
+			return -1;
+		}
+#undef GO
+	}
+	VH_CHECK(hipGetLastError());
+	return 0;
+}
+
 // ----------------------------------------------------------- route launcher
 
 int colour_route(const int *steps, int n_steps, double alpha_scale, const VipsHipRegion *in,
@@ -855,6 +1016,12 @@ int vips_hip_colour_route_gen(const int *steps, int n_steps, double alpha_scale,
 	const VipsHipRegion *in, const VipsHipRegion *out)
 {
 	return colour_route(steps, n_steps, alpha_scale, in, out);
+}
+
+int vips_hip_premultiply_gen(const VipsHipRegion *in, const VipsHipRegion *out, double max_alpha,
+	int uchar, int inverse)
+{
+	return premultiply_region(in, out, max_alpha, uchar, inverse);
 }
 
 int vips_hip_cast_gen(const VipsHipRegion *in, const VipsHipRegion *out)

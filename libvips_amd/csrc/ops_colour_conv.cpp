@@ -332,6 +332,40 @@ int vips_hip_cast(VipsHipImage *in, VipsHipImage **out, int format)
 	return cast_image(in, out, format);
 }
 
+static int premultiply_image(VipsHipImage *in, VipsHipImage **out, int uchar, int inverse)
+{
+	const char *domain = inverse ? "unpremultiply" : "premultiply";
+	if (in->bands == 1) { // "Trivial case: fall back to copy()."
+		return cast_image(in, out, in->format);
+	}
+	if (in->format == VIPS_HIP_FORMAT_DOUBLE) {
+		error(domain, "double images are outside the HIP path");
+		return -1;
+	}
+	const bool fast = uchar && in->format == VIPS_HIP_FORMAT_UCHAR;
+	ImageRef o(vips_hip_image_new(in->width, in->height, in->bands,
+		fast ? VIPS_HIP_FORMAT_UCHAR : VIPS_HIP_FORMAT_FLOAT, in->interpretation));
+	if (!o.im)
+		return -1;
+	VipsHipRegion ri, ro;
+	vips_hip_image_region(in, &ri);
+	vips_hip_image_region(o.im, &ro);
+	if (vips_hip_premultiply_gen(&ri, &ro, max_alpha(in->interpretation), uchar, inverse))
+		return -1;
+	*out = o.release();
+	return 0;
+}
+
+int vips_hip_premultiply(VipsHipImage *in, VipsHipImage **out, int uchar)
+{
+	return premultiply_image(in, out, uchar, 0);
+}
+
+int vips_hip_unpremultiply(VipsHipImage *in, VipsHipImage **out, int uchar)
+{
+	return premultiply_image(in, out, uchar, 1);
+}
+
 // vips_colourspace_build, colour/colourspace.c:551-612
 int vips_hip_colourspace(VipsHipImage *in, VipsHipImage **out, int space)
 {
@@ -470,15 +504,36 @@ int vips_hip_thumbnail_image(VipsHipImage *in, VipsHipImage **out, int width, in
 	hshrink = hshrink < cur->width ? hshrink : cur->width;
 	vshrink = vshrink < cur->height ? vshrink : cur->height;
 
-	// vips_image_hasalpha: premultiply before shrinking (thumbnail.c:848-860)
+	// vips_image_hasalpha: premultiply before shrinking (thumbnail.c:848-860), staying in
+	// uchar when the image is uchar
+	int unpremultiplied_format = -1;
+	ImageRef pre;
 	if (cur->bands > 3 && hshrink != 1.0 && vshrink != 1.0) {
-		error(domain, "images with alpha need vips_premultiply, which is outside the HIP path");
-		return -1;
+		unpremultiplied_format = cur->format;
+		if (vips_hip_premultiply(cur, &pre.im, cur->format == VIPS_HIP_FORMAT_UCHAR))
+			return -1;
+		cur = pre.im;
 	}
 
 	ImageRef resized;
 	if (vips_hip_resize(cur, &resized.im, 1.0 / hshrink, 1.0 / vshrink, VIPS_HIP_KERNEL_LANCZOS3, 2.0))
 		return -1;
+
+	if (unpremultiplied_format >= 0) { // thumbnail.c:886-904
+		ImageRef un;
+		if (unpremultiplied_format == VIPS_HIP_FORMAT_UCHAR) {
+			if (vips_hip_unpremultiply(resized.im, &un.im, 1))
+				return -1;
+		}
+		else {
+			ImageRef f;
+			if (vips_hip_unpremultiply(resized.im, &f.im, 0) ||
+				vips_hip_cast(f.im, &un.im, unpremultiplied_format))
+				return -1;
+		}
+		vips_hip_image_unref(resized.im);
+		resized.im = un.release();
+	}
 
 	if (linear) // thumbnail.c:973-987: back to sRGB
 		return vips_hip_colourspace(resized.im, out, VIPS_HIP_INTERPRETATION_sRGB);

@@ -260,6 +260,12 @@ class Image(object):
     def colourspace(self, space):
         return self._unary(lib.vips_hip_colourspace, _enum(INTERPRETATIONS, space, "interpretation"))
 
+    def premultiply(self, uchar=False):
+        return self._unary(lib.vips_hip_premultiply, int(bool(uchar)))
+
+    def unpremultiply(self, uchar=False):
+        return self._unary(lib.vips_hip_unpremultiply, int(bool(uchar)))
+
     def cast(self, format):
         return self._unary(lib.vips_hip_cast, _enum(FORMATS, format, "format"))
 

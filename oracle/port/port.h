@@ -68,5 +68,7 @@ void port_scRGB2sRGB_16(const float *p, int n, unsigned short *q);
 void port_Lab2LabS(const float *p, int n, short *q);
 void port_LabS2Lab(const short *p, int n, float *q);
 int port_cast(const void *in, size_t n, int in_format, int out_format, void *out);
+int port_premultiply(const void *in, size_t n, int bands, int format, double max_alpha,
+	int uchar_fast, int inverse, void *out);
 
 #endif

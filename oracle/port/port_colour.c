@@ -361,3 +361,73 @@ port_cast(const void *in, size_t n, int in_format, int out_format, void *out)
 	}
 	return 0;
 }
+
+/* premultiply / unpremultiply: conversion/premultiply.c:78-128,163-176,252-258 and
+ * conversion/unpremultiply.c:85-186,222-235,316-323.  The last band is alpha.
+ * uchar_fast: the uchar -> uchar fixed-point path; else the output is float.
+ * Real, non-double formats.
+ */
+#define PREMUL(IN) \
+	for (size_t x = 0; x < n; x++) { \
+		const IN *p = (const IN *) in + x * bands; \
+		float *q = (float *) out + x * bands; \
+		IN alpha = p[bands - 1]; \
+		if (!inverse) { \
+			IN clip_alpha = VCLIP(0, alpha, max_alpha); \
+			float nalpha = (float) clip_alpha / max_alpha; \
+			for (int i = 0; i < bands - 1; i++) \
+				q[i] = p[i] * nalpha; \
+			q[bands - 1] = alpha; \
+		} \
+		else { \
+			float factor = is_float \
+				? (fabs(alpha) < 0.01 ? 0 : max_alpha / alpha) \
+				: (alpha == 0 ? 0 : max_alpha / alpha); \
+			for (int i = 0; i < bands - 1; i++) \
+				q[i] = factor * p[i]; \
+			q[bands - 1] = VCLIP(0, alpha, max_alpha); \
+		} \
+	}
+
+int
+port_premultiply(const void *in, size_t n, int bands, int format, double max_alpha, int uchar_fast,
+	int inverse, void *out)
+{
+	if (uchar_fast && format == PORT_FORMAT_UCHAR) {
+		int scale[256];
+
+		for (int i = 0; i < 256; i++) {
+			double clip = VCLIP(0, i, max_alpha);
+
+			if (inverse)
+				scale[i] = clip == 0 ? 0 : 256 * max_alpha / clip;
+			else
+				scale[i] = 256 * clip / max_alpha;
+		}
+		for (size_t x = 0; x < n; x++) {
+			const unsigned char *p = (const unsigned char *) in + x * bands;
+			unsigned char *q = (unsigned char *) out + x * bands;
+			unsigned char alpha = p[bands - 1];
+			int s = scale[alpha];
+			int i;
+
+			for (i = 0; i < bands - 1; i++)
+				q[i] = (p[i] * s + 128) >> 8;
+			q[i] = alpha;
+		}
+		return 0;
+	}
+
+	const int is_float = format == PORT_FORMAT_FLOAT;
+	switch (format) {
+	case PORT_FORMAT_UCHAR: PREMUL(unsigned char); break;
+	case PORT_FORMAT_CHAR: PREMUL(signed char); break;
+	case PORT_FORMAT_USHORT: PREMUL(unsigned short); break;
+	case PORT_FORMAT_SHORT: PREMUL(short); break;
+	case PORT_FORMAT_UINT: PREMUL(unsigned int); break;
+	case PORT_FORMAT_INT: PREMUL(int); break;
+	case PORT_FORMAT_FLOAT: PREMUL(float); break;
+	default: return -1;
+	}
+	return 0;
+}

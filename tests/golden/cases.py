@@ -141,6 +141,30 @@ _cc("thumbnail|force", kind="op", op="thumbnail_image", args="width=100,height=4
 _cc("thumbnail|linear", kind="op", op="thumbnail_image", args="width=90,linear=true",
     method="thumbnail_image", kwargs=dict(width=90, linear=True), width=517, height=389, bands=3,
     dtype=np.dtype(np.uint8), seed=45, interp="srgb")
+# alpha: premultiply / unpremultiply and the RGBA thumbnail around them
+for _dtype in (np.uint8, np.uint16, np.int16, np.float32):
+    for _uchar in (False, True):
+        _cc("premultiply|%s|%d" % (np.dtype(_dtype).name, _uchar), kind="op", op="premultiply",
+            args="uchar=%s" % ("true" if _uchar else "false"), method="premultiply",
+            kwargs=dict(uchar=_uchar), width=45, height=31, bands=4, dtype=np.dtype(_dtype), seed=46,
+            interp="srgb")
+        if _uchar and _dtype != np.uint8:
+            # vips_unpremultiply_gen takes its uchar loop whenever the flag is set, whatever
+            # the format (unpremultiply.c:222): undefined on non-uchar data, not a parity case
+            continue
+        _cc("unpremultiply|%s|%d" % (np.dtype(_dtype).name, _uchar), kind="op", op="unpremultiply",
+            args="uchar=%s" % ("true" if _uchar else "false"), method="unpremultiply",
+            kwargs=dict(uchar=_uchar), width=45, height=31, bands=4, dtype=np.dtype(_dtype), seed=47,
+            interp="srgb")
+_cc("premultiply|uint8|5band", kind="op", op="premultiply", args="uchar=true", method="premultiply",
+    kwargs=dict(uchar=True), width=33, height=21, bands=5, dtype=np.dtype(np.uint8), seed=48,
+    interp="multiband")
+_cc("thumbnail|rgba", kind="op", op="thumbnail_image", args="width=100", method="thumbnail_image",
+    kwargs=dict(width=100), width=517, height=389, bands=4, dtype=np.dtype(np.uint8), seed=49,
+    interp="srgb")
+_cc("thumbnail|rgba16-linear", kind="op", op="thumbnail_image", args="width=80,linear=true",
+    method="thumbnail_image", kwargs=dict(width=80, linear=True), width=400, height=300, bands=4,
+    dtype=np.dtype(np.uint8), seed=50, interp="srgb")
 _FMT = {"uint8": "uchar", "int8": "char", "uint16": "ushort", "int16": "short", "uint32": "uint",
         "int32": "int", "float32": "float", "float64": "double"}
 for _a in (np.uint8, np.int16, np.uint32, np.float32, np.float64):

@@ -365,6 +365,7 @@ def _port_conv_setup(lib):
         getattr(lib, name).argtypes = [vp, ci, vp]
         getattr(lib, name).restype = None
     lib.port_cast.argtypes = [vp, ctypes.c_size_t, ci, ci, vp]
+    lib.port_premultiply.argtypes = [vp, ctypes.c_size_t, ci, ci, cd, ci, ci, vp]
     lib._conv_ready = True
 
 
@@ -499,9 +500,24 @@ class PortCC(object):
         return a
 
     @classmethod
+    def premultiply(cls, array, interpretation="srgb", uchar=False, inverse=False):
+        """vips_premultiply / vips_unpremultiply, alpha = last band, default max_alpha."""
+        a = Port._prep(array)
+        h, w, b = a.shape
+        fast = uchar and a.dtype == np.uint8
+        out = np.empty(a.shape, dtype=np.uint8 if fast else np.float32)
+        r = cls.lib().port_premultiply(a.ctypes.data, h * w, b, DTYPE_FORMATS[a.dtype],
+                                       cls._MAX_ALPHA.get(interpretation, 255.0), int(uchar), int(inverse),
+                                       out.ctypes.data)
+        if r != 0:
+            raise RuntimeError("port premultiply failed")
+        return out
+
+    @classmethod
     def thumbnail_image(cls, array, interpretation, width, height=None, size="both", linear=False):
-        """vips_thumbnail_image (thumbnail.c:678-1067, shrink :413-467), no alpha / crop / ICC."""
+        """vips_thumbnail_image (thumbnail.c:678-1067, shrink :413-467), no crop / ICC."""
         a = cls.colourspace(array, "scrgb" if linear else "srgb", interpretation)
+        space = "scrgb" if linear else "srgb"
         h, w, _ = a.shape
         height = height or width
         hshrink, vshrink = w / width, h / height
@@ -515,7 +531,16 @@ class PortCC(object):
         elif size == "down":
             hshrink, vshrink = max(1, hshrink), max(1, vshrink)
         hshrink, vshrink = min(hshrink, w), min(vshrink, h)
+        fmt = None
+        if a.shape[2] > 3 and hshrink != 1.0 and vshrink != 1.0:  # vips_image_hasalpha
+            fmt = a.dtype
+            a = cls.premultiply(a, space, uchar=(a.dtype == np.uint8))
         out = Port.resize(a, 1.0 / hshrink, 1.0 / vshrink)
+        if fmt is not None:
+            if fmt == np.uint8:
+                out = cls.premultiply(out, space, uchar=True, inverse=True)
+            else:
+                out = cls.cast(cls.premultiply(out, space, inverse=True), fmt)
         if linear:
             out = cls.colourspace(out, "srgb", "scrgb")
         return out

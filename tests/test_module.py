@@ -13,7 +13,7 @@ needs_module = pytest.mark.skipif(not helpers.have_module(), reason="oracle/_ref
 
 HIP_OPS = ["reduce_hip", "reduceh_hip", "reducev_hip", "shrink_hip", "shrinkh_hip", "shrinkv_hip",
            "resize_hip", "thumbnail_image_hip", "conv_hip", "convsep_hip", "gaussblur_hip", "sharpen_hip", "colourspace_hip",
-           "cast_hip"]
+           "cast_hip", "premultiply_hip", "unpremultiply_hip"]
 
 
 @needs_module
@@ -68,6 +68,14 @@ class TestModuleOnGpu(object):
             self.same("shrinkv_hip", "shrinkv", src, "vshrink=5")
             self.same("resize_hip", "resize", src, "scale=0.125")
             self.same("resize_hip", "resize", src, "scale=0.3,vscale=0.21,kernel=mitchell")
+
+    def test_alpha(self):
+        srgb = cases.INTERP["srgb"]
+        src = helpers.lcg_image(400, 300, 4, np.uint8, 79)
+        self.same("premultiply_hip", "premultiply", src, "uchar=true", srgb)
+        self.same("premultiply_hip", "premultiply", src, "", srgb)
+        self.same("unpremultiply_hip", "unpremultiply", src, "uchar=true", srgb)
+        self.same("thumbnail_image_hip", "thumbnail_image", src, "width=100", srgb)
 
     def test_thumbnail(self):
         srgb = cases.INTERP["srgb"]

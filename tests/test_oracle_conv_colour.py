@@ -23,6 +23,9 @@ def port_call(case, src):
         return PortCC.colourspace(src, kw["space"], case["interp"])
     if case["method"] == "sharpen":
         return PortCC.sharpen(src, case["interp"], **kw)
+    if case["method"] in ("premultiply", "unpremultiply"):
+        return PortCC.premultiply(src, case["interp"], uchar=kw["uchar"],
+                                  inverse=case["method"] == "unpremultiply")
     if case["method"] == "thumbnail_image":
         return PortCC.thumbnail_image(src, case["interp"], **kw)
     if case["method"] == "cast":
