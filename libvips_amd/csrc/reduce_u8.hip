@@ -27,6 +27,9 @@
 // the summation order; rounding/clipping is templates.h:152-157.
 #include "reduce_u8.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace vh {
 
 typedef short short2v __attribute__((ext_vector_type(2)));
@@ -67,6 +70,8 @@ struct FusedArgs {
 	int owt, oht;              // tile size in output pixels
 	int tiles_x, tiles;
 	int aligned8;           // input base and stride are multiples of 8 bytes
+	int small_window;       // the input window spans < 2 GB: 32-bit byte offsets are safe
+	int debug;              // VIPS_HIP_FUSED_DEBUG ablation bits (profiling only; 0 in production)
 };
 
 // Coefficients travel BY VALUE in the kernel-argument segment: they are read with
@@ -307,6 +312,341 @@ reduce_fused_u8x4(FusedArgs a, FusedCoefs<S, D> k_by_value)
 	}
 }
 
+// ------------------------------------------------ both passes on the matrix cores
+//
+// reduce_fused_u8x4_mfma<D, NB> (S = 8): the same tiles and thread <-> column mapping as
+// reduce_fused_u8x4, but every tap runs on the MFMA pipe with v_mfma_f32_4x4x4_16b_f16
+// (16 independent 4x4x4 blocks, block = 4 lanes):
+//
+//   B[k][j]  lane j of the block supplies 4 halves = ITS OWN column's bytes of input rows
+//            k = 0..3 (a quad of the 8-row group) -- lanes keep their columns, no shuffles
+//   A[i][k]  lane i of the block supplies the coefficients of accumulator row i for
+//            those 4 rows (the same in all 16 blocks)
+//   D[i][j]  lane j, register i: 4 of the 8 live output rows of lane j's column
+//
+// so one instruction does 16 multiply-adds per lane (v_dot2: 2) on a pipe that the rest of
+// the kernel leaves idle.  Exactness: a pixel byte p is used as the f16 DENORMAL with bit
+// pattern 0x00pp = p * 2^-24 (one v_perm, no conversion; the MFMA honours f16 denormals,
+// tools/mfma_probe.hip), coefficients (|c| < 2048) are exact halves, products are exact in
+// f32 and every partial sum is (an integer below 2^23) * 2^-24, so the f32 accumulator holds
+// exactly n * 2^-24 with n = sum c * p.  Retire: y = fma(acc, 2^12, 2^-13) = n / 4096 + 2^-13
+// exactly, and v_cvt_pk_u8_f32 (round to nearest, saturate 0..255; the 2^-13 turns every
+// tie into "up") gives clip((n + 2048) >> 12) -- reduceh.cpp:120-141's rounding -- and
+// packs the byte, two instructions per sample.  The host checks the bounds and otherwise
+// keeps the VALU kernel.
+//
+// 8 accumulator rows ("slots") per column rotate through the D <= 8 tap groups: at group g
+// (ROT = g mod 8) slot s is d = (ROT - s) mod 8 groups old (d >= D: idle, zero coefficients).
+// ROT is a template argument; the A operands come from a 1 KB LDS table indexed by it.
+// The horizontal pass is the same computation along x on the u8 T planes in LDS.
+//
+// Output rows are staged in LDS for the whole tile and written in one burst at its end: on
+// this part a 1.5 % stream of writes trickling into a streaming read costs 13 % of the
+// read rate (tools/write_probe.hip: 0.175 -> 0.198 ms per GiB), a burst at the end 4 %.
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+constexpr int MFMA_SLOTS = 8;
+
+struct MfmaTables {
+	// [flip][ROT 8][quad 2][half 2][row 4] x 4 halves
+	unsigned short a[2][MFMA_SLOTS * 2 * 2 * 4 * 4];
+	unsigned short ah[MFMA_SLOTS * 2 * 2 * 4 * 4]; // the same for the horizontal taps
+};
+
+constexpr int MFMA_TABLE_ENTRIES = MFMA_SLOTS * 2 * 2 * 4; // half4v entries per table
+constexpr int HSEG_OUT = 8;                                // outputs per horizontal segment
+// bytes per (row, channel) T plane: 512 samples + 4, so that the 32 planes a half-wave of the
+// horizontal pass reads (8 rows x 4 channels, one dword each) fall in 32 distinct banks
+constexpr int MFMA_PLANE = FUSED_SPAN + 4;
+constexpr int MFMA_PLANES_BYTES = MFMA_SLOTS * 4 * MFMA_PLANE;
+constexpr int MFMA_STAGE_PITCH = 60; // dwords per staged output row (owt <= 59)
+constexpr int MFMA_MAX_OHT = 88;     // 4 blocks per CU: (160 KB / 4) - planes - tables
+
+static constexpr size_t mfma_lds_bytes(int oht)
+{
+	return (size_t) MFMA_PLANES_BYTES + 2 * MFMA_TABLE_ENTRIES * 8 + (size_t) oht * MFMA_STAGE_PITCH * 4;
+}
+
+template <int D>
+struct MfmaStep {
+	static constexpr int S = 8;
+
+	// Rows first_row + dir * i, I0 <= i < I0 + N.  The launcher only picks this kernel for
+	// windows < 2 GB, so every address is the uniform base (an SGPR pair) plus one 32-bit lane
+	// offset: the saddr form of global_load, no 64-bit VALU address arithmetic.  Interior
+	// tiles fetch their two pixels as one dwordx2; edge tiles clamp each column.
+	template <int I0, int N>
+	static __device__ __forceinline__ void load_rows(const FusedArgs &a, uint2 (&px)[S], int first_row,
+		int dir, int ca, int cb, bool interior)
+	{
+		const unsigned int stride32 = (unsigned int) a.in_stride;
+		if (interior) {
+#pragma unroll
+			for (int i = I0; i < I0 + N; i++) {
+				const int row = min(max(first_row + dir * i, 0), a.im_height - 1) - a.in_top;
+				const unsigned int off = (unsigned int) row * stride32 + (unsigned int) (4 * ca);
+				px[i] = *reinterpret_cast<const uint2 *>(a.in + (size_t) off);
+			}
+		}
+		else {
+#pragma unroll
+			for (int i = I0; i < I0 + N; i++) {
+				const int row = min(max(first_row + dir * i, 0), a.im_height - 1) - a.in_top;
+				const unsigned int base = (unsigned int) row * stride32;
+				px[i].x = *reinterpret_cast<const unsigned int *>(a.in + (size_t) (base + (unsigned int) (4 * ca)));
+				px[i].y = *reinterpret_cast<const unsigned int *>(a.in + (size_t) (base + (unsigned int) (4 * cb)));
+			}
+		}
+	}
+
+	// channel C of rows r0..r3 as four f16 denormals
+	template <int C>
+	static __device__ __forceinline__ half4v make_b(unsigned int r0, unsigned int r1, unsigned int r2,
+		unsigned int r3)
+	{
+		constexpr unsigned int sel = 0x0c000c00u | (unsigned) C | ((4u + C) << 16);
+		uint2 v;
+		v.x = __builtin_amdgcn_perm(r1, r0, sel);
+		v.y = __builtin_amdgcn_perm(r3, r2, sel);
+		return __builtin_bit_cast(half4v, v);
+	}
+
+	// four consecutive T bytes as four f16 denormals
+	static __device__ __forceinline__ half4v bytes_b(unsigned int w)
+	{
+		uint2 v;
+		v.x = __builtin_amdgcn_perm(0u, w, 0x0c010c00u);
+		v.y = __builtin_amdgcn_perm(0u, w, 0x0c030c02u);
+		return __builtin_bit_cast(half4v, v);
+	}
+
+	// acc = n * 2^-24 -> clip((n + 2048) >> 12) into byte `byte` of `old`
+	static __device__ __forceinline__ unsigned int fin_pack(float acc, unsigned int byte, unsigned int old)
+	{
+		return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(acc, 4096.0f, 0x1p-13f), byte, old);
+	}
+
+	// One quad (rows 4*Q .. 4*Q+3 of the group) of both pixels; once its B operands exist the
+	// quad's buffer registers are refilled with the rows of group g + NB.
+	template <int ROT, int Q>
+	static __device__ __forceinline__ void quad(const FusedArgs &a, uint2 (&px)[S], float4v (&acc)[8][2],
+		const half4v *lane_a /* &table[lane & 3] */, bool more, int next_row, int dir, int ca, int cb,
+		bool interior)
+	{
+		const half4v a0 = lane_a[((ROT * 2 + Q) * 2 + 0) * 4];
+		const half4v a1 = lane_a[((ROT * 2 + Q) * 2 + 1) * 4];
+#pragma unroll
+		for (int p = 0; p < 2; p++) {
+			const unsigned int r0 = p ? px[4 * Q + 0].y : px[4 * Q + 0].x;
+			const unsigned int r1 = p ? px[4 * Q + 1].y : px[4 * Q + 1].x;
+			const unsigned int r2 = p ? px[4 * Q + 2].y : px[4 * Q + 2].x;
+			const unsigned int r3 = p ? px[4 * Q + 3].y : px[4 * Q + 3].x;
+			half4v b[4];
+			b[0] = make_b<0>(r0, r1, r2, r3);
+			b[1] = make_b<1>(r0, r1, r2, r3);
+			b[2] = make_b<2>(r0, r1, r2, r3);
+			b[3] = make_b<3>(r0, r1, r2, r3);
+			if (p == 1 && more)
+				load_rows<4 * Q, 4>(a, px, next_row, dir, ca, cb, interior);
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				acc[p * 4 + c][0] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, b[c], acc[p * 4 + c][0], 0, 0, 0);
+				acc[p * 4 + c][1] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, b[c], acc[p * 4 + c][1], 0, 0, 0);
+			}
+		}
+	}
+
+	// Slot (ROT - (D - 1)) mod 8 has seen all its taps: round it into T row `lds_row`.
+	template <int ROT>
+	static __device__ __forceinline__ void retire(float4v (&acc)[8][2], unsigned char *planes, int lds_row,
+		int t, bool store)
+	{
+		constexpr int SLOT = (ROT - (D - 1) + 2 * MFMA_SLOTS) % MFMA_SLOTS;
+		constexpr int H = SLOT >> 2, I = SLOT & 3;
+		if (store) {
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				const unsigned int v = fin_pack(acc[4 + c][H][I], 1, fin_pack(acc[c][H][I], 0, 0));
+				*reinterpret_cast<unsigned short *>(planes + (lds_row * 4 + c) * MFMA_PLANE + 2 * t) =
+					(unsigned short) v;
+			}
+		}
+#pragma unroll
+		for (int o = 0; o < 8; o++)
+			acc[o][H][I] = 0.0f;
+	}
+
+	// The horizontal pass is the same computation along x: a lane owns one (row, channel)
+	// line segment of the T planes and walks it in groups of 8 samples; sample group G
+	// is d = (G - s) mod 8 groups into output xo = first + s, one output retires per group.
+	// The four channel lanes of a quad OR their bytes together (two quad_perm DPP moves)
+	// and lane O / 2 keeps the RGBA pixel of output O.
+	template <int G>
+	static __device__ __forceinline__ void hwalk(float4v (&hacc)[2], const unsigned char *line,
+		const half4v *lane_ah, int hc, unsigned int (&pix)[2])
+	{
+		constexpr int NG = HSEG_OUT + D - 1;
+		if constexpr (G < NG) {
+			constexpr int ROT = G % MFMA_SLOTS;
+			const half4v b0 = bytes_b(*reinterpret_cast<const unsigned int *>(line + 8 * G));
+			const half4v b1 = bytes_b(*reinterpret_cast<const unsigned int *>(line + 8 * G + 4));
+			hacc[0] = __builtin_amdgcn_mfma_f32_4x4x4f16(lane_ah[((ROT * 2 + 0) * 2 + 0) * 4], b0, hacc[0], 0, 0, 0);
+			hacc[1] = __builtin_amdgcn_mfma_f32_4x4x4f16(lane_ah[((ROT * 2 + 0) * 2 + 1) * 4], b0, hacc[1], 0, 0, 0);
+			hacc[0] = __builtin_amdgcn_mfma_f32_4x4x4f16(lane_ah[((ROT * 2 + 1) * 2 + 0) * 4], b1, hacc[0], 0, 0, 0);
+			hacc[1] = __builtin_amdgcn_mfma_f32_4x4x4f16(lane_ah[((ROT * 2 + 1) * 2 + 1) * 4], b1, hacc[1], 0, 0, 0);
+			constexpr int SLOT = (ROT - (D - 1) + 2 * MFMA_SLOTS) % MFMA_SLOTS;
+			constexpr int H = SLOT >> 2, I = SLOT & 3;
+			if constexpr (G >= D - 1) {
+				constexpr int O = G - (D - 1);
+				int v = (int) fin_pack(hacc[H][I], (unsigned int) hc, 0);
+				v |= __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
+				v |= __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
+				if (hc == O / 2)
+					pix[O & 1] = (unsigned int) v;
+			}
+			hacc[H][I] = 0.0f;
+			if constexpr ((G & 1) == 1)
+				__builtin_amdgcn_sched_barrier(0); // keep the unrolled walk's LDS reads from piling up
+			hwalk<G + 1>(hacc, line, lane_ah, hc, pix);
+		}
+	}
+
+	// NB = prefetch depth: group g lives in ring buffer g mod NB (NB divides 8, so the index is
+	// static) and each of its quads is refilled with group g + NB as soon as it has been consumed.
+	template <int ROT, int NB>
+	static __device__ __forceinline__ void batch(const FusedArgs &a, uint2 (&px)[NB][S], int g0, int ngroups,
+		float4v (&acc)[8][2], unsigned char *planes, const half4v *lane_a, int t, int row0, int dir, int ca,
+		int cb, bool interior, int oh)
+	{
+		if constexpr (ROT < MFMA_SLOTS) {
+			const int g = g0 + ROT;
+			if (g < ngroups) {
+				const bool more = g + NB < ngroups;
+				const int next_row = row0 + dir * S * (g + NB);
+				quad<ROT, 0>(a, px[ROT % NB], acc, lane_a, more, next_row, dir, ca, cb, interior);
+				quad<ROT, 1>(a, px[ROT % NB], acc, lane_a, more, next_row, dir, ca, cb, interior);
+				const int j = g - (D - 1);
+				retire<ROT>(acc, planes, ROT, t, j >= 0 && j < oh);
+			}
+			batch<ROT + 1, NB>(a, px, g0, ngroups, acc, planes, lane_a, t, row0, dir, ca, cb, interior, oh);
+		}
+	}
+};
+
+// Tile t of the launch -> (bx, by).  Tiles are numbered column-major and XCD k (blocks
+// b = k mod 8) takes a contiguous range of them, so both the vertical neighbours (which the
+// serpentine walk makes read their shared halo rows at the same time) and most horizontal
+// neighbours share an L2.
+template <int D, int NB, int OCC>
+__global__ void __launch_bounds__(FUSED_THREADS, OCC)
+reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
+{
+	constexpr int S = 8;
+	typedef MfmaStep<D> Step;
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	// T planes (the horizontal walker over-reads the end of a plane by up to 8 * (D - 1)
+	// samples: into the next plane / the tables -- any byte is a finite f16 denormal), the two
+	// A-operand tables, the staged output rows of the tile
+	unsigned char *planes = lds_raw;
+	half4v *lds_a = reinterpret_cast<half4v *>(lds_raw + MFMA_PLANES_BYTES);
+	half4v *lds_ah = lds_a + MFMA_TABLE_ENTRIES;
+	unsigned int *stage = reinterpret_cast<unsigned int *>(lds_ah + MFMA_TABLE_ENTRIES);
+
+	const int per_xcd = gridDim.x / 8;
+	const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+	if (tile >= a.tiles)
+		return;
+
+	const int t = threadIdx.x;
+	const int tiles_y = a.tiles / a.tiles_x;
+	const int bx = tile / tiles_y;
+	const int by = tile - bx * tiles_y;
+	const int x0 = bx * a.owt;
+	const int y0 = by * a.oht;
+	const int ow = min(a.owt, a.out_width - x0);
+	const int oh = min(a.oht, a.out_height - y0);
+
+	const int tile_col0 = a.fx0 + S * x0;
+	const int col0 = tile_col0 + 2 * t;
+	const int ca = min(max(col0, 0), a.im_width - 1) - a.in_left;
+	const int cb = min(max(col0 + 1, 0), a.im_width - 1) - a.in_left;
+	const bool interior = a.aligned8 && tile_col0 >= 0 && tile_col0 + FUSED_SPAN <= a.im_width &&
+		(((tile_col0 - a.in_left) & 1) == 0);
+	const bool flip = (by & 1) != 0;
+	const int dir = flip ? -1 : 1;
+	const int row0 = flip ? a.fy0 + S * (y0 + oh - 1) + S * D - 1 : a.fy0 + S * y0;
+
+	// the A-operand tables (vertical: this tile's walking direction), 128 entries of 4 halves
+	if (t < MFMA_TABLE_ENTRIES) {
+		reinterpret_cast<uint2 *>(lds_a)[t] = reinterpret_cast<const uint2 *>(tables->a[flip ? 1 : 0])[t];
+		reinterpret_cast<uint2 *>(lds_ah)[t] = reinterpret_cast<const uint2 *>(tables->ah)[t];
+	}
+	const half4v *lane_a = lds_a + (t & 3);
+
+	float4v acc[8][2];
+#pragma unroll
+	for (int o = 0; o < 8; o++)
+#pragma unroll
+		for (int h = 0; h < 2; h++)
+			acc[o][h] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+
+	const int ngroups = oh + D - 1;
+	uint2 px[NB][S];
+#pragma unroll
+	for (int b = 0; b < NB; b++)
+		if (b < ngroups)
+			Step::template load_rows<0, S>(a, px[b], row0 + dir * S * b, dir, ca, cb, interior);
+	__syncthreads();
+
+	for (int g0 = 0; g0 < ngroups; g0 += MFMA_SLOTS) {
+		Step::template batch<0, NB>(a, px, g0, ngroups, acc, planes, lane_a, t, row0, dir, ca, cb, interior,
+			oh);
+
+		// ---- horizontal pass over the rows this batch completed (T row r <-> group g0 + r)
+		const int jlo = max(g0 - (D - 1), 0);
+		const int jhi = min(g0 + MFMA_SLOTS - 1 - (D - 1), oh - 1); // inclusive
+		if (jhi < jlo)
+			continue;
+		__syncthreads();
+		const int nrows = jhi - jlo + 1;
+		const int r_lo = jlo - (g0 - (D - 1));
+		if (!(a.debug & 1)) {
+			// thread -> (T row, segment of HSEG_OUT outputs, channel)
+			const int hc = t & 3, hr = (t >> 2) & 7, hseg = t >> 5;
+			const half4v *lane_ah = lds_ah + hc;
+			const bool row_ok = hr < nrows;
+			const int lrow = r_lo + (row_ok ? hr : 0);
+			const unsigned char *line = planes + (lrow * 4 + hc) * MFMA_PLANE + 8 * HSEG_OUT * hseg;
+			float4v hacc[2];
+			hacc[0] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+			hacc[1] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+			unsigned int pix[2] = { 0, 0 };
+			Step::template hwalk<0>(hacc, line, lane_ah, hc, pix);
+			// lane hc of the quad holds output pixels 2*hc, 2*hc + 1 of the segment
+			const int xo = HSEG_OUT * hseg + 2 * hc;
+			if (row_ok && xo < MFMA_STAGE_PITCH) {
+				const int jj = jlo + hr;
+				unsigned int *srow = stage + (flip ? oh - 1 - jj : jj) * MFMA_STAGE_PITCH + xo;
+				*reinterpret_cast<uint2 *>(srow) = make_uint2(pix[0], pix[1]);
+			}
+		}
+		__syncthreads();
+	}
+
+	// ---- the tile's output, one burst: a wave per row, a lane per pixel
+	if (!(a.debug & 2)) {
+		const int lane = t & 63;
+		for (int row = t >> 6; row < oh; row += FUSED_THREADS / 64) {
+			if (lane < ow) {
+				unsigned int *dst = reinterpret_cast<unsigned int *>(
+					a.out + (long long) (y0 + row) * a.out_stride + (long long) x0 * 4);
+				dst[lane] = stage[row * MFMA_STAGE_PITCH + lane];
+			}
+		}
+	}
+}
+
 // Is pos[] an arithmetic progression first0 + S*k with one phase?  (What an
 // integer shrink of a size-divisible image produces.)
 static bool positions_regular(const std::vector<ReducePos> &pos, int *first0, int *step, int *phase)
@@ -350,6 +690,64 @@ struct FusedPlan {
 	unsigned int *d_ch;
 	int fx0, fy0, step, d;
 };
+
+// f16 bit pattern of an integer |v| < 2048 (exact)
+static unsigned short half_bits(int v)
+{
+	const _Float16 h = (_Float16) (float) v;
+	unsigned short bits;
+	memcpy(&bits, &h, sizeof(bits));
+	return bits;
+}
+
+// The MFMA kernel's A-operand tables (both walking directions) for taps c[0 .. 8*D).
+static void mfma_build_tables(const std::vector<int> &taps, const std::vector<int> &taps_h, int D,
+	MfmaTables *tab)
+{
+	const int nt = 8 * D;
+	for (int rot = 0; rot < MFMA_SLOTS; rot++)
+		for (int q = 0; q < 2; q++)
+			for (int h = 0; h < 2; h++)
+				for (int i = 0; i < 4; i++) {
+					const int d = (rot - (4 * h + i) + 2 * MFMA_SLOTS) % MFMA_SLOTS;
+					for (int k = 0; k < 4; k++)
+						tab->ah[((((rot * 2 + q) * 2 + h) * 4 + i) * 4) + k] =
+							half_bits(d < D ? taps_h[8 * d + 4 * q + k] : 0);
+				}
+	for (int flip = 0; flip < 2; flip++)
+		for (int rot = 0; rot < MFMA_SLOTS; rot++)
+			for (int q = 0; q < 2; q++)
+				for (int h = 0; h < 2; h++)
+					for (int i = 0; i < 4; i++) {
+						const int slot = 4 * h + i;
+						const int d = (rot - slot + 2 * MFMA_SLOTS) % MFMA_SLOTS;
+						for (int k = 0; k < 4; k++) {
+							int c = 0;
+							if (d < D) {
+								const int tap = 8 * d + 4 * q + k;
+								c = flip ? taps[nt - 1 - tap] : taps[tap];
+							}
+							tab->a[flip][((((rot * 2 + q) * 2 + h) * 4 + i) * 4) + k] = half_bits(c);
+						}
+					}
+}
+
+template <int D>
+static int launch_fused_mfma(const FusedArgs &args, int tiles, const MfmaTables *d_tables)
+{
+	Gate gate("reduce_fused_u8_mfma");
+	const int grid = (tiles + 7) / 8 * 8; // XCD remap wants a multiple of 8
+	const size_t lds = mfma_lds_bytes(args.oht);
+	const int nb = getenv("VIPS_HIP_MFMA_NB") ? atoi(getenv("VIPS_HIP_MFMA_NB")) : 1;
+	if (nb == 2)
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 2, 3>), dim3(grid), dim3(FUSED_THREADS), lds, stream(),
+			args, d_tables);
+	else
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4>), dim3(grid), dim3(FUSED_THREADS), lds, stream(),
+			args, d_tables);
+	VH_CHECK(hipGetLastError());
+	return 0;
+}
 
 template <int S, int D>
 static int launch_fused(const FusedArgs &args, int tiles, const std::vector<unsigned int> &pairs_v,
@@ -669,14 +1067,83 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 	args.out_width = out->width;
 	args.out_height = out->height;
 	args.aligned8 = !(((uintptr_t) in->data & 7) || (in->stride & 7));
+	args.small_window = in->stride > 0 && (long long) in->stride * in->height < (1LL << 31);
+	{
+		const int debug_bits = getenv("VIPS_HIP_FUSED_DEBUG") ? atoi(getenv("VIPS_HIP_FUSED_DEBUG")) : 0;
+		args.debug = debug_bits;
+	}
 	args.fx0 = fx0;
 	args.fy0 = fy0;
 	args.owt = FUSED_SPAN / S - D + 1;
 	args.tiles_x = (out->width + args.owt - 1) / args.owt;
-	// Tile height: tall tiles amortise the (D-1)*S-row vertical halo (which the
-	// serpentine walk turns into L2 / Infinity-Cache hits anyway); short tiles
-	// balance the 256 CUs better.  Measured on C2: two residency waves (256 CUs x
-	// 4 resident blocks x 2) is the sweet spot -- 0.249 ms vs 0.259 ms at one wave.
+
+	_VipsHipReduce *rv = const_cast<_VipsHipReduce *>(reducev);
+	// S = 8: both passes on the matrix cores when the exactness bounds hold
+	// (|c| < 2048 is an exact half, sum |c| * 255 < 2^23 keeps 2n + 1 in 24 bits)
+	if (S == 8 && args.small_window && !getenv("VIPS_HIP_NO_MFMA")) {
+		const short *c = &rv->matrixs[(size_t) phase_y * rv->n_point];
+		const short *ch = &reduceh->matrixs[(size_t) phase_x * reduceh->n_point];
+		std::vector<int> taps(8 * D, 0), taps_h(8 * D, 0);
+		long long abs_sum = 0, abs_sum_h = 0;
+		int abs_max = 0;
+		for (int k = 0; k < 8 * D; k++) {
+			if (k < rv->n_point)
+				taps[k] = c[k];
+			if (k < reduceh->n_point)
+				taps_h[k] = ch[k];
+			const int av = taps[k] < 0 ? -taps[k] : taps[k];
+			const int ah = taps_h[k] < 0 ? -taps_h[k] : taps_h[k];
+			abs_sum += av;
+			abs_sum_h += ah;
+			abs_max = av > abs_max ? av : abs_max;
+			abs_max = ah > abs_max ? ah : abs_max;
+		}
+		if (abs_max < 2048 && abs_sum * 255 < (1 << 23) && abs_sum_h * 255 < (1 << 23)) {
+			// Tile height: ONE residency round (256 CUs x 4 blocks) when the staged rows fit in
+			// LDS -- every tile then ends, and bursts its output, at the same time, and
+			// neighbouring tiles read their shared halos in lock-step (L2 hits); else the
+			// smallest whole number of rounds.
+			{
+				const int slots = getenv("VIPS_HIP_FUSED_CAP") ? atoi(getenv("VIPS_HIP_FUSED_CAP")) : 256 * 4;
+				const int base = slots / args.tiles_x > 0 ? slots / args.tiles_x : 1;
+				int oht = out->height;
+				for (int k = 1; k <= 4096; k++) {
+					oht = (out->height + base * k - 1) / (base * k);
+					if (oht <= MFMA_MAX_OHT)
+						break;
+				}
+				args.oht = oht < 1 ? 1 : oht;
+			}
+			const int tiles_y = (out->height + args.oht - 1) / args.oht;
+			const int tiles = args.tiles_x * tiles_y;
+			args.tiles = tiles;
+			const MfmaTables *d_tables;
+			{
+				std::lock_guard<std::mutex> lock(rv->mutex);
+				auto key = std::make_tuple(-3, phase_y * 128 + phase_x, 8 * D);
+				auto it = rv->pos_cache.find(key);
+				if (it == rv->pos_cache.end()) {
+					MfmaTables tab;
+					mfma_build_tables(taps, taps_h, D, &tab);
+					void *d = upload(&tab, sizeof(tab));
+					if (!d)
+						return -1;
+					rv->pos_cache[key] = (ReducePos *) d;
+					d_tables = (const MfmaTables *) d;
+				}
+				else
+					d_tables = (const MfmaTables *) it->second;
+			}
+			if (D == 6)
+				return launch_fused_mfma<6>(args, tiles, d_tables);
+			if (D == 7)
+				return launch_fused_mfma<7>(args, tiles, d_tables);
+		}
+	}
+
+	// The VALU kernel.  Tile height: tall tiles amortise the (D-1)*S-row vertical halo; short
+	// tiles balance the 256 CUs better.  Measured on C2: two residency rounds (256 CUs x
+	// 4 resident blocks x 2) is the sweet spot -- 0.249 ms vs 0.259 ms at one round.
 	{
 		const int capacity = 256 * 8;
 		int rows_of_tiles = capacity / args.tiles_x;
