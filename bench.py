@@ -76,10 +76,10 @@ def traffic_for(kernel_name):
         table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except (IOError, ValueError):
         return None
-    for key, entry in table.items():
-        if not key.startswith("_") and kernel_name.startswith(key):
-            return entry.get("traffic_bytes")
-    return None
+    keys = [k for k in table if not k.startswith("_") and kernel_name.startswith(k)]
+    if not keys:
+        return None
+    return table[max(keys, key=len)].get("traffic_bytes")
 
 
 def main():

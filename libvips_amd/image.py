@@ -122,6 +122,11 @@ class Image(object):
 
         if not tensor.is_cuda or not tensor.is_contiguous():
             raise ValueError("need a contiguous CUDA tensor")
+        # The library's own streams are non-blocking: work torch has queued on the tensor
+        # (fills, copies) must be complete before a kernel on another stream reads it.
+        cur = torch.cuda.current_stream(tensor.device)
+        if (lib.vips_hip_get_stream() or 0) != cur.cuda_stream:
+            cur.synchronize()
         t = tensor if tensor.dim() == 3 else tensor.unsqueeze(-1)
         np_dtype = np.dtype(str(t.dtype).replace("torch.", ""))
         fmt = DTYPE_FORMATS[np_dtype]
