@@ -18,22 +18,6 @@
 #include <climits>
 #include <cmath>
 
-struct _VipsHipConv {
-	int precision;
-	int mask_width, mask_height;
-	int nnz;
-	std::vector<int> coeffi;
-	std::vector<double> coefff;
-	std::vector<int> pos; // index into the mask, row-major
-	int scale_i, rounding, offset_i;
-	double scale, offset;
-	// device tables
-	void *d_coeff; // int[nnz] or double[nnz]
-	short *d_dx, *d_dy;
-	void *d_dense; // int / double [mask_width * mask_height], zeros kept (tiled kernels)
-	std::mutex mutex;
-};
-
 namespace vh {
 
 struct ConvArgs {

@@ -296,6 +296,23 @@ int vips_hip_convsep(VipsHipImage *in, VipsHipImage **out, const double *mask, i
 		error("convsep", "separable matrix images must have width or height 1");
 		return -1;
 	}
+	// float images: both passes in one streaming kernel (convsep_f32.hip)
+	if (in->format == VIPS_HIP_FORMAT_FLOAT) {
+		ConvPtr c(vips_hip_conv_new(mask, mask_n, 1, scale, offset, precision));
+		if (!c)
+			return -1;
+		ImageRef o(vips_hip_image_new(in->width, in->height, in->bands, VIPS_HIP_FORMAT_FLOAT,
+			in->interpretation));
+		if (!o.im)
+			return -1;
+		const int r = vh::convsep_f32_fused(in, o.im, c.get(), 0.0);
+		if (r < 0)
+			return -1;
+		if (r == 0) {
+			*out = o.release();
+			return 0;
+		}
+	}
 	ImageRef t1;
 	// first pass: the mask as given (1 row of mask_n)
 	if (conv_image(in, &t1.im, mask, mask_n, 1, scale, offset, precision))

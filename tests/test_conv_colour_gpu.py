@@ -167,3 +167,48 @@ def test_c5_conv31_reduced():
     else:
         want = PortCC.conv(src, mask, scale, 0.0, "float")
     assert_same(got, want)
+
+
+@pytest.mark.parametrize("precision", ["integer", "float"])
+@pytest.mark.parametrize("shape", [(700, 300, 3), (1500, 90, 1), (37, 411, 4), (2300, 140, 2), (5, 3, 3)])
+@pytest.mark.parametrize("sigma", [0.6, 2.0, 8.0])
+def test_fused_convsep_float(shape, sigma, precision):
+    """convsep_f32.hip (both passes of a float separable conv in one streaming kernel):
+    several strips wide, several row segments, narrow / tiny images (all edges clamped),
+    1..4 bands, masks of 3..29 taps, convi-on-float and convf arithmetic; bit-exact against
+    the two-operation port and against the device's own two-pass path."""
+    w, h, b = shape
+    src = helpers.lcg_image(w, h, b, np.float32, 67)
+    lib = _ffi.lib
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    try:
+        got = Image.new_from_array(src).gaussblur(sigma, precision=precision).numpy()
+        report = libvips_amd.gate_report()
+    finally:
+        lib.vips_hip_gate_enable(0)
+        lib.vips_hip_gate_reset()
+    assert any(k.startswith("convsep_f32") for k in report), report
+    want = PortCC.gaussblur(src, sigma, precision=precision)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    os.environ["VIPS_HIP_NO_FUSED_CONVSEP"] = "1"
+    try:
+        two_pass = Image.new_from_array(src).gaussblur(sigma, precision=precision).numpy()
+    finally:
+        del os.environ["VIPS_HIP_NO_FUSED_CONVSEP"]
+    assert np.array_equal(got, two_pass)
+
+
+def test_fused_convsep_float_offsets_and_nonfinite():
+    """An explicit convsep mask with scale and offset (the offset applies to the first pass
+    only, convsep.c:91-106), negative taps, and inf / nan pixels propagating exactly as in
+    the reference."""
+    src = helpers.lcg_image(333, 200, 3, np.float32, 68)
+    src[17, 40, 1] = np.inf
+    src[90, 300, 0] = np.nan
+    src[150, 5, 2] = -np.inf
+    mask = np.array([[-1.0, 2.0, 5.0, 7.0, 5.0, 3.0, -2.0]])
+    for precision, scale, offset in (("integer", 19.0, 3.0), ("float", 18.5, -0.75), ("integer", 1.0, 0.0)):
+        got = Image.new_from_array(src).convsep(mask, scale=scale, offset=offset, precision=precision).numpy()
+        want = PortCC.convsep(src, mask, scale, offset, precision)
+        assert np.array_equal(got, want, equal_nan=True), precision

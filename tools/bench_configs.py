@@ -18,6 +18,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="", help="comma list of c3,c4,c5")
     args = ap.parse_args()
 
     import numpy as np
@@ -58,7 +59,9 @@ def main():
         print(json.dumps(rec), flush=True)
         return out
 
+    only = set(x for x in args.only.lower().split(",") if x)
     with torch.cuda.stream(stream):
+      if not only or "c3" in only:
         # ---- C3: gaussblur(sigma 8) -> colourspace(LAB) on float sRGB
         n = 8192 if args.quick else 32768
         src = bench.lcg_image_device(torch, n, n, 3, 12345, dev).float()
@@ -72,6 +75,7 @@ def main():
         torch.cuda.empty_cache()
         lib.vips_hip_pool_trim()
 
+      if not only or "c4" in only:
         # ---- C4 per image: resize(1/8) -> sharpen on 8192^2 x3 u8
         n = 8192
         src = bench.lcg_image_device(torch, n, n, 3, 12345, dev)
@@ -82,6 +86,7 @@ def main():
         timed("C4a resize(1/8) only", lambda: im.resize(0.125), n * n * 3 + (n // 8) ** 2 * 3, reps=5)
         del im, src
 
+      if not only or "c5" in only:
         # ---- C5 kernel: 31x31 float mask on ushort (one GPU's share is 65536 x 8192)
         w, h = (4096, 1024) if args.quick else (16384, 2048)
         src = bench.lcg_image_device(torch, w, h, 2, 12345, dev).view(torch.uint16).reshape(h, w, 1)

@@ -38,6 +38,59 @@ __global__ void k(int *out, int n, unsigned seed)
 	out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// f64 ops: 8 independent chains per lane
+template <int OP>
+__global__ void kd(double *out, int n, double seed)
+{
+	double a[8];
+	double x = threadIdx.x * 1.25 + seed, y = 0.999 + seed * 1e-9;
+	float xf = (float) x;
+	for (int i = 0; i < 8; i++)
+		a[i] = i + threadIdx.x;
+	for (int it = 0; it < n; it++) {
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			if (OP == 0)
+				a[i] = __fma_rn(a[i], y, x);
+			else if (OP == 1)
+				a[i] = __dadd_rn(a[i], x);
+			else if (OP == 2)
+				a[i] = __dmul_rn(a[i], y);
+			else if (OP == 3)
+				a[i] += (double) (xf + (float) i); // cvt_f64_f32 + add_f32 + add_f64
+		}
+		x += 3.0;
+		xf += 1.0f;
+	}
+	double s = 0;
+	for (int i = 0; i < 8; i++)
+		s += a[i];
+	out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int OP>
+void rund(const char *name)
+{
+	double *out;
+	hipMalloc(&out, 256 * 1024 * 8 * sizeof(double));
+	const int n = 4096, blocks = 256 * 8;
+	hipEvent_t a, b;
+	hipEventCreate(&a);
+	hipEventCreate(&b);
+	kd<OP><<<blocks, 256>>>(out, n, 1);
+	hipDeviceSynchronize();
+	hipEventRecord(a);
+	kd<OP><<<blocks, 256>>>(out, n, 2);
+	hipEventRecord(b);
+	hipEventSynchronize(b);
+	float ms;
+	hipEventElapsedTime(&ms, a, b);
+	double wi = (double) blocks * 4 / 1024 * n * 8;
+	printf("%-14s %.3f ms  -> %.2f ns per wave-instr per SIMD (%.2f cycles @2.4GHz)\n", name, ms,
+		ms * 1e6 / wi, ms * 1e6 / wi * 2.4);
+	hipFree(out);
+}
+
 template <int OP>
 void run(const char *name)
 {
@@ -71,5 +124,9 @@ int main()
 	run<4>("mad i32 full");
 	run<5>("perm_b32");
 	run<6>("add_u32");
+	rund<0>("fma_f64");
+	rund<1>("add_f64");
+	rund<2>("mul_f64");
+	rund<3>("cvt+addf32+add_f64");
 	return 0;
 }
