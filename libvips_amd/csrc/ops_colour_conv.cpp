@@ -7,7 +7,10 @@
 
 #include <cmath>
 #include <cstring>
+#include <list>
 #include <memory>
+#include <mutex>
+#include <vector>
 
 using namespace vh;
 
@@ -28,15 +31,106 @@ struct ImageRef {
 	}
 };
 
-struct ConvDeleter {
-	void operator()(VipsHipConv *c) const { vips_hip_conv_free(c); }
+// Operation cache (the role of iofuncs/cache.c for this path): a mask's device tables are
+// built and uploaded once, not per call -- a table upload synchronises the stream, which on a
+// 1024^2 thumbnail costs more than the kernels.  LRU, shared_ptr so an eviction cannot pull
+// tables out from under a running call; leaked on purpose (no device frees at exit).
+typedef std::shared_ptr<VipsHipConv> ConvPtr;
+
+struct ConvKey {
+	std::vector<double> mask;
+	int mw, mh, precision;
+	double scale, offset;
+	bool operator==(const ConvKey &o) const
+	{
+		return mw == o.mw && mh == o.mh && precision == o.precision &&
+			memcmp(&scale, &o.scale, sizeof(double)) == 0 &&
+			memcmp(&offset, &o.offset, sizeof(double)) == 0 && mask.size() == o.mask.size() &&
+			memcmp(mask.data(), o.mask.data(), mask.size() * sizeof(double)) == 0;
+	}
 };
-typedef std::unique_ptr<VipsHipConv, ConvDeleter> ConvPtr;
+
+std::mutex &g_conv_mutex = *new std::mutex;
+std::list<std::pair<ConvKey, ConvPtr>> &g_conv_cache = *new std::list<std::pair<ConvKey, ConvPtr>>;
+const size_t CONV_CACHE_MAX = 64;
+
+ConvPtr conv_cached(const double *mask, int mw, int mh, double scale, double offset, int precision)
+{
+	if (!mask || mw <= 0 || mh <= 0 || (long long) mw * mh > 65536)
+		return ConvPtr(vips_hip_conv_new(mask, mw, mh, scale, offset, precision), vips_hip_conv_free);
+	ConvKey key = { std::vector<double>(mask, mask + (size_t) mw * mh), mw, mh, precision, scale, offset };
+	{
+		std::lock_guard<std::mutex> lock(g_conv_mutex);
+		for (auto it = g_conv_cache.begin(); it != g_conv_cache.end(); ++it)
+			if (it->first == key) {
+				g_conv_cache.splice(g_conv_cache.begin(), g_conv_cache, it);
+				return g_conv_cache.front().second;
+			}
+	}
+	VipsHipConv *raw = vips_hip_conv_new(mask, mw, mh, scale, offset, precision);
+	if (!raw)
+		return ConvPtr();
+	ConvPtr c(raw, vips_hip_conv_free);
+	std::lock_guard<std::mutex> lock(g_conv_mutex);
+	g_conv_cache.emplace_front(std::move(key), c);
+	while (g_conv_cache.size() > CONV_CACHE_MAX)
+		g_conv_cache.pop_back();
+	return c;
+}
+
+// the sharpen LUT (sharpen.c:230-257), cached by its parameters
+struct LutKey {
+	double p[5];
+	bool operator==(const LutKey &o) const { return memcmp(p, o.p, sizeof(p)) == 0; }
+};
+typedef std::shared_ptr<int> LutPtr;
+std::list<std::pair<LutKey, LutPtr>> &g_lut_cache = *new std::list<std::pair<LutKey, LutPtr>>;
+
+LutPtr sharpen_lut_cached(double x1, double y2, double y3, double m1, double m2)
+{
+	LutKey key = { { x1, y2, y3, m1, m2 } };
+	{
+		std::lock_guard<std::mutex> lock(g_conv_mutex);
+		for (auto it = g_lut_cache.begin(); it != g_lut_cache.end(); ++it)
+			if (it->first == key) {
+				g_lut_cache.splice(g_lut_cache.begin(), g_lut_cache, it);
+				return g_lut_cache.front().second;
+			}
+	}
+	std::vector<int> lut(65536);
+	for (int i = 0; i < 65536; i++) {
+		double v = (i - 32767) / 327.67;
+		double y;
+
+		if (v < -x1)
+			y = (v + x1) * m2 + -x1 * m1;
+		else if (v < x1)
+			y = v * m1;
+		else
+			y = (v - x1) * m2 + x1 * m1;
+
+		if (y < -y3)
+			y = -y3;
+		if (y > y2)
+			y = y2;
+
+		lut[i] = rint(y * 327.67);
+	}
+	int *d_lut = (int *) upload(lut.data(), lut.size() * sizeof(int));
+	if (!d_lut)
+		return LutPtr();
+	LutPtr l(d_lut, [](int *d) { vips_hip_free(d); });
+	std::lock_guard<std::mutex> lock(g_conv_mutex);
+	g_lut_cache.emplace_front(key, l);
+	while (g_lut_cache.size() > 16)
+		g_lut_cache.pop_back();
+	return l;
+}
 
 int conv_image(VipsHipImage *in, VipsHipImage **out, const double *mask, int mw, int mh,
 	double scale, double offset, int precision)
 {
-	ConvPtr c(vips_hip_conv_new(mask, mw, mh, scale, offset, precision));
+	ConvPtr c = conv_cached(mask, mw, mh, scale, offset, precision);
 	if (!c)
 		return -1;
 	const int fmt = vips_hip_conv_out_format(c.get(), in->format);
@@ -298,7 +392,7 @@ int vips_hip_convsep(VipsHipImage *in, VipsHipImage **out, const double *mask, i
 	}
 	// float images: both passes in one streaming kernel (convsep_f32.hip)
 	if (in->format == VIPS_HIP_FORMAT_FLOAT) {
-		ConvPtr c(vips_hip_conv_new(mask, mask_n, 1, scale, offset, precision));
+		ConvPtr c = conv_cached(mask, mask_n, 1, scale, offset, precision);
 		if (!c)
 			return -1;
 		ImageRef o(vips_hip_image_new(in->width, in->height, in->bands, VIPS_HIP_FORMAT_FLOAT,
@@ -590,29 +684,10 @@ int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out, double sigma, double 
 		cur = shorts.im;
 	}
 
-	// the LUT, sharpen.c:230-257
-	std::vector<int> lut(65536);
-	for (int i = 0; i < 65536; i++) {
-		double v = (i - 32767) / 327.67;
-		double y;
-
-		if (v < -x1)
-			y = (v + x1) * m2 + -x1 * m1;
-		else if (v < x1)
-			y = v * m1;
-		else
-			y = (v - x1) * m2 + x1 * m1;
-
-		if (y < -y3)
-			y = -y3;
-		if (y > y2)
-			y = y2;
-
-		lut[i] = rint(y * 327.67);
-	}
-	int *d_lut = (int *) upload(lut.data(), lut.size() * sizeof(int));
-	if (!d_lut)
+	LutPtr lut = sharpen_lut_cached(x1, y2, y3, m1, m2);
+	if (!lut)
 		return -1;
+	int *d_lut = lut.get();
 
 	// extract L, blur it with the integer separable mask (sharpen.c:274-278)
 	ImageRef L(vips_hip_image_new(cur->width, cur->height, 1, VIPS_HIP_FORMAT_SHORT,
@@ -633,7 +708,6 @@ int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out, double sigma, double 
 			result = vips_hip_sharpen_gen(d_lut, &rc, &rb, &rs);
 		}
 	}
-	vips_hip_free(d_lut);
 	if (result)
 		return -1;
 

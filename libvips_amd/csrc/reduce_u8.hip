@@ -646,6 +646,204 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 	}
 }
 
+// ------------------------------------------------ the wide variant (experiment, opt-in)
+//
+// reduce_fused_u8x4_mfma_wide<D>: the same kernel with ONE pixel column per lane and 1024
+// threads, i.e. a 1024-pixel span per block, one block per CU (256 tiles of 123 x ~137 for
+// C2 instead of 1015 of 59 x 71).  Halving the per-lane state (32 accumulator registers)
+// pays for a 4-deep ring of row-group buffers, and the bigger tile cuts the re-read traffic
+// from 8.6 % to 2.4 % over algorithmic (PMC).  It is nevertheless SLOWER on C2 -- 0.276 ms
+// against 0.216 -- because a single 16-wave block per CU serialises on its two barriers per
+// 8 rows and leaves half its waves idle in the horizontal pass, where the narrow kernel's
+// four independent blocks per CU overlap each other's phases.  Kept (VIPS_HIP_MFMA_WIDE=1)
+// as the measured counter-example: on this path fewer re-reads do not buy time, overlap does.
+constexpr int WIDE_THREADS = 1024;
+constexpr int WIDE_SPAN = 1024;
+constexpr int WIDE_PLANE = WIDE_SPAN + 4; // bytes per (row, channel) T plane, bank-skewed
+constexpr int WIDE_PLANES_BYTES = MFMA_SLOTS * 4 * WIDE_PLANE;
+constexpr int WIDE_STAGE_PITCH = 124; // dwords per staged output row (owt <= 123)
+constexpr int WIDE_NB = 4;
+constexpr int WIDE_MAX_OHT = 248; // 158 KB - planes - tables
+
+static constexpr size_t wide_lds_bytes(int oht)
+{
+	return (size_t) WIDE_PLANES_BYTES + 2 * MFMA_TABLE_ENTRIES * 8 + (size_t) oht * WIDE_STAGE_PITCH * 4;
+}
+
+template <int D>
+struct MfmaStepW {
+	typedef MfmaStep<D> Base;
+	static constexpr int S = 8;
+
+	// rows first_row + dir * i, I0 <= i < I0 + N, of this lane's (clamped) column
+	template <int I0, int N>
+	static __device__ __forceinline__ void load_rows(const FusedArgs &a, unsigned int (&px)[S], int first_row,
+		int dir, int ca)
+	{
+		const unsigned int stride32 = (unsigned int) a.in_stride;
+#pragma unroll
+		for (int i = I0; i < I0 + N; i++) {
+			const int row = min(max(first_row + dir * i, 0), a.im_height - 1) - a.in_top;
+			const unsigned int off = (unsigned int) row * stride32 + (unsigned int) (4 * ca);
+			px[i] = *reinterpret_cast<const unsigned int *>(a.in + (size_t) off);
+		}
+	}
+
+	template <int ROT, int Q>
+	static __device__ __forceinline__ void quad(const FusedArgs &a, unsigned int (&px)[S], float4v (&acc)[4][2],
+		const half4v *lane_a, bool more, int next_row, int dir, int ca)
+	{
+		const half4v a0 = lane_a[((ROT * 2 + Q) * 2 + 0) * 4];
+		const half4v a1 = lane_a[((ROT * 2 + Q) * 2 + 1) * 4];
+		const unsigned int r0 = px[4 * Q + 0], r1 = px[4 * Q + 1], r2 = px[4 * Q + 2], r3 = px[4 * Q + 3];
+		half4v b[4];
+		b[0] = Base::template make_b<0>(r0, r1, r2, r3);
+		b[1] = Base::template make_b<1>(r0, r1, r2, r3);
+		b[2] = Base::template make_b<2>(r0, r1, r2, r3);
+		b[3] = Base::template make_b<3>(r0, r1, r2, r3);
+		if (more)
+			load_rows<4 * Q, 4>(a, px, next_row, dir, ca);
+#pragma unroll
+		for (int c = 0; c < 4; c++) {
+			acc[c][0] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, b[c], acc[c][0], 0, 0, 0);
+			acc[c][1] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, b[c], acc[c][1], 0, 0, 0);
+		}
+	}
+
+	template <int ROT>
+	static __device__ __forceinline__ void retire(float4v (&acc)[4][2], unsigned char *planes, int lds_row,
+		int t, bool store)
+	{
+		constexpr int SLOT = (ROT - (D - 1) + 2 * MFMA_SLOTS) % MFMA_SLOTS;
+		constexpr int H = SLOT >> 2, I = SLOT & 3;
+		if (store) {
+#pragma unroll
+			for (int c = 0; c < 4; c++)
+				planes[(lds_row * 4 + c) * WIDE_PLANE + t] = (unsigned char) Base::fin_pack(acc[c][H][I], 0, 0);
+		}
+#pragma unroll
+		for (int c = 0; c < 4; c++)
+			acc[c][H][I] = 0.0f;
+	}
+
+	template <int ROT>
+	static __device__ __forceinline__ void batch(const FusedArgs &a, unsigned int (&px)[WIDE_NB][S], int g0,
+		int ngroups, float4v (&acc)[4][2], unsigned char *planes, const half4v *lane_a, int t, int row0,
+		int dir, int ca, int oh)
+	{
+		if constexpr (ROT < MFMA_SLOTS) {
+			const int g = g0 + ROT;
+			if (g < ngroups) {
+				const bool more = g + WIDE_NB < ngroups;
+				const int next_row = row0 + dir * S * (g + WIDE_NB);
+				quad<ROT, 0>(a, px[ROT % WIDE_NB], acc, lane_a, more, next_row, dir, ca);
+				quad<ROT, 1>(a, px[ROT % WIDE_NB], acc, lane_a, more, next_row, dir, ca);
+				const int j = g - (D - 1);
+				retire<ROT>(acc, planes, ROT, t, j >= 0 && j < oh);
+			}
+			batch<ROT + 1>(a, px, g0, ngroups, acc, planes, lane_a, t, row0, dir, ca, oh);
+		}
+	}
+};
+
+template <int D>
+__global__ void __launch_bounds__(WIDE_THREADS)
+reduce_fused_u8x4_mfma_wide(FusedArgs a, const MfmaTables *__restrict__ tables)
+{
+	constexpr int S = 8;
+	typedef MfmaStepW<D> Step;
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	unsigned char *planes = lds_raw;
+	half4v *lds_a = reinterpret_cast<half4v *>(lds_raw + WIDE_PLANES_BYTES);
+	half4v *lds_ah = lds_a + MFMA_TABLE_ENTRIES;
+	unsigned int *stage = reinterpret_cast<unsigned int *>(lds_ah + MFMA_TABLE_ENTRIES);
+
+	const int per_xcd = gridDim.x / 8;
+	const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+	if (tile >= a.tiles)
+		return;
+
+	const int t = threadIdx.x;
+	const int by = tile / a.tiles_x;
+	const int bx = tile - by * a.tiles_x;
+	const int x0 = bx * a.owt;
+	const int y0 = by * a.oht;
+	const int ow = min(a.owt, a.out_width - x0);
+	const int oh = min(a.oht, a.out_height - y0);
+
+	const int col0 = a.fx0 + S * x0 + t;
+	const int ca = min(max(col0, 0), a.im_width - 1) - a.in_left;
+	const bool flip = (by & 1) != 0;
+	const int dir = flip ? -1 : 1;
+	const int row0 = flip ? a.fy0 + S * (y0 + oh - 1) + S * D - 1 : a.fy0 + S * y0;
+
+	if (t < MFMA_TABLE_ENTRIES) {
+		reinterpret_cast<uint2 *>(lds_a)[t] = reinterpret_cast<const uint2 *>(tables->a[flip ? 1 : 0])[t];
+		reinterpret_cast<uint2 *>(lds_ah)[t] = reinterpret_cast<const uint2 *>(tables->ah)[t];
+	}
+	const half4v *lane_a = lds_a + (t & 3);
+
+	float4v acc[4][2];
+#pragma unroll
+	for (int c = 0; c < 4; c++)
+#pragma unroll
+		for (int h = 0; h < 2; h++)
+			acc[c][h] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+
+	const int ngroups = oh + D - 1;
+	unsigned int px[WIDE_NB][S];
+#pragma unroll
+	for (int b = 0; b < WIDE_NB; b++)
+		if (b < ngroups)
+			Step::template load_rows<0, S>(a, px[b], row0 + dir * S * b, dir, ca);
+	__syncthreads();
+
+	for (int g0 = 0; g0 < ngroups; g0 += MFMA_SLOTS) {
+		Step::template batch<0>(a, px, g0, ngroups, acc, planes, lane_a, t, row0, dir, ca, oh);
+
+		const int jlo = max(g0 - (D - 1), 0);
+		const int jhi = min(g0 + MFMA_SLOTS - 1 - (D - 1), oh - 1); // inclusive
+		if (jhi < jlo)
+			continue;
+		__syncthreads();
+		const int nrows = jhi - jlo + 1;
+		const int r_lo = jlo - (g0 - (D - 1));
+		if (t < 512 && !(a.debug & 1)) {
+			// waves 0..7: thread -> (T row, one of 16 segments of HSEG_OUT outputs, channel)
+			const int hc = t & 3, hr = (t >> 2) & 7, hseg = t >> 5;
+			const half4v *lane_ah = lds_ah + hc;
+			const bool row_ok = hr < nrows;
+			const int lrow = r_lo + (row_ok ? hr : 0);
+			const unsigned char *line = planes + (lrow * 4 + hc) * WIDE_PLANE + 8 * HSEG_OUT * hseg;
+			float4v hacc[2];
+			hacc[0] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+			hacc[1] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+			unsigned int pix[2] = { 0, 0 };
+			MfmaStep<D>::template hwalk<0>(hacc, line, lane_ah, hc, pix);
+			const int xo = HSEG_OUT * hseg + 2 * hc;
+			if (row_ok && xo < WIDE_STAGE_PITCH) {
+				const int jj = jlo + hr;
+				unsigned int *srow = stage + (flip ? oh - 1 - jj : jj) * WIDE_STAGE_PITCH + xo;
+				*reinterpret_cast<uint2 *>(srow) = make_uint2(pix[0], pix[1]);
+			}
+		}
+		__syncthreads();
+	}
+
+	// ---- the tile's output, one burst: a wave per row, two pixels per lane
+	if (!(a.debug & 2)) {
+		const int lane = t & 63;
+		for (int row = t >> 6; row < oh; row += WIDE_THREADS / 64) {
+			unsigned int *dst = reinterpret_cast<unsigned int *>(
+				a.out + (long long) (y0 + row) * a.out_stride + (long long) x0 * 4);
+			if (lane < ow)
+				dst[lane] = stage[row * WIDE_STAGE_PITCH + lane];
+			if (lane + 64 < ow)
+				dst[lane + 64] = stage[row * WIDE_STAGE_PITCH + lane + 64];
+		}
+	}
+}
+
 // Is pos[] an arithmetic progression first0 + S*k with one phase?  (What an
 // integer shrink of a size-divisible image produces.)
 static bool positions_regular(const std::vector<ReducePos> &pos, int *first0, int *step, int *phase)
@@ -748,6 +946,23 @@ static int launch_fused_mfma(const FusedArgs &args, int tiles, const MfmaTables 
 	return 0;
 }
 
+template <int D>
+static int launch_fused_mfma_wide(const FusedArgs &args, int tiles, const MfmaTables *d_tables)
+{
+	static bool attr_done = false;
+	if (!attr_done) {
+		VH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&reduce_fused_u8x4_mfma_wide<D>),
+			hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+		attr_done = true;
+	}
+	Gate gate("reduce_fused_u8_mfma_wide");
+	const int grid = (tiles + 7) / 8 * 8; // XCD remap wants a multiple of 8
+	hipLaunchKernelGGL((reduce_fused_u8x4_mfma_wide<D>), dim3(grid), dim3(WIDE_THREADS),
+		wide_lds_bytes(args.oht), stream(), args, d_tables);
+	VH_CHECK(hipGetLastError());
+	return 0;
+}
+
 template <int S, int D>
 static int launch_fused(const FusedArgs &args, int tiles, const std::vector<unsigned int> &pairs_v,
 	const std::vector<unsigned int> &pairs_h)
@@ -788,12 +1003,19 @@ struct VerticalArgs {
 template <int DW>
 __global__ void __launch_bounds__(256)
 reducev_u8_kernel(VerticalArgs a, int n_point, const ReducePos *__restrict__ pos,
-	const short *__restrict__ table)
+	const short *__restrict__ table, int gx, int band)
 {
-	const int t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t * DW >= a.ndw)
+	// Neighbouring output rows share most of their input rows, and an L2 is per XCD: block b
+	// runs on XCD b % 8, so give each XCD one contiguous band of output rows (a row-major
+	// grid would make all 8 L2s fetch every input row).
+	const int local = blockIdx.x / 8;
+	const int yb = local / gx;
+	const int t = (local - yb * gx) * blockDim.x + threadIdx.x;
+	const int y = (blockIdx.x % 8) * band + yb;
+	if (t * DW >= a.ndw || y >= a.out_height)
 		return;
-	for (int y = blockIdx.y; y < a.out_height; y += gridDim.y) {
+	constexpr int BATCH = 8; // rows fetched before any is used: 8 loads in flight per lane
+	{
 		const ReducePos p = pos[y];
 		const short *c = table + (size_t) p.phase * n_point;
 		int acc[DW][4];
@@ -802,36 +1024,38 @@ reducev_u8_kernel(VerticalArgs a, int n_point, const ReducePos *__restrict__ pos
 #pragma unroll
 			for (int k = 0; k < 4; k++)
 				acc[w][k] = 0;
-		for (int i = 0; i < n_point; i += 2) {
-			const int ra = min(max(p.first + i, 0), a.im_height - 1) - a.in_top;
-			const int rb = min(max(p.first + i + 1, 0), a.im_height - 1) - a.in_top;
-			const unsigned int lo = (unsigned short) c[i];
-			const unsigned int hi = i + 1 < n_point ? (unsigned short) c[i + 1] : 0u;
-			const unsigned int coef = lo | (hi << 16);
-			const unsigned int *pa = (const unsigned int *) (a.in + ra * a.in_stride) + t * DW;
-			const unsigned int *pb = (const unsigned int *) (a.in + rb * a.in_stride) + t * DW;
-			unsigned int va[DW], vb[DW];
-			if (DW == 4) {
-				const uint4 xa = *reinterpret_cast<const uint4 *>(pa);
-				const uint4 xb = *reinterpret_cast<const uint4 *>(pb);
-				va[0] = xa.x, va[1 % DW] = xa.y, va[2 % DW] = xa.z, va[3 % DW] = xa.w;
-				vb[0] = xb.x, vb[1 % DW] = xb.y, vb[2 % DW] = xb.z, vb[3 % DW] = xb.w;
-			}
-			else {
+		for (int i0 = 0; i0 < n_point; i0 += BATCH) {
+			unsigned int v[BATCH][DW];
 #pragma unroll
-				for (int w = 0; w < DW; w++) {
-					va[w] = pa[w];
-					vb[w] = pb[w];
+			for (int j = 0; j < BATCH; j++) {
+				// past the last tap: re-fetch the last row (the window need not hold more), coefficient 0
+				const int r = min(max(p.first + min(i0 + j, n_point - 1), 0), a.im_height - 1) - a.in_top;
+				const unsigned int *pr = (const unsigned int *) (a.in + r * a.in_stride) + t * DW;
+				if (DW == 4) {
+					const uint4 x = *reinterpret_cast<const uint4 *>(pr);
+					v[j][0] = x.x, v[j][1 % DW] = x.y, v[j][2 % DW] = x.z, v[j][3 % DW] = x.w;
+				}
+				else {
+#pragma unroll
+					for (int w = 0; w < DW; w++)
+						v[j][w] = pr[w];
 				}
 			}
 #pragma unroll
-			for (int w = 0; w < DW; w++)
+			for (int j = 0; j < BATCH; j += 2) {
+				const int i = i0 + j;
+				const unsigned int lo = i < n_point ? (unsigned short) c[i] : 0u;
+				const unsigned int hi = i + 1 < n_point ? (unsigned short) c[i + 1] : 0u;
+				const unsigned int coef = lo | (hi << 16);
 #pragma unroll
-				for (int k = 0; k < 4; k++) {
-					const unsigned int pair = __builtin_amdgcn_perm(vb[w], va[w],
-						0x0c000c00u | (unsigned) k | ((4u + k) << 16));
-					acc[w][k] = dot2(pair, coef, acc[w][k]);
-				}
+				for (int w = 0; w < DW; w++)
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						const unsigned int pair = __builtin_amdgcn_perm(v[j + 1][w], v[j][w],
+							0x0c000c00u | (unsigned) k | ((4u + k) << 16));
+						acc[w][k] = dot2(pair, coef, acc[w][k]);
+					}
+			}
 		}
 		unsigned int *dst = (unsigned int *) (a.out + (long long) y * a.out_stride) + t * DW;
 		unsigned int o[DW];
@@ -939,12 +1163,18 @@ int reducev_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsH
 		return 0;
 	const int threads = (a.ndw + dw - 1) / dw;
 	dim3 block(256, 1, 1);
-	dim3 grid((threads + 255) / 256, out->height < 32768 ? out->height : 32768, 1);
+	const int gx = (threads + 255) / 256;
+	const int band = (out->height + 7) / 8;
+	if ((long long) gx * band * 8 > 0x7fffffffLL)
+		return 0;
+	dim3 grid(gx * band * 8, 1, 1);
 	Gate gate("reducev_u8");
 	if (dw == 4)
-		hipLaunchKernelGGL(reducev_u8_kernel<4>, grid, block, 0, stream(), a, r->n_point, pos, table);
+		hipLaunchKernelGGL(reducev_u8_kernel<4>, grid, block, 0, stream(), a, r->n_point, pos, table, gx,
+			band);
 	else
-		hipLaunchKernelGGL(reducev_u8_kernel<1>, grid, block, 0, stream(), a, r->n_point, pos, table);
+		hipLaunchKernelGGL(reducev_u8_kernel<1>, grid, block, 0, stream(), a, r->n_point, pos, table, gx,
+			band);
 	if (hipGetLastError() != hipSuccess) {
 		error("reducev", "kernel launch failed");
 		return -1;
@@ -1098,17 +1328,25 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 			abs_max = ah > abs_max ? ah : abs_max;
 		}
 		if (abs_max < 2048 && abs_sum * 255 < (1 << 23) && abs_sum_h * 255 < (1 << 23)) {
+			// the wide kernel (1024-pixel spans, one block per CU) is opt-in: measured slower
+			const char *wide_env = getenv("VIPS_HIP_MFMA_WIDE");
+			const bool wide = wide_env && atoi(wide_env) != 0;
 			// Tile height: ONE residency round (256 CUs x 4 blocks) when the staged rows fit in
 			// LDS -- every tile then ends, and bursts its output, at the same time, and
 			// neighbouring tiles read their shared halos in lock-step (L2 hits); else the
 			// smallest whole number of rounds.
 			{
-				const int slots = getenv("VIPS_HIP_FUSED_CAP") ? atoi(getenv("VIPS_HIP_FUSED_CAP")) : 256 * 4;
+				if (wide) {
+					args.owt = WIDE_SPAN / S - D + 1;
+					args.tiles_x = (out->width + args.owt - 1) / args.owt;
+				}
+				const int slots = getenv("VIPS_HIP_FUSED_CAP") ? atoi(getenv("VIPS_HIP_FUSED_CAP"))
+					: wide ? 256 : 256 * 4;
 				const int base = slots / args.tiles_x > 0 ? slots / args.tiles_x : 1;
 				int oht = out->height;
 				for (int k = 1; k <= 4096; k++) {
 					oht = (out->height + base * k - 1) / (base * k);
-					if (oht <= MFMA_MAX_OHT)
+					if (oht <= (wide ? WIDE_MAX_OHT : MFMA_MAX_OHT))
 						break;
 				}
 				args.oht = oht < 1 ? 1 : oht;
@@ -1133,6 +1371,10 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 				else
 					d_tables = (const MfmaTables *) it->second;
 			}
+			if (wide && D == 6)
+				return launch_fused_mfma_wide<6>(args, tiles, d_tables);
+			if (wide && D == 7)
+				return launch_fused_mfma_wide<7>(args, tiles, d_tables);
 			if (D == 6)
 				return launch_fused_mfma<6>(args, tiles, d_tables);
 			if (D == 7)

@@ -212,3 +212,32 @@ def test_fused_reduce_rgba(shrink, size):
         lib.vips_hip_gate_reset()
     assert any(k.startswith("reduce_fused_u8") for k in report), report
     assert_same(got, Port.reduce(src, shrink, shrink, "lanczos3"), str((shrink, size)))
+
+
+@pytest.mark.parametrize("kernel", ["lanczos3"])
+@pytest.mark.parametrize("size", [(4099, 3001), (2048, 1024), (1000, 8), (96, 2600), (9000, 700), (8192, 8197)])
+@pytest.mark.parametrize("wide", [0, 1])
+def test_fused_reduce_mfma_variants(wide, size, kernel):
+    """Both matrix-core kernels on the same inputs: the 256-thread / 2-pixel-per-lane one and the
+    1024-thread / 1-pixel-per-lane wide one (forced either way with VIPS_HIP_MFMA_WIDE), shrink
+    8, sizes with partial tiles on every side, several tiles in both directions, 6 and 7 tap
+    groups (phase 0 and a constant non-zero phase), all edges clamped."""
+    import os
+
+    from libvips_amd import lib
+
+    w, h = size
+    src = helpers.lcg_image(w, h, 4, np.uint8, 47)
+    os.environ["VIPS_HIP_MFMA_WIDE"] = str(wide)
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    try:
+        got = Image.new_from_array(src).reduce(8, 8, kernel=kernel).numpy()
+        report = libvips_amd.gate_report()
+    finally:
+        del os.environ["VIPS_HIP_MFMA_WIDE"]
+        lib.vips_hip_gate_enable(0)
+        lib.vips_hip_gate_reset()
+    want_gate = "reduce_fused_u8_mfma_wide" if wide else "reduce_fused_u8_mfma"
+    assert list(report) == [want_gate], report
+    assert_same(got, Port.reduce(src, 8, 8, kernel), str((wide, size, kernel)))

@@ -17,7 +17,7 @@ from bench import lcg_image_device  # noqa: E402
 from libvips_amd import Image, lib  # noqa: E402
 
 KNOBS = ("VIPS_HIP_FUSED_DEBUG", "VIPS_HIP_MFMA_NB", "VIPS_HIP_FUSED_CAP", "VIPS_HIP_NO_MFMA",
-         "VIPS_HIP_FUSED_X")
+         "VIPS_HIP_MFMA_WIDE")
 ROUNDS = int(os.environ.get("TUNE_ROUNDS", "5"))
 LAUNCHES = int(os.environ.get("TUNE_LAUNCHES", "15"))
 
@@ -38,6 +38,7 @@ def main():
     torch.cuda.synchronize()
     im = Image.new_from_tensor(src)
     times = {name: [] for name, _ in variants}
+    kernels = {}
     with torch.cuda.stream(stream):
         for rnd in range(ROUNDS + 1):
             for name, env in variants:
@@ -52,11 +53,12 @@ def main():
                 lib.vips_hip_gate_enable(0)
                 rep = libvips_amd.gate_report()
                 kname, (launches, total_ms) = max(rep.items(), key=lambda kv: kv[1][1])
+                kernels[name] = kname
                 if rnd:  # round 0 = warm-up
                     times[name].append(total_ms / launches)
     for name, _ in variants:
         t = times[name]
-        print("%-24s min %.4f  med %.4f  max %.4f ms" % (name, min(t), statistics.median(t), max(t)))
+        print("%-24s min %.4f  med %.4f  max %.4f ms  %s" % (name, min(t), statistics.median(t), max(t), kernels[name]))
 
 
 if __name__ == "__main__":
