@@ -110,7 +110,9 @@ def main():
     device = torch.device("cuda", local_rank)
     libvips_amd.init(local_rank)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1 takes the RCCL path with a single rank too (how the N > 1 code is
+    # smoke-tested on a one-GPU box)
+    if world > 1 or (os.environ.get("BENCH_FORCE_DIST") and "RANK" in os.environ):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

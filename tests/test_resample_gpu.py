@@ -241,3 +241,39 @@ def test_fused_reduce_mfma_variants(wide, size, kernel):
     want_gate = "reduce_fused_u8_mfma_wide" if wide else "reduce_fused_u8_mfma"
     assert list(report) == [want_gate], report
     assert_same(got, Port.reduce(src, 8, 8, kernel), str((wide, size, kernel)))
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+def test_fused_reduce_region_windows(wide):
+    """vips_hip_reduce_gen the way a strip owner (one GPU of several, libvips_amd/sharding.py)
+    calls it: an output sub-rect and an input window that only just covers the rows and
+    columns vips_hip_reduce{v,h}_need report, at image edges and in the middle; must equal
+    the same rect of the whole-image result."""
+    lib = _ffi.lib
+    w, h = 2400, 1608
+    src = helpers.lcg_image(w, h, 4, np.uint8, 48)
+    full = Image.new_from_array(src).reduce(8, 8, kernel="lanczos3").numpy()
+    oh, ow = full.shape[:2]
+    rv = _ffi.check_handle(lib.vips_hip_reduce_new(5, 8.0, h, oh, math.nan))
+    rh = _ffi.check_handle(lib.vips_hip_reduce_new(5, 8.0, w, ow, math.nan))
+    os.environ["VIPS_HIP_MFMA_WIDE"] = str(wide)
+    try:
+        for (left, top, width, height) in ((0, 0, ow, 37), (0, 37, ow, oh - 37), (10, 50, 200, 100),
+                                           (ow - 61, oh - 40, 61, 40), (0, 100, 59, 1)):
+            t0, tn, l0, ln = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            lib.vips_hip_reducev_need(rv, top, height, ctypes.byref(t0), ctypes.byref(tn))
+            lib.vips_hip_reduceh_need(rh, left, width, ctypes.byref(l0), ctypes.byref(ln))
+            win = np.ascontiguousarray(src[t0.value:t0.value + tn.value, l0.value:l0.value + ln.value])
+            dwin = Image.new_from_array(win)
+            rin = dwin.region()
+            rin.left, rin.top, rin.im_width, rin.im_height = l0.value, t0.value, w, h
+            dout = Image.new_from_array(np.zeros((height, width, 4), np.uint8))
+            rout = dout.region()
+            rout.left, rout.top, rout.im_width, rout.im_height = left, top, ow, oh
+            r = lib.vips_hip_reduce_gen(rv, rh, ctypes.byref(rin), ctypes.byref(rout))
+            assert r == 0, (r, _ffi.error_buffer())
+            assert np.array_equal(dout.numpy(), full[top:top + height, left:left + width]), (left, top, width, height)
+    finally:
+        del os.environ["VIPS_HIP_MFMA_WIDE"]
+        lib.vips_hip_reduce_free(rv)
+        lib.vips_hip_reduce_free(rh)
