@@ -21,6 +21,21 @@
 
 namespace vh {
 
+// The pointwise kernels below give a thread one element column and RU rows per loop trip,
+// all RU loads issued before the first is used: with one load in flight per thread these
+// kernels sit at ~1 TB/s (bytes in flight, not bandwidth, bound them); four gets 3-4x.
+constexpr int RU = 4;
+
+// grid.y for a row-looping kernel: enough blocks to fill the part, few enough that per-block
+// setup is amortised over many rows
+static inline int rows_grid(int gx, int height)
+{
+	const int groups = (height + RU - 1) / RU;
+	int gy = 16384 / (gx > 0 ? gx : 1);
+	gy = gy < 1 ? 1 : gy;
+	return groups < gy ? groups : gy;
+}
+
 // ------------------------------------------------------------------ tables
 
 struct ColourTables {
@@ -479,32 +494,57 @@ colour_route_kernel(RouteArgs a)
 	const int x = blockIdx.x * blockDim.x + threadIdx.x;
 	if (x >= a.width)
 		return;
-	for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
-		const TIN *p = (const TIN *) (a.in + (long long) y * a.in_stride) + (long long) x * a.in_bands;
-		TOUT *q = (TOUT *) (a.out + (long long) y * a.out_stride) + (long long) x * a.out_bands;
-		route_pixel<TIN, TOUT>(a, p[0], p[1], p[2], q[0], q[1], q[2]);
-		for (int e = 0; e < a.extra_bands; e++)
-			q[3 + e] = Carry<TIN, TOUT>::run(p[3 + e], a.alpha_scale);
+	for (int y0 = blockIdx.y * RU; y0 < a.height; y0 += gridDim.y * RU) {
+		TIN i0[RU], i1[RU], i2[RU];
+#pragma unroll
+		for (int r = 0; r < RU; r++) {
+			const int y = min(y0 + r, a.height - 1);
+			const TIN *p = (const TIN *) (a.in + (long long) y * a.in_stride) + (long long) x * a.in_bands;
+			i0[r] = p[0];
+			i1[r] = p[1];
+			i2[r] = p[2];
+		}
+#pragma unroll
+		for (int r = 0; r < RU; r++) {
+			const int y = y0 + r;
+			if (y < a.height) {
+				const TIN *p = (const TIN *) (a.in + (long long) y * a.in_stride) + (long long) x * a.in_bands;
+				TOUT *q = (TOUT *) (a.out + (long long) y * a.out_stride) + (long long) x * a.out_bands;
+				route_pixel<TIN, TOUT>(a, i0[r], i1[r], i2[r], q[0], q[1], q[2]);
+				for (int e = 0; e < a.extra_bands; e++)
+					q[3 + e] = Carry<TIN, TOUT>::run(p[3 + e], a.alpha_scale);
+			}
+		}
 	}
 }
 
-// float RGB -> float RGB, 4 pixels (48 bytes = three 16-byte accesses) per thread: the
-// BASELINE config 3 shape (colourspace on a 3-band float image).
+// 3 bands -> 3 bands, 4 pixels per thread: the 12 input elements arrive as three aligned
+// vector loads and the 12 outputs leave as three aligned vector stores (dword / dwordx2 /
+// dwordx4 for 1 / 2 / 4-byte elements).  One element per store instruction, as the scalar
+// kernel does for interleaved bands, makes every wave store touch all of the wave's cache
+// lines (3x the L1->L2 write requests); this is the shape of every BASELINE colour config
+// (C3: float -> float, thumbnails: uchar -> float / short and back).
+template <typename T>
+struct __attribute__((aligned(4 * sizeof(T)))) Vec4 {
+	T v[4];
+};
+
+template <typename TIN, typename TOUT>
 __global__ void __launch_bounds__(256)
-colour_route_f32x4_kernel(RouteArgs a)
+colour_route_x4_kernel(RouteArgs a)
 {
 	const int x4 = blockIdx.x * blockDim.x + threadIdx.x;
 	if (x4 * 4 >= a.width)
 		return;
 	for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
-		const float4 *p = (const float4 *) (a.in + (long long) y * a.in_stride) + (long long) x4 * 3;
-		float4 *q = (float4 *) (a.out + (long long) y * a.out_stride) + (long long) x4 * 3;
-		const float4 v0 = p[0], v1 = p[1], v2 = p[2];
-		float4 r0, r1, r2;
-		route_pixel<float, float>(a, v0.x, v0.y, v0.z, r0.x, r0.y, r0.z);
-		route_pixel<float, float>(a, v0.w, v1.x, v1.y, r0.w, r1.x, r1.y);
-		route_pixel<float, float>(a, v1.z, v1.w, v2.x, r1.z, r1.w, r2.x);
-		route_pixel<float, float>(a, v2.y, v2.z, v2.w, r2.y, r2.z, r2.w);
+		const Vec4<TIN> *p = (const Vec4<TIN> *) (a.in + (long long) y * a.in_stride) + (long long) x4 * 3;
+		Vec4<TOUT> *q = (Vec4<TOUT> *) (a.out + (long long) y * a.out_stride) + (long long) x4 * 3;
+		const Vec4<TIN> v0 = p[0], v1 = p[1], v2 = p[2];
+		Vec4<TOUT> r0, r1, r2;
+		route_pixel<TIN, TOUT>(a, v0.v[0], v0.v[1], v0.v[2], r0.v[0], r0.v[1], r0.v[2]);
+		route_pixel<TIN, TOUT>(a, v0.v[3], v1.v[0], v1.v[1], r0.v[3], r1.v[0], r1.v[1]);
+		route_pixel<TIN, TOUT>(a, v1.v[2], v1.v[3], v2.v[0], r1.v[2], r1.v[3], r2.v[0]);
+		route_pixel<TIN, TOUT>(a, v2.v[1], v2.v[2], v2.v[3], r2.v[1], r2.v[2], r2.v[3]);
 		q[0] = r0;
 		q[1] = r1;
 		q[2] = r2;
@@ -608,11 +648,19 @@ cast_kernel(CastArgs a)
 		return;
 	const int x = e / a.take;
 	const int b = e - x * a.take;
-	for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
-		const TIN *p = (const TIN *) (a.in + (long long) y * a.in_stride);
-		TOUT *q = (TOUT *) (a.out + (long long) y * a.out_stride);
-		q[(long long) x * a.out_bands + a.out_first + b] =
-			CastOne<TIN, TOUT>::run(p[(long long) x * a.in_bands + a.in_first + b]);
+	const long long ie = (long long) x * a.in_bands + a.in_first + b;
+	const long long oe = (long long) x * a.out_bands + a.out_first + b;
+	for (int y0 = blockIdx.y * RU; y0 < a.height; y0 += gridDim.y * RU) {
+		TIN v[RU];
+#pragma unroll
+		for (int r = 0; r < RU; r++) {
+			const int y = min(y0 + r, a.height - 1);
+			v[r] = ((const TIN *) (a.in + (long long) y * a.in_stride))[ie];
+		}
+#pragma unroll
+		for (int r = 0; r < RU; r++)
+			if (y0 + r < a.height)
+				((TOUT *) (a.out + (long long) (y0 + r) * a.out_stride))[oe] = CastOne<TIN, TOUT>::run(v[r]);
 	}
 }
 
@@ -620,7 +668,7 @@ template <typename TIN>
 static int launch_cast_out(const CastArgs &a, int out_format)
 {
 	dim3 block(256, 1, 1);
-	dim3 grid((a.ne + 255) / 256, a.height < 32768 ? a.height : 32768, 1);
+	dim3 grid((a.ne + 255) / 256, rows_grid((a.ne + 255) / 256, a.height), 1);
 	Gate gate("cast");
 #define GO(TOUT) \
 	hipLaunchKernelGGL((cast_kernel<TIN, TOUT>), grid, block, 0, stream(), a); \
@@ -711,18 +759,28 @@ sharpen_kernel(SharpenArgs a)
 	const int x = blockIdx.x * blockDim.x + threadIdx.x;
 	if (x >= a.width)
 		return;
-	for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
-		const short *p1 = (const short *) (a.in + (long long) y * a.in_stride) + (long long) x * a.bands;
-		const short *p2 = (const short *) (a.blur + (long long) y * a.blur_stride) + x;
-		short *q = (short *) (a.out + (long long) y * a.out_stride) + (long long) x * a.bands;
-		const int v1 = p1[0];
-		const int v2 = p2[0];
-		const int diff = (v1 & 0x7fff) - (v2 & 0x7fff);
-		int out = v1 + a.lut[diff + 32768];
-		out = min(max(out, 0), 32767);
-		q[0] = (short) out;
-		for (int b = 1; b < a.bands; b++)
-			q[b] = p1[b];
+	for (int y0 = blockIdx.y * RU; y0 < a.height; y0 += gridDim.y * RU) {
+		int v1[RU], v2[RU];
+#pragma unroll
+		for (int r = 0; r < RU; r++) {
+			const int y = min(y0 + r, a.height - 1);
+			v1[r] = ((const short *) (a.in + (long long) y * a.in_stride))[(long long) x * a.bands];
+			v2[r] = ((const short *) (a.blur + (long long) y * a.blur_stride))[x];
+		}
+#pragma unroll
+		for (int r = 0; r < RU; r++) {
+			const int y = y0 + r;
+			if (y < a.height) {
+				const short *p1 = (const short *) (a.in + (long long) y * a.in_stride) + (long long) x * a.bands;
+				short *q = (short *) (a.out + (long long) y * a.out_stride) + (long long) x * a.bands;
+				const int diff = (v1[r] & 0x7fff) - (v2[r] & 0x7fff);
+				int out = v1[r] + a.lut[diff + 32768];
+				out = min(max(out, 0), 32767);
+				q[0] = (short) out;
+				for (int b = 1; b < a.bands; b++)
+					q[b] = p1[b];
+			}
+		}
 	}
 }
 
@@ -747,20 +805,34 @@ premul_u8_kernel(PremulArgs a)
 	const int x = blockIdx.x * blockDim.x + threadIdx.x;
 	if (x >= a.width)
 		return;
+	if (a.bands == 4) {
+		for (int y0 = blockIdx.y * RU; y0 < a.height; y0 += gridDim.y * RU) {
+			unsigned int vv[RU];
+#pragma unroll
+			for (int r = 0; r < RU; r++) {
+				const int y = min(y0 + r, a.height - 1);
+				vv[r] = *reinterpret_cast<const unsigned int *>(a.in + (long long) y * a.in_stride + (long long) x * 4);
+			}
+#pragma unroll
+			for (int r = 0; r < RU; r++) {
+				if (y0 + r >= a.height)
+					break;
+				const unsigned int v = vv[r];
+				const unsigned int alpha = v >> 24;
+				const int s = scale[alpha];
+				const unsigned int cr = ((int) (v & 0xff) * s + 128) >> 8;
+				const unsigned int cg = ((int) ((v >> 8) & 0xff) * s + 128) >> 8;
+				const unsigned int cb = ((int) ((v >> 16) & 0xff) * s + 128) >> 8;
+				*reinterpret_cast<unsigned int *>(a.out + (long long) (y0 + r) * a.out_stride + (long long) x * 4) =
+					(cr & 0xff) | ((cg & 0xff) << 8) | ((cb & 0xff) << 16) | (alpha << 24);
+			}
+		}
+		return;
+	}
 	for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
 		const unsigned char *p = a.in + (long long) y * a.in_stride + (long long) x * a.bands;
 		unsigned char *q = a.out + (long long) y * a.out_stride + (long long) x * a.bands;
-		if (a.bands == 4) {
-			const unsigned int v = *reinterpret_cast<const unsigned int *>(p);
-			const unsigned int alpha = v >> 24;
-			const int s = scale[alpha];
-			const unsigned int r = ((int) (v & 0xff) * s + 128) >> 8;
-			const unsigned int g = ((int) ((v >> 8) & 0xff) * s + 128) >> 8;
-			const unsigned int b = ((int) ((v >> 16) & 0xff) * s + 128) >> 8;
-			*reinterpret_cast<unsigned int *>(q) =
-				(r & 0xff) | ((g & 0xff) << 8) | ((b & 0xff) << 16) | (alpha << 24);
-		}
-		else {
+		{
 			const int alpha = p[a.bands - 1];
 			const int s = scale[alpha];
 			for (int i = 0; i < a.bands - 1; i++)
@@ -772,6 +844,38 @@ premul_u8_kernel(PremulArgs a)
 
 // PRE_MANY / PRE_RGBA (premultiply.c:78-128) and UNPRE / FUNPRE (unpremultiply.c:85-186),
 // float output.
+// one pixel of NB bands (alpha last); ptr-free so that the vector path stays in registers
+template <typename TIN, bool INVERSE, int NB>
+static __device__ __forceinline__ void premul_pixel(const TIN (&p)[NB], float (&q)[NB], double max_alpha)
+{
+	constexpr int ab = NB - 1;
+	const TIN alpha = p[ab];
+	// VIPS_CLIP(0, alpha, max_alpha) is evaluated in double
+	double clip = (double) alpha;
+	clip = max_alpha < clip ? max_alpha : clip;
+	clip = 0.0 > clip ? 0.0 : clip;
+	if (!INVERSE) {
+		// IN clip_alpha = CLIP(...); OUT nalpha = (OUT) clip_alpha / max_alpha
+		const TIN clip_alpha = (TIN) clip;
+		const float nalpha = (float) __ddiv_rn((double) (float) clip_alpha, max_alpha);
+#pragma unroll
+		for (int i = 0; i < ab; i++)
+			q[i] = __fmul_rn((float) p[i], nalpha);
+		q[ab] = (float) alpha;
+	}
+	else {
+		float factor;
+		if (sizeof(TIN) == 4 && ((TIN) 0.5f != (TIN) 0)) // float input: FUNPRE
+			factor = fabs((double) alpha) < 0.01 ? 0.0f : (float) __ddiv_rn(max_alpha, (double) alpha);
+		else
+			factor = alpha == (TIN) 0 ? 0.0f : (float) __ddiv_rn(max_alpha, (double) alpha);
+#pragma unroll
+		for (int i = 0; i < ab; i++)
+			q[i] = __fmul_rn(factor, (float) p[i]);
+		q[ab] = (float) clip;
+	}
+}
+
 template <typename TIN, bool INVERSE>
 __global__ void __launch_bounds__(256)
 premul_float_kernel(PremulArgs a)
@@ -779,6 +883,17 @@ premul_float_kernel(PremulArgs a)
 	const int x = blockIdx.x * blockDim.x + threadIdx.x;
 	if (x >= a.width)
 		return;
+	// RGBA with aligned rows: one vector load and one 16-byte store per pixel
+	if (a.bands == 4 && !(((uintptr_t) a.in | (uintptr_t) a.in_stride) % (4 * sizeof(TIN))) &&
+		!(((uintptr_t) a.out | (uintptr_t) a.out_stride) & 15)) {
+		for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
+			const Vec4<TIN> pv = ((const Vec4<TIN> *) (a.in + (long long) y * a.in_stride))[x];
+			float qv[4];
+			premul_pixel<TIN, INVERSE, 4>(pv.v, qv, a.max_alpha);
+			((float4 *) (a.out + (long long) y * a.out_stride))[x] = make_float4(qv[0], qv[1], qv[2], qv[3]);
+		}
+		return;
+	}
 	const int ab = a.bands - 1;
 	for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
 		const TIN *p = (const TIN *) (a.in + (long long) y * a.in_stride) + (long long) x * a.bands;
@@ -853,7 +968,7 @@ int premultiply_region(const VipsHipRegion *in, const VipsHipRegion *out, double
 			a.scale[i] = (int) (256 * clip / max_alpha);
 	}
 	dim3 block(256, 1, 1);
-	dim3 grid((a.width + 255) / 256, a.height < 32768 ? a.height : 32768, 1);
+	dim3 grid((a.width + 255) / 256, rows_grid((a.width + 255) / 256, a.height), 1);
 	Gate gate(inverse ? "unpremultiply" : "premultiply");
 	if (fast) {
 		if (a.bands == 4 && (((uintptr_t) a.in | (uintptr_t) a.out | a.in_stride | a.out_stride) & 3)) {
@@ -967,18 +1082,19 @@ int colour_route(const int *steps, int n_steps, double alpha_scale, const VipsHi
 	a.tables = g_tables;
 
 	dim3 block(256, 1, 1);
-	dim3 grid((a.width + 255) / 256, a.height < 32768 ? a.height : 32768, 1);
+	dim3 grid((a.width + 255) / 256, rows_grid((a.width + 255) / 256, a.height), 1);
 	Gate gate("colour_route");
-	if (in->format == VIPS_HIP_FORMAT_FLOAT && want_out == VIPS_HIP_FORMAT_FLOAT && in->bands == 3 &&
-		!(a.width & 3) && !((uintptr_t) a.in & 15) && !((uintptr_t) a.out & 15) &&
-		!(a.in_stride & 15) && !(a.out_stride & 15)) {
-		dim3 grid4((a.width / 4 + 255) / 256, grid.y, 1);
-		hipLaunchKernelGGL(colour_route_f32x4_kernel, grid4, block, 0, stream(), a);
-		VH_CHECK(hipGetLastError());
-		return 0;
-	}
+	// 3 bands in and out, rows that start and advance on 4-element boundaries: 4 pixels per thread
+	const int oes = format_sizeof(want_out);
+	const bool x4 = in->bands == 3 && out->bands == 3 && !(a.width & 3) &&
+		!((uintptr_t) a.in % (4 * ies)) && !((uintptr_t) a.out % (4 * oes)) &&
+		!(a.in_stride % (4 * ies)) && !(a.out_stride % (4 * oes));
+	const dim3 grid4((a.width / 4 + 255) / 256, rows_grid((a.width / 4 + 255) / 256, a.height) * RU, 1);
 #define GO(TIN, TOUT) \
-	hipLaunchKernelGGL((colour_route_kernel<TIN, TOUT>), grid, block, 0, stream(), a)
+	if (x4) \
+		hipLaunchKernelGGL((colour_route_x4_kernel<TIN, TOUT>), grid4, block, 0, stream(), a); \
+	else \
+		hipLaunchKernelGGL((colour_route_kernel<TIN, TOUT>), grid, block, 0, stream(), a)
 #define GO_IN(TOUT) \
 	switch (in->format) { \
 	case VIPS_HIP_FORMAT_UCHAR: GO(unsigned char, TOUT); break; \
@@ -1072,7 +1188,7 @@ int vips_hip_sharpen_gen(const int *lut_device, const VipsHipRegion *in,
 	a.bands = in->bands;
 	a.lut = lut_device;
 	dim3 block(256, 1, 1);
-	dim3 grid((a.width + 255) / 256, a.height < 32768 ? a.height : 32768, 1);
+	dim3 grid((a.width + 255) / 256, rows_grid((a.width + 255) / 256, a.height), 1);
 	Gate gate("sharpen");
 	hipLaunchKernelGGL(sharpen_kernel, grid, block, 0, stream(), a);
 	VH_CHECK(hipGetLastError());

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 
 #include "vips_hip.h"
 
@@ -111,4 +112,12 @@ struct _VipsHipImage {
 	int width, height, bands, format, interpretation;
 	size_t stride;
 	bool owns; // data came from the pool
+	// library memory is shared between image objects (vips_copy-style no-op results): the
+	// last holder returns it to the pool
+	std::shared_ptr<void> hold;
 };
+
+namespace vh {
+// A second image object on the same pixels (library-owned images only; nullptr otherwise).
+_VipsHipImage *image_share(const _VipsHipImage *in);
+} // namespace vh

@@ -351,6 +351,19 @@ int step_out_format(int step)
 
 int cast_image(VipsHipImage *in, VipsHipImage **out, int format)
 {
+	// same format: vips_cast / vips_colourspace return the input (a pointer copy in the
+	// reference).  Library-owned pixels are shared; caller-owned device memory is copied.
+	if (format == in->format) {
+		if (VipsHipImage *shared = image_share(in)) {
+			*out = shared;
+			return 0;
+		}
+		ImageRef c(vips_hip_image_new(in->width, in->height, in->bands, format, in->interpretation));
+		if (!c.im || vips_hip_memcpy_d2d(c.im->data, in->data, in->stride * in->height))
+			return -1;
+		*out = c.release();
+		return 0;
+	}
 	ImageRef o(vips_hip_image_new(in->width, in->height, in->bands, format, in->interpretation));
 	if (!o.im)
 		return -1;

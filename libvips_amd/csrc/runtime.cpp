@@ -63,6 +63,13 @@ hipStream_t stream()
 	return tls_stream;
 }
 
+_VipsHipImage *image_share(const _VipsHipImage *in)
+{
+	if (!in || !in->owns || !in->hold)
+		return nullptr;
+	return new _VipsHipImage(*in);
+}
+
 int check_region(const char *domain, const VipsHipRegion *r)
 {
 	if (!r || !r->data) {
@@ -526,6 +533,7 @@ VipsHipImage *vips_hip_image_new(int width, int height, int bands, int format,
 		delete im;
 		return nullptr;
 	}
+	im->hold = std::shared_ptr<void>(im->data, [](void *p) { g_pool.release(p); });
 	return im;
 }
 
@@ -568,9 +576,7 @@ void vips_hip_image_unref(VipsHipImage *image)
 {
 	if (!image)
 		return;
-	if (image->owns)
-		g_pool.release(image->data);
-	delete image;
+	delete image; // library memory goes back to the pool with its last holder
 }
 
 int vips_hip_image_write_to_memory(const VipsHipImage *image, void *host_data)
