@@ -403,13 +403,16 @@ int vips_hip_convsep(VipsHipImage *in, VipsHipImage **out, const double *mask, i
 		error("convsep", "separable matrix images must have width or height 1");
 		return -1;
 	}
-	// float images: both passes in one streaming kernel (convsep_f32.hip)
-	if (in->format == VIPS_HIP_FORMAT_FLOAT) {
+	// float images, and uchar / ushort / short with integer precision: both passes in one
+	// streaming kernel (convsep_f32.hip)
+	if (in->format == VIPS_HIP_FORMAT_FLOAT ||
+		(precision == VIPS_HIP_PRECISION_INTEGER &&
+			(in->format == VIPS_HIP_FORMAT_UCHAR || in->format == VIPS_HIP_FORMAT_USHORT ||
+				in->format == VIPS_HIP_FORMAT_SHORT))) {
 		ConvPtr c = conv_cached(mask, mask_n, 1, scale, offset, precision);
 		if (!c)
 			return -1;
-		ImageRef o(vips_hip_image_new(in->width, in->height, in->bands, VIPS_HIP_FORMAT_FLOAT,
-			in->interpretation));
+		ImageRef o(vips_hip_image_new(in->width, in->height, in->bands, in->format, in->interpretation));
 		if (!o.im)
 			return -1;
 		const int r = vh::convsep_f32_fused(in, o.im, c.get(), 0.0);

@@ -212,3 +212,45 @@ def test_fused_convsep_float_offsets_and_nonfinite():
         got = Image.new_from_array(src).convsep(mask, scale=scale, offset=offset, precision=precision).numpy()
         want = PortCC.convsep(src, mask, scale, offset, precision)
         assert np.array_equal(got, want, equal_nan=True), precision
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16])
+@pytest.mark.parametrize("shape", [(700, 300, 3), (1500, 90, 1), (37, 411, 4), (2300, 140, 2), (5, 3, 3)])
+@pytest.mark.parametrize("sigma", [0.6, 2.0, 8.0])
+def test_fused_convsep_integer(shape, sigma, dtype):
+    """The same streaming kernel on uchar / ushort / short images with an integer mask (the
+    convi C path: 32-bit sums, C division by the scale, clip; the intermediate image keeps
+    the format): bit-exact against the two-operation port and the device's two-pass path."""
+    w, h, b = shape
+    src = helpers.lcg_image(w, h, b, dtype, 69)
+    lib = _ffi.lib
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    try:
+        got = Image.new_from_array(src).gaussblur(sigma).numpy()
+        report = libvips_amd.gate_report()
+    finally:
+        lib.vips_hip_gate_enable(0)
+        lib.vips_hip_gate_reset()
+    if sigma >= 2.0:  # masks shorter than 7 taps stay on the two register-tiled passes
+        assert any(k.startswith("convsep_") for k in report), report
+    want = PortCC.gaussblur(src, sigma)
+    assert got.dtype == src.dtype and np.array_equal(got, want)
+    os.environ["VIPS_HIP_NO_FUSED_CONVSEP"] = "1"
+    try:
+        two_pass = Image.new_from_array(src).gaussblur(sigma).numpy()
+    finally:
+        del os.environ["VIPS_HIP_NO_FUSED_CONVSEP"]
+    assert np.array_equal(got, two_pass)
+
+
+def test_fused_convsep_integer_signs_and_offsets():
+    """Negative taps, a negative sum (the C division truncates toward zero), scale and offset,
+    clipping at both ends, on all three integer formats."""
+    mask = np.array([[-3.0, 2.0, 9.0, -14.0, 9.0, 2.0, -3.0]])
+    for dtype in (np.uint8, np.uint16, np.int16):
+        src = helpers.lcg_image(257, 190, 3, dtype, 70)
+        for scale, offset in ((2.0, 0.0), (3.0, 37.0), (1.0, -5.0), (7.0, 200.0)):
+            got = Image.new_from_array(src).convsep(mask, scale=scale, offset=offset, precision="integer").numpy()
+            want = PortCC.convsep(src, mask, scale, offset, "integer")
+            assert np.array_equal(got, want), (dtype, scale, offset)
