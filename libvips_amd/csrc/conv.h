@@ -19,6 +19,8 @@ struct _VipsHipConv {
 	void *d_coeff; // int[nnz] or double[nnz]
 	short *d_dx, *d_dy;
 	void *d_dense; // int / double [mask_width * mask_height], zeros kept (tiled kernels)
+	double *d_dense8; // convf: rows zero-padded to np8 doubles (grouped kernel)
+	int np8;
 	std::mutex mutex;
 };
 

@@ -16,6 +16,7 @@
 #include "conv.h"
 
 #include <climits>
+#include <type_traits>
 #include <cmath>
 
 namespace vh {
@@ -25,12 +26,15 @@ struct ConvArgs {
 	unsigned char *out;
 	long long in_stride, out_stride;
 	int in_left, in_top, im_width, im_height;
+	int in_right; // in_left + window width
 	int out_left, out_top, out_width, out_height;
 	int epp;
 	int nnz;
 	int half_w, half_h;
 	const void *coeff;
 	const void *dense;
+	const double *dense8; // convf: rows padded with zeros to np8 = roundup(mask_width, 8) + 16 doubles
+	int np8;
 	int mask_width, mask_height;
 	const short *dx, *dy;
 	int scale_i, rounding, offset_i;
@@ -298,11 +302,163 @@ static int launch_conv_tiled(const ConvArgs &a, const char *gate_name)
 	return 0;
 }
 
+// convf on an integer image, taps in groups of 8: the 8 coefficients of a group are one scalar
+// load, and the 8 window elements of the NEXT group are fetched before the current group's 128
+// multiplies and adds are issued, so a load's latency hides behind arithmetic of the same wave
+// (conv_tiled waits for one load per tap: 45 % of the FP64 mul+add rate on C5).  The window is
+// two groups of 8 values whose roles swap every group (two groups per loop trip keep the
+// register names static).  Zero taps are multiplied through instead of skipped: for integer
+// pixels c * v = 0 exactly and sum + 0 = sum, so the result equals the reference's sum over
+// its squeezed non-zero taps bit for bit.  Float images keep conv_tiled (0 * inf).
+template <typename TIN, int EPP, bool INTERIOR>
+struct ConvGroupLoad {
+	// elements gx + i0 .. gx + i0 + 7 of row `row` (band b).  INTERIOR (the whole block: no tap,
+	// nor the two groups read ahead, leaves the window): step a pointer, immediate offsets (EPP
+	// is a template argument).  Otherwise clamp every column to [0, im_width) and to the last
+	// element any tap of the thread needs (the window holds no more).  The choice is made per
+	// wave, outside the loops, so that no load sits in a divergent branch (a branch join
+	// forces the wait for the loads just issued, i.e. no prefetch).
+	static __device__ __forceinline__ void run(const ConvArgs &a, const TIN *row, int b, int gx, int i0,
+		int last, int e_base, TIN (&raw)[8])
+	{
+		const int epp = EPP ? EPP : a.epp;
+		if (INTERIOR) {
+			const TIN *p = row + (e_base + i0 * epp);
+#pragma unroll
+			for (int m = 0; m < 8; m++)
+				raw[m] = p[m * epp];
+		}
+		else {
+#pragma unroll
+			for (int m = 0; m < 8; m++) {
+				const int col = min(gx + i0 + m, last);
+				const int cc = min(max(col, 0), a.im_width - 1) - a.in_left;
+				raw[m] = row[cc * epp + b];
+			}
+		}
+	}
+};
+
+template <typename TIN, int EPP, bool INTERIOR>
+static __device__ __forceinline__ void convf_grouped_rows(const ConvArgs &a, double (&acc)[CONV_TILE], int b,
+	int gx, int gy, int last, int e_base)
+{
+	constexpr int T = CONV_TILE;
+	typedef ConvGroupLoad<TIN, EPP, INTERIOR> Load;
+	const int n = a.mask_width;
+	for (int j = 0; j < a.mask_height; j++) {
+		const int rr = min(max(gy + j, 0), a.im_height - 1) - a.in_top;
+		const TIN *row = (const TIN *) (a.in + rr * a.in_stride);
+		const double *crow = a.dense8 + (size_t) j * a.np8;
+		double g0[8], g1[8];
+		TIN raw[8];
+		Load::run(a, row, b, gx, 0, last, e_base, raw);
+#pragma unroll
+		for (int m = 0; m < 8; m++)
+			g0[m] = (double) raw[m];
+		Load::run(a, row, b, gx, 8, last, e_base, raw);
+#pragma unroll
+		for (int m = 0; m < 8; m++)
+			g1[m] = (double) raw[m];
+		// the taps too are fetched a group ahead (scalar loads into SGPR operands)
+		double c0[8], c1[8];
+#pragma unroll
+		for (int m = 0; m < 8; m++)
+			c0[m] = crow[m];
+		for (int i0 = 0; i0 < n; i0 += 16) {
+#pragma unroll
+			for (int m = 0; m < 8; m++)
+				c1[m] = crow[i0 + 8 + m];
+			Load::run(a, row, b, gx, i0 + 16, last, e_base, raw);
+#pragma unroll
+			for (int ii = 0; ii < 8; ii++)
+#pragma unroll
+				for (int k = 0; k < T; k++)
+					acc[k] = __dadd_rn(acc[k], __dmul_rn(c0[ii], ii + k < 8 ? g0[ii + k] : g1[ii + k - 8]));
+#pragma unroll
+			for (int m = 0; m < 8; m++)
+				g0[m] = (double) raw[m];
+			if (i0 + 8 >= n)
+				break;
+#pragma unroll
+			for (int m = 0; m < 8; m++)
+				c0[m] = crow[i0 + 16 + m];
+			Load::run(a, row, b, gx, i0 + 24, last, e_base, raw);
+#pragma unroll
+			for (int ii = 0; ii < 8; ii++)
+#pragma unroll
+				for (int k = 0; k < T; k++)
+					acc[k] = __dadd_rn(acc[k], __dmul_rn(c1[ii], ii + k < 8 ? g1[ii + k] : g0[ii + k - 8]));
+#pragma unroll
+			for (int m = 0; m < 8; m++)
+				g1[m] = (double) raw[m];
+		}
+	}
+}
+
+template <typename TIN, typename TOUT, int EPP>
+__global__ void __launch_bounds__(256)
+convf_grouped(ConvArgs a)
+{
+	constexpr int T = CONV_TILE;
+	const int epp = EPP ? EPP : a.epp;
+	const int tiles = (a.out_width + T - 1) / T;
+	const int id_lo = blockIdx.x * blockDim.x;
+	const int id = id_lo + threadIdx.x;
+	if (id >= tiles * epp)
+		return;
+	const int tile = id / epp;
+	const int b = id - tile * epp;
+	const int x0 = tile * T;
+	const int y0 = blockIdx.y;
+
+	double acc[T];
+#pragma unroll
+	for (int k = 0; k < T; k++)
+		acc[k] = a.offset;
+
+	const int gx = a.out_left + x0 - a.half_w;
+	const int gy = a.out_top + y0 - a.half_h;
+	const int last = gx + a.mask_width - 1 + T - 1;
+	const int e_base = (gx - a.in_left) * epp + b;
+	// one choice per wave (a wave-uniform branch): is every lane interior?  The loop reads up
+	// to 16 elements past the last tap's window.
+	const bool mine = gx >= a.in_left && gx >= 0 && last + 16 < a.in_right && last + 16 < a.im_width;
+	if (__all(mine))
+		convf_grouped_rows<TIN, EPP, true>(a, acc, b, gx, gy, last, e_base);
+	else
+		convf_grouped_rows<TIN, EPP, false>(a, acc, b, gx, gy, last, e_base);
+
+#pragma unroll
+	for (int k = 0; k < T; k++) {
+		const int ox = x0 + k;
+		if (ox < a.out_width) {
+			TOUT *dst = (TOUT *) (a.out + (long long) y0 * a.out_stride);
+			dst[(long long) ox * epp + b] = (TOUT) acc[k];
+		}
+	}
+}
+
 // The tiled kernel wins whenever a thread's TILE outputs share taps; masks that are a
 // single element (or tiny images) keep the general kernel.
 template <typename TIN, typename TOUT, int MODE>
 static int launch_conv_best(const ConvArgs &a, const char *name)
 {
+	if constexpr (MODE == 2 && std::is_integral<TIN>::value) {
+		if (a.mask_width >= 8 && a.out_height <= 65535 && a.dense8 && !getenv("VIPS_HIP_NO_GROUPED_CONV")) {
+			const int ids = ((a.out_width + CONV_TILE - 1) / CONV_TILE) * a.epp;
+			dim3 grid((ids + 255) / 256, a.out_height, 1);
+			Gate gate(name);
+			switch (a.epp) {
+			case 1: hipLaunchKernelGGL((convf_grouped<TIN, TOUT, 1>), grid, dim3(256, 1, 1), 0, stream(), a); break;
+			case 3: hipLaunchKernelGGL((convf_grouped<TIN, TOUT, 3>), grid, dim3(256, 1, 1), 0, stream(), a); break;
+			case 4: hipLaunchKernelGGL((convf_grouped<TIN, TOUT, 4>), grid, dim3(256, 1, 1), 0, stream(), a); break;
+			default: hipLaunchKernelGGL((convf_grouped<TIN, TOUT, 0>), grid, dim3(256, 1, 1), 0, stream(), a); break;
+			}
+			VH_CHECK(hipGetLastError());
+			return 0;
+		}
+	}
 	if (a.mask_width * a.mask_height >= 3 && a.out_height <= 65535 * (a.mask_width == 1 ? CONV_TILE : 1)) {
 		const int r = launch_conv_tiled<TIN, TOUT, MODE>(a, name);
 		if (r <= 0)
@@ -340,6 +496,14 @@ static int conv_tables(_VipsHipConv *c)
 		for (int i = 0; i < c->nnz; i++)
 			dense[c->pos[i]] = c->coefff[i];
 		c->d_dense = upload(dense.data(), dense.size() * sizeof(double));
+		// rows padded to whole groups of 8 taps plus one group (the grouped kernel reads ahead)
+		c->np8 = (c->mask_width + 7) / 8 * 8 + 16;
+		std::vector<double> dense8((size_t) c->np8 * c->mask_height, 0.0);
+		for (int i = 0; i < c->nnz; i++)
+			dense8[(size_t) (c->pos[i] / c->mask_width) * c->np8 + c->pos[i] % c->mask_width] = c->coefff[i];
+		c->d_dense8 = (double *) upload(dense8.data(), dense8.size() * sizeof(double));
+		if (!c->d_dense8)
+			return -1;
 	}
 	if (!c->d_dx || !c->d_dy || !c->d_coeff || !c->d_dense)
 		return -1;
@@ -382,6 +546,8 @@ VipsHipConv *vips_hip_conv_new(const double *mask, int mask_width, int mask_heig
 	c->d_coeff = nullptr;
 	c->d_dx = c->d_dy = nullptr;
 	c->d_dense = nullptr;
+	c->d_dense8 = nullptr;
+	c->np8 = 0;
 	c->scale_i = c->rounding = c->offset_i = 0;
 	const int ne = mask_width * mask_height;
 	if (precision == VIPS_HIP_PRECISION_INTEGER) {
@@ -435,6 +601,7 @@ void vips_hip_conv_free(VipsHipConv *c)
 	vips_hip_free(c->d_dx);
 	vips_hip_free(c->d_dy);
 	vips_hip_free(c->d_dense);
+	vips_hip_free(c->d_dense8);
 	delete c;
 }
 
@@ -498,6 +665,7 @@ int vips_hip_conv_gen(const VipsHipConv *conv, const VipsHipRegion *in, const Vi
 	a.out_stride = (long long) out->stride;
 	a.in_left = in->left;
 	a.in_top = in->top;
+	a.in_right = in->left + in->width;
 	a.im_width = in->im_width;
 	a.im_height = in->im_height;
 	a.out_left = out->left;
@@ -510,6 +678,8 @@ int vips_hip_conv_gen(const VipsHipConv *conv, const VipsHipRegion *in, const Vi
 	a.half_h = half_h;
 	a.coeff = c->d_coeff;
 	a.dense = c->d_dense;
+	a.dense8 = c->d_dense8;
+	a.np8 = c->np8;
 	a.mask_width = c->mask_width;
 	a.mask_height = c->mask_height;
 	a.dx = c->d_dx;
