@@ -1182,6 +1182,8 @@ int reducev_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsH
 	return 1;
 }
 
+// The horizontal passes have no uchar specialisation: after the vertical pass the image is
+// small, and resample.hip's row-batched general kernels are launch-latency bound there.
 int reduceh_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out,
 	const ReducePos *pos, const short *table)
 {

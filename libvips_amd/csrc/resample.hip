@@ -175,6 +175,17 @@ reducev_general(RegionArgs in, RegionArgs out, int ne, int epp /* elements per p
 	}
 }
 
+constexpr int HRU = 4; // rows per loop trip of the horizontal kernels
+
+// grid.y for a kernel that takes HRU rows per trip
+static inline int hru_grid(int gx, int height)
+{
+	const int groups = (height + HRU - 1) / HRU;
+	int gy = 16384 / (gx > 0 ? gx : 1);
+	gy = gy < 1 ? 1 : gy;
+	return groups < gy ? groups : gy;
+}
+
 // One thread per output element (x, band).
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -190,16 +201,31 @@ reduceh_general(RegionArgs in, RegionArgs out, int epp, int n_point,
 	const int b = e - x * epp;
 	const ReducePos p = pos[x];
 	const typename ReduceTraits<T>::coef_t *c = table + (size_t) p.phase * n_point;
-	for (int y = blockIdx.y; y < out.height; y += gridDim.y) {
-		// same row of the input (reduceh.cpp:238)
-		const T *src = (const T *) (in.data + (long long) (out.top + y - in.top) * in.stride);
-		ACC sum = 0;
+	// HRU rows per trip: position, phase and the coefficient of a tap are shared by the rows,
+	// and the rows' loads of one tap are independent (the tap loop is a dependent chain of
+	// n_point loads per output otherwise: latency, not bandwidth, bounds these small images)
+	for (int y0 = blockIdx.y * HRU; y0 < out.height; y0 += gridDim.y * HRU) {
+		const T *src[HRU];
+		ACC sum[HRU];
+#pragma unroll
+		for (int r = 0; r < HRU; r++) {
+			// same row of the input (reduceh.cpp:238)
+			const int y = min(y0 + r, out.height - 1);
+			src[r] = (const T *) (in.data + (long long) (out.top + y - in.top) * in.stride);
+			sum[r] = 0;
+		}
 		for (int i = 0; i < n_point; i++) {
 			const int colx = clampi(p.first + i, 0, in.im_width - 1) - in.left;
-			sum = mac<ACC>(sum, c[i], src[(long long) colx * epp + b]);
+			const long long off = (long long) colx * epp + b;
+			const typename ReduceTraits<T>::coef_t ci = c[i];
+#pragma unroll
+			for (int r = 0; r < HRU; r++)
+				sum[r] = mac<ACC>(sum[r], ci, src[r][off]);
 		}
-		T *dst = (T *) (out.data + (long long) y * out.stride);
-		dst[e] = ReduceTraits<T>::fin(sum);
+#pragma unroll
+		for (int r = 0; r < HRU; r++)
+			if (y0 + r < out.height)
+				((T *) (out.data + (long long) (y0 + r) * out.stride))[e] = ReduceTraits<T>::fin(sum[r]);
 	}
 }
 
@@ -226,7 +252,7 @@ static int launch_reduceh(const _VipsHipReduce *r, const VipsHipRegion *in,
 	const int epp = region_elems_per_pel(out);
 	const int ne = out->width * epp;
 	dim3 block(256, 1, 1);
-	dim3 grid((ne + 255) / 256, out->height < 32768 ? out->height : 32768, 1);
+	dim3 grid((ne + 255) / 256, hru_grid((ne + 255) / 256, out->height), 1);
 	Gate gate("reduceh_general");
 	hipLaunchKernelGGL(reduceh_general<T>, grid, block, 0, stream(),
 		region_args(in), region_args(out), epp, r->n_point, pos,
@@ -473,15 +499,27 @@ shrinkh_general(RegionArgs in, RegionArgs out, int epp, int hshrink, unsigned in
 	const int x = e / epp;
 	const int b = e - x * epp;
 	const int x0 = (out.left + x) * hshrink;
-	for (int y = blockIdx.y; y < out.height; y += gridDim.y) {
-		const T *src = (const T *) (in.data + (long long) (out.top + y - in.top) * in.stride);
-		ACC sum = shrink_seed<T>(hshrink / 2);
+	for (int y0 = blockIdx.y * HRU; y0 < out.height; y0 += gridDim.y * HRU) {
+		const T *src[HRU];
+		ACC sum[HRU];
+#pragma unroll
+		for (int r = 0; r < HRU; r++) {
+			const int y = min(y0 + r, out.height - 1);
+			src[r] = (const T *) (in.data + (long long) (out.top + y - in.top) * in.stride);
+			sum[r] = shrink_seed<T>(hshrink / 2);
+		}
 		for (int i = 0; i < hshrink; i++) {
 			const int colx = min(x0 + i, in.im_width - 1) - in.left;
-			sum = shrink_add<ACC, T>(sum, src[(long long) colx * epp + b]);
+			const long long off = (long long) colx * epp + b;
+#pragma unroll
+			for (int r = 0; r < HRU; r++)
+				sum[r] = shrink_add<ACC, T>(sum[r], src[r][off]);
 		}
-		T *dst = (T *) (out.data + (long long) y * out.stride);
-		dst[e] = ShrinkTraits<T>::fin(sum, hshrink, mult8, mult16, inv);
+#pragma unroll
+		for (int r = 0; r < HRU; r++)
+			if (y0 + r < out.height)
+				((T *) (out.data + (long long) (y0 + r) * out.stride))[e] =
+					ShrinkTraits<T>::fin(sum[r], hshrink, mult8, mult16, inv);
 	}
 }
 
@@ -518,7 +556,7 @@ static int launch_shrinkh(int hshrink, const VipsHipRegion *in, const VipsHipReg
 	const unsigned int mult8 = (unsigned int) ((1LL << 32) / ((1 << 8) * (long long) hshrink));
 	const unsigned long long mult16 = ((1ULL << 32) + hshrink - 1) / hshrink;
 	dim3 block(256, 1, 1);
-	dim3 grid((ne + 255) / 256, out->height < 32768 ? out->height : 32768, 1);
+	dim3 grid((ne + 255) / 256, hru_grid((ne + 255) / 256, out->height), 1);
 	Gate gate("shrinkh_general");
 	hipLaunchKernelGGL(shrinkh_general<T>, grid, block, 0, stream(), region_args(in),
 		region_args(out), epp, hshrink, mult8, mult16, 1.0 / hshrink);
