@@ -62,6 +62,13 @@ typedef enum {
 	VIPS_HIP_KERNEL_MKS2021 = 7
 } VipsHipKernel;
 
+/* The interpolators vips_resize picks for upsizing (resample/resize.c:118-133). */
+typedef enum {
+	VIPS_HIP_INTERPOLATE_NEAREST = 0,
+	VIPS_HIP_INTERPOLATE_BILINEAR = 1,
+	VIPS_HIP_INTERPOLATE_BICUBIC = 2
+} VipsHipInterpolate;
+
 /* Same values as VipsPrecision, include/vips/basic.h:106-110. */
 typedef enum {
 	VIPS_HIP_PRECISION_INTEGER = 0,
@@ -253,6 +260,26 @@ VIPS_HIP_API int vips_hip_shrinkv_gen(int vshrink,
 /* Output sizes: shrinkh.c:414-416, shrinkv.c:566-568. */
 VIPS_HIP_API int vips_hip_shrink_out_size(int in_size, int shrink, int ceil_mode);
 
+/* ------------------------------------------------------------------ upsizing */
+
+/* vips_affine_gen (resample/affine.c:230-397) for the pure scale vips_resize asks for
+ * (resize.c:268-300: matrix (hscale, 0, 0, vscale), "idx"/"idy" displacements, EXTEND_COPY,
+ * premultiplied) with vips_interpolate_nearest / _bilinear (resample/interpolate.c:336-352,
+ * 432-484) or _bicubic (resample/bicubic.cpp:482-600): fills @out's rect of the
+ * vips_hip_affine_out_size() image from @in, whose window must hold the stencils.  The
+ * reference accumulates a row's x coordinate from the first pixel of each generate rect;
+ * @tile_width says where those rects start (multiples of it; 0 = whole rows, the FATSTRIP
+ * geometry a scale-only affine requests, affine.c:575-579).  uchar ... int and float
+ * (complex as float pairs); double images are refused (no-table bicubic).
+ */
+VIPS_HIP_API int vips_hip_upsize_gen(const VipsHipRegion *in, const VipsHipRegion *out,
+	double hscale, double vscale, double idx, double idy, int interpolate, int tile_width);
+/* Output size of the affine: VIPS_ROUND_INT(scale * in_size), resample/transform.c:220-231. */
+VIPS_HIP_API int vips_hip_affine_out_size(int in_size, double scale);
+/* vips_zoom (conversion/zoom.c): integral pixel replication, what vips_resize uses for
+ * kernel nearest with integral scales (resize.c:257-266). */
+VIPS_HIP_API int vips_hip_zoom_gen(const VipsHipRegion *in, const VipsHipRegion *out, int xfac, int yfac);
+
 /* -------------------------------------------------------------- convolution */
 
 /* Host-side state of one convi/convf: vips_convi_build (convolution/convi.c:
@@ -377,8 +404,10 @@ VIPS_HIP_API int vips_hip_shrinkh(VipsHipImage *in, VipsHipImage **out, int hshr
 VIPS_HIP_API int vips_hip_shrinkv(VipsHipImage *in, VipsHipImage **out, int vshrink, int ceil_mode);
 VIPS_HIP_API int vips_hip_shrink(VipsHipImage *in, VipsHipImage **out,
 	double hshrink, double vshrink, int ceil_mode);
-/* vips_resize for scale <= 1 (resample/resize.c:135-329); vscale <= 0 means
- * == scale; gap < 0 selects the default 2.0 (resize.c:397). */
+/* vips_resize (resample/resize.c:135-329): integer shrink + reduce for scales < 1, vips_affine
+ * with the kernel's interpolator (or vips_zoom) for scales > 1; vscale <= 0 means == scale;
+ * gap < 0 selects the default 2.0 (resize.c:397).  Nearest-neighbour DOWNsizing
+ * (vips_subsample) is outside the path. */
 VIPS_HIP_API int vips_hip_resize(VipsHipImage *in, VipsHipImage **out,
 	double scale, double vscale, int kernel, double gap);
 /* vips_thumbnail_image (resample/thumbnail.c:678-1067 with vips_thumbnail_calculate_shrink

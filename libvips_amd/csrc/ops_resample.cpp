@@ -288,7 +288,7 @@ int vips_hip_shrink(VipsHipImage *in, VipsHipImage **out, double hshrink, double
 	return shrink_axis(t0.im, out, hshrink_int, ceil_mode, false);
 }
 
-// vips_resize_build, resample/resize.c:135-329, downsizing half.
+// vips_resize_build, resample/resize.c:135-329.
 int vips_hip_resize(VipsHipImage *in, VipsHipImage **out, double scale, double vscale_arg,
 	int kernel, double gap)
 {
@@ -296,12 +296,12 @@ int vips_hip_resize(VipsHipImage *in, VipsHipImage **out, double scale, double v
 	double vscale = vscale_arg > 0.0 ? vscale_arg : scale;
 	if (gap < 0.0)
 		gap = 2.0; // resize.c:397
-	if (kernel == VIPS_HIP_KERNEL_NEAREST) {
-		error("resize", "nearest-neighbour resize is outside the HIP path (vips_subsample)");
-		return -1;
-	}
 	if (hscale <= 0.0 || vscale <= 0.0) {
 		error("resize", "scale must be > 0");
+		return -1;
+	}
+	if (kernel == VIPS_HIP_KERNEL_NEAREST && (hscale < 1.0 || vscale < 1.0)) {
+		error("resize", "nearest-neighbour downsizing (vips_subsample) is outside the HIP path");
 		return -1;
 	}
 	// "Don't let either axis drop below 1 px."
@@ -309,25 +309,62 @@ int vips_hip_resize(VipsHipImage *in, VipsHipImage **out, double scale, double v
 		hscale = 1.0 / in->width;
 	if (vscale < 1.0 / in->height)
 		vscale = 1.0 / in->height;
-	if (hscale > 1.0 || vscale > 1.0) {
-		error("resize", "upsizing (vips_affine) is outside the HIP path");
-		return -1;
-	}
 
-	ImageRef t2;
+	// any residual downsizing (the integer pre-shrink lives in reduce_axis)
+	ImageRef t2, t3;
 	VipsHipImage *cur = in;
 	if (vscale < 1.0) {
 		if (reduce_axis(cur, &t2.im, 1.0 / vscale, kernel, gap, true))
 			return -1;
 		cur = t2.im;
 	}
-	if (hscale < 1.0)
-		return reduce_axis(cur, out, 1.0 / hscale, kernel, gap, false);
+	if (hscale < 1.0) {
+		if (reduce_axis(cur, &t3.im, 1.0 / hscale, kernel, gap, false))
+			return -1;
+		cur = t3.im;
+	}
+
+	// any upsizing, resize.c:230-300
+	if (hscale > 1.0 || vscale > 1.0) {
+		const int interpolate = kernel == VIPS_HIP_KERNEL_NEAREST ? VIPS_HIP_INTERPOLATE_NEAREST
+			: kernel == VIPS_HIP_KERNEL_LINEAR                     ? VIPS_HIP_INTERPOLATE_BILINEAR
+																   : VIPS_HIP_INTERPOLATE_BICUBIC;
+		// "For centre sampling, shift by 0.5 down and right.  Except if this is nearest"
+		const double idx = kernel == VIPS_HIP_KERNEL_NEAREST ? 0.0 : 0.5 * (1.0 - 1.0 / hscale);
+		const double idy = kernel == VIPS_HIP_KERNEL_NEAREST ? 0.0 : 0.5 * (1.0 - 1.0 / vscale);
+		VipsHipRegion ri, ro;
+		vips_hip_image_region(cur, &ri);
+		if (kernel == VIPS_HIP_KERNEL_NEAREST && hscale == floor(hscale) && vscale == floor(vscale)) {
+			const int xfac = (int) floor(hscale), yfac = (int) floor(vscale);
+			ImageRef o(vips_hip_image_new(cur->width * xfac, cur->height * yfac, cur->bands, cur->format,
+				cur->interpretation));
+			if (!o.im)
+				return -1;
+			vips_hip_image_region(o.im, &ro);
+			if (vips_hip_zoom_gen(&ri, &ro, xfac, yfac))
+				return -1;
+			*out = o.release();
+			return 0;
+		}
+		// one axis only: the other one's scale is exactly 1 (its displacement is still passed)
+		const double a = hscale > 1.0 ? hscale : 1.0;
+		const double d = vscale > 1.0 ? vscale : 1.0;
+		ImageRef o(vips_hip_image_new(vips_hip_affine_out_size(cur->width, a),
+			vips_hip_affine_out_size(cur->height, d), cur->bands, cur->format, cur->interpretation));
+		if (!o.im)
+			return -1;
+		vips_hip_image_region(o.im, &ro);
+		if (vips_hip_upsize_gen(&ri, &ro, a, d, idx, idy, interpolate, 0))
+			return -1;
+		*out = o.release();
+		return 0;
+	}
+
 	if (cur == in) {
 		*out = copy_image(in);
 		return *out ? 0 : -1;
 	}
-	*out = t2.release();
+	*out = cur == t3.im ? t3.release() : t2.release();
 	return 0;
 }
 

@@ -1,0 +1,506 @@
+// Upsizing half of vips_resize (resample/resize.c:230-300) for gfx950: vips_affine restricted
+// to a pure scale (b = c = 0) with the nearest / bilinear / bicubic interpolators, and vips_zoom.
+//
+//   transform   resample/transform.c:40-75, :180-252; build resample/affine.c:420-620 (embed by
+//               window_offset + 1 with EXTEND_COPY -- never materialised: coordinates clamp)
+//   generate    resample/affine.c:230-397.  Per generate rect the input coordinate of the
+//               first pixel is computed from scratch and then ACCUMULATED (`ix += ddx`) along
+//               the row, so a pixel's x coordinate depends on where its rect starts; the
+//               host replays that accumulation into a table of one double per output column
+//               (rects start at multiples of `tile_width`, 0 = whole rows: the FATSTRIP
+//               geometry a scale-only affine asks for).  y is computed fresh per row.
+//   nearest     resample/interpolate.c:336-352
+//   bilinear    resample/interpolate.c:432-484: 12-bit fixed point for 8 / 16 bit formats,
+//               double for uint / int / float
+//   bicubic     resample/bicubic.cpp:482-600, tables :620-633, arithmetic
+//               resample/templates.h:152-290: fixed point for (u)char, double with clip for the
+//               16 / 32-bit integers, double rounded to float per row for float
+// One thread per output pixel column position; all float arithmetic in the reference's
+// order with separately rounded operations (the library is built with -ffp-contract=off).
+#include "resample.h"
+
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <type_traits>
+#include <list>
+#include <mutex>
+#include <vector>
+
+namespace vh {
+
+// TRANSFORM_SCALE (64), INTERPOLATE_SHIFT (12), INTERPOLATE_SCALE: resample.h
+
+struct BicubicTables {
+	int mi[TRANSFORM_SCALE + 1][4];
+	double mf[TRANSFORM_SCALE + 1][4];
+};
+
+struct UpsizeArgs {
+	const unsigned char *in;
+	unsigned char *out;
+	long long in_stride, out_stride;
+	int in_left, in_top;       // origin of the input window
+	int im_width, im_height;   // the whole input image
+	int out_left, out_top, out_width, out_height; // the rect being generated
+	int bands;
+	int window_offset;
+	double id, tidy;           // y = id * oy - tidy + window_offset
+	const double *tabx;        // x coordinate (embedded space) of output column out_left + i
+	const BicubicTables *tables;
+};
+
+template <typename T>
+static __device__ __forceinline__ T fetch(const UpsizeArgs &a, int ex, int ey, int z)
+{
+	// the embedded image (affine.c:520-532): original pixel (px, py) sits at (px + off, py + off)
+	const int off = a.window_offset + 1;
+	const int px = min(max(ex - off, 0), a.im_width - 1) - a.in_left;
+	const int py = min(max(ey - off, 0), a.im_height - 1) - a.in_top;
+	return ((const T *) (a.in + (long long) py * a.in_stride))[(long long) px * a.bands + z];
+}
+
+static __device__ __forceinline__ int unsigned_fixed_round(int v)
+{
+	return (v + (INTERPOLATE_SCALE >> 1)) >> INTERPOLATE_SHIFT;
+}
+
+static __device__ __forceinline__ int signed_fixed_round(int v)
+{
+	const int sign_of_v = 2 * (v >= 0) - 1;
+	const int round_by = sign_of_v * (INTERPOLATE_SCALE >> 1);
+	return (v + round_by) >> INTERPOLATE_SHIFT;
+}
+
+template <typename T>
+struct UpTraits; // INT_PATH: fixed-point bilinear / bicubic; LO / HI: clip of the double bicubic
+#define UP_TRAITS(TYPE, FIXED, SIGNED_, LO_, HI_) \
+	template <> \
+	struct UpTraits<TYPE> { \
+		static constexpr bool fixed_bilinear = FIXED; \
+		static constexpr bool is_signed = SIGNED_; \
+		static __device__ __forceinline__ double lo() { return (double) (LO_); } \
+		static __device__ __forceinline__ double hi() { return (double) (HI_); } \
+	};
+UP_TRAITS(unsigned char, true, false, 0, UCHAR_MAX)
+UP_TRAITS(signed char, true, true, SCHAR_MIN, SCHAR_MAX)
+UP_TRAITS(unsigned short, true, false, 0, USHRT_MAX)
+UP_TRAITS(short, true, true, SHRT_MIN, SHRT_MAX)
+UP_TRAITS(unsigned int, false, false, 0, INT_MAX)
+UP_TRAITS(int, false, true, INT_MIN, INT_MAX)
+UP_TRAITS(float, false, true, 0, 0)
+#undef UP_TRAITS
+
+// a * b + c * d + e * f + g * h, left to right, every operation rounded (cubic_float)
+static __device__ __forceinline__ double dot4(double c0, double v0, double c1, double v1, double c2,
+	double v2, double c3, double v3)
+{
+	double s = __dmul_rn(c0, v0);
+	s = __dadd_rn(s, __dmul_rn(c1, v1));
+	s = __dadd_rn(s, __dmul_rn(c2, v2));
+	s = __dadd_rn(s, __dmul_rn(c3, v3));
+	return s;
+}
+
+template <typename T, int INTERP>
+__global__ void __launch_bounds__(256)
+upsize_kernel(UpsizeArgs a)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= a.out_width)
+		return;
+	const double x = a.tabx[i];
+	const int wo = a.window_offset;
+	// affine.c:330-336: the clip rectangle, embedded coordinates
+	const int ile = wo, ito = wo, iri = wo + a.im_width, ibo = wo + a.im_height;
+	const int fx = (int) floor(x);
+	const int ix = (int) x;
+
+	for (int yy = blockIdx.y; yy < a.out_height; yy += gridDim.y) {
+		// affine.c:343-365 with ib = ic = -0: y = id * oy, -= idy, += window_offset
+		double y = __dmul_rn(a.id, (double) (a.out_top + yy));
+		y = __dsub_rn(y, a.tidy);
+		y = __dadd_rn(y, (double) wo);
+		const int fy = (int) floor(y);
+		const int iy = (int) y;
+		T *q = (T *) (a.out + (long long) yy * a.out_stride) + (long long) i * a.bands;
+
+		if (!(fx >= ile && fx <= iri && fy >= ito && fy <= ibo)) {
+			for (int z = 0; z < a.bands; z++)
+				q[z] = (T) 0;
+			continue;
+		}
+		if (INTERP == 0) {
+			for (int z = 0; z < a.bands; z++)
+				q[z] = fetch<T>(a, ix, iy, z);
+		}
+		else if (INTERP == 1) {
+			if (UpTraits<T>::fixed_bilinear) {
+				const int X = (int) __dmul_rn(__dsub_rn(x, (double) ix), (double) INTERPOLATE_SCALE);
+				const int Y = (int) __dmul_rn(__dsub_rn(y, (double) iy), (double) INTERPOLATE_SCALE);
+				const int Yd = INTERPOLATE_SCALE - Y;
+				const int c4 = (Y * X) >> INTERPOLATE_SHIFT;
+				const int c2 = (Yd * X) >> INTERPOLATE_SHIFT;
+				const int c3 = Y - c4;
+				const int c1 = Yd - c2;
+				for (int z = 0; z < a.bands; z++)
+					q[z] = (T) ((c1 * (int) fetch<T>(a, ix, iy, z) + c2 * (int) fetch<T>(a, ix + 1, iy, z) +
+									c3 * (int) fetch<T>(a, ix, iy + 1, z) + c4 * (int) fetch<T>(a, ix + 1, iy + 1, z) +
+									(1 << INTERPOLATE_SHIFT) / 2) >>
+						INTERPOLATE_SHIFT);
+			}
+			else {
+				const double X = __dsub_rn(x, (double) ix);
+				const double Y = __dsub_rn(y, (double) iy);
+				const double Yd = __dsub_rn(1.0, Y);
+				const double c4 = __dmul_rn(Y, X);
+				const double c2 = __dmul_rn(Yd, X);
+				const double c3 = __dsub_rn(Y, c4);
+				const double c1 = __dsub_rn(Yd, c2);
+				for (int z = 0; z < a.bands; z++)
+					q[z] = (T) dot4(c1, (double) fetch<T>(a, ix, iy, z), c2, (double) fetch<T>(a, ix + 1, iy, z), c3,
+						(double) fetch<T>(a, ix, iy + 1, z), c4, (double) fetch<T>(a, ix + 1, iy + 1, z));
+			}
+		}
+		else {
+			// bicubic.cpp:488-502: table index with round to nearest
+			const int sx = (int) __dmul_rn(__dmul_rn(x, (double) TRANSFORM_SCALE), 2.0);
+			const int sy = (int) __dmul_rn(__dmul_rn(y, (double) TRANSFORM_SCALE), 2.0);
+			const int tx = ((sx & (TRANSFORM_SCALE * 2 - 1)) + 1) >> 1;
+			const int ty = ((sy & (TRANSFORM_SCALE * 2 - 1)) + 1) >> 1;
+			if (sizeof(T) == 1) {
+				const int *cx = a.tables->mi[tx];
+				const int *cy = a.tables->mi[ty];
+				for (int z = 0; z < a.bands; z++) {
+					int r[4];
+#pragma unroll
+					for (int j = 0; j < 4; j++) {
+						const int s = cx[0] * (int) fetch<T>(a, ix - 1, iy - 1 + j, z) +
+							cx[1] * (int) fetch<T>(a, ix, iy - 1 + j, z) +
+							cx[2] * (int) fetch<T>(a, ix + 1, iy - 1 + j, z) +
+							cx[3] * (int) fetch<T>(a, ix + 2, iy - 1 + j, z);
+						r[j] = UpTraits<T>::is_signed ? signed_fixed_round(s) : unsigned_fixed_round(s);
+					}
+					const int s = cy[0] * r[0] + cy[1] * r[1] + cy[2] * r[2] + cy[3] * r[3];
+					int v = UpTraits<T>::is_signed ? signed_fixed_round(s) : unsigned_fixed_round(s);
+					v = min(max(v, (int) UpTraits<T>::lo()), (int) UpTraits<T>::hi());
+					q[z] = (T) v;
+				}
+			}
+			else {
+				const double *cx = a.tables->mf[tx];
+				const double *cy = a.tables->mf[ty];
+				for (int z = 0; z < a.bands; z++) {
+					double r[4];
+#pragma unroll
+					for (int j = 0; j < 4; j++) {
+						r[j] = dot4(cx[0], (double) fetch<T>(a, ix - 1, iy - 1 + j, z), cx[1],
+							(double) fetch<T>(a, ix, iy - 1 + j, z), cx[2], (double) fetch<T>(a, ix + 1, iy - 1 + j, z),
+							cx[3], (double) fetch<T>(a, ix + 2, iy - 1 + j, z));
+						if (std::is_floating_point<T>::value)
+							r[j] = (double) (float) r[j]; // cubic_float<float> returns a float
+					}
+					double v = dot4(cy[0], r[0], cy[1], r[1], cy[2], r[2], cy[3], r[3]);
+					if (!std::is_floating_point<T>::value) {
+						// VIPS_CLIP(lo, v, hi), then the C conversion
+						v = v < UpTraits<T>::lo() ? UpTraits<T>::lo() : (v > UpTraits<T>::hi() ? UpTraits<T>::hi() : v);
+					}
+					q[z] = (T) v;
+				}
+			}
+		}
+	}
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+zoom_kernel(UpsizeArgs a, int xfac, int yfac)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= a.out_width)
+		return;
+	const int px = (a.out_left + i) / xfac - a.in_left;
+	for (int yy = blockIdx.y; yy < a.out_height; yy += gridDim.y) {
+		const int py = (a.out_top + yy) / yfac - a.in_top;
+		const T *p = (const T *) (a.in + (long long) py * a.in_stride) + (long long) px * a.bands;
+		T *q = (T *) (a.out + (long long) yy * a.out_stride) + (long long) i * a.bands;
+		for (int z = 0; z < a.bands; z++)
+			q[z] = p[z];
+	}
+}
+
+// ---------------------------------------------------------------------- host side
+
+// templates.h:296-320
+static void coefficients_catmull(double c[4], const double x)
+{
+	const double cr1 = 1. - x;
+	const double cr2 = -.5 * x;
+	const double cr3 = cr1 * cr2;
+	const double cone = cr1 * cr3;
+	const double cfou = x * cr3;
+	const double cr4 = cfou - cone;
+	const double ctwo = cr1 - cone + cr4;
+	const double cthr = x - cfou - cr4;
+	c[0] = cone;
+	c[3] = cfou;
+	c[1] = ctwo;
+	c[2] = cthr;
+}
+
+static std::mutex &g_up_mutex = *new std::mutex;
+static const BicubicTables *g_bicubic = nullptr;
+
+static const BicubicTables *bicubic_tables()
+{
+	std::lock_guard<std::mutex> lock(g_up_mutex);
+	if (!g_bicubic) {
+		BicubicTables t;
+		// bicubic.cpp:624-633
+		for (int x = 0; x < TRANSFORM_SCALE + 1; x++) {
+			coefficients_catmull(t.mf[x], (float) x / TRANSFORM_SCALE);
+			for (int i = 0; i < 4; i++)
+				t.mi[x][i] = t.mf[x][i] * INTERPOLATE_SCALE;
+		}
+		g_bicubic = (const BicubicTables *) upload(&t, sizeof(t));
+	}
+	return g_bicubic;
+}
+
+// the per-column x coordinates, cached (a table upload synchronises the stream)
+struct TabKey {
+	int out_left, out_width, window_offset, tile_width;
+	double ia, tidx;
+	bool operator==(const TabKey &o) const
+	{
+		return out_left == o.out_left && out_width == o.out_width && window_offset == o.window_offset &&
+			tile_width == o.tile_width && memcmp(&ia, &o.ia, sizeof(double)) == 0 &&
+			memcmp(&tidx, &o.tidx, sizeof(double)) == 0;
+	}
+};
+typedef std::shared_ptr<double> TabPtr;
+static std::list<std::pair<TabKey, TabPtr>> &g_tabs = *new std::list<std::pair<TabKey, TabPtr>>;
+
+static TabPtr column_table(const TabKey &key, int full_width)
+{
+	{
+		std::lock_guard<std::mutex> lock(g_up_mutex);
+		for (auto it = g_tabs.begin(); it != g_tabs.end(); ++it)
+			if (it->first == key) {
+				g_tabs.splice(g_tabs.begin(), g_tabs, it);
+				return g_tabs.front().second;
+			}
+	}
+	// affine.c:343-392, ib * oy = -0: x = ia * le, -= idx, += window_offset, then += ia per pixel
+	std::vector<double> tab(key.out_width);
+	const int tw = key.tile_width > 0 ? key.tile_width : full_width;
+	int col = (key.out_left / tw) * tw;
+	while (col < key.out_left + key.out_width) {
+		const int end = col + tw;
+		double x = key.ia * (double) col;
+		x -= key.tidx;
+		x += key.window_offset;
+		for (int xx = col; xx < end && xx < key.out_left + key.out_width; xx++) {
+			if (xx >= key.out_left)
+				tab[xx - key.out_left] = x;
+			x += key.ia;
+		}
+		col = end;
+	}
+	double *d = (double *) upload(tab.data(), tab.size() * sizeof(double));
+	if (!d)
+		return TabPtr();
+	TabPtr p(d, [](double *q) { vips_hip_free(q); });
+	std::lock_guard<std::mutex> lock(g_up_mutex);
+	g_tabs.emplace_front(key, p);
+	while (g_tabs.size() > 32)
+		g_tabs.pop_back();
+	return p;
+}
+
+static int rows_grid(int gx, int height)
+{
+	int gy = 16384 / (gx > 0 ? gx : 1);
+	gy = gy < 1 ? 1 : gy;
+	return height < gy ? height : gy;
+}
+
+template <typename T>
+static int launch_upsize(const UpsizeArgs &a, int interpolate)
+{
+	dim3 block(256, 1, 1);
+	const int gx = (a.out_width + 255) / 256;
+	dim3 grid(gx, rows_grid(gx, a.out_height), 1);
+	Gate gate("upsize");
+	if (interpolate == VIPS_HIP_INTERPOLATE_NEAREST)
+		hipLaunchKernelGGL((upsize_kernel<T, 0>), grid, block, 0, stream(), a);
+	else if (interpolate == VIPS_HIP_INTERPOLATE_BILINEAR)
+		hipLaunchKernelGGL((upsize_kernel<T, 1>), grid, block, 0, stream(), a);
+	else
+		hipLaunchKernelGGL((upsize_kernel<T, 2>), grid, block, 0, stream(), a);
+	VH_CHECK(hipGetLastError());
+	return 0;
+}
+
+template <typename T>
+static int launch_zoom(const UpsizeArgs &a, int xfac, int yfac)
+{
+	dim3 block(256, 1, 1);
+	const int gx = (a.out_width + 255) / 256;
+	dim3 grid(gx, rows_grid(gx, a.out_height), 1);
+	Gate gate("zoom");
+	hipLaunchKernelGGL((zoom_kernel<T>), grid, block, 0, stream(), a, xfac, yfac);
+	VH_CHECK(hipGetLastError());
+	return 0;
+}
+
+static int fill_args(const char *domain, const VipsHipRegion *in, const VipsHipRegion *out, UpsizeArgs *a)
+{
+	if (ensure_init())
+		return -1;
+	if (check_region(domain, in) || check_region(domain, out))
+		return -1;
+	if (in->bands != out->bands || in->format != out->format) {
+		error(domain, "input and output must have the same bands and format");
+		return -1;
+	}
+	a->in = (const unsigned char *) in->data;
+	a->out = (unsigned char *) out->data;
+	a->in_stride = (long long) in->stride;
+	a->out_stride = (long long) out->stride;
+	a->in_left = in->left;
+	a->in_top = in->top;
+	a->im_width = in->im_width;
+	a->im_height = in->im_height;
+	a->out_left = out->left;
+	a->out_top = out->top;
+	a->out_width = out->width;
+	a->out_height = out->height;
+	a->bands = region_elems_per_pel(in);
+	return 0;
+}
+
+#define UP_DISPATCH(FMT, CALL) \
+	switch (FMT) { \
+	case VIPS_HIP_FORMAT_UCHAR: return CALL(unsigned char); \
+	case VIPS_HIP_FORMAT_CHAR: return CALL(signed char); \
+	case VIPS_HIP_FORMAT_USHORT: return CALL(unsigned short); \
+	case VIPS_HIP_FORMAT_SHORT: return CALL(short); \
+	case VIPS_HIP_FORMAT_UINT: return CALL(unsigned int); \
+	case VIPS_HIP_FORMAT_INT: return CALL(int); \
+	case VIPS_HIP_FORMAT_FLOAT: \
+	case VIPS_HIP_FORMAT_COMPLEX: return CALL(float); \
+	default: break; \
+	}
+
+} // namespace vh
+
+using namespace vh;
+
+extern "C" {
+
+int vips_hip_affine_out_size(int in_size, double scale)
+{
+	// transform.c:220-231: the corners 0 and scale * in_size, VIPS_ROUND_INT
+	const double right = scale * in_size;
+	return (int) (right > 0 ? right + 0.5 : right - 0.5);
+}
+
+int vips_hip_upsize_gen(const VipsHipRegion *in, const VipsHipRegion *out, double hscale, double vscale,
+	double idx, double idy, int interpolate, int tile_width)
+{
+	const char *domain = "affine";
+	UpsizeArgs a;
+	if (fill_args(domain, in, out, &a))
+		return -1;
+	if (!(hscale > 0.0) || !(vscale > 0.0)) {
+		error(domain, "scale factors should be > 0");
+		return -1;
+	}
+	if (interpolate < VIPS_HIP_INTERPOLATE_NEAREST || interpolate > VIPS_HIP_INTERPOLATE_BICUBIC) {
+		error(domain, "interpolator %d is outside the HIP path (nearest, bilinear, bicubic)", interpolate);
+		return -1;
+	}
+	const int window_size = interpolate == VIPS_HIP_INTERPOLATE_NEAREST ? 1
+		: interpolate == VIPS_HIP_INTERPOLATE_BILINEAR               ? 2
+																	 : 4;
+	// interpolate.c:150-167
+	const int window_offset = window_size / 2 - 1 > 0 ? window_size / 2 - 1 : 0;
+	// the window must hold every pixel the stencils of this rect touch, after clamping (with a
+	// one-pixel margin for the accumulated rounding of the column coordinates)
+	{
+		const double tmp0 = 1.0 / (hscale * vscale);
+		const double iax = tmp0 * vscale, iay = tmp0 * hscale;
+		const int s_left = interpolate == VIPS_HIP_INTERPOLATE_BICUBIC ? 1 : 0;
+		const int s_right = window_size - 1 - s_left;
+		const int shift = window_offset + 1; // embedded -> original coordinates
+		const int x_lo = (int) floor(iax * out->left - (idx - 1) + window_offset) - s_left - shift - 1;
+		const int x_hi = (int) floor(iax * (out->left + out->width - 1) - (idx - 1) + window_offset) + s_right - shift + 1;
+		const int y_lo = (int) floor(iay * out->top - (idy - 1) + window_offset) - s_left - shift - 1;
+		const int y_hi = (int) floor(iay * (out->top + out->height - 1) - (idy - 1) + window_offset) + s_right - shift + 1;
+		const int nx0 = x_lo < 0 ? 0 : (x_lo > in->im_width - 1 ? in->im_width - 1 : x_lo);
+		const int ny0 = y_lo < 0 ? 0 : (y_lo > in->im_height - 1 ? in->im_height - 1 : y_lo);
+		const int nx1 = x_hi > in->im_width - 1 ? in->im_width - 1 : (x_hi < 0 ? 0 : x_hi);
+		const int ny1 = y_hi > in->im_height - 1 ? in->im_height - 1 : (y_hi < 0 ? 0 : y_hi);
+		if (nx0 < in->left || ny0 < in->top || nx1 >= in->left + in->width || ny1 >= in->top + in->height) {
+			error(domain, "input region too small");
+			return -1;
+		}
+	}
+	// transform.c:40-75 with b = c = 0
+	const double det = hscale * vscale - 0.0 * 0.0;
+	const double tmp = 1.0 / det;
+	const double ia = tmp * vscale;
+	a.id = tmp * hscale;
+	a.tidy = idy - 1; // affine.c:538-539
+	a.window_offset = window_offset;
+	TabKey key = { out->left, out->width, window_offset, tile_width, ia, idx - 1 };
+	TabPtr tab = column_table(key, out->im_width);
+	if (!tab)
+		return -1;
+	a.tabx = tab.get();
+	a.tables = bicubic_tables();
+	if (!a.tables)
+		return -1;
+#define CALL(T) launch_upsize<T>(a, interpolate)
+	UP_DISPATCH(in->format, CALL)
+#undef CALL
+	error(domain, "band format %d is outside the HIP path (double images use the no-table bicubic)", in->format);
+	return -1;
+}
+
+int vips_hip_zoom_gen(const VipsHipRegion *in, const VipsHipRegion *out, int xfac, int yfac)
+{
+	const char *domain = "zoom";
+	UpsizeArgs a;
+	if (fill_args(domain, in, out, &a))
+		return -1;
+	if (xfac < 1 || yfac < 1) {
+		error(domain, "zoom factors should be >= 1");
+		return -1;
+	}
+	if (out->left / xfac < in->left || out->top / yfac < in->top ||
+		(out->left + out->width - 1) / xfac >= in->left + in->width ||
+		(out->top + out->height - 1) / yfac >= in->top + in->height) {
+		error(domain, "input region too small");
+		return -1;
+	}
+	a.window_offset = 0;
+	a.id = a.tidy = 0.0;
+	a.tabx = nullptr;
+	a.tables = nullptr;
+	// pixel replication is format-blind: move whole pels of 1, 2, 4 bytes per band
+	const int es = format_sizeof(format_real(in->format));
+	switch (es) {
+	case 1: return launch_zoom<unsigned char>(a, xfac, yfac);
+	case 2: return launch_zoom<unsigned short>(a, xfac, yfac);
+	case 4: return launch_zoom<unsigned int>(a, xfac, yfac);
+	case 8: return launch_zoom<unsigned long long>(a, xfac, yfac);
+	default: break;
+	}
+	error(domain, "unsupported band format %d", in->format);
+	return -1;
+}
+
+} // extern "C"

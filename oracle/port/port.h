@@ -45,6 +45,13 @@ int port_shrinkh(const void *in, int width, int height, int bands, int format, i
 int port_shrinkv(const void *in, int width, int height, int bands, int format, int vshrink,
 	int ceil_mode, void *out);
 
+/* upsizing (port_affine.c): vips_affine for a pure scale + interpolators, vips_zoom */
+int port_affine_out_size(int in_size, double scale);
+int port_affine_scale(const void *in, int width, int height, int bands, int format,
+	double hscale, double vscale, double idx, double idy, int interp, int tile_width, void *out);
+int port_zoom(const void *in, int width, int height, int bands, int format, int xfac, int yfac, void *out);
+void port_bicubic_tables(int *matrixi, double *matrixf);
+
 /* convolution (port_conv.c) */
 int port_convi(const void *in, int width, int height, int bands, int format,
 	const double *mask, int mw, int mh, double scale, double offset, void *out);

@@ -57,6 +57,20 @@ for _bands in (3, 4):
                                 call=("resize", dict(scale=0.125))))
 RESAMPLE_CASES.append(_case("resize", "scale=0.3,vscale=0.21,kernel=mitchell", 300, 260, 3, np.uint16, 21,
                             call=("resize", dict(scale=0.3, vscale=0.21, kernel="mitchell"))))
+# upsizing half of resize (resize.c:230-300): vips_affine with the nearest / bilinear / bicubic
+# interpolators, vips_zoom for integral nearest; mixed up / down; every format of the path
+for _dtype in (np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.float32):
+    for _kernel in ("linear", "cubic"):
+        RESAMPLE_CASES.append(_case("resize", "scale=2.3,kernel=%s" % _kernel, 61, 45, 3, _dtype, 22,
+                                    call=("resize", dict(scale=2.3, kernel=_kernel))))
+for _args, _kw in (("scale=3,vscale=2,kernel=nearest", dict(scale=3.0, vscale=2.0, kernel="nearest")),
+                   ("scale=2.5,vscale=1.7,kernel=nearest", dict(scale=2.5, vscale=1.7, kernel="nearest")),
+                   ("scale=1.5,vscale=0.7,kernel=lanczos3", dict(scale=1.5, vscale=0.7, kernel="lanczos3")),
+                   ("scale=0.6,vscale=1.9,kernel=linear", dict(scale=0.6, vscale=1.9, kernel="linear")),
+                   ("scale=4,kernel=lanczos3", dict(scale=4.0, kernel="lanczos3")),
+                   ("scale=1.01,vscale=7.3,kernel=mitchell", dict(scale=1.01, vscale=7.3, kernel="mitchell"))):
+    for _bands, _dtype in ((4, np.uint8), (1, np.uint16), (2, np.float32)):
+        RESAMPLE_CASES.append(_case("resize", _args, 83, 37, _bands, _dtype, 23, call=("resize", _kw)))
 
 
 # ----------------------------------------------------------------- conv / colour cases

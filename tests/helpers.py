@@ -327,8 +327,37 @@ class Port(object):
         return cls.shrinkh(cls.shrinkv(array, int(vshrink), ceil), int(hshrink), ceil)
 
     @classmethod
+    def affine_scale(cls, array, hscale, vscale, idx=0.0, idy=0.0, interpolate="bicubic", tile_width=0):
+        """vips_affine for a pure scale (affine.c:230-620) with nearest / bilinear / bicubic."""
+        a = cls._prep(array)
+        lib = cls.lib()
+        lib.port_affine_out_size.argtypes = [ctypes.c_int, ctypes.c_double]
+        lib.port_affine_scale.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        h, w, b = a.shape
+        ow = lib.port_affine_out_size(w, hscale)
+        oh = lib.port_affine_out_size(h, vscale)
+        out = np.empty((oh, ow, b), dtype=a.dtype)
+        interp = {"nearest": 0, "bilinear": 1, "bicubic": 2}[interpolate]
+        r = lib.port_affine_scale(a.ctypes.data, w, h, b, DTYPE_FORMATS[a.dtype], hscale, vscale, idx, idy,
+                                  interp, tile_width, out.ctypes.data)
+        if r != 0:
+            raise ValueError("port_affine_scale: unsupported format")
+        return out
+
+    @classmethod
+    def zoom(cls, array, xfac, yfac):
+        """vips_zoom (conversion/zoom.c)."""
+        a = cls._prep(array)
+        return np.ascontiguousarray(np.repeat(np.repeat(a, yfac, axis=0), xfac, axis=1))
+
+    @classmethod
     def resize(cls, array, scale, vscale=None, kernel="lanczos3", gap=2.0, tile=16):
-        """vips_resize_build (resize.c:135-329), downsizing half."""
+        """vips_resize_build (resize.c:135-329): residual reduce, then any upsizing through
+        vips_affine / vips_zoom (nearest downsizing by vips_subsample is outside the port)."""
+        import math
+
         a = cls._prep(array)
         hscale = scale
         vscale = scale if vscale is None else vscale
@@ -338,6 +367,18 @@ class Port(object):
             a = cls.reducev(a, 1.0 / vscale, kernel, gap, tile)
         if hscale < 1.0:
             a = cls.reduceh(a, 1.0 / hscale, kernel, gap)
+        if hscale > 1.0 or vscale > 1.0:
+            interpolate = {"nearest": "nearest", "linear": "bilinear"}.get(kernel, "bicubic")
+            idx = 0.0 if kernel == "nearest" else 0.5 * (1.0 - 1.0 / hscale)
+            idy = 0.0 if kernel == "nearest" else 0.5 * (1.0 - 1.0 / vscale)
+            if kernel == "nearest" and hscale == math.floor(hscale) and vscale == math.floor(vscale):
+                a = cls.zoom(a, int(math.floor(hscale)), int(math.floor(vscale)))
+            elif hscale > 1.0 and vscale > 1.0:
+                a = cls.affine_scale(a, hscale, vscale, idx, idy, interpolate)
+            elif hscale > 1.0:
+                a = cls.affine_scale(a, hscale, 1.0, idx, idy, interpolate)
+            else:
+                a = cls.affine_scale(a, 1.0, vscale, idx, idy, interpolate)
         return a
 
 
