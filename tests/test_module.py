@@ -122,5 +122,7 @@ class TestModuleOnGpu(object):
 
     def test_error_propagates_as_vips_error(self):
         src = helpers.lcg_image(64, 48, 3, np.uint8, 77)
-        with pytest.raises(RuntimeError, match="upsizing"):
-            Ref.run("resize_hip", src, "scale=2")
+        with pytest.raises(RuntimeError, match="nearest-neighbour downsizing"):
+            Ref.run("resize_hip", src, "scale=0.5,kernel=nearest")
+        # upsizing goes through the module too (vips_affine + bicubic on the device)
+        assert np.array_equal(Ref.run("resize_hip", src, "scale=2.5"), Ref.run("resize", src, "scale=2.5"))
