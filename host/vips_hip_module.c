@@ -207,6 +207,14 @@ vips_hip_op_build(VipsObject *object)
 		vips_hip_image_unref(fresh);
 		return hip_fail(class->nickname);
 	}
+	/* The kernels were queued on THIS thread's stream; generate runs on libvips worker
+	 * threads with their own (non-blocking) streams, and a downstream *_hip op may build on
+	 * yet another thread: finish the work before anyone else can see the result, and before
+	 * the uploaded input goes back to the pool. */
+	if (vips_hip_synchronize()) {
+		vips_hip_image_unref(fresh);
+		return hip_fail(class->nickname);
+	}
 	vips_hip_image_unref(fresh);
 
 	g_object_set(object, "out", vips_image_new(), NULL);

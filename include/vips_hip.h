@@ -279,6 +279,10 @@ VIPS_HIP_API int vips_hip_affine_out_size(int in_size, double scale);
 /* vips_zoom (conversion/zoom.c): integral pixel replication, what vips_resize uses for
  * kernel nearest with integral scales (resize.c:257-266). */
 VIPS_HIP_API int vips_hip_zoom_gen(const VipsHipRegion *in, const VipsHipRegion *out, int xfac, int yfac);
+/* vips_subsample (conversion/subsample.c:148-240): out(x, y) = in(x * xfac, y * yfac), output
+ * size in / fac; what vips_resize uses for the integer part of a nearest-neighbour shrink
+ * (resize.c:165-203). */
+VIPS_HIP_API int vips_hip_subsample_gen(const VipsHipRegion *in, const VipsHipRegion *out, int xfac, int yfac);
 
 /* -------------------------------------------------------------- convolution */
 
@@ -406,8 +410,8 @@ VIPS_HIP_API int vips_hip_shrink(VipsHipImage *in, VipsHipImage **out,
 	double hshrink, double vshrink, int ceil_mode);
 /* vips_resize (resample/resize.c:135-329): integer shrink + reduce for scales < 1, vips_affine
  * with the kernel's interpolator (or vips_zoom) for scales > 1; vscale <= 0 means == scale;
- * gap < 0 selects the default 2.0 (resize.c:397).  Nearest-neighbour DOWNsizing
- * (vips_subsample) is outside the path. */
+ * gap < 0 selects the default 2.0 (resize.c:397).  Kernel nearest shrinks by vips_subsample
+ * first (resize.c:165-203). */
 VIPS_HIP_API int vips_hip_resize(VipsHipImage *in, VipsHipImage **out,
 	double scale, double vscale, int kernel, double gap);
 /* vips_thumbnail_image (resample/thumbnail.c:678-1067 with vips_thumbnail_calculate_shrink

@@ -108,6 +108,7 @@ _SIGNATURES = {
     "vips_hip_upsize_gen": (c_int, [RegionP, RegionP, c_double, c_double, c_double, c_double, c_int, c_int]),
     "vips_hip_affine_out_size": (c_int, [c_int, c_double]),
     "vips_hip_zoom_gen": (c_int, [RegionP, RegionP, c_int, c_int]),
+    "vips_hip_subsample_gen": (c_int, [RegionP, RegionP, c_int, c_int]),
     "vips_hip_reduce_gen": (c_int, [c_void_p, c_void_p, RegionP, RegionP]),
     "vips_hip_reduce_gen_tiled": (c_int, [c_void_p, c_void_p, RegionP, RegionP, c_int]),
     # shrink

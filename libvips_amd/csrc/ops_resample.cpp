@@ -300,19 +300,49 @@ int vips_hip_resize(VipsHipImage *in, VipsHipImage **out, double scale, double v
 		error("resize", "scale must be > 0");
 		return -1;
 	}
-	if (kernel == VIPS_HIP_KERNEL_NEAREST && (hscale < 1.0 || vscale < 1.0)) {
-		error("resize", "nearest-neighbour downsizing (vips_subsample) is outside the HIP path");
-		return -1;
+	ImageRef t1, t2, t3;
+	VipsHipImage *cur = in;
+	if (kernel == VIPS_HIP_KERNEL_NEAREST) {
+		// the int part of the scale by vips_subsample, resize.c:165-203
+		int int_hshrink, int_vshrink;
+		if (gap < 1.0) {
+			int_hshrink = (int) floor(1.0 / hscale);
+			int_vshrink = (int) floor(1.0 / vscale);
+		}
+		else {
+			const int target_width = (int) (in->width * hscale + 0.5);   // VIPS_ROUND_UINT
+			const int target_height = (int) (in->height * vscale + 0.5);
+			int_hshrink = (int) floor((double) in->width / target_width / gap);
+			int_vshrink = (int) floor((double) in->height / target_height / gap);
+		}
+		int_hshrink = int_hshrink > 1 ? int_hshrink : 1;
+		int_vshrink = int_vshrink > 1 ? int_vshrink : 1;
+		if (int_vshrink > 1 || int_hshrink > 1) {
+			const int sw = in->width / int_hshrink, sh = in->height / int_vshrink;
+			if (sw <= 0 || sh <= 0) {
+				error("subsample", "image has shrunk to nothing");
+				return -1;
+			}
+			t1.im = vips_hip_image_new(sw, sh, in->bands, in->format, in->interpretation);
+			if (!t1.im)
+				return -1;
+			VipsHipRegion ri, ro;
+			vips_hip_image_region(in, &ri);
+			vips_hip_image_region(t1.im, &ro);
+			if (vips_hip_subsample_gen(&ri, &ro, int_hshrink, int_vshrink))
+				return -1;
+			cur = t1.im;
+			hscale *= int_hshrink;
+			vscale *= int_vshrink;
+		}
 	}
 	// "Don't let either axis drop below 1 px."
-	if (hscale < 1.0 / in->width)
-		hscale = 1.0 / in->width;
-	if (vscale < 1.0 / in->height)
-		vscale = 1.0 / in->height;
+	if (hscale < 1.0 / cur->width)
+		hscale = 1.0 / cur->width;
+	if (vscale < 1.0 / cur->height)
+		vscale = 1.0 / cur->height;
 
-	// any residual downsizing (the integer pre-shrink lives in reduce_axis)
-	ImageRef t2, t3;
-	VipsHipImage *cur = in;
+	// any residual downsizing (the integer pre-shrink of the other kernels lives in reduce_axis)
 	if (vscale < 1.0) {
 		if (reduce_axis(cur, &t2.im, 1.0 / vscale, kernel, gap, true))
 			return -1;
@@ -364,7 +394,7 @@ int vips_hip_resize(VipsHipImage *in, VipsHipImage **out, double scale, double v
 		*out = copy_image(in);
 		return *out ? 0 : -1;
 	}
-	*out = cur == t3.im ? t3.release() : t2.release();
+	*out = cur == t3.im ? t3.release() : cur == t2.im ? t2.release() : t1.release();
 	return 0;
 }
 

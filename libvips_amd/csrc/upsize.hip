@@ -230,6 +230,24 @@ zoom_kernel(UpsizeArgs a, int xfac, int yfac)
 	}
 }
 
+// vips_subsample (conversion/subsample.c): out(x, y) = in(x * xfac, y * yfac)
+template <typename T>
+__global__ void __launch_bounds__(256)
+subsample_kernel(UpsizeArgs a, int xfac, int yfac)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= a.out_width)
+		return;
+	const long long px = (long long) (a.out_left + i) * xfac - a.in_left;
+	for (int yy = blockIdx.y; yy < a.out_height; yy += gridDim.y) {
+		const long long py = (long long) (a.out_top + yy) * yfac - a.in_top;
+		const T *p = (const T *) (a.in + py * a.in_stride) + px * a.bands;
+		T *q = (T *) (a.out + (long long) yy * a.out_stride) + (long long) i * a.bands;
+		for (int z = 0; z < a.bands; z++)
+			q[z] = p[z];
+	}
+}
+
 // ---------------------------------------------------------------------- host side
 
 // templates.h:296-320
@@ -339,6 +357,18 @@ static int launch_upsize(const UpsizeArgs &a, int interpolate)
 		hipLaunchKernelGGL((upsize_kernel<T, 1>), grid, block, 0, stream(), a);
 	else
 		hipLaunchKernelGGL((upsize_kernel<T, 2>), grid, block, 0, stream(), a);
+	VH_CHECK(hipGetLastError());
+	return 0;
+}
+
+template <typename T>
+static int launch_subsample(const UpsizeArgs &a, int xfac, int yfac)
+{
+	dim3 block(256, 1, 1);
+	const int gx = (a.out_width + 255) / 256;
+	dim3 grid(gx, rows_grid(gx, a.out_height), 1);
+	Gate gate("subsample");
+	hipLaunchKernelGGL((subsample_kernel<T>), grid, block, 0, stream(), a, xfac, yfac);
 	VH_CHECK(hipGetLastError());
 	return 0;
 }
@@ -497,6 +527,38 @@ int vips_hip_zoom_gen(const VipsHipRegion *in, const VipsHipRegion *out, int xfa
 	case 2: return launch_zoom<unsigned short>(a, xfac, yfac);
 	case 4: return launch_zoom<unsigned int>(a, xfac, yfac);
 	case 8: return launch_zoom<unsigned long long>(a, xfac, yfac);
+	default: break;
+	}
+	error(domain, "unsupported band format %d", in->format);
+	return -1;
+}
+
+int vips_hip_subsample_gen(const VipsHipRegion *in, const VipsHipRegion *out, int xfac, int yfac)
+{
+	const char *domain = "subsample";
+	UpsizeArgs a;
+	if (fill_args(domain, in, out, &a))
+		return -1;
+	if (xfac < 1 || yfac < 1) {
+		error(domain, "factors should be positive");
+		return -1;
+	}
+	if ((long long) out->left * xfac < in->left || (long long) out->top * yfac < in->top ||
+		(long long) (out->left + out->width - 1) * xfac >= in->left + in->width ||
+		(long long) (out->top + out->height - 1) * yfac >= in->top + in->height) {
+		error(domain, "input region too small");
+		return -1;
+	}
+	a.window_offset = 0;
+	a.id = a.tidy = 0.0;
+	a.tabx = nullptr;
+	a.tables = nullptr;
+	const int es = format_sizeof(format_real(in->format));
+	switch (es) {
+	case 1: return launch_subsample<unsigned char>(a, xfac, yfac);
+	case 2: return launch_subsample<unsigned short>(a, xfac, yfac);
+	case 4: return launch_subsample<unsigned int>(a, xfac, yfac);
+	case 8: return launch_subsample<unsigned long long>(a, xfac, yfac);
 	default: break;
 	}
 	error(domain, "unsupported band format %d", in->format);

@@ -63,6 +63,11 @@ for _dtype in (np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.f
     for _kernel in ("linear", "cubic"):
         RESAMPLE_CASES.append(_case("resize", "scale=2.3,kernel=%s" % _kernel, 61, 45, 3, _dtype, 22,
                                     call=("resize", dict(scale=2.3, kernel=_kernel))))
+for _args, _kw in (("scale=0.1,kernel=nearest", dict(scale=0.1, kernel="nearest")),
+                   ("scale=0.37,vscale=0.21,kernel=nearest", dict(scale=0.37, vscale=0.21, kernel="nearest")),
+                   ("scale=0.05,vscale=1.6,kernel=nearest", dict(scale=0.05, vscale=1.6, kernel="nearest"))):
+    RESAMPLE_CASES.append(_case("resize", _args, 413, 290, 3, np.uint8, 24, call=("resize", _kw)))
+    RESAMPLE_CASES.append(_case("resize", _args, 211, 300, 2, np.int16, 24, call=("resize", _kw)))
 for _args, _kw in (("scale=3,vscale=2,kernel=nearest", dict(scale=3.0, vscale=2.0, kernel="nearest")),
                    ("scale=2.5,vscale=1.7,kernel=nearest", dict(scale=2.5, vscale=1.7, kernel="nearest")),
                    ("scale=1.5,vscale=0.7,kernel=lanczos3", dict(scale=1.5, vscale=0.7, kernel="lanczos3")),

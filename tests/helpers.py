@@ -355,12 +355,25 @@ class Port(object):
     @classmethod
     def resize(cls, array, scale, vscale=None, kernel="lanczos3", gap=2.0, tile=16):
         """vips_resize_build (resize.c:135-329): residual reduce, then any upsizing through
-        vips_affine / vips_zoom (nearest downsizing by vips_subsample is outside the port)."""
+        vips_affine / vips_zoom; kernel nearest shrinks by vips_subsample first."""
         import math
 
         a = cls._prep(array)
         hscale = scale
         vscale = scale if vscale is None else vscale
+        if kernel == "nearest":
+            # the int part by vips_subsample (resize.c:165-203; conversion/subsample.c)
+            h, w = a.shape[:2]
+            if gap < 1.0:
+                ih, iv = math.floor(1.0 / hscale), math.floor(1.0 / vscale)
+            else:
+                tw, th = int(w * hscale + 0.5), int(h * vscale + 0.5)
+                ih, iv = math.floor(w / tw / gap), math.floor(h / th / gap)
+            ih, iv = max(1, int(ih)), max(1, int(iv))
+            if ih > 1 or iv > 1:
+                a = np.ascontiguousarray(a[::iv, ::ih][:h // iv, :w // ih])
+                hscale *= ih
+                vscale *= iv
         hscale = max(hscale, 1.0 / a.shape[1])
         vscale = max(vscale, 1.0 / a.shape[0])
         if vscale < 1.0:

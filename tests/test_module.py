@@ -122,7 +122,10 @@ class TestModuleOnGpu(object):
 
     def test_error_propagates_as_vips_error(self):
         src = helpers.lcg_image(64, 48, 3, np.uint8, 77)
-        with pytest.raises(RuntimeError, match="nearest-neighbour downsizing"):
-            Ref.run("resize_hip", src, "scale=0.5,kernel=nearest")
+        with pytest.raises(RuntimeError, match="approximate"):
+            Ref.run("gaussblur_hip", src, "sigma=2,precision=approximate")
+        # nearest-neighbour downsizing: vips_subsample on the device
+        assert np.array_equal(Ref.run("resize_hip", src, "scale=0.2,kernel=nearest"),
+                              Ref.run("resize", src, "scale=0.2,kernel=nearest"))
         # upsizing goes through the module too (vips_affine + bicubic on the device)
         assert np.array_equal(Ref.run("resize_hip", src, "scale=2.5"), Ref.run("resize", src, "scale=2.5"))

@@ -152,8 +152,8 @@ def test_error_behaviour():
         im.shrinkh(0)
     with pytest.raises(libvips_amd.VipsHipError, match="reduce gap should be >= 1.0"):
         im.reducev(2.0, gap=0.5)
-    with pytest.raises(libvips_amd.VipsHipError, match="nearest-neighbour downsizing"):
-        im.resize(0.5, kernel="nearest")
+    with pytest.raises(libvips_amd.VipsHipError, match="scale must be > 0"):
+        im.resize(-0.5)
 
 
 def test_c2_quarter_size_vs_reference_checksum():
