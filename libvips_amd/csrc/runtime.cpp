@@ -89,17 +89,39 @@ int check_region(const char *domain, const VipsHipRegion *r)
 
 // ---------------------------------------------------------------- the pool
 //
-// Size-bucketed free lists (power-of-two classes from 256 B, exact size above
-// 1 GiB).  Frees are stream-ordered in practice because every thread uses one
-// stream; blocks freed by one thread and reused by another are separated by the
-// hipStreamSynchronize in image download / explicit synchronize, which is the
-// only place results leave the device.
+// Size-bucketed free lists (power-of-two classes from 256 B, 2 MB granules above 1 GiB).
+// A freed block goes to the FREEING THREAD's own list and is handed out again only to that
+// thread: every thread queues its work on one stream, so a block whose last kernel is still
+// in flight can only be reused behind that kernel on the same stream (stream-ordered reuse
+// without events).  Blocks cross threads only through the global list, which receives the
+// lists of threads that exit and everything at vips_hip_pool_trim(); results cross threads
+// only after a synchronize (image download, the module's build()).
 struct Pool {
 	std::mutex mutex;
-	std::map<size_t, std::vector<void *>> free_lists;
+	std::map<size_t, std::vector<void *>> free_lists; // global: orphaned blocks
 	std::unordered_map<void *, size_t> live;
 	size_t cached_bytes = 0;
 	size_t live_bytes = 0;
+
+	struct Local {
+		std::map<size_t, std::vector<void *>> lists;
+		Pool *pool = nullptr;
+		~Local()
+		{
+			// thread exit: pointer moves only (no HIP calls: this also runs at process exit)
+			if (!pool)
+				return;
+			std::lock_guard<std::mutex> lock(pool->mutex);
+			for (auto &kv : lists)
+				for (void *p : kv.second)
+					pool->free_lists[kv.first].push_back(p);
+		}
+	};
+	static Local &local()
+	{
+		static thread_local Local l;
+		return l;
+	}
 
 	static size_t bucket(size_t size)
 	{
@@ -116,19 +138,30 @@ struct Pool {
 	void *alloc(size_t size)
 	{
 		size_t b = bucket(size);
+		void *p = nullptr;
 		{
+			Local &l = local();
+			auto it = l.lists.find(b);
+			if (it != l.lists.end() && !it->second.empty()) {
+				p = it->second.back();
+				it->second.pop_back();
+			}
+		}
+		if (!p) {
 			std::lock_guard<std::mutex> lock(mutex);
 			auto it = free_lists.find(b);
 			if (it != free_lists.end() && !it->second.empty()) {
-				void *p = it->second.back();
+				p = it->second.back();
 				it->second.pop_back();
-				cached_bytes -= b;
-				live[p] = b;
-				live_bytes += b;
-				return p;
 			}
 		}
-		void *p = nullptr;
+		if (p) {
+			std::lock_guard<std::mutex> lock(mutex);
+			cached_bytes -= b;
+			live[p] = b;
+			live_bytes += b;
+			return p;
+		}
 		hipError_t err = hipMalloc(&p, b);
 		if (err != hipSuccess) {
 			// Out of HBM: drop the cache and retry once.
@@ -149,25 +182,39 @@ struct Pool {
 	{
 		if (!p)
 			return;
-		std::lock_guard<std::mutex> lock(mutex);
-		auto it = live.find(p);
-		if (it == live.end())
-			return; // not ours
-		size_t b = it->second;
-		live.erase(it);
-		live_bytes -= b;
-		free_lists[b].push_back(p);
-		cached_bytes += b;
+		size_t b;
+		{
+			std::lock_guard<std::mutex> lock(mutex);
+			auto it = live.find(p);
+			if (it == live.end())
+				return; // not ours
+			b = it->second;
+			live.erase(it);
+			live_bytes -= b;
+			cached_bytes += b;
+		}
+		Local &l = local();
+		l.pool = this;
+		l.lists[b].push_back(p);
 	}
 
+	// frees the calling thread's cache and the global list (other threads keep theirs)
 	void trim()
 	{
+		Local &l = local();
 		std::lock_guard<std::mutex> lock(mutex);
-		for (auto &kv : free_lists)
-			for (void *p : kv.second)
+		for (auto &kv : l.lists)
+			for (void *p : kv.second) {
 				(void) hipFree(p);
+				cached_bytes -= kv.first;
+			}
+		l.lists.clear();
+		for (auto &kv : free_lists)
+			for (void *p : kv.second) {
+				(void) hipFree(p);
+				cached_bytes -= kv.first;
+			}
 		free_lists.clear();
-		cached_bytes = 0;
 	}
 };
 
