@@ -153,15 +153,21 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 reducev_general(RegionArgs in, RegionArgs out, int ne, int epp /* elements per pel */,
 	int n_point, const ReducePos *__restrict__ pos,
-	const typename ReduceTraits<T>::coef_t *__restrict__ table)
+	const typename ReduceTraits<T>::coef_t *__restrict__ table, int gx, int band)
 {
 	typedef typename ReduceTraits<T>::acc_t ACC;
-	const int e = blockIdx.x * blockDim.x + threadIdx.x;
-	if (e >= ne)
+	// Neighbouring output rows share most of their input rows and an L2 is per XCD: block b
+	// runs on XCD b % 8, so each XCD takes one contiguous band of output rows (1-D grid of
+	// 8 * band * gx blocks; a row-major grid would make all 8 L2s fetch every input row).
+	const int local = blockIdx.x / 8;
+	const int yb = local / gx;
+	const int e = (local - yb * gx) * blockDim.x + threadIdx.x;
+	const int y = (blockIdx.x % 8) * band + yb;
+	if (e >= ne || y >= out.height)
 		return;
 	// out.left is also the column in the input (reducev.cpp:536)
 	const long long col = (long long) (out.left - in.left) * epp + e;
-	for (int y = blockIdx.y; y < out.height; y += gridDim.y) {
+	{
 		const ReducePos p = pos[y];
 		const typename ReduceTraits<T>::coef_t *c = table + (size_t) p.phase * n_point;
 		ACC sum = 0;
@@ -236,11 +242,17 @@ static int launch_reducev(const _VipsHipReduce *r, const VipsHipRegion *in,
 	const int epp = region_elems_per_pel(out);
 	const int ne = out->width * epp;
 	dim3 block(256, 1, 1);
-	dim3 grid((ne + 255) / 256, out->height < 32768 ? out->height : 32768, 1);
+	const int gx = (ne + 255) / 256;
+	const int band = (out->height + 7) / 8;
+	if ((long long) gx * band * 8 > 0x7fffffffLL) {
+		error("reducev", "region too large for one launch");
+		return -1;
+	}
+	dim3 grid(gx * band * 8, 1, 1);
 	Gate gate("reducev_general");
 	hipLaunchKernelGGL(reducev_general<T>, grid, block, 0, stream(),
 		region_args(in), region_args(out), ne, epp, r->n_point, pos,
-		(const typename ReduceTraits<T>::coef_t *) table);
+		(const typename ReduceTraits<T>::coef_t *) table, gx, band);
 	VH_CHECK(hipGetLastError());
 	return 0;
 }
