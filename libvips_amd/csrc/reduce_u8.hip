@@ -1182,14 +1182,6 @@ int reducev_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsH
 	return 1;
 }
 
-// The horizontal passes have no uchar specialisation: after the vertical pass the image is
-// small, and resample.hip's row-batched general kernels are launch-latency bound there.
-int reduceh_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out,
-	const ReducePos *pos, const short *table)
-{
-	return 0;
-}
-
 int shrinkv_u8_try(int vshrink, const VipsHipRegion *in, const VipsHipRegion *out)
 {
 	VerticalArgs a;
@@ -1212,10 +1204,6 @@ int shrinkv_u8_try(int vshrink, const VipsHipRegion *in, const VipsHipRegion *ou
 	return 1;
 }
 
-int shrinkh_u8_try(int hshrink, const VipsHipRegion *in, const VipsHipRegion *out)
-{
-	return 0;
-}
 
 } // namespace vh
 

@@ -386,10 +386,8 @@ static int reduce_gen(const char *domain, const VipsHipReduce *reduce, const Vip
 	if (!pos)
 		return -1;
 
-	if (fmt == VIPS_HIP_FORMAT_UCHAR) {
-		int done = vertical
-			? reducev_u8_try(r, in, out, pos, (const short *) table)
-			: reduceh_u8_try(r, in, out, pos, (const short *) table);
+	if (fmt == VIPS_HIP_FORMAT_UCHAR && vertical) {
+		int done = reducev_u8_try(r, in, out, pos, (const short *) table);
 		if (done < 0)
 			return -1;
 		if (done > 0)
@@ -636,8 +634,8 @@ static int shrink_gen(const char *domain, int shrink, const VipsHipRegion *in,
 	}
 
 	const int fmt = format_real(out->format);
-	if (fmt == VIPS_HIP_FORMAT_UCHAR) {
-		int done = vertical ? shrinkv_u8_try(shrink, in, out) : shrinkh_u8_try(shrink, in, out);
+	if (fmt == VIPS_HIP_FORMAT_UCHAR && vertical) {
+		int done = shrinkv_u8_try(shrink, in, out);
 		if (done < 0)
 			return -1;
 		if (done > 0)
