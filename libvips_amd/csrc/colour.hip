@@ -1089,7 +1089,8 @@ int colour_route(const int *steps, int n_steps, double alpha_scale, const VipsHi
 	const bool x4 = in->bands == 3 && out->bands == 3 && !(a.width & 3) &&
 		!((uintptr_t) a.in % (4 * ies)) && !((uintptr_t) a.out % (4 * oes)) &&
 		!(a.in_stride % (4 * ies)) && !(a.out_stride % (4 * oes));
-	const dim3 grid4((a.width / 4 + 255) / 256, rows_grid((a.width / 4 + 255) / 256, a.height) * RU, 1);
+	// (one row per block: the table-gathering route kernels measured faster with many short blocks)
+	const dim3 grid4((a.width / 4 + 255) / 256, a.height < 32768 ? a.height : 32768, 1);
 #define GO(TIN, TOUT) \
 	if (x4) \
 		hipLaunchKernelGGL((colour_route_x4_kernel<TIN, TOUT>), grid4, block, 0, stream(), a); \
