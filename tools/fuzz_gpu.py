@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (device vs oracle/port) beyond the fixed test cases: random sizes,
+bands, formats and parameters for reduce / resize (down and up) / gaussblur / conv / shrink.
+usage: python tools/fuzz_gpu.py [seconds] [seed].  Prints every mismatch; exit code 1 if any."""
+import os
+import random
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import libvips_amd  # noqa: E402
+from libvips_amd import Image  # noqa: E402
+from tests import helpers  # noqa: E402
+from tests.helpers import Port, PortCC  # noqa: E402
+
+INT_TYPES = [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32]
+ALL_TYPES = INT_TYPES + [np.float32]
+KERNELS = ["nearest", "linear", "cubic", "mitchell", "lanczos2", "lanczos3", "mks2013", "mks2021"]
+
+
+def same(a, b):
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    if a.dtype == np.float32:
+        return np.array_equal(a.view(np.int32), b.view(np.int32)) or np.array_equal(a, b, equal_nan=True)
+    return np.array_equal(a, b)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    libvips_amd.init(0)
+    t0 = time.time()
+    n = bad = 0
+    while time.time() - t0 < budget:
+        kind = rng.choice(["reduce8", "reduce", "resize", "upsize", "gaussblur", "conv", "shrink", "thumb"])
+        seed = rng.randrange(1 << 30)
+        try:
+            if kind == "reduce8":
+                w, h = rng.randrange(8, 3000), rng.randrange(8, 2200)
+                src = helpers.lcg_image(w, h, 4, np.uint8, seed)
+                s = rng.choice([2, 4, 8, 8, 8])
+                got = Image.new_from_array(src).reduce(s, s, kernel="lanczos3").numpy()
+                want = Port.reduce(src, s, s, "lanczos3")
+                desc = (kind, w, h, s)
+            elif kind == "reduce":
+                w, h, b = rng.randrange(1, 400), rng.randrange(1, 400), rng.randrange(1, 6)
+                dt = rng.choice(ALL_TYPES)
+                hs, vs = 1 + rng.random() * 6, 1 + rng.random() * 6
+                k = rng.choice(KERNELS)
+                src = helpers.lcg_image(w, h, b, dt, seed)
+                got = Image.new_from_array(src).reduce(hs, vs, kernel=k).numpy()
+                want = Port.reduce(src, hs, vs, k)
+                desc = (kind, w, h, b, dt.__name__, hs, vs, k)
+            elif kind in ("resize", "upsize"):
+                w, h, b = rng.randrange(2, 300), rng.randrange(2, 300), rng.randrange(1, 5)
+                dt = rng.choice(ALL_TYPES)
+                lo, hi = (0.05, 1.0) if kind == "resize" else (0.5, 5.0)
+                hs, vs = lo + rng.random() * (hi - lo), lo + rng.random() * (hi - lo)
+                k = rng.choice(KERNELS)
+                src = helpers.lcg_image(w, h, b, dt, seed)
+                got = Image.new_from_array(src).resize(hs, vscale=vs, kernel=k).numpy()
+                want = Port.resize(src, hs, vs, kernel=k)
+                desc = (kind, w, h, b, dt.__name__, hs, vs, k)
+            elif kind == "gaussblur":
+                w, h, b = rng.randrange(1, 1600), rng.randrange(1, 500), rng.randrange(1, 5)
+                dt = rng.choice([np.uint8, np.uint16, np.int16, np.float32])
+                sigma = 0.3 + rng.random() * 9
+                prec = rng.choice(["integer", "float"])
+                src = helpers.lcg_image(w, h, b, dt, seed)
+                got = Image.new_from_array(src).gaussblur(sigma, precision=prec).numpy()
+                want = PortCC.gaussblur(src, sigma, precision=prec)
+                desc = (kind, w, h, b, dt.__name__, sigma, prec)
+            elif kind == "conv":
+                w, h, b = rng.randrange(1, 300), rng.randrange(1, 300), rng.randrange(1, 4)
+                dt = rng.choice(INT_TYPES + [np.float32])
+                mw, mh = rng.randrange(1, 34), rng.randrange(1, 6)
+                mask = np.round(np.array([[rng.gauss(0, 3) for _ in range(mw)] for _ in range(mh)]), 2)
+                if rng.random() < 0.3:
+                    mask[rng.randrange(mh), rng.randrange(mw)] = 0.0
+                scale = rng.choice([1.0, 2.5, 7.0])
+                prec = rng.choice(["integer", "float"])
+                src = helpers.lcg_image(w, h, b, dt, seed)
+                got = Image.new_from_array(src).conv(mask, scale=scale, offset=1.0, precision=prec).numpy()
+                want = PortCC.conv(src, mask, scale, 1.0, prec)
+                desc = (kind, w, h, b, dt.__name__, mw, mh, scale, prec)
+            elif kind == "shrink":
+                w, h, b = rng.randrange(1, 500), rng.randrange(1, 500), rng.randrange(1, 5)
+                dt = rng.choice(ALL_TYPES)
+                hs, vs = rng.randrange(1, 9), rng.randrange(1, 9)
+                src = helpers.lcg_image(w, h, b, dt, seed)
+                ceil = rng.random() < 0.5
+                got = Image.new_from_array(src).shrink(hs, vs, ceil=ceil).numpy()
+                want = Port.shrink(src, hs, vs, ceil)
+                desc = (kind, w, h, b, dt.__name__, hs, vs, ceil)
+            else:
+                w, h, b = rng.randrange(40, 900), rng.randrange(40, 700), rng.choice([3, 4])
+                src = helpers.lcg_image(w, h, b, np.uint8, seed)
+                target = rng.randrange(8, 400)
+                got = Image.new_from_array(src, interpretation="srgb").thumbnail_image(target).numpy()
+                want = PortCC.thumbnail_image(src, "srgb", target)
+                desc = (kind, w, h, b, target)
+            n += 1
+            if not same(got, want):
+                bad += 1
+                print("MISMATCH", desc, "seed", seed, flush=True)
+        except libvips_amd.VipsHipError as exc:
+            # loud refusals are fine only where the port refuses too
+            try:
+                _ = want  # noqa: F841
+                print("DEVICE REFUSED", desc, str(exc)[:100], flush=True)
+                bad += 1
+            except NameError:
+                pass
+        except Exception as exc:  # port-side refusal of an out-of-scope case
+            if "unsupported" not in repr(exc) and "shrunk" not in repr(exc):
+                print("ERROR", kind, repr(exc)[:200], flush=True)
+        finally:
+            want = None
+            del want
+    print("fuzz: %d cases, %d bad, %.0f s" % (n, bad, time.time() - t0))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
