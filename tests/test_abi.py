@@ -112,3 +112,38 @@ def test_no_gpu_fails_loudly():
     assert "no HIP device" in _ffi.error_buffer()
     with pytest.raises(libvips_amd.VipsHipError):
         libvips_amd.Image.new_from_array(np.zeros((4, 4, 3), np.uint8))
+
+
+def test_affine_out_size():
+    # VIPS_ROUND_INT(scale * in_size), resample/transform.c:220-231; host-only entry point
+    import ctypes
+
+    from tests.helpers import Port
+
+    lib = _ffi.lib
+    port = Port.lib()
+    port.port_affine_out_size.argtypes = [ctypes.c_int, ctypes.c_double]
+    for size in (1, 2, 7, 100, 4097, 16384):
+        for scale in (1.0, 1.01, 1.5, 2.0, 2.3, 2.5, 3.999, 7.3, 10.0):
+            assert lib.vips_hip_affine_out_size(size, scale) == port.port_affine_out_size(size, scale)
+
+
+def test_port_affine_vs_ref_mixed():
+    """The upsizing port against the compiled reference beyond the golden cases: every
+    interpolator, odd sizes, up / down mixes (the goldens pin it where the reference is absent)."""
+    import numpy as np
+
+    from tests import helpers
+    from tests.helpers import Port, Ref
+
+    if not helpers.have_ref():
+        pytest.skip("oracle/_ref not built")
+    for dtype in (np.uint8, np.int16, np.float32):
+        for kernel in ("nearest", "linear", "cubic"):
+            for (w, h, b, hs, vs) in ((33, 21, 3, 1.7, 2.9), (19, 40, 1, 5.0, 1.2), (64, 9, 4, 2.0, 0.4)):
+                if kernel == "nearest" and vs < 1:
+                    continue
+                src = helpers.lcg_image(w, h, b, dtype, 31)
+                want = Ref.run("resize", src, "scale=%r,vscale=%r,kernel=%s" % (hs, vs, kernel))
+                got = Port.resize(src, hs, vs, kernel=kernel)
+                assert got.shape == want.shape and np.array_equal(got, want), (dtype, kernel, w, h, hs, vs)
