@@ -158,3 +158,46 @@ def conv_strip(window, window_top, plan, rank, mask, scale=1.0, offset=0.0, prec
         return out
     finally:
         lib.vips_hip_conv_free(conv)
+
+
+def reduce_strip(window, window_top, plan, rank, in_width, hshrink, vshrink, kernel="lanczos3"):
+    """Run the fused vips_hip_reduce_gen on this rank's window of a strip-partitioned image
+    (BASELINE config 2 split across GPUs): returns its strip of output rows (a torch CUDA
+    tensor).  ``plan`` was built with ``reducev_need`` of a reduce made for the WHOLE image
+    (in_height -> out_height), so strips are bit-identical to the single-device result."""
+    import math
+
+    import torch
+
+    from . import KERNELS
+    from ._ffi import Region, check, check_handle, lib
+    from .image import DTYPE_FORMATS
+
+    rows, width, bands = window.shape
+    assert width == in_width
+    fmt = DTYPE_FORMATS[np.dtype(str(window.dtype).replace("torch.", ""))]
+    out_width = int(in_width / hshrink + 0.5)  # VIPS_ROUND_UINT, reduceh.cpp:437
+    rv = check_handle(lib.vips_hip_reduce_new(KERNELS[kernel], float(vshrink), plan.in_height, plan.out_height,
+                                              math.nan))
+    rh = check_handle(lib.vips_hip_reduce_new(KERNELS[kernel], float(hshrink), in_width, out_width, math.nan))
+    try:
+        o0, o1 = plan.out_bounds[rank]
+        out = torch.empty((o1 - o0, out_width, bands), device=window.device, dtype=window.dtype)
+        rin = Region(window.data_ptr(), 0, window_top, width, rows, width, plan.in_height, bands, fmt,
+                     width * bands * window.element_size())
+        rout = Region(out.data_ptr(), 0, o0, out_width, o1 - o0, out_width, plan.out_height, bands, fmt,
+                      out_width * bands * out.element_size())
+        r = lib.vips_hip_reduce_gen(rv, rh, ctypes.byref(rin), ctypes.byref(rout))
+        if r == 1:  # not an even-integer RGBA uchar case: the two general passes
+            mid = torch.empty((o1 - o0, width, bands), device=window.device, dtype=window.dtype)
+            rmid = Region(mid.data_ptr(), 0, o0, width, o1 - o0, width, plan.out_height, bands, fmt,
+                          width * bands * mid.element_size())
+            check(lib.vips_hip_reducev_gen(rv, ctypes.byref(rin), ctypes.byref(rmid)))
+            check(lib.vips_hip_reduceh_gen(rh, ctypes.byref(rmid), ctypes.byref(rout)))
+        else:
+            check(r)
+        check(lib.vips_hip_synchronize())
+        return out
+    finally:
+        lib.vips_hip_reduce_free(rv)
+        lib.vips_hip_reduce_free(rh)

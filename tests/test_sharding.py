@@ -133,3 +133,33 @@ def test_conv_strips_on_gpu_match_whole_image():
         out = sharding.conv_strip(window.view(torch.uint16), w0, plan, rank, mask, scale, 0.0, "float")
         o0, o1 = plan.out_bounds[rank]
         assert np.array_equal(out.cpu().numpy().view(np.uint8), whole[o0:o1].view(np.uint8))
+
+
+@pytest.mark.gpu
+def test_reduce_strips_on_gpu_match_whole_image():
+    """BASELINE config 2 split into row strips (single GPU, world emulated sequentially): each
+    rank's window (its rows plus the halo vips_hip_reducev_need reports) through the fused
+    vips_hip_reduce_gen gives exactly its rows of the whole-image reduce."""
+    import math
+
+    import libvips_amd
+    from libvips_amd import KERNELS, Image, lib
+    from libvips_amd._ffi import check_handle
+
+    libvips_amd.init(0)
+    height, width = 2051, 1600
+    full = helpers.lcg_image(width, height, 4, np.uint8, 93)
+    whole = Image.new_from_array(full).reduce(8, 8, kernel="lanczos3").numpy()
+    out_height = whole.shape[0]
+    world = 4
+    rv = check_handle(lib.vips_hip_reduce_new(KERNELS["lanczos3"], 8.0, height, out_height, math.nan))
+    try:
+        plan = sharding.StripPlan(height, out_height, world, sharding.reducev_need(rv))
+        for rank in range(world):
+            w0, w1 = plan.windows[rank]
+            window = torch.from_numpy(np.ascontiguousarray(full[w0:w1])).cuda()
+            out = sharding.reduce_strip(window, w0, plan, rank, width, 8.0, 8.0)
+            o0, o1 = plan.out_bounds[rank]
+            assert np.array_equal(out.cpu().numpy(), whole[o0:o1]), rank
+    finally:
+        lib.vips_hip_reduce_free(rv)
