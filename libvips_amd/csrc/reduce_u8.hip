@@ -646,6 +646,150 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 	}
 }
 
+// ------------------------------------------------ the persistent variant (experiment, opt-in)
+//
+// reduce_fused_u8x4_mfma_persist<D>: the same tile body, but 1024 resident blocks pull SMALL
+// tiles from per-XCD atomic counters (dynamic balance: in the static one-round kernel the
+// spread of tile finish times costs ~3 %), keep every tile's output rows staged in LDS and
+// write them when the stage is full or the work is gone, i.e. mostly in one burst at the end.
+// VIPS_HIP_MFMA_PERSIST=<resident-tile budget, e.g. 4096>.  Measured on C2: 0.231 ms against the
+// static kernel's 0.219 -- the per-tile pipeline ramp and the extra halo rows of small tiles
+// cost more than the balance gains; kept as the measured counter-example.
+template <int D>
+__global__ void __launch_bounds__(FUSED_THREADS, 4)
+reduce_fused_u8x4_mfma_persist(FusedArgs a, const MfmaTables *__restrict__ tables, int *__restrict__ counters,
+	int stage_rows)
+{
+	constexpr int S = 8;
+	constexpr int NB = 1;
+	constexpr int MAX_STAGED = 16;
+	typedef MfmaStep<D> Step;
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	unsigned char *planes = lds_raw;
+	half4v *lds_a = reinterpret_cast<half4v *>(lds_raw + MFMA_PLANES_BYTES);
+	half4v *lds_ah = lds_a + MFMA_TABLE_ENTRIES;
+	unsigned int *stage = reinterpret_cast<unsigned int *>(lds_ah + MFMA_TABLE_ENTRIES);
+	__shared__ int s_next;
+	__shared__ int s_meta[MAX_STAGED][4]; // x0, y0, ow, oh of the staged tiles
+
+	const int t = threadIdx.x;
+	const int xcd = blockIdx.x % 8;
+	const int per_xcd = (a.tiles + 7) / 8;
+	const half4v *lane_a = lds_a + (t & 3);
+	int staged_rows = 0, staged_tiles = 0;
+
+	auto flush = [&]() {
+		__syncthreads();
+		if (!(a.debug & 2)) {
+			const int lane = t & 63;
+			int base = 0;
+			for (int m = 0; m < staged_tiles; m++) {
+				const int mx0 = s_meta[m][0], my0 = s_meta[m][1], mow = s_meta[m][2], moh = s_meta[m][3];
+				for (int row = t >> 6; row < moh; row += FUSED_THREADS / 64) {
+					if (lane < mow) {
+						unsigned int *dst = reinterpret_cast<unsigned int *>(
+							a.out + (long long) (my0 + row) * a.out_stride + (long long) mx0 * 4);
+						dst[lane] = stage[(base + row) * MFMA_STAGE_PITCH + lane];
+					}
+				}
+				base += moh;
+			}
+		}
+		__syncthreads();
+	};
+
+	for (;;) {
+		__syncthreads();
+		if (t == 0)
+			s_next = atomicAdd(&counters[xcd], 1);
+		__syncthreads();
+		const int local = __builtin_amdgcn_readfirstlane(s_next);
+		const int tile = xcd * per_xcd + local;
+		if (local >= per_xcd || tile >= a.tiles)
+			break;
+
+		const int by = tile / a.tiles_x;
+		const int bx = tile - by * a.tiles_x;
+		const int x0 = bx * a.owt;
+		const int y0 = by * a.oht;
+		const int ow = min(a.owt, a.out_width - x0);
+		const int oh = min(a.oht, a.out_height - y0);
+		if (staged_rows + oh > stage_rows || staged_tiles == MAX_STAGED) {
+			flush();
+			staged_rows = 0;
+			staged_tiles = 0;
+		}
+		unsigned int *stage_t = stage + staged_rows * MFMA_STAGE_PITCH;
+		if (t == 0) {
+			s_meta[staged_tiles][0] = x0;
+			s_meta[staged_tiles][1] = y0;
+			s_meta[staged_tiles][2] = ow;
+			s_meta[staged_tiles][3] = oh;
+		}
+
+		const int tile_col0 = a.fx0 + S * x0;
+		const int col0 = tile_col0 + 2 * t;
+		const int ca = min(max(col0, 0), a.im_width - 1) - a.in_left;
+		const int cb = min(max(col0 + 1, 0), a.im_width - 1) - a.in_left;
+		const bool interior = a.aligned8 && tile_col0 >= 0 && tile_col0 + FUSED_SPAN <= a.im_width &&
+			(((tile_col0 - a.in_left) & 1) == 0);
+		const bool flip = (by & 1) != 0;
+		const int dir = flip ? -1 : 1;
+		const int row0 = flip ? a.fy0 + S * (y0 + oh - 1) + S * D - 1 : a.fy0 + S * y0;
+
+		if (t < MFMA_TABLE_ENTRIES) {
+			reinterpret_cast<uint2 *>(lds_a)[t] = reinterpret_cast<const uint2 *>(tables->a[flip ? 1 : 0])[t];
+			reinterpret_cast<uint2 *>(lds_ah)[t] = reinterpret_cast<const uint2 *>(tables->ah)[t];
+		}
+
+		float4v acc[8][2];
+#pragma unroll
+		for (int o = 0; o < 8; o++)
+#pragma unroll
+			for (int h = 0; h < 2; h++)
+				acc[o][h] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+
+		const int ngroups = oh + D - 1;
+		uint2 px[NB][S];
+		Step::template load_rows<0, S>(a, px[0], row0, dir, ca, cb, interior);
+		__syncthreads();
+
+		for (int g0 = 0; g0 < ngroups; g0 += MFMA_SLOTS) {
+			Step::template batch<0, NB>(a, px, g0, ngroups, acc, planes, lane_a, t, row0, dir, ca, cb,
+				interior, oh);
+			const int jlo = max(g0 - (D - 1), 0);
+			const int jhi = min(g0 + MFMA_SLOTS - 1 - (D - 1), oh - 1); // inclusive
+			if (jhi < jlo)
+				continue;
+			__syncthreads();
+			const int nrows = jhi - jlo + 1;
+			const int r_lo = jlo - (g0 - (D - 1));
+			if (!(a.debug & 1)) {
+				const int hc = t & 3, hr = (t >> 2) & 7, hseg = t >> 5;
+				const half4v *lane_ah = lds_ah + hc;
+				const bool row_ok = hr < nrows;
+				const int lrow = r_lo + (row_ok ? hr : 0);
+				const unsigned char *line = planes + (lrow * 4 + hc) * MFMA_PLANE + 8 * HSEG_OUT * hseg;
+				float4v hacc[2];
+				hacc[0] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+				hacc[1] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+				unsigned int pix[2] = { 0, 0 };
+				Step::template hwalk<0>(hacc, line, lane_ah, hc, pix);
+				const int xo = HSEG_OUT * hseg + 2 * hc;
+				if (row_ok && xo < MFMA_STAGE_PITCH) {
+					const int jj = jlo + hr;
+					unsigned int *srow = stage_t + (flip ? oh - 1 - jj : jj) * MFMA_STAGE_PITCH + xo;
+					*reinterpret_cast<uint2 *>(srow) = make_uint2(pix[0], pix[1]);
+				}
+			}
+			__syncthreads();
+		}
+		staged_rows += oh;
+		staged_tiles++;
+	}
+	flush();
+}
+
 // ------------------------------------------------ the wide variant (experiment, opt-in)
 //
 // reduce_fused_u8x4_mfma_wide<D>: the same kernel with ONE pixel column per lane and 1024
@@ -943,6 +1087,26 @@ static int launch_fused_mfma(const FusedArgs &args, int tiles, const MfmaTables 
 		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4>), dim3(grid), dim3(FUSED_THREADS), lds, stream(),
 			args, d_tables);
 	VH_CHECK(hipGetLastError());
+	return 0;
+}
+
+template <int D>
+static int launch_fused_mfma_persist(const FusedArgs &args, int tiles, const MfmaTables *d_tables)
+{
+	int *counters = (int *) vips_hip_malloc(8 * sizeof(int));
+	if (!counters)
+		return -1;
+	if (hipMemsetAsync(counters, 0, 8 * sizeof(int), stream()) != hipSuccess) {
+		vips_hip_free(counters);
+		return hip_failed(hipErrorUnknown, "hipMemsetAsync");
+	}
+	Gate gate("reduce_fused_u8_mfma_persist");
+	const int blocks = tiles < 1024 ? (tiles + 7) / 8 * 8 : 1024;
+	hipLaunchKernelGGL((reduce_fused_u8x4_mfma_persist<D>), dim3(blocks), dim3(FUSED_THREADS),
+		mfma_lds_bytes(MFMA_MAX_OHT), stream(), args, d_tables, counters, MFMA_MAX_OHT);
+	const hipError_t err = hipGetLastError();
+	vips_hip_free(counters);
+	VH_CHECK(err);
 	return 0;
 }
 
@@ -1318,6 +1482,7 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 			abs_max = ah > abs_max ? ah : abs_max;
 		}
 		if (abs_max < 2048 && abs_sum * 255 < (1 << 23) && abs_sum_h * 255 < (1 << 23)) {
+			bool persist = false;
 			// the wide kernel (1024-pixel spans, one block per CU) is opt-in: measured slower
 			const char *wide_env = getenv("VIPS_HIP_MFMA_WIDE");
 			const bool wide = wide_env && atoi(wide_env) != 0;
@@ -1330,8 +1495,12 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 					args.owt = WIDE_SPAN / S - D + 1;
 					args.tiles_x = (out->width + args.owt - 1) / args.owt;
 				}
-				const int slots = getenv("VIPS_HIP_FUSED_CAP") ? atoi(getenv("VIPS_HIP_FUSED_CAP"))
-					: wide ? 256 : 256 * 4;
+				const char *persist_env = getenv("VIPS_HIP_MFMA_PERSIST");
+				persist = !wide && persist_env && atoi(persist_env) > 0;
+				const int slots = persist ? atoi(persist_env)
+					: getenv("VIPS_HIP_FUSED_CAP")        ? atoi(getenv("VIPS_HIP_FUSED_CAP"))
+					: wide                                  ? 256
+															: 256 * 4;
 				const int base = slots / args.tiles_x > 0 ? slots / args.tiles_x : 1;
 				int oht = out->height;
 				for (int k = 1; k <= 4096; k++) {
@@ -1361,6 +1530,10 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 				else
 					d_tables = (const MfmaTables *) it->second;
 			}
+			if (persist && D == 6)
+				return launch_fused_mfma_persist<6>(args, tiles, d_tables);
+			if (persist && D == 7)
+				return launch_fused_mfma_persist<7>(args, tiles, d_tables);
 			if (wide && D == 6)
 				return launch_fused_mfma_wide<6>(args, tiles, d_tables);
 			if (wide && D == 7)
