@@ -1,5 +1,6 @@
+"""Host-side cost per operation (enqueue time vs enqueue + sync), C4 shapes."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench, libvips_amd
 from libvips_amd import Image, lib
 libvips_amd.init(0)
