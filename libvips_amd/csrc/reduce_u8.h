@@ -12,7 +12,7 @@
 namespace vh {
 
 int reducev_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out,
-	const ReducePos *pos, const short *table);
+	const ReducePos *pos, const short *table, int tile);
 int shrinkv_u8_try(int vshrink, const VipsHipRegion *in, const VipsHipRegion *out);
 
 const ReducePos *reduce_device_positions(_VipsHipReduce *r, int start, int count, int tile);

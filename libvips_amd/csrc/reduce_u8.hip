@@ -988,6 +988,152 @@ reduce_fused_u8x4_mfma_wide(FusedArgs a, const MfmaTables *__restrict__ tables)
 	}
 }
 
+// ------------------------------------------------ vertical-only pass on the matrix cores
+//
+// reducev_u8_mfma<D>: vips_reducev by an integer 8 with one coefficient phase on a uchar image
+// of ANY band count.  A scanline is a byte array to a vertical filter, so this is the fused
+// kernel's vertical pass alone: a lane owns 8 consecutive bytes of the row, walks down the
+// rows in groups of 8 with the same rotating MFMA accumulators, and each group retires one
+// output row straight to memory (8 bytes per lane, a wave writes 512 contiguous bytes).  Every
+// input byte is read once (the row-pair dot2 kernel re-reads each row n / 8 times through L2).
+struct VStreamArgs {
+	const unsigned char *in;  // first byte of the columns of the rect, row in_top of the image
+	unsigned char *out;
+	long long in_stride, out_stride;
+	int in_top, im_height;
+	int out_height;          // rows of the rect
+	int fy0;                 // first tap (input row) of output row 0 of the rect
+	int row_u2;              // 8-byte columns per row
+	int oht, tiles_x, tiles; // tile = 256 columns x oht output rows
+};
+
+template <int D>
+struct VStreamStep {
+	typedef MfmaStep<D> Base;
+	static constexpr int S = 8;
+
+	template <int I0, int N>
+	static __device__ __forceinline__ void load_rows(const VStreamArgs &a, uint2 (&px)[S], int first_row,
+		unsigned int coff)
+	{
+		const unsigned int stride32 = (unsigned int) a.in_stride;
+#pragma unroll
+		for (int i = I0; i < I0 + N; i++) {
+			const int row = min(max(first_row + i, 0), a.im_height - 1) - a.in_top;
+			px[i] = *reinterpret_cast<const uint2 *>(a.in + (size_t) ((unsigned int) row * stride32 + coff));
+		}
+	}
+
+	template <int ROT, int Q>
+	static __device__ __forceinline__ void quad(const VStreamArgs &a, uint2 (&px)[S], float4v (&acc)[8][2],
+		const half4v *lane_a, bool more, int next_row, unsigned int coff)
+	{
+		const half4v a0 = lane_a[((ROT * 2 + Q) * 2 + 0) * 4];
+		const half4v a1 = lane_a[((ROT * 2 + Q) * 2 + 1) * 4];
+#pragma unroll
+		for (int p = 0; p < 2; p++) {
+			const unsigned int r0 = p ? px[4 * Q + 0].y : px[4 * Q + 0].x;
+			const unsigned int r1 = p ? px[4 * Q + 1].y : px[4 * Q + 1].x;
+			const unsigned int r2 = p ? px[4 * Q + 2].y : px[4 * Q + 2].x;
+			const unsigned int r3 = p ? px[4 * Q + 3].y : px[4 * Q + 3].x;
+			half4v b[4];
+			b[0] = Base::template make_b<0>(r0, r1, r2, r3);
+			b[1] = Base::template make_b<1>(r0, r1, r2, r3);
+			b[2] = Base::template make_b<2>(r0, r1, r2, r3);
+			b[3] = Base::template make_b<3>(r0, r1, r2, r3);
+			if (p == 1 && more)
+				load_rows<4 * Q, 4>(a, px, next_row, coff);
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				acc[p * 4 + c][0] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, b[c], acc[p * 4 + c][0], 0, 0, 0);
+				acc[p * 4 + c][1] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, b[c], acc[p * 4 + c][1], 0, 0, 0);
+			}
+		}
+	}
+
+	template <int ROT>
+	static __device__ __forceinline__ void retire(float4v (&acc)[8][2], unsigned char *dst, bool store)
+	{
+		constexpr int SLOT = (ROT - (D - 1) + 2 * MFMA_SLOTS) % MFMA_SLOTS;
+		constexpr int H = SLOT >> 2, I = SLOT & 3;
+		if (store) {
+			uint2 v;
+			v.x = Base::fin_pack(acc[3][H][I], 3,
+				Base::fin_pack(acc[2][H][I], 2, Base::fin_pack(acc[1][H][I], 1, Base::fin_pack(acc[0][H][I], 0, 0))));
+			v.y = Base::fin_pack(acc[7][H][I], 3,
+				Base::fin_pack(acc[6][H][I], 2, Base::fin_pack(acc[5][H][I], 1, Base::fin_pack(acc[4][H][I], 0, 0))));
+			*reinterpret_cast<uint2 *>(dst) = v;
+		}
+#pragma unroll
+		for (int o = 0; o < 8; o++)
+			acc[o][H][I] = 0.0f;
+	}
+
+	template <int ROT>
+	static __device__ __forceinline__ void batch(const VStreamArgs &a, uint2 (&px)[S], int g0, int ngroups,
+		float4v (&acc)[8][2], const half4v *lane_a, int row0, unsigned int coff, unsigned char *out_col, int oh,
+		bool active)
+	{
+		if constexpr (ROT < MFMA_SLOTS) {
+			const int g = g0 + ROT;
+			if (g < ngroups) {
+				const bool more = g + 1 < ngroups;
+				const int next_row = row0 + S * (g + 1);
+				quad<ROT, 0>(a, px, acc, lane_a, more, next_row, coff);
+				quad<ROT, 1>(a, px, acc, lane_a, more, next_row, coff);
+				const int j = g - (D - 1);
+				retire<ROT>(acc, out_col + (long long) j * a.out_stride, active && j >= 0 && j < oh);
+			}
+			batch<ROT + 1>(a, px, g0, ngroups, acc, lane_a, row0, coff, out_col, oh, active);
+		}
+	}
+};
+
+template <int D>
+__global__ void __launch_bounds__(FUSED_THREADS, 4)
+reducev_u8_mfma(VStreamArgs a, const MfmaTables *__restrict__ tables)
+{
+	constexpr int S = 8;
+	typedef VStreamStep<D> Step;
+	__shared__ __attribute__((aligned(16))) half4v lds_a[MFMA_TABLE_ENTRIES];
+
+	// each XCD takes a contiguous range of tiles (row-major: a tile row shares input rows)
+	const int per_xcd = gridDim.x / 8;
+	const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+	if (tile >= a.tiles)
+		return;
+	const int t = threadIdx.x;
+	const int by = tile / a.tiles_x;
+	const int bx = tile - by * a.tiles_x;
+	const int y0 = by * a.oht;
+	const int oh = min(a.oht, a.out_height - y0);
+	const int col = bx * FUSED_THREADS + t;
+	const bool active = col < a.row_u2;
+	const unsigned int coff = 8u * (unsigned int) min(col, a.row_u2 - 1);
+	const int row0 = a.fy0 + S * y0;
+
+	if (t < MFMA_TABLE_ENTRIES)
+		reinterpret_cast<uint2 *>(lds_a)[t] = reinterpret_cast<const uint2 *>(tables->a[0])[t];
+	const half4v *lane_a = lds_a + (t & 3);
+
+	float4v acc[8][2];
+#pragma unroll
+	for (int o = 0; o < 8; o++)
+#pragma unroll
+		for (int h = 0; h < 2; h++)
+			acc[o][h] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+
+	const int ngroups = oh + D - 1;
+	uint2 px[S];
+	Step::template load_rows<0, S>(a, px, row0, coff);
+	__syncthreads();
+
+	unsigned char *out_col = a.out + (long long) y0 * a.out_stride + coff;
+	for (int g0 = 0; g0 < ngroups; g0 += MFMA_SLOTS) {
+		Step::template batch<0>(a, px, g0, ngroups, acc, lane_a, row0, coff, out_col, oh, active);
+	}
+}
+
 // Is pos[] an arithmetic progression first0 + S*k with one phase?  (What an
 // integer shrink of a size-divisible image produces.)
 static bool positions_regular(const std::vector<ReducePos> &pos, int *first0, int *step, int *phase)
@@ -1318,9 +1464,100 @@ static bool vertical_args(const VipsHipRegion *in, const VipsHipRegion *out, Ver
 	return true;
 }
 
-int reducev_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out,
-	const ReducePos *pos, const short *table)
+// The matrix-core streaming kernel: integer-8 shrink, one phase, rows of whole 8-byte columns.
+static int reducev_stream_try(const _VipsHipReduce *rc, const VipsHipRegion *in, const VipsHipRegion *out, int tile)
 {
+	if (getenv("VIPS_HIP_NO_MFMA"))
+		return 0;
+	_VipsHipReduce *r = const_cast<_VipsHipReduce *>(rc);
+	const long long nbytes = (long long) out->width * in->bands;
+	const unsigned char *src = (const unsigned char *) in->data + (size_t) (out->left - in->left) * in->bands;
+	if ((nbytes & 7) || ((uintptr_t) src & 7) || (in->stride & 7) || ((uintptr_t) out->data & 7) ||
+		(out->stride & 7))
+		return 0;
+	if (!(in->stride > 0 && (long long) in->stride * in->height < (1LL << 31)))
+		return 0;
+	std::vector<ReducePos> pv;
+	reduce_positions(r, out->top, out->height, tile, pv);
+	int fy0, sy, phase;
+	if (!positions_regular(pv, &fy0, &sy, &phase) || (out->height > 1 && sy != 8))
+		return 0;
+	const int n = effective_taps(r, phase);
+	const int D = (n + 7) / 8;
+	if (D != 6 && D != 7)
+		return 0;
+	const short *c = &r->matrixs[(size_t) phase * r->n_point];
+	std::vector<int> taps(8 * D, 0);
+	long long abs_sum = 0;
+	int abs_max = 0;
+	for (int k = 0; k < 8 * D; k++) {
+		if (k < r->n_point)
+			taps[k] = c[k];
+		const int av = taps[k] < 0 ? -taps[k] : taps[k];
+		abs_sum += av;
+		abs_max = av > abs_max ? av : abs_max;
+	}
+	if (!(abs_max < 2048 && abs_sum * 255 < (1 << 23)))
+		return 0;
+	const MfmaTables *d_tables;
+	{
+		std::lock_guard<std::mutex> lock(r->mutex);
+		auto key = std::make_tuple(-4, phase, 8 * D);
+		auto it = r->pos_cache.find(key);
+		if (it == r->pos_cache.end()) {
+			MfmaTables tab;
+			mfma_build_tables(taps, taps, D, &tab);
+			void *d = upload(&tab, sizeof(tab));
+			if (!d)
+				return -1;
+			r->pos_cache[key] = (ReducePos *) d;
+			d_tables = (const MfmaTables *) d;
+		}
+		else
+			d_tables = (const MfmaTables *) it->second;
+	}
+	VStreamArgs a;
+	a.in = src;
+	a.out = (unsigned char *) out->data;
+	a.in_stride = (long long) in->stride;
+	a.out_stride = (long long) out->stride;
+	a.in_top = in->top;
+	a.im_height = in->im_height;
+	a.out_height = out->height;
+	a.fy0 = fy0;
+	a.row_u2 = (int) (nbytes >> 3);
+	a.tiles_x = (a.row_u2 + FUSED_THREADS - 1) / FUSED_THREADS;
+	// two residency rounds of tiles (no LDS staging here, so several rounds cost nothing)
+	int rows_of_tiles = 2048 / a.tiles_x;
+	if (rows_of_tiles < 1)
+		rows_of_tiles = 1;
+	int oht = (out->height + rows_of_tiles - 1) / rows_of_tiles;
+	if (oht < 16)
+		oht = 16;
+	a.oht = oht;
+	const int tiles_y = (out->height + oht - 1) / oht;
+	a.tiles = a.tiles_x * tiles_y;
+	const int grid = (a.tiles + 7) / 8 * 8;
+	Gate gate("reducev_u8_mfma");
+	if (D == 6)
+		hipLaunchKernelGGL((reducev_u8_mfma<6>), dim3(grid), dim3(FUSED_THREADS), 0, stream(), a, d_tables);
+	else
+		hipLaunchKernelGGL((reducev_u8_mfma<7>), dim3(grid), dim3(FUSED_THREADS), 0, stream(), a, d_tables);
+	if (hipGetLastError() != hipSuccess) {
+		error("reducev", "kernel launch failed");
+		return -1;
+	}
+	return 1;
+}
+
+int reducev_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out,
+	const ReducePos *pos, const short *table, int tile)
+{
+	{
+		const int done = reducev_stream_try(r, in, out, tile);
+		if (done != 0)
+			return done;
+	}
 	VerticalArgs a;
 	int dw;
 	if (!vertical_args(in, out, &a, &dw))

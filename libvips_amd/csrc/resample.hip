@@ -387,7 +387,7 @@ static int reduce_gen(const char *domain, const VipsHipReduce *reduce, const Vip
 		return -1;
 
 	if (fmt == VIPS_HIP_FORMAT_UCHAR && vertical) {
-		int done = reducev_u8_try(r, in, out, pos, (const short *) table);
+		int done = reducev_u8_try(r, in, out, pos, (const short *) table, tile);
 		if (done < 0)
 			return -1;
 		if (done > 0)

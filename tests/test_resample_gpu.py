@@ -334,3 +334,29 @@ def test_upsize_region_rects_and_reference():
         big = helpers.lcg_image(1024, 700, 4, np.uint8, 80)
         got = Image.new_from_array(big).resize(2.0, kernel="lanczos3").numpy()
         assert np.array_equal(got, Ref.run("resize", big, "scale=2,kernel=lanczos3"))
+
+
+@pytest.mark.parametrize("bands", [1, 2, 3, 4])
+def test_reducev_mfma_any_bands(bands):
+    """reducev_u8_mfma: the vertical pass on the matrix cores for uchar images of any band
+    count (integer-8 shrink, one phase, rows of whole 8-byte columns), alone and as the first
+    half of vips_reduce on RGB; several tiles wide and tall, ragged heights, clamped edges."""
+    from libvips_amd import lib
+
+    for (w, h) in ((2048, 1603), (8 * 40 // bands * bands if bands != 3 else 640, 4099), (4096, 200)):
+        if (w * bands) % 8:
+            continue
+        src = helpers.lcg_image(w, h, bands, np.uint8, 49)
+        im = Image.new_from_array(src)
+        lib.vips_hip_gate_reset()
+        lib.vips_hip_gate_enable(1)
+        try:
+            got_v = im.reducev(8.0, kernel="lanczos3").numpy()
+            got = im.reduce(8.0, 8.0, kernel="lanczos3").numpy()
+            report = libvips_amd.gate_report()
+        finally:
+            lib.vips_hip_gate_enable(0)
+            lib.vips_hip_gate_reset()
+        assert "reducev_u8_mfma" in report or bands == 4, report
+        assert_same(got_v, Port.reducev(src, 8.0, "lanczos3"), str((bands, w, h)))
+        assert_same(got, Port.reduce(src, 8.0, 8.0, "lanczos3"), str((bands, w, h)))
