@@ -368,6 +368,8 @@ class Port(object):
                 ih, iv = math.floor(1.0 / hscale), math.floor(1.0 / vscale)
             else:
                 tw, th = int(w * hscale + 0.5), int(h * vscale + 0.5)
+                if tw == 0 or th == 0:
+                    raise ValueError("unsupported: nearest target rounds to zero pixels")
                 ih, iv = math.floor(w / tw / gap), math.floor(h / th / gap)
             ih, iv = max(1, int(ih)), max(1, int(iv))
             if ih > 1 or iv > 1:

@@ -40,11 +40,14 @@ def main():
         try:
             if kind == "reduce8":
                 w, h = rng.randrange(8, 3000), rng.randrange(8, 2200)
-                src = helpers.lcg_image(w, h, 4, np.uint8, seed)
+                b = rng.choice([4, 4, 3, 1, 2])
+                if rng.random() < 0.5:
+                    w = (w + 7) // 8 * 8  # rows of whole 8-byte columns: the streaming vertical kernel
+                src = helpers.lcg_image(w, h, b, np.uint8, seed)
                 s = rng.choice([2, 4, 8, 8, 8])
                 got = Image.new_from_array(src).reduce(s, s, kernel="lanczos3").numpy()
                 want = Port.reduce(src, s, s, "lanczos3")
-                desc = (kind, w, h, s)
+                desc = (kind, w, h, b, s)
             elif kind == "reduce":
                 w, h, b = rng.randrange(1, 400), rng.randrange(1, 400), rng.randrange(1, 6)
                 dt = rng.choice(ALL_TYPES)
