@@ -312,6 +312,10 @@ int vips_hip_resize(VipsHipImage *in, VipsHipImage **out, double scale, double v
 		else {
 			const int target_width = (int) (in->width * hscale + 0.5);   // VIPS_ROUND_UINT
 			const int target_height = (int) (in->height * vscale + 0.5);
+			if (target_width <= 0 || target_height <= 0) {
+				error("resize", "image has shrunk to nothing");
+				return -1;
+			}
 			int_hshrink = (int) floor((double) in->width / target_width / gap);
 			int_vshrink = (int) floor((double) in->height / target_height / gap);
 		}
