@@ -235,6 +235,118 @@ reduceh_general(RegionArgs in, RegionArgs out, int epp, int n_point,
 	}
 }
 
+// uchar horizontal reduce through LDS: a block makes HB_PX output pixels of HB_ROWS rows.  The
+// input bytes those pixels' taps touch are staged with coalesced dword loads (a strided gather
+// straight from memory touches ~5 cache lines per wave instruction, and there is one per tap),
+// then thread (pixel, band) sums its taps from LDS.  Same i32 arithmetic as reduceh_general.
+constexpr int HB_PX = 64;     // output pixels per block (x 4 band lanes = 256 threads)
+constexpr int HB_ROWS = 4;    // rows per block trip
+constexpr int HB_SPAN = 4096; // staged bytes per row, at most
+
+struct ReducehLdsArgs {
+	const unsigned char *in; // row 0 of the rect in the window, byte 0 of the WINDOW's first pixel
+	unsigned char *out;
+	long long in_stride, out_stride;
+	int in_left, im_width;   // window origin (pixels), image width
+	int out_width, out_height, bands, n_point;
+};
+
+__global__ void __launch_bounds__(256)
+reduceh_u8_lds(ReducehLdsArgs a, const ReducePos *__restrict__ pos, const short *__restrict__ table)
+{
+	__shared__ __attribute__((aligned(16))) unsigned int stage[HB_ROWS][HB_SPAN / 4 + 2];
+	const int t = threadIdx.x;
+	const int x0 = blockIdx.x * HB_PX;
+	const int nx = min(HB_PX, a.out_width - x0);
+	const int B = a.bands;
+	// the pixel range the block's taps touch, clamped to the image (vips_embed COPY)
+	const int p_lo = min(max(pos[x0].first, 0), a.im_width - 1);
+	const int p_hi = min(max(pos[x0 + nx - 1].first + a.n_point - 1, 0), a.im_width - 1);
+	const long long byte_lo = (long long) (p_lo - a.in_left) * B;
+	const long long byte_hi = (long long) (p_hi - a.in_left + 1) * B; // exclusive
+	const long long start_al = byte_lo & ~3LL;
+	const int nfull = (int) ((byte_hi - start_al) >> 2); // whole dwords; the tail goes bytewise
+	const int ntail = (int) ((byte_hi - start_al) & 3);  // (never read past the last needed byte)
+	const int skew = (int) (byte_lo - start_al);
+
+	const int px = t >> 2, band = t & 3;
+	const bool mine = px < nx && band < B;
+	ReducePos p = { 0, 0 };
+	if (mine)
+		p = pos[x0 + px];
+	const short *c = table + (size_t) p.phase * a.n_point;
+
+	for (int y0 = blockIdx.y * HB_ROWS; y0 < a.out_height; y0 += gridDim.y * HB_ROWS) {
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < HB_ROWS; r++) {
+			const int y = min(y0 + r, a.out_height - 1);
+			const unsigned int *src = reinterpret_cast<const unsigned int *>(a.in + (long long) y * a.in_stride + start_al);
+			for (int i = t; i < nfull; i += 256)
+				stage[r][i] = src[i];
+			if (t < ntail)
+				reinterpret_cast<unsigned char *>(stage[r])[4 * nfull + t] =
+					reinterpret_cast<const unsigned char *>(src)[4 * nfull + t];
+		}
+		__syncthreads();
+		if (mine) {
+			int sum[HB_ROWS];
+#pragma unroll
+			for (int r = 0; r < HB_ROWS; r++)
+				sum[r] = 0;
+			for (int i = 0; i < a.n_point; i++) {
+				const int s = min(max(p.first + i, 0), a.im_width - 1);
+				const int off = (s - p_lo) * B + band + skew;
+				const int ci = c[i];
+#pragma unroll
+				for (int r = 0; r < HB_ROWS; r++)
+					sum[r] += ci * (int) reinterpret_cast<const unsigned char *>(stage[r])[off];
+			}
+#pragma unroll
+			for (int r = 0; r < HB_ROWS; r++)
+				if (y0 + r < a.out_height)
+					a.out[(long long) (y0 + r) * a.out_stride + (long long) (x0 + px) * B + band] =
+						ReduceTraits<unsigned char>::fin(sum[r]);
+		}
+	}
+}
+
+// 1 = handled, 0 = not this kernel's case (the general kernel runs), -1 = error
+static int reduceh_u8_lds_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out,
+	const ReducePos *pos, const short *table)
+{
+	if (getenv("VIPS_HIP_NO_REDUCEH_LDS"))
+		return 0;
+	const int B = in->bands;
+	if (B < 1 || B > 4 || out->width < 1)
+		return 0;
+	// dword-aligned window rows; the staged span of a block must fit
+	if (((uintptr_t) in->data & 3) || (in->stride & 3))
+		return 0;
+	if (((double) HB_PX * r->shrink + r->n_point + 2) * B + 8 > HB_SPAN)
+		return 0;
+	ReducehLdsArgs a;
+	a.in = (const unsigned char *) in->data + (size_t) (out->top - in->top) * in->stride;
+	a.out = (unsigned char *) out->data;
+	a.in_stride = (long long) in->stride;
+	a.out_stride = (long long) out->stride;
+	a.in_left = in->left;
+	a.im_width = in->im_width;
+	a.out_width = out->width;
+	a.out_height = out->height;
+	a.bands = B;
+	a.n_point = r->n_point;
+	const int gx = (out->width + HB_PX - 1) / HB_PX;
+	int gy = 16384 / gx;
+	gy = gy < 1 ? 1 : gy;
+	const int groups = (out->height + HB_ROWS - 1) / HB_ROWS;
+	gy = groups < gy ? groups : gy;
+	Gate gate("reduceh_u8_lds");
+	hipLaunchKernelGGL(reduceh_u8_lds, dim3(gx, gy, 1), dim3(256, 1, 1), 0, stream(), a, pos, table);
+	VH_CHECK(hipGetLastError());
+	return 1;
+}
+
 template <typename T>
 static int launch_reducev(const _VipsHipReduce *r, const VipsHipRegion *in,
 	const VipsHipRegion *out, const ReducePos *pos, const void *table)
@@ -386,8 +498,9 @@ static int reduce_gen(const char *domain, const VipsHipReduce *reduce, const Vip
 	if (!pos)
 		return -1;
 
-	if (fmt == VIPS_HIP_FORMAT_UCHAR && vertical) {
-		int done = reducev_u8_try(r, in, out, pos, (const short *) table, tile);
+	if (fmt == VIPS_HIP_FORMAT_UCHAR) {
+		int done = vertical ? reducev_u8_try(r, in, out, pos, (const short *) table, tile)
+							: reduceh_u8_lds_try(r, in, out, pos, (const short *) table);
 		if (done < 0)
 			return -1;
 		if (done > 0)
