@@ -579,6 +579,8 @@ typedef struct _VipsConvHip {
 	VipsHipOp parent_instance;
 	VipsImage *mask;
 	VipsPrecision precision;
+	int layers;
+	int cluster;
 } VipsConvHip;
 
 typedef VipsConvHip VipsConvsepHip;
@@ -600,9 +602,18 @@ vips_conv_hip_run(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out, gboolean 
 			g_object_unref(M);
 			return -1;
 		}
-		result = vips_hip_convsep(in, out, VIPS_MATRIX(M, 0, 0), M->Xsize * M->Ysize,
-			vips_image_get_scale(M), vips_image_get_offset(M), conv->precision);
+		/* convsep.c:81-87: approximate goes to vips_convasep with the layers argument */
+		if (conv->precision == VIPS_PRECISION_APPROXIMATE)
+			result = vips_hip_convasep(in, out, VIPS_MATRIX(M, 0, 0), M->Xsize * M->Ysize,
+				vips_image_get_scale(M), vips_image_get_offset(M), conv->layers);
+		else
+			result = vips_hip_convsep(in, out, VIPS_MATRIX(M, 0, 0), M->Xsize * M->Ysize,
+				vips_image_get_scale(M), vips_image_get_offset(M), conv->precision);
 	}
+	/* conv.c:99-107 */
+	else if (conv->precision == VIPS_PRECISION_APPROXIMATE)
+		result = vips_hip_conva(in, out, VIPS_MATRIX(M, 0, 0), M->Xsize, M->Ysize,
+			vips_image_get_scale(M), vips_image_get_offset(M), conv->layers, conv->cluster);
 	else
 		result = vips_hip_conv(in, out, VIPS_MATRIX(M, 0, 0), M->Xsize, M->Ysize,
 			vips_image_get_scale(M), vips_image_get_offset(M), conv->precision);
@@ -631,7 +642,11 @@ HIP_SUBCLASS(VipsConvsepHip, vips_convsep_hip, "convsep_hip", "separable convolu
 		VIPS_ARGUMENT_REQUIRED_INPUT, G_STRUCT_OFFSET(VipsConvHip, mask)); \
 	VIPS_ARG_ENUM(class, "precision", 103, "Precision", "Convolve with this precision", \
 		VIPS_ARGUMENT_OPTIONAL_INPUT, G_STRUCT_OFFSET(VipsConvHip, precision), \
-		VIPS_TYPE_PRECISION, VIPS_PRECISION_FLOAT);
+		VIPS_TYPE_PRECISION, VIPS_PRECISION_FLOAT); \
+	VIPS_ARG_INT(class, "layers", 104, "Layers", "Use this many layers in approximation", \
+		VIPS_ARGUMENT_OPTIONAL_INPUT, G_STRUCT_OFFSET(VipsConvHip, layers), 1, 1000, 5); \
+	VIPS_ARG_INT(class, "cluster", 105, "Cluster", "Cluster lines closer than this in approximation", \
+		VIPS_ARGUMENT_OPTIONAL_INPUT, G_STRUCT_OFFSET(VipsConvHip, cluster), 1, 100, 1);
 
 static void
 vips_conv_hip_args(VipsConvHipClass *class)
@@ -649,12 +664,16 @@ static void
 vips_conv_hip_init(VipsConvHip *conv)
 {
 	conv->precision = VIPS_PRECISION_FLOAT;
+	conv->layers = 5;
+	conv->cluster = 1;
 }
 
 static void
 vips_convsep_hip_init(VipsConvsepHip *conv)
 {
 	conv->precision = VIPS_PRECISION_FLOAT;
+	conv->layers = 5;
+	conv->cluster = 1;
 }
 
 /* gaussblur_hip: convolution/gaussblur.c:118-175 */

@@ -307,6 +307,38 @@ VIPS_HIP_API int vips_hip_conv_out_format(const VipsHipConv *conv, int format);
 VIPS_HIP_API int vips_hip_conv_gen(const VipsHipConv *conv,
 	const VipsHipRegion *in, const VipsHipRegion *out);
 
+/* precision=approximate.  Host-side state of one vips_conva (convolution/conva.c:676-767: the
+ * rint()ed mask cut into `layers` slabs, every slab row a run of ones, near-identical runs
+ * clustered within `cluster`, runs on consecutive rows joined into boxes) or one vips_convasep
+ * (convolution/convasep.c:152-330, the 1-D form).  The decomposition fixes the approximated mask,
+ * the divisor and the rounding term, so it has to be the reference's, quirk for quirk.
+ */
+typedef struct _VipsHipConva VipsHipConva;
+
+VIPS_HIP_API VipsHipConva *vips_hip_conva_new(const double *mask,
+	int mask_width, int mask_height, double scale, double offset, int layers, int cluster);
+VIPS_HIP_API VipsHipConva *vips_hip_convasep_new(const double *mask,
+	int mask_n, double scale, double offset, int layers);
+VIPS_HIP_API void vips_hip_conva_free(VipsHipConva *plan);
+/* The decomposition, for inspection (host only, no device needed).
+ *   conva:    info = {n_runs, n_columns, divisor, rounding, offset, longest run};
+ *             lines = n_runs x {start, end} then n_columns x {run, factor, first row, last row + 1}
+ *             (the hlines and vlines of conva.c:140-205)
+ *   convasep: info = {n_lines, divisor, rounding, offset, 0, 0}; lines = n x {start, end, factor}
+ * Returns the number of ints written to @lines, or -1.
+ */
+VIPS_HIP_API int vips_hip_conva_get_lines(const VipsHipConva *plan, int *info, int *lines, int max_ints);
+/* Fill out->valid: vips_conva_hgenerate + vips_conva_vgenerate (conva.c:876-1020, 1099-1198) in
+ * one pass over the UN-embedded image; output format == input format.
+ */
+VIPS_HIP_API int vips_hip_conva_gen(const VipsHipConva *plan,
+	const VipsHipRegion *in, const VipsHipRegion *out);
+/* One pass of vips_convasep: vips_convasep_generate_horizontal (convasep.c:516-590, no offset) or
+ * _vertical (:677-750, adds the offset).
+ */
+VIPS_HIP_API int vips_hip_convasep_gen(const VipsHipConva *plan,
+	const VipsHipRegion *in, const VipsHipRegion *out, int vertical);
+
 /* vips_gaussmat (create/gaussmat.c:95-167).  Writes at most @max doubles,
  * returns the mask width (height is 1 when separable, else == width), or -1.
  */
@@ -428,6 +460,13 @@ VIPS_HIP_API int vips_hip_conv(VipsHipImage *in, VipsHipImage **out,
 	int precision);
 VIPS_HIP_API int vips_hip_convsep(VipsHipImage *in, VipsHipImage **out,
 	const double *mask, int mask_n, double scale, double offset, int precision);
+/* vips_conva (conva.c:1231-1280) / vips_convasep (convasep.c:775-828): what vips_conv /
+ * vips_convsep / vips_gaussblur run for precision APPROXIMATE (with layers 5, cluster 1). */
+VIPS_HIP_API int vips_hip_conva(VipsHipImage *in, VipsHipImage **out,
+	const double *mask, int mask_width, int mask_height, double scale, double offset,
+	int layers, int cluster);
+VIPS_HIP_API int vips_hip_convasep(VipsHipImage *in, VipsHipImage **out,
+	const double *mask, int mask_n, double scale, double offset, int layers);
 VIPS_HIP_API int vips_hip_gaussblur(VipsHipImage *in, VipsHipImage **out,
 	double sigma, double min_ampl, int precision);
 VIPS_HIP_API int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out,

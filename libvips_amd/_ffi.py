@@ -121,6 +121,12 @@ _SIGNATURES = {
     "vips_hip_conv_get_nnz": (c_int, [c_void_p]),
     "vips_hip_conv_out_format": (c_int, [c_void_p, c_int]),
     "vips_hip_conv_gen": (c_int, [c_void_p, RegionP, RegionP]),
+    "vips_hip_conva_new": (c_void_p, [P(c_double), c_int, c_int, c_double, c_double, c_int, c_int]),
+    "vips_hip_convasep_new": (c_void_p, [P(c_double), c_int, c_double, c_double, c_int]),
+    "vips_hip_conva_free": (None, [c_void_p]),
+    "vips_hip_conva_get_lines": (c_int, [c_void_p, P(c_int), P(c_int), c_int]),
+    "vips_hip_conva_gen": (c_int, [c_void_p, RegionP, RegionP]),
+    "vips_hip_convasep_gen": (c_int, [c_void_p, RegionP, RegionP, c_int]),
     "vips_hip_gaussmat": (c_int, [c_double, c_double, c_int, c_int, P(c_double), c_int, P(c_double)]),
     # colour
     "vips_hip_colour_gen": (c_int, [c_int, RegionP, RegionP]),
@@ -154,6 +160,8 @@ _SIGNATURES = {
     "vips_hip_thumbnail_image": (c_int, [c_void_p, P(c_void_p), c_int, c_int, c_int, c_int]),
     "vips_hip_conv": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_int, c_double, c_double, c_int]),
     "vips_hip_convsep": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_double, c_double, c_int]),
+    "vips_hip_conva": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_int, c_double, c_double, c_int, c_int]),
+    "vips_hip_convasep": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_double, c_double, c_int]),
     "vips_hip_gaussblur": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_int]),
     "vips_hip_sharpen": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_double, c_double, c_double, c_double]),
     "vips_hip_colourspace": (c_int, [c_void_p, P(c_void_p), c_int]),

@@ -31,4 +31,7 @@ namespace vh {
 int convsep_f32_fused(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConv *pass1,
 	double offset2);
 
+// approx.hip: both passes of a convasep plan through the fused kernel above; 1 when not covered.
+int convasep_fused(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConva *plan);
+
 } // namespace vh

@@ -78,6 +78,48 @@ ConvPtr conv_cached(const double *mask, int mw, int mh, double scale, double off
 	return c;
 }
 
+// the same for the box / line decompositions of precision=approximate (approx.hip): the
+// clustering is host work worth keeping
+typedef std::shared_ptr<VipsHipConva> ConvaPtr;
+
+struct ConvaKey {
+	ConvKey mask; // precision field: 1 = separable
+	int layers, cluster;
+	bool operator==(const ConvaKey &o) const { return layers == o.layers && cluster == o.cluster && mask == o.mask; }
+};
+
+std::list<std::pair<ConvaKey, ConvaPtr>> &g_conva_cache = *new std::list<std::pair<ConvaKey, ConvaPtr>>;
+
+ConvaPtr conva_cached(const double *mask, int mw, int mh, double scale, double offset, int layers, int cluster,
+	bool separable)
+{
+	auto make = [&]() {
+		return separable ? vips_hip_convasep_new(mask, mw * mh, scale, offset, layers)
+						 : vips_hip_conva_new(mask, mw, mh, scale, offset, layers, cluster);
+	};
+	if (!mask || mw <= 0 || mh <= 0 || (long long) mw * mh > 65536)
+		return ConvaPtr(make(), vips_hip_conva_free);
+	ConvaKey key = { { std::vector<double>(mask, mask + (size_t) mw * mh), mw, mh, separable ? 1 : 0, scale, offset },
+		layers, cluster };
+	{
+		std::lock_guard<std::mutex> lock(g_conv_mutex);
+		for (auto it = g_conva_cache.begin(); it != g_conva_cache.end(); ++it)
+			if (it->first == key) {
+				g_conva_cache.splice(g_conva_cache.begin(), g_conva_cache, it);
+				return g_conva_cache.front().second;
+			}
+	}
+	VipsHipConva *raw = make();
+	if (!raw)
+		return ConvaPtr();
+	ConvaPtr c(raw, vips_hip_conva_free);
+	std::lock_guard<std::mutex> lock(g_conv_mutex);
+	g_conva_cache.emplace_front(std::move(key), c);
+	while (g_conva_cache.size() > CONV_CACHE_MAX)
+		g_conva_cache.pop_back();
+	return c;
+}
+
 // the sharpen LUT (sharpen.c:230-257), cached by its parameters
 struct LutKey {
 	double p[5];
@@ -384,21 +426,81 @@ extern "C" {
 int vips_hip_conv(VipsHipImage *in, VipsHipImage **out, const double *mask, int mask_width,
 	int mask_height, double scale, double offset, int precision)
 {
-	if (precision == VIPS_HIP_PRECISION_APPROXIMATE) {
-		error("conv", "precision 'approximate' (vips_conva) is outside the HIP path");
+	// conv.c:99-107 with the class defaults layers = 5, cluster = 1 (:159-160)
+	if (precision == VIPS_HIP_PRECISION_APPROXIMATE)
+		return vips_hip_conva(in, out, mask, mask_width, mask_height, scale, offset, 5, 1);
+	return conv_image(in, out, mask, mask_width, mask_height, scale, offset, precision);
+}
+
+// vips_conva_build, convolution/conva.c:1231-1280
+int vips_hip_conva(VipsHipImage *in, VipsHipImage **out, const double *mask, int mask_width,
+	int mask_height, double scale, double offset, int layers, int cluster)
+{
+	if (!in || !out) {
+		error("conva", "null argument");
 		return -1;
 	}
-	return conv_image(in, out, mask, mask_width, mask_height, scale, offset, precision);
+	ConvaPtr c = conva_cached(mask, mask_width, mask_height, scale, offset, layers, cluster, false);
+	if (!c)
+		return -1;
+	ImageRef o(vips_hip_image_new(in->width, in->height, in->bands, in->format, in->interpretation));
+	if (!o.im)
+		return -1;
+	VipsHipRegion ri, ro;
+	vips_hip_image_region(in, &ri);
+	vips_hip_image_region(o.im, &ro);
+	if (vips_hip_conva_gen(c.get(), &ri, &ro))
+		return -1;
+	*out = o.release();
+	return 0;
+}
+
+// vips_convasep_build, convolution/convasep.c:775-828: horizontal pass, then vertical
+int vips_hip_convasep(VipsHipImage *in, VipsHipImage **out, const double *mask, int mask_n,
+	double scale, double offset, int layers)
+{
+	if (!in || !out) {
+		error("convasep", "null argument");
+		return -1;
+	}
+	if (mask_n <= 0) {
+		error("convasep", "separable matrix images must have width or height 1");
+		return -1;
+	}
+	ConvaPtr c = conva_cached(mask, mask_n, 1, scale, offset, layers, 1, true);
+	if (!c)
+		return -1;
+	ImageRef o(vips_hip_image_new(in->width, in->height, in->bands, in->format, in->interpretation));
+	if (!o.im)
+		return -1;
+	// 8/16-bit images whose sums cannot wrap: both passes in the fused separable kernel
+	const int r = vh::convasep_fused(in, o.im, c.get());
+	if (r < 0)
+		return -1;
+	if (r == 0) {
+		*out = o.release();
+		return 0;
+	}
+	ImageRef t(vips_hip_image_new(in->width, in->height, in->bands, in->format, in->interpretation));
+	if (!t.im)
+		return -1;
+	VipsHipRegion ri, rt, ro;
+	vips_hip_image_region(in, &ri);
+	vips_hip_image_region(t.im, &rt);
+	vips_hip_image_region(o.im, &ro);
+	if (vips_hip_convasep_gen(c.get(), &ri, &rt, 0) || vips_hip_convasep_gen(c.get(), &rt, &ro, 1))
+		return -1;
+	*out = o.release();
+	return 0;
 }
 
 // vips_convsep_build, convolution/convsep.c:61-118: conv(M) then conv(rot90(M), offset 0)
 int vips_hip_convsep(VipsHipImage *in, VipsHipImage **out, const double *mask, int mask_n,
 	double scale, double offset, int precision)
 {
-	if (precision == VIPS_HIP_PRECISION_APPROXIMATE) {
-		error("convsep", "precision 'approximate' (vips_convasep) is outside the HIP path");
-		return -1;
-	}
+	// convsep.c:81-87 with the class default layers = 5 (:155)
+	if (precision == VIPS_HIP_PRECISION_APPROXIMATE)
+		return vips_hip_convasep(in, out, mask, mask_n, scale, offset, 5);
 	if (mask_n <= 0) {
 		error("convsep", "separable matrix images must have width or height 1");
 		return -1;

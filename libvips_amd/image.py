@@ -229,8 +229,10 @@ class Image(object):
             m = m[None, :]
         return m
 
-    def conv(self, mask, scale=1.0, offset=0.0, precision="float"):
+    def conv(self, mask, scale=1.0, offset=0.0, precision="float", layers=5, cluster=1):
         m = self._mask(mask)
+        if precision == "approximate":  # conv.c:99-107
+            return self.conva(m, scale, offset, layers, cluster)
         return self._unary(
             lib.vips_hip_conv,
             m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
@@ -241,8 +243,36 @@ class Image(object):
             _enum(PRECISIONS, precision, "precision"),
         )
 
-    def convsep(self, mask, scale=1.0, offset=0.0, precision="float"):
+    def conva(self, mask, scale=1.0, offset=0.0, layers=5, cluster=1):
+        """vips_conva: approximate integer convolution (conva.c:1231-1280)."""
+        m = self._mask(mask)
+        return self._unary(
+            lib.vips_hip_conva,
+            m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+            m.shape[1],
+            m.shape[0],
+            float(scale),
+            float(offset),
+            int(layers),
+            int(cluster),
+        )
+
+    def convasep(self, mask, scale=1.0, offset=0.0, layers=5):
+        """vips_convasep: approximate separable integer convolution (convasep.c:775-828)."""
         m = self._mask(mask).reshape(-1)
+        return self._unary(
+            lib.vips_hip_convasep,
+            m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+            m.size,
+            float(scale),
+            float(offset),
+            int(layers),
+        )
+
+    def convsep(self, mask, scale=1.0, offset=0.0, precision="float", layers=5):
+        m = self._mask(mask).reshape(-1)
+        if precision == "approximate":  # convsep.c:81-87
+            return self.convasep(m, scale, offset, layers)
         return self._unary(
             lib.vips_hip_convsep,
             m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),

@@ -63,6 +63,16 @@ void port_sharpen_lut(double x1, double y2, double y3, double m1, double m2, int
 void port_sharpen_apply(const short *in, const short *blur, int n_pixels, int bands,
 	const int *lut, short *out);
 
+/* approximate convolution (port_conva.c): vips_conva / vips_convasep */
+int port_conva_decompose(const double *mask, int mw, int mh, double scale, double offset, int layers,
+	int cluster, int *info, int *lines, int max_ints);
+int port_conva(const void *in, int width, int height, int bands, int format, const double *mask,
+	int mw, int mh, double scale, double offset, int layers, int cluster, void *out);
+int port_convasep_decompose(const double *mask, int n, double scale, double offset, int layers,
+	int *info, int *lines, int max_ints);
+int port_convasep(const void *in, int width, int height, int bands, int format, const double *mask,
+	int n, double scale, double offset, int layers, void *out);
+
 /* colour (port_colour.c): n pixels of 3 bands */
 void port_sRGB2scRGB_8(const unsigned char *p, int n, float *q);
 void port_sRGB2scRGB_16(const unsigned short *p, int n, float *q);

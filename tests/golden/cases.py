@@ -230,8 +230,92 @@ def cc_reference(case):
     return helpers.Ref.run(case["op"], src, case["args"], interp)
 
 
+# ----------------------------------------------------------------- precision=approximate
+# vips_conva / vips_convasep.  Float inputs are k + j/256 pixels, whose
+# box sums are exact in float, so the reference's rolling sums do not depend on tile geometry.
+# double convasep is left out: its second pass sums inexact doubles in tile order.
+_g3 = np.array([[1, 2, 4, 2, 1], [2, 6, 12, 6, 2], [4, 12, 20, 12, 4], [2, 6, 12, 6, 2], [1, 2, 4, 2, 1]],
+               dtype=np.float64)
+_g13 = np.rint(20 * np.exp(-(np.arange(-6, 7)[None, :] ** 2 + np.arange(-6, 7)[:, None] ** 2) / 18.0))
+_log7 = np.array([[0, 0, -1, -1, -1, 0, 0], [0, -1, -3, -3, -3, -1, 0], [-1, -3, 0, 7, 0, -3, -1],
+                  [-1, -3, 7, 24, 7, -3, -1], [-1, -3, 0, 7, 0, -3, -1], [0, -1, -3, -3, -3, -1, 0],
+                  [0, 0, -1, -1, -1, 0, 0]], dtype=np.float64)
+_row29 = np.array([[4, 5, 6, 8, 9, 11, 12, 14, 15, 16, 18, 19, 19, 20, 20, 20, 19, 19, 18, 16, 15, 14, 12, 11, 9,
+                    8, 6, 5, 4]], dtype=np.float64)
+CA_MASKS = {
+    "g5": (_g3, float(_g3.sum()), 0.0),
+    "g13": (_g13, float(_g13.sum()), 0.0),
+    "box5": (np.ones((5, 5)), 25.0, 0.0),
+    "log7": (_log7, 4.0, 100.0),
+    "frac": (np.round(_rng.rand(4, 6) * 9 - 1.5, 2), 31.5, -2.4),
+    "row29": (_row29, 372.0, 0.0),
+    "row5": (np.array([[1.0, 2, 3, 4, 10]]), 20.0, 3.0),
+    "rowneg": (np.array([[-1.0, -3, 12, -3, -1]]), 4.0, 10.0),
+}
+CA_CASES = []
+
+
+def _ca(name, **kw):
+    kw["name"] = name
+    CA_CASES.append(kw)
+
+
+_ALL = (np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.float32, np.float64)
+for _dtype in _ALL:
+    for _m in ("g5", "g13", "log7"):
+        _ca("conva|%s|%s" % (np.dtype(_dtype).name, _m), op="conva", mask=_m, args="",
+            method="conva", kwargs={}, width=53, height=41, bands=3, dtype=np.dtype(_dtype), seed=71)
+for _m, _layers, _cluster in (("g13", 3, 2), ("g13", 12, 1), ("g13", 7, 4), ("box5", 5, 1), ("frac", 9, 1),
+                              ("log7", 20, 3), ("g5", 1, 1)):
+    for _dtype in (np.uint8, np.int16, np.float32):
+        _ca("conva|%s|%s|l%d|c%d" % (np.dtype(_dtype).name, _m, _layers, _cluster), op="conva", mask=_m,
+            args="layers=%d,cluster=%d" % (_layers, _cluster), method="conva",
+            kwargs=dict(layers=_layers, cluster=_cluster), width=47, height=39, bands=2,
+            dtype=np.dtype(_dtype), seed=72)
+for _dtype in _ALL[:-1]:
+    for _m in ("row29", "row5", "rowneg"):
+        _ca("convasep|%s|%s" % (np.dtype(_dtype).name, _m), op="convasep", mask=_m, args="",
+            method="convasep", kwargs={}, width=61, height=45, bands=3, dtype=np.dtype(_dtype), seed=73)
+for _layers in (1, 3, 12):
+    for _dtype in (np.uint8, np.uint16, np.float32):
+        _ca("convasep|%s|row29|l%d" % (np.dtype(_dtype).name, _layers), op="convasep", mask="row29",
+            args="layers=%d" % _layers, method="convasep", kwargs=dict(layers=_layers), width=64, height=40,
+            bands=1, dtype=np.dtype(_dtype), seed=74)
+# the front doors: vips_conv / vips_convsep / vips_gaussblur with precision=approximate
+_ca("conv|approximate|uint8", op="conv", mask="g13", args="precision=approximate", method="conv",
+    kwargs=dict(precision="approximate"), width=80, height=60, bands=3, dtype=np.dtype(np.uint8), seed=75)
+_ca("conv|approximate|uint16|l8", op="conv", mask="g13", args="precision=approximate,layers=8,cluster=2",
+    method="conv", kwargs=dict(precision="approximate", layers=8, cluster=2), width=80, height=60, bands=1,
+    dtype=np.dtype(np.uint16), seed=76)
+_ca("convsep|approximate|uint8", op="convsep", mask="row29", args="precision=approximate", method="convsep",
+    kwargs=dict(precision="approximate"), width=80, height=60, bands=4, dtype=np.dtype(np.uint8), seed=77)
+for _dtype in (np.uint8, np.uint16, np.int16, np.float32):
+    _ca("gaussblur|approximate|%s" % np.dtype(_dtype).name, op="gaussblur", mask=None,
+        args="sigma=8,precision=approximate", method="gaussblur", kwargs=dict(sigma=8.0, precision="approximate"),
+        width=120, height=90, bands=3, dtype=np.dtype(_dtype), seed=78)
+
+
+def ca_input(case):
+    from tests import helpers
+
+    return helpers.lcg_image(case["width"], case["height"], case["bands"], case["dtype"], case["seed"])
+
+
+def ca_reference(case):
+    from tests import helpers
+
+    src = ca_input(case)
+    if case["mask"] is None:
+        return helpers.Ref.run(case["op"], src, case["args"])
+    mask, scale, offset = CA_MASKS[case["mask"]]
+    return helpers.Ref.run_mask(case["op"], src, mask, scale, offset, case["args"])
+
+
 def extra_groups():
     def make():
         return {c["name"]: cc_reference(c) for c in CC_CASES}
 
-    return [("conv_colour.npz", make)]
+    def make_ca():
+        return {c["name"]: ca_reference(c) for c in CA_CASES}
+
+    return [("conv_colour.npz", make), ("conva.npz", make_ca)]

@@ -420,6 +420,11 @@ def _port_conv_setup(lib):
                  "port_Lab2LabS", "port_LabS2Lab"):
         getattr(lib, name).argtypes = [vp, ci, vp]
         getattr(lib, name).restype = None
+    pi = ctypes.POINTER(ci)
+    lib.port_conva.argtypes = [vp, ci, ci, ci, ci, pd, ci, ci, cd, cd, ci, ci, vp]
+    lib.port_convasep.argtypes = [vp, ci, ci, ci, ci, pd, ci, cd, cd, ci, vp]
+    lib.port_conva_decompose.argtypes = [pd, ci, ci, cd, cd, ci, ci, pi, pi, ci]
+    lib.port_convasep_decompose.argtypes = [pd, ci, cd, cd, ci, pi, pi, ci]
     lib.port_cast.argtypes = [vp, ctypes.c_size_t, ci, ci, vp]
     lib.port_premultiply.argtypes = [vp, ctypes.c_size_t, ci, ci, cd, ci, ci, vp]
     lib._conv_ready = True
@@ -442,8 +447,10 @@ class PortCC(object):
         return m
 
     @classmethod
-    def conv(cls, array, mask, scale=1.0, offset=0.0, precision="float"):
+    def conv(cls, array, mask, scale=1.0, offset=0.0, precision="float", layers=5, cluster=1):
         """vips_conv (conv.c:62-118)."""
+        if precision == "approximate":
+            return cls.conva(array, mask, scale, offset, layers, cluster)
         a = Port._prep(array)
         m = cls._mask(mask)
         h, w, b = a.shape
@@ -462,11 +469,70 @@ class PortCC(object):
         return out
 
     @classmethod
-    def convsep(cls, array, mask, scale=1.0, offset=0.0, precision="float"):
+    def convsep(cls, array, mask, scale=1.0, offset=0.0, precision="float", layers=5):
         """vips_convsep (convsep.c:61-118): conv(M) then conv(rot90(M), offset 0)."""
+        if precision == "approximate":
+            return cls.convasep(array, mask, scale, offset, layers)
         m = cls._mask(mask).reshape(1, -1)
         t = cls.conv(array, m, scale, offset, precision)
         return cls.conv(t, m.reshape(-1, 1), scale, 0.0, precision)
+
+    @classmethod
+    def conva(cls, array, mask, scale=1.0, offset=0.0, layers=5, cluster=1):
+        """vips_conva (conva.c:1231-1280)."""
+        a = Port._prep(array)
+        m = cls._mask(mask)
+        h, w, b = a.shape
+        out = np.empty_like(a)
+        r = cls.lib().port_conva(a.ctypes.data, w, h, b, DTYPE_FORMATS[a.dtype],
+                                 m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), m.shape[1], m.shape[0],
+                                 scale, offset, layers, cluster, out.ctypes.data)
+        if r != 0:
+            raise RuntimeError("port conva failed")
+        return out
+
+    @classmethod
+    def convasep(cls, array, mask, scale=1.0, offset=0.0, layers=5):
+        """vips_convasep (convasep.c:775-828)."""
+        a = Port._prep(array)
+        m = cls._mask(mask).reshape(-1)
+        h, w, b = a.shape
+        out = np.empty_like(a)
+        r = cls.lib().port_convasep(a.ctypes.data, w, h, b, DTYPE_FORMATS[a.dtype],
+                                    m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), m.size,
+                                    scale, offset, layers, out.ctypes.data)
+        if r != 0:
+            raise RuntimeError("port convasep failed")
+        return out
+
+    @classmethod
+    def conva_decompose(cls, mask, scale=1.0, offset=0.0, layers=5, cluster=1):
+        """(info, hlines, vlines) of the box decomposition (conva.c:676-767)."""
+        m = cls._mask(mask)
+        info = (ctypes.c_int * 6)()
+        lines = (ctypes.c_int * 6000)()
+        n = cls.lib().port_conva_decompose(m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), m.shape[1],
+                                           m.shape[0], scale, offset, layers, cluster, info, lines, 6000)
+        if n < 0:
+            raise RuntimeError("port conva decompose failed")
+        nh, nv = info[0], info[1]
+        flat = list(lines[:n])
+        hl = [tuple(flat[2 * i:2 * i + 2]) for i in range(nh)]
+        vl = [tuple(flat[2 * nh + 4 * i:2 * nh + 4 * i + 4]) for i in range(nv)]
+        return list(info), hl, vl
+
+    @classmethod
+    def convasep_decompose(cls, mask, scale=1.0, offset=0.0, layers=5):
+        """(info, lines) of the line decomposition (convasep.c:152-330)."""
+        m = cls._mask(mask).reshape(-1)
+        info = (ctypes.c_int * 4)()
+        lines = (ctypes.c_int * 3000)()
+        n = cls.lib().port_convasep_decompose(m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), m.size,
+                                              scale, offset, layers, info, lines, 3000)
+        if n < 0:
+            raise RuntimeError("port convasep decompose failed")
+        flat = list(lines[:n])
+        return list(info), [tuple(flat[3 * i:3 * i + 3]) for i in range(info[0])]
 
     @classmethod
     def gaussmat(cls, sigma, min_ampl, separable=False, precision="integer"):

@@ -122,8 +122,16 @@ class TestModuleOnGpu(object):
 
     def test_error_propagates_as_vips_error(self):
         src = helpers.lcg_image(64, 48, 3, np.uint8, 77)
-        with pytest.raises(RuntimeError, match="approximate"):
-            Ref.run("gaussblur_hip", src, "sigma=2,precision=approximate")
+        neg = -np.ones((3, 3))
+        with pytest.raises(RuntimeError, match="positive"):
+            Ref.run_mask("conv_hip", src, neg, 1.0, 0.0, "precision=approximate")
+        # precision=approximate (vips_conva / vips_convasep) runs on the device too
+        assert np.array_equal(Ref.run("gaussblur_hip", src, "sigma=2,precision=approximate"),
+                              Ref.run("gaussblur", src, "sigma=2,precision=approximate"))
+        g = cases.CA_MASKS["g13"]
+        assert np.array_equal(
+            Ref.run_mask("conv_hip", src, g[0], g[1], g[2], "precision=approximate,layers=8,cluster=2"),
+            Ref.run_mask("conv", src, g[0], g[1], g[2], "precision=approximate,layers=8,cluster=2"))
         # nearest-neighbour downsizing: vips_subsample on the device
         assert np.array_equal(Ref.run("resize_hip", src, "scale=0.2,kernel=nearest"),
                               Ref.run("resize", src, "scale=0.2,kernel=nearest"))
