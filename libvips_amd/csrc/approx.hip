@@ -30,7 +30,9 @@
 // negative, a pass IS an integer convolution with the approximated mask W (the per-element
 // sum of line factors), scale = divisor, rounding = (divisor + 1) / 2 -- so it runs on the
 // convi kernels (conv.hip) or, for convasep, the fused separable kernel (convsep_f32.hip).
-// VIPS_HIP_NO_APPROX_FAST=1 forces the generic kernels.
+// Float images take the same route for convasep (double sums; see fast_ok).  32-bit integer and
+// double images, and conva on float (float sums), stay on the generic kernels.
+// VIPS_HIP_NO_APPROX_FAST=1 forces the generic kernels everywhere.
 #include "conv.h"
 
 #include <climits>
@@ -770,6 +772,12 @@ bool fast_ok(const _VipsHipConva *c, int format)
 {
 	if (getenv("VIPS_HIP_NO_APPROX_FAST"))
 		return false;
+	// float images, separable: the line sums are taken in double, so while they are exact (the
+	// only regime in which the reference's rolling sums do not depend on tile geometry) the
+	// weighted total equals the convolution with W summed in double -- convi on a float image
+	// (convi.c:721-741), fused in convsep_f32.hip.  |W| is far below the 2^29 that kernel needs.
+	if (format == VIPS_HIP_FORMAT_FLOAT)
+		return c->separable && c->w_abs_sum < (1LL << 29);
 	long long maxval;
 	bool is_unsigned;
 	switch (format) {
