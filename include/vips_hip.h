@@ -421,6 +421,30 @@ VIPS_HIP_API int vips_hip_image_get_interpretation(const VipsHipImage *image);
 VIPS_HIP_API size_t vips_hip_image_get_stride(const VipsHipImage *image);
 VIPS_HIP_API void vips_hip_image_region(const VipsHipImage *image, VipsHipRegion *region);
 
+/* The native ".v" format (doc/file-format.md; iofuncs/vips.c:283-441): 64-byte header, then
+ * band-interleaved scanlines without padding, then optional XML metadata (not carried here).
+ * vips_hip_vfile_read_header is host-only (vips__read_header_bytes plus the file-length check of
+ * iofuncs/image.c:966-979); the loader and the saver move the pixels between the file and HBM
+ * through two pinned buffers so that disc and PCIe transfers overlap (the role of the two
+ * write-behind buffers of iofuncs/sinkdisc.c:195-220).  Files with big-endian pixels or LABQ /
+ * RAD coding are refused.
+ */
+typedef struct _VipsHipVHeader {
+	int width, height, bands;
+	int format;         /* VipsBandFormat */
+	int coding;         /* VipsCoding: 0 none, 2 LABQ, 6 RAD */
+	int interpretation; /* VipsInterpretation, -1 when the file holds an unknown value */
+	float xres, yres;   /* pixels per mm */
+	int xoffset, yoffset;
+	int msb_first;         /* pixel data is big-endian */
+	long long data_offset; /* == 64 */
+	long long data_size;   /* width * height * bands * sizeof(format) */
+} VipsHipVHeader;
+
+VIPS_HIP_API int vips_hip_vfile_read_header(const char *path, VipsHipVHeader *header);
+VIPS_HIP_API VipsHipImage *vips_hip_image_new_from_vfile(const char *path);
+VIPS_HIP_API int vips_hip_image_write_to_vfile(const VipsHipImage *image, const char *path);
+
 /* Emulate the reference sink's strip height when seeding the reduce position
  * accumulators (see vips_hip_reducev_gen_tiled); default 16 = vips__fatstrip_height
  * (include/vips/private.h:147-153). */

@@ -33,6 +33,26 @@ class Region(ctypes.Structure):
     ]
 
 
+class VHeader(ctypes.Structure):
+    """VipsHipVHeader: the fields of a .v file header (include/vips_hip.h)."""
+
+    _fields_ = [
+        ("width", ctypes.c_int),
+        ("height", ctypes.c_int),
+        ("bands", ctypes.c_int),
+        ("format", ctypes.c_int),
+        ("coding", ctypes.c_int),
+        ("interpretation", ctypes.c_int),
+        ("xres", ctypes.c_float),
+        ("yres", ctypes.c_float),
+        ("xoffset", ctypes.c_int),
+        ("yoffset", ctypes.c_int),
+        ("msb_first", ctypes.c_int),
+        ("data_offset", ctypes.c_longlong),
+        ("data_size", ctypes.c_longlong),
+    ]
+
+
 def _load():
     # PyTorch-ROCm carries its own HIP runtime (soname libamdhip64.so).  Import it first so
     # libvipship.so, which needs that soname, binds to the SAME runtime: device pointers,
@@ -160,6 +180,9 @@ _SIGNATURES = {
     "vips_hip_thumbnail_image": (c_int, [c_void_p, P(c_void_p), c_int, c_int, c_int, c_int]),
     "vips_hip_conv": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_int, c_double, c_double, c_int]),
     "vips_hip_convsep": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_double, c_double, c_int]),
+    "vips_hip_vfile_read_header": (c_int, [c_char_p, P(VHeader)]),
+    "vips_hip_image_new_from_vfile": (c_void_p, [c_char_p]),
+    "vips_hip_image_write_to_vfile": (c_int, [c_void_p, c_char_p]),
     "vips_hip_conva": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_int, c_double, c_double, c_int, c_int]),
     "vips_hip_convasep": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_double, c_double, c_int]),
     "vips_hip_gaussblur": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_int]),

@@ -8,6 +8,7 @@ parity tests read like the reference's tests.  Every method is a single call
 through the C ABI (include/vips_hip.h); no pixel is touched in Python.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -114,6 +115,15 @@ class Image(object):
             a.ctypes.data, w, h, b, fmt, _enum(INTERPRETATIONS, interpretation, "interpretation")
         )
         return cls(check_handle(handle))
+
+    @classmethod
+    def new_from_file(cls, path):
+        """Load a libvips native .v file into HBM (iofuncs/vips.c; pinned double-buffered upload)."""
+        return cls(check_handle(lib.vips_hip_image_new_from_vfile(os.fsencode(path))))
+
+    def write_to_file(self, path):
+        """Save as a libvips native .v file."""
+        check(lib.vips_hip_image_write_to_vfile(self._h, os.fsencode(path)))
 
     @classmethod
     def new_from_tensor(cls, tensor, interpretation="multiband"):

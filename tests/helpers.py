@@ -693,8 +693,9 @@ def write_v(path, array, interpretation=22):
     a = np.ascontiguousarray(array)
     h, w, b = a.shape
     magic = bytes([0xB6, 0xA6, 0xF2, 0x08])  # VIPS_MAGIC_INTEL, always written MSB first (iofuncs/vips.c:427)
-    header = magic + struct.pack("<iiiiiiiffiiii", w, h, b, 0, DTYPE_FORMATS[a.dtype], 0, interpretation,
-                                 1.0, 1.0, 0, 0, 0, 0)
+    # Bbits (offset 16) is deprecated but still written: sizeof(element) * 8 (iofuncs/vips.c:352)
+    header = magic + struct.pack("<iiiiiiiffiiii", w, h, b, a.dtype.itemsize * 8, DTYPE_FORMATS[a.dtype], 0,
+                                 interpretation, 1.0, 1.0, 0, 0, 0, 0)
     header = header.ljust(64, b"\0")
     with open(path, "wb") as f:
         f.write(header)
