@@ -445,6 +445,31 @@ VIPS_HIP_API int vips_hip_vfile_read_header(const char *path, VipsHipVHeader *he
 VIPS_HIP_API VipsHipImage *vips_hip_image_new_from_vfile(const char *path);
 VIPS_HIP_API int vips_hip_image_write_to_vfile(const VipsHipImage *image, const char *path);
 
+/* JPEG shrink-on-load in front of the device path.  The entropy decode is
+ * libjpeg's, on the host, exactly as foreign/jpeg2vips.c:517-640,800-905 drives it (scale 1/shrink,
+ * output cropped to size / shrink rounded down, CMYK inverted); libjpeg.so.9 is bound with dlopen
+ * at first use.  vips_hip_thumbnail is vips_thumbnail() (resample/thumbnail.c:549-676 open +
+ * :678-1067 build) for JPEG and .v files: vips_thumbnail_find_jpegshrink (:488-519) picks the
+ * block shrink, the pre-shrunk image is uploaded, the rest is vips_hip_thumbnail_image.  Files
+ * that need auto-rotation or ICC colour management are refused.
+ */
+typedef struct _VipsHipJpegHeader {
+	int width, height;             /* after the shrink */
+	int bands;                     /* 1 grey, 3 RGB, 4 CMYK */
+	int interpretation;            /* B_W, sRGB or CMYK (15) */
+	int image_width, image_height; /* of the file */
+	int orientation;               /* EXIF orientation, 0 when absent */
+	int has_icc;
+} VipsHipJpegHeader;
+
+VIPS_HIP_API int vips_hip_thumbnail_find_jpegshrink(int in_width, int in_height,
+	int width, int height, int size, int linear);
+VIPS_HIP_API int vips_hip_jpeg_read_header(const char *path, int shrink, VipsHipJpegHeader *header);
+VIPS_HIP_API int vips_hip_jpeg_read_to_memory(const char *path, int shrink, void *host_data, size_t size);
+VIPS_HIP_API VipsHipImage *vips_hip_image_new_from_jpeg(const char *path, int shrink);
+VIPS_HIP_API int vips_hip_thumbnail(const char *path, VipsHipImage **out,
+	int width, int height, int size, int linear);
+
 /* Emulate the reference sink's strip height when seeding the reduce position
  * accumulators (see vips_hip_reducev_gen_tiled); default 16 = vips__fatstrip_height
  * (include/vips/private.h:147-153). */

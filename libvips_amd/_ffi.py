@@ -53,6 +53,21 @@ class VHeader(ctypes.Structure):
     ]
 
 
+class JpegHeader(ctypes.Structure):
+    """VipsHipJpegHeader (include/vips_hip.h)."""
+
+    _fields_ = [
+        ("width", ctypes.c_int),
+        ("height", ctypes.c_int),
+        ("bands", ctypes.c_int),
+        ("interpretation", ctypes.c_int),
+        ("image_width", ctypes.c_int),
+        ("image_height", ctypes.c_int),
+        ("orientation", ctypes.c_int),
+        ("has_icc", ctypes.c_int),
+    ]
+
+
 def _load():
     # PyTorch-ROCm carries its own HIP runtime (soname libamdhip64.so).  Import it first so
     # libvipship.so, which needs that soname, binds to the SAME runtime: device pointers,
@@ -183,6 +198,11 @@ _SIGNATURES = {
     "vips_hip_vfile_read_header": (c_int, [c_char_p, P(VHeader)]),
     "vips_hip_image_new_from_vfile": (c_void_p, [c_char_p]),
     "vips_hip_image_write_to_vfile": (c_int, [c_void_p, c_char_p]),
+    "vips_hip_thumbnail_find_jpegshrink": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "vips_hip_jpeg_read_header": (c_int, [c_char_p, c_int, P(JpegHeader)]),
+    "vips_hip_jpeg_read_to_memory": (c_int, [c_char_p, c_int, c_void_p, c_size_t]),
+    "vips_hip_image_new_from_jpeg": (c_void_p, [c_char_p, c_int]),
+    "vips_hip_thumbnail": (c_int, [c_char_p, P(c_void_p), c_int, c_int, c_int, c_int]),
     "vips_hip_conva": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_int, c_double, c_double, c_int, c_int]),
     "vips_hip_convasep": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_double, c_double, c_int]),
     "vips_hip_gaussblur": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_int]),

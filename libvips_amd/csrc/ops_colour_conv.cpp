@@ -701,16 +701,26 @@ int vips_hip_thumbnail_image(VipsHipImage *in, VipsHipImage **out, int width, in
 	}
 
 	// processing space (thumbnail.c:763-823)
-	if (in->bands < 3) {
-		error(domain, "images with fewer than 3 bands (B_W / GREY16 processing space) are "
-					  "outside the HIP path");
-		return -1;
-	}
 	ImageRef space;
-	if (vips_hip_colourspace(in, &space.im,
-			linear ? VIPS_HIP_INTERPRETATION_scRGB : VIPS_HIP_INTERPRETATION_sRGB))
-		return -1;
-	VipsHipImage *cur = space.im;
+	VipsHipImage *cur;
+	if (in->bands < 3) {
+		// B_W is the processing space of images with fewer than 3 bands (thumbnail.c:806-820); a
+		// one-band uchar B_W image (a greyscale JPEG) is already in it.  GREY16 (linear) and
+		// grey + alpha are outside the path.
+		if (linear || in->bands != 1 || in->format != VIPS_HIP_FORMAT_UCHAR ||
+			guess_interpretation(in) != VIPS_HIP_INTERPRETATION_B_W) {
+			error(domain, "images with fewer than 3 bands are outside the HIP path unless they are "
+						  "one-band uchar B_W, not linear");
+			return -1;
+		}
+		cur = in;
+	}
+	else {
+		if (vips_hip_colourspace(in, &space.im,
+				linear ? VIPS_HIP_INTERPRETATION_scRGB : VIPS_HIP_INTERPRETATION_sRGB))
+			return -1;
+		cur = space.im;
+	}
 
 	// vips_thumbnail_calculate_shrink, thumbnail.c:413-467 (crop NONE, no rotate)
 	double hshrink = (double) cur->width / width;

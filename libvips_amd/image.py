@@ -227,6 +227,20 @@ class Image(object):
             float(gap),
         )
 
+    @classmethod
+    def new_from_jpeg(cls, path, shrink=1):
+        """jpegload with shrink-on-load 1/2/4/8 (foreign/jpeg2vips.c): host decode, upload."""
+        return cls(check_handle(lib.vips_hip_image_new_from_jpeg(os.fsencode(path), int(shrink))))
+
+    @classmethod
+    def thumbnail(cls, path, width, height=None, size="both", linear=False):
+        """vips_thumbnail() for JPEG and .v files: shrink-on-load, then the thumbnail_image pipeline."""
+        sizes = {"both": 0, "up": 1, "down": 2, "force": 3}
+        out = ctypes.c_void_p()
+        check(lib.vips_hip_thumbnail(os.fsencode(path), ctypes.byref(out), int(width), int(height) if height else 0,
+                                     sizes[size] if isinstance(size, str) else int(size), int(bool(linear))))
+        return cls(out.value)
+
     def thumbnail_image(self, width, height=None, size="both", linear=False):
         sizes = {"both": 0, "up": 1, "down": 2, "force": 3}
         return self._unary(lib.vips_hip_thumbnail_image, int(width), int(height) if height else 0,

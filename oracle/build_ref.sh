@@ -57,7 +57,15 @@ sed -e 's/@VIPS_VERSION@/8.19.0/' -e 's/@VIPS_VERSION_STRING@/8.19.0/' \
 	-e 's/@VIPS_ENABLE_DEPRECATED@/0/' \
 	"$INC/vips/version.h.in" >"$GEN/vips/version.h"
 
-# 4. config.h: no HAVE_HWY / HAVE_ORC / codecs / modules / deprecated
+# 4. config.h: no HAVE_HWY / HAVE_ORC / modules / deprecated.  The one codec: the IJG libjpeg that
+# ships in $GLIB_PREFIX (jpeglib.h + libjpeg.so), for the shrink-on-load thumbnail path
+# (foreign/jpeg2vips.c).  No libexif, no lcms: no auto-rotate, no ICC.
+JPEG_DEFINE=""
+JPEG_LIB=""
+if [ -f "$GLIB_PREFIX/include/jpeglib.h" ] && [ -e "$GLIB_PREFIX/lib/libjpeg.so" ]; then
+	JPEG_DEFINE="#define HAVE_JPEG 1"
+	JPEG_LIB="-ljpeg"
+fi
 cat >"$GEN/config.h" <<EOF
 #ifndef ORACLE_CONFIG_H
 #define ORACLE_CONFIG_H
@@ -76,13 +84,14 @@ cat >"$GEN/config.h" <<EOF
 #define HAVE_PPM 1
 #define HAVE_ANALYZE 1
 #define HAVE_RADIANCE 1
+$JPEG_DEFINE
 #define _VIPS_PUBLIC __attribute__((visibility("default")))
 #endif
 EOF
 
 CFLAGS_COMMON="-O3 -DHAVE_CONFIG_H -DG_DISABLE_CAST_CHECKS -DG_DISABLE_CHECKS -DG_DISABLE_ASSERT \
  -I$GEN -I$GEN/vips -I$INC -I$REF/libvips -I$GLIB_PREFIX/include/glib-2.0 \
- -I$GLIB_PREFIX/lib/glib-2.0/include -fPIC -w"
+ -I$GLIB_PREFIX/lib/glib-2.0/include -idirafter $GLIB_PREFIX/include -fPIC -w"
 
 # 5. compile
 cd "$REF/libvips"
@@ -107,7 +116,7 @@ gcc -std=gnu99 $CFLAGS_COMMON -c "$GEN/vipsmarshal.c" -o "$OUT/obj/gen_vipsmarsh
 # 6. link
 g++ -shared "$OUT"/obj/*.o -o "$OUT/lib/libvips.so" \
 	-L"$GLIB_PREFIX/lib" -Wl,-rpath,"$GLIB_PREFIX/lib" \
-	-lgio-2.0 -lgobject-2.0 -lgmodule-2.0 -lglib-2.0 -lexpat -lm -lpthread
+	-lgio-2.0 -lgobject-2.0 -lgmodule-2.0 -lglib-2.0 -lexpat $JPEG_LIB -lm -lpthread
 
 # 7. the reference's own CLI tools, unchanged, for config C1
 for t in vips vipsthumbnail vipsheader; do

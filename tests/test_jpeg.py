@@ -1,0 +1,212 @@
+"""JPEG shrink-on-load in front of the device path.
+
+CPU: the host decode (libjpeg driven the way foreign/jpeg2vips.c drives it) against the
+REFERENCE's jpegload for every shrink, and the choice of the block shrink against what the
+reference's vipsthumbnail logs.  GPU: vips_hip_thumbnail against the reference's vipsthumbnail
+CLI on the same file.  The test JPEGs are made with Pillow (present in the image)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import helpers
+from tests.helpers import Ref
+
+PIL = pytest.importorskip("PIL.Image")
+VIPSTHUMBNAIL = os.path.join(helpers.ROOT, "oracle", "_ref", "bin", "vipsthumbnail")
+
+
+def _ref_has_jpeg():
+    if not helpers.have_ref():
+        return False
+    try:
+        Ref.lib()
+        lib = ctypes.CDLL(helpers.REF_LIB.replace("libref_shim", "libvips"))
+        lib.vips_type_find.restype = ctypes.c_size_t
+        lib.vips_type_find.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        return lib.vips_type_find(b"VipsOperation", b"jpegload") != 0
+    except Exception:
+        return False
+
+
+needs_ref_jpeg = pytest.mark.skipif(not _ref_has_jpeg(), reason="oracle/_ref built without libjpeg")
+
+
+def make_jpeg(path, width, height, grey=False, quality=90, subsampling=None, **extra):
+    y, x = np.mgrid[0:height, 0:width]
+    img = np.stack([(np.sin(x / 37.0) + 1) * 127, (np.cos(y / 23.0) + 1) * 127, (x + y) % 256], axis=2)
+    img = (img.astype(int) + helpers.lcg_image(width, height, 3, np.uint8, 97) // 8).clip(0, 255).astype(np.uint8)
+    im = PIL.fromarray(img)
+    if grey:
+        im = im.convert("L")
+    kw = dict(extra)
+    if subsampling is not None:
+        kw["subsampling"] = subsampling
+    im.save(path, quality=quality, **kw)
+
+
+def product_header(path, shrink=1):
+    from libvips_amd import _ffi
+
+    h = _ffi.JpegHeader()
+    if _ffi.lib.vips_hip_jpeg_read_header(os.fsencode(path), shrink, ctypes.byref(h)) != 0:
+        msg = _ffi.error_buffer()
+        _ffi.lib.vips_hip_error_clear()
+        raise RuntimeError(msg)
+    return h
+
+
+def product_decode(path, shrink):
+    from libvips_amd import _ffi
+
+    h = product_header(path, shrink)
+    out = np.empty((h.height, h.width, h.bands), np.uint8)
+    if _ffi.lib.vips_hip_jpeg_read_to_memory(os.fsencode(path), shrink, out.ctypes.data, out.size) != 0:
+        msg = _ffi.error_buffer()
+        _ffi.lib.vips_hip_error_clear()
+        raise RuntimeError(msg)
+    return out, h
+
+
+CASES = [(641, 487, False, None), (1801, 1203, False, 0), (1000, 750, True, None), (333, 517, False, 2),
+         (64, 48, False, None), (17, 9, True, None)]
+
+
+@needs_ref_jpeg
+@pytest.mark.parametrize("width,height,grey,sub", CASES)
+def test_decode_matches_reference_jpegload(tmp_path, width, height, grey, sub):
+    path = str(tmp_path / "t.jpg")
+    make_jpeg(path, width, height, grey, subsampling=sub)
+    for shrink in (1, 2, 4, 8):
+        if width // shrink < 1 or height // shrink < 1:
+            continue
+        want, _, _ = Ref.create("jpegload", "filename=%s,shrink=%d" % (path, shrink))
+        got, h = product_decode(path, shrink)
+        assert (h.image_width, h.image_height) == (width, height)
+        assert got.shape == want.shape == (height // shrink, width // shrink, 1 if grey else 3)
+        assert h.interpretation == (1 if grey else 22)
+        assert np.array_equal(got, want), shrink
+
+
+@needs_ref_jpeg
+def test_progressive_and_quality_variants(tmp_path):
+    path = str(tmp_path / "p.jpg")
+    for kw in (dict(progressive=True), dict(quality=30), dict(quality=100, subsampling=0), dict(optimize=True)):
+        make_jpeg(path, 413, 305, **kw)
+        for shrink in (1, 4):
+            want, _, _ = Ref.create("jpegload", "filename=%s,shrink=%d" % (path, shrink))
+            got, _ = product_decode(path, shrink)
+            assert np.array_equal(got, want), (kw, shrink)
+
+
+def test_header_flags_and_errors(tmp_path):
+    path = str(tmp_path / "t.jpg")
+    make_jpeg(path, 120, 80)
+    h = product_header(path)
+    assert (h.width, h.height, h.bands, h.orientation, h.has_icc) == (120, 80, 3, 0, 0)
+    # EXIF orientation 6 and an ICC profile are seen (and make vips_hip_thumbnail refuse the file)
+    exif = PIL.Exif()
+    exif[0x0112] = 6
+    make_jpeg(path, 120, 80, exif=exif.tobytes())
+    assert product_header(path).orientation == 6
+    make_jpeg(path, 120, 80, icc_profile=b"\0" * 200)
+    assert product_header(path).has_icc == 1
+
+    make_jpeg(path, 120, 80)
+    with pytest.raises(RuntimeError, match="bad shrink factor"):
+        product_header(path, 3)
+    with pytest.raises(RuntimeError, match="unable to open"):
+        product_header(str(tmp_path / "missing.jpg"))
+    bad = str(tmp_path / "bad.jpg")
+    open(bad, "wb").write(b"\xff\xd8" + b"garbage" * 10)
+    with pytest.raises(RuntimeError):
+        product_header(bad)
+    trunc = str(tmp_path / "trunc.jpg")
+    raw = open(path, "rb").read()
+    open(trunc, "wb").write(raw[:len(raw) // 2])
+    out, _ = product_decode(trunc, 1)  # a truncated scan is a warning, not an error (fail_on none)
+    assert out.shape == (80, 120, 3)
+
+
+@needs_ref_jpeg
+def test_truncated_file_decodes_like_the_reference(tmp_path):
+    path, trunc = str(tmp_path / "t.jpg"), str(tmp_path / "trunc.jpg")
+    make_jpeg(path, 200, 160)
+    raw = open(path, "rb").read()
+    open(trunc, "wb").write(raw[:len(raw) * 2 // 3])
+    want, _, _ = Ref.create("jpegload", "filename=%s" % trunc)
+    got, _ = product_decode(trunc, 1)
+    assert np.array_equal(got, want)
+
+
+def cli_thumbnail(tmp_path, src, size, extra=()):
+    out_path = os.path.join(str(tmp_path), "cli_out.v")
+    env = dict(os.environ, VIPS_INFO="1")
+    proc = subprocess.run([VIPSTHUMBNAIL, src, "--size", size, "-o", out_path] + list(extra),
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, text=True)
+    assert proc.returncode == 0, proc.stdout
+    out, _ = helpers.read_v(out_path)
+    factor = [ln for ln in proc.stdout.splitlines() if "pre-shrink" in ln]
+    return out, int(factor[0].split("factor ")[1].split(" ")[0]) if factor else None
+
+
+@needs_ref_jpeg
+def test_find_jpegshrink_matches_what_the_reference_logs(tmp_path):
+    from libvips_amd import _ffi
+
+    path = str(tmp_path / "t.jpg")
+    for (w, h, size, args, mode, linear) in ((2000, 1500, "200x200", (), 0, 0), (1801, 1203, "100x100", (), 0, 0),
+                                             (640, 480, "300x300", (), 0, 0), (4000, 3000, "128x128", (), 0, 0),
+                                             (1600, 1200, "100x100", ("--linear",), 0, 1),
+                                             (1600, 400, "100x100!", (), 3, 0), (1000, 800, "125x100", (), 0, 0)):
+        make_jpeg(path, w, h, quality=60)
+        _, factor = cli_thumbnail(tmp_path, path, size, args)
+        tw, th = [int(v) for v in size.rstrip("!").split("x")]
+        assert _ffi.lib.vips_hip_thumbnail_find_jpegshrink(w, h, tw, th, mode, linear) == factor, (w, h, size)
+
+
+@pytest.mark.gpu
+@needs_ref_jpeg
+@pytest.mark.parametrize("width,height,grey,size", [(2000, 1500, False, "200x200"), (1801, 1203, False, "100x100"),
+                                                     (3001, 1999, True, "150x150"), (640, 480, False, "300x300"),
+                                                     (1000, 800, False, "900x900")])
+def test_thumbnail_of_a_jpeg_matches_the_reference_cli(tmp_path, width, height, grey, size):
+    import libvips_amd
+    from libvips_amd import Image
+
+    libvips_amd.init(0)
+    path = str(tmp_path / "t.jpg")
+    make_jpeg(path, width, height, grey)
+    want, _ = cli_thumbnail(tmp_path, path, size)
+    tw, th = [int(v) for v in size.split("x")]
+    got = Image.thumbnail(path, tw, th).numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_thumbnail_of_a_v_file_and_refusals(tmp_path):
+    import libvips_amd
+    from libvips_amd import Image
+
+    libvips_amd.init(0)
+    src = helpers.lcg_image(517, 389, 3, np.uint8, 98)
+    vpath = str(tmp_path / "src.v")
+    helpers.write_v(vpath, src, interpretation=22)
+    got = Image.thumbnail(vpath, 100).numpy()
+    want = Image.new_from_array(src, interpretation="srgb").thumbnail_image(100).numpy()
+    assert np.array_equal(got, want)
+    jpath = str(tmp_path / "rot.jpg")
+    exif = PIL.Exif()
+    exif[0x0112] = 8
+    make_jpeg(jpath, 300, 200, exif=exif.tobytes())
+    with pytest.raises(libvips_amd.VipsHipError, match="auto-rotation"):
+        Image.thumbnail(jpath, 64)
+    make_jpeg(jpath, 300, 200, icc_profile=b"\0" * 200)
+    with pytest.raises(libvips_amd.VipsHipError, match="ICC"):
+        Image.thumbnail(jpath, 64)
+    # shrink-on-load on its own
+    make_jpeg(jpath, 300, 200)
+    im = Image.new_from_jpeg(jpath, 2)
+    assert (im.width, im.height, im.bands) == (150, 100, 3)
