@@ -35,7 +35,8 @@ def main():
     t0 = time.time()
     n = bad = 0
     while time.time() - t0 < budget:
-        kind = rng.choice(["reduce8", "reduce", "resize", "upsize", "gaussblur", "conv", "shrink", "thumb"])
+        kind = rng.choice(["reduce8", "reduce", "resize", "upsize", "gaussblur", "conv", "shrink", "thumb",
+                           "approx"])
         seed = rng.randrange(1 << 30)
         try:
             if kind == "reduce8":
@@ -89,6 +90,26 @@ def main():
                 got = Image.new_from_array(src).conv(mask, scale=scale, offset=1.0, precision=prec).numpy()
                 want = PortCC.conv(src, mask, scale, 1.0, prec)
                 desc = (kind, w, h, b, dt.__name__, mw, mh, scale, prec)
+            elif kind == "approx":
+                # precision=approximate: conva / convasep (float sums are exact for these pixels,
+                # double convasep is tile-order dependent in the reference: left out)
+                w, h, b = rng.randrange(1, 260), rng.randrange(1, 200), rng.randrange(1, 4)
+                dt = rng.choice(INT_TYPES + [np.float32])
+                layers, cluster = rng.randrange(1, 16), rng.randrange(1, 6)
+                src = helpers.lcg_image(w, h, b, dt, seed)
+                if rng.random() < 0.5:
+                    mw, mh = rng.randrange(1, 14), rng.randrange(1, 14)
+                    mask = np.array([[float(rng.randrange(-4, 16)) for _ in range(mw)] for _ in range(mh)])
+                    mask[rng.randrange(mh), rng.randrange(mw)] = 17.0
+                    scale, offset = float(rng.randrange(1, 50)), float(rng.randrange(-4, 5))
+                    got = Image.new_from_array(src).conva(mask, scale, offset, layers, cluster).numpy()
+                    want = PortCC.conva(src, mask, scale, offset, layers, cluster)
+                    desc = (kind, "conva", w, h, b, dt.__name__, mw, mh, layers, cluster)
+                else:
+                    sigma = 0.5 + rng.random() * 9
+                    got = Image.new_from_array(src).gaussblur(sigma, precision="approximate").numpy()
+                    want = PortCC.gaussblur(src, sigma, precision="approximate")
+                    desc = (kind, "gaussblur", w, h, b, dt.__name__, sigma)
             elif kind == "shrink":
                 w, h, b = rng.randrange(1, 500), rng.randrange(1, 500), rng.randrange(1, 5)
                 dt = rng.choice(ALL_TYPES)
