@@ -638,8 +638,11 @@ class PortCC(object):
     @classmethod
     def thumbnail_image(cls, array, interpretation, width, height=None, size="both", linear=False):
         """vips_thumbnail_image (thumbnail.c:678-1067, shrink :413-467), no crop / ICC."""
-        a = cls.colourspace(array, "scrgb" if linear else "srgb", interpretation)
         space = "scrgb" if linear else "srgb"
+        if interpretation == "b-w" and not linear and np.asarray(array).shape[2] == 1:
+            a = Port._prep(array)  # B_W is the processing space of one-band images (thumbnail.c:806-820)
+        else:
+            a = cls.colourspace(array, space, interpretation)
         h, w, _ = a.shape
         height = height or width
         hshrink, vshrink = w / width, h / height

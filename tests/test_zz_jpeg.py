@@ -210,3 +210,23 @@ def test_thumbnail_of_a_v_file_and_refusals(tmp_path):
     make_jpeg(jpath, 300, 200)
     im = Image.new_from_jpeg(jpath, 2)
     assert (im.width, im.height, im.bands) == (150, 100, 3)
+
+
+@needs_ref_jpeg
+@pytest.mark.parametrize("width,height,grey,size", [(2000, 1500, False, "200x200"), (1801, 1203, False, "100x100"),
+                                                     (3001, 1999, True, "150x150"), (640, 480, False, "300x300")])
+def test_jpeg_pipeline_through_the_port_matches_the_reference_cli(tmp_path, width, height, grey, size):
+    """The CPU twin of the GPU test above: product shrink choice + product host decode + the
+    oracle port's thumbnail pipeline == the reference's vipsthumbnail on the same file."""
+    from libvips_amd import _ffi
+
+    path = str(tmp_path / "t.jpg")
+    make_jpeg(path, width, height, grey)
+    want, _ = cli_thumbnail(tmp_path, path, size)
+    tw, th = [int(v) for v in size.split("x")]
+    factor = _ffi.lib.vips_hip_thumbnail_find_jpegshrink(width, height, tw, th, 0, 0)
+    pre, _ = product_decode(path, factor)
+    from tests.helpers import PortCC
+
+    got = PortCC.thumbnail_image(pre, "b-w" if grey else "srgb", tw, th)
+    assert got.shape == want.shape and np.array_equal(got, want)
