@@ -537,6 +537,7 @@ typedef struct _VipsThumbnailHip {
 	int width, height;
 	VipsSize size;
 	gboolean linear;
+	VipsInteresting crop;
 } VipsThumbnailHip;
 
 static int
@@ -545,8 +546,8 @@ vips_thumbnail_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
 	VipsThumbnailHip *thumbnail = (VipsThumbnailHip *) op;
 	int height = vips_object_argument_isset(VIPS_OBJECT(op), "height") ? thumbnail->height : 0;
 
-	return vips_hip_thumbnail_image(in, out, thumbnail->width, height, thumbnail->size,
-		thumbnail->linear);
+	return vips_hip_thumbnail_image_crop(in, out, thumbnail->width, height, thumbnail->size,
+		thumbnail->linear, thumbnail->crop);
 }
 
 HIP_SUBCLASS(VipsThumbnailHip, vips_thumbnail_hip, "thumbnail_image_hip",
@@ -564,6 +565,9 @@ vips_thumbnail_hip_args(VipsThumbnailHipClass *class)
 		VIPS_TYPE_SIZE, VIPS_SIZE_BOTH);
 	VIPS_ARG_BOOL(class, "linear", 118, "Linear", "Reduce in linear light",
 		VIPS_ARGUMENT_OPTIONAL_INPUT, G_STRUCT_OFFSET(VipsThumbnailHip, linear), FALSE);
+	VIPS_ARG_ENUM(class, "crop", 116, "Crop", "Reduce to fill target rectangle, then crop",
+		VIPS_ARGUMENT_OPTIONAL_INPUT, G_STRUCT_OFFSET(VipsThumbnailHip, crop),
+		VIPS_TYPE_INTERESTING, VIPS_INTERESTING_NONE);
 }
 
 static void
@@ -572,6 +576,7 @@ vips_thumbnail_hip_init(VipsThumbnailHip *thumbnail)
 	thumbnail->width = 1;
 	thumbnail->height = 1;
 	thumbnail->size = VIPS_SIZE_BOTH;
+	thumbnail->crop = VIPS_INTERESTING_NONE;
 }
 
 /* conv_hip / convsep_hip: convolution/conv.c:120-175, convsep.c:120-170 */

@@ -463,12 +463,12 @@ typedef struct _VipsHipJpegHeader {
 } VipsHipJpegHeader;
 
 VIPS_HIP_API int vips_hip_thumbnail_find_jpegshrink(int in_width, int in_height,
-	int width, int height, int size, int linear);
+	int width, int height, int size, int linear, int crop);
 VIPS_HIP_API int vips_hip_jpeg_read_header(const char *path, int shrink, VipsHipJpegHeader *header);
 VIPS_HIP_API int vips_hip_jpeg_read_to_memory(const char *path, int shrink, void *host_data, size_t size);
 VIPS_HIP_API VipsHipImage *vips_hip_image_new_from_jpeg(const char *path, int shrink);
 VIPS_HIP_API int vips_hip_thumbnail(const char *path, VipsHipImage **out,
-	int width, int height, int size, int linear);
+	int width, int height, int size, int linear, int crop);
 
 /* Emulate the reference sink's strip height when seeding the reduce position
  * accumulators (see vips_hip_reducev_gen_tiled); default 16 = vips__fatstrip_height
@@ -504,6 +504,16 @@ VIPS_HIP_API int vips_hip_resize(VipsHipImage *in, VipsHipImage **out,
  */
 VIPS_HIP_API int vips_hip_thumbnail_image(VipsHipImage *in, VipsHipImage **out,
 	int width, int height, int size, int linear);
+/* ... with the crop argument (a VipsInteresting, include/vips/conversion.h:97-107): the box is
+ * filled instead of fitted (thumbnail.c:432-437) and the result cut to it by vips_smartcrop's
+ * positional modes (conversion/smartcrop.c:359-400): 0 none, 1 centre, 4 low, 5 high, 6 all.
+ * The content-driven modes (2 entropy, 3 attention) are refused.
+ */
+VIPS_HIP_API int vips_hip_thumbnail_image_crop(VipsHipImage *in, VipsHipImage **out,
+	int width, int height, int size, int linear, int crop);
+/* vips_extract_area (conversion/extract.c:137-187). */
+VIPS_HIP_API int vips_hip_extract_area(VipsHipImage *in, VipsHipImage **out,
+	int left, int top, int width, int height);
 VIPS_HIP_API int vips_hip_conv(VipsHipImage *in, VipsHipImage **out,
 	const double *mask, int mask_width, int mask_height, double scale, double offset,
 	int precision);

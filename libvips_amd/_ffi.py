@@ -198,11 +198,13 @@ _SIGNATURES = {
     "vips_hip_vfile_read_header": (c_int, [c_char_p, P(VHeader)]),
     "vips_hip_image_new_from_vfile": (c_void_p, [c_char_p]),
     "vips_hip_image_write_to_vfile": (c_int, [c_void_p, c_char_p]),
-    "vips_hip_thumbnail_find_jpegshrink": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "vips_hip_thumbnail_find_jpegshrink": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "vips_hip_jpeg_read_header": (c_int, [c_char_p, c_int, P(JpegHeader)]),
     "vips_hip_jpeg_read_to_memory": (c_int, [c_char_p, c_int, c_void_p, c_size_t]),
     "vips_hip_image_new_from_jpeg": (c_void_p, [c_char_p, c_int]),
-    "vips_hip_thumbnail": (c_int, [c_char_p, P(c_void_p), c_int, c_int, c_int, c_int]),
+    "vips_hip_thumbnail": (c_int, [c_char_p, P(c_void_p), c_int, c_int, c_int, c_int, c_int]),
+    "vips_hip_thumbnail_image_crop": (c_int, [c_void_p, P(c_void_p), c_int, c_int, c_int, c_int, c_int]),
+    "vips_hip_extract_area": (c_int, [c_void_p, P(c_void_p), c_int, c_int, c_int, c_int]),
     "vips_hip_conva": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_int, c_double, c_double, c_int, c_int]),
     "vips_hip_convasep": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_double, c_double, c_int]),
     "vips_hip_gaussblur": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_int]),

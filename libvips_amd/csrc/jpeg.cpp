@@ -37,12 +37,12 @@ namespace {
 
 // vips_thumbnail_calculate_shrink (thumbnail.c:413-467; crop none, no rotation) -- the same
 // arithmetic vips_hip_thumbnail_image applies to the image it is handed.
-void calculate_shrink(int in_width, int in_height, int width, int height, int size, double *hshrink,
+void calculate_shrink(int in_width, int in_height, int width, int height, int size, int crop, double *hshrink,
 	double *vshrink)
 {
 	double hs = (double) in_width / width;
 	double vs = (double) in_height / height;
-	const bool horizontal = !(hs < vs);
+	const bool horizontal = crop != 0 ? (hs < vs) : !(hs < vs);
 	if (size != 3) { // != VIPS_SIZE_FORCE
 		if (horizontal)
 			vs = hs;
@@ -287,7 +287,7 @@ bool is_jpeg(const char *path)
 extern "C" {
 
 int vips_hip_thumbnail_find_jpegshrink(int in_width, int in_height, int width, int height, int size,
-	int linear)
+	int linear, int crop)
 {
 	if (in_width <= 0 || in_height <= 0 || width <= 0) {
 		error("thumbnail", "bad dimensions");
@@ -296,7 +296,7 @@ int vips_hip_thumbnail_find_jpegshrink(int in_width, int in_height, int width, i
 	if (height <= 0)
 		height = width;
 	double hshrink, vshrink;
-	calculate_shrink(in_width, in_height, width, height, size, &hshrink, &vshrink);
+	calculate_shrink(in_width, in_height, width, height, size, crop, &hshrink, &vshrink);
 	const double shrink = hshrink < vshrink ? hshrink : vshrink;
 	// libjpeg shrinks in Y of YCbCr, not in linear light (thumbnail.c:497-501)
 	if (linear)
@@ -353,7 +353,8 @@ VipsHipImage *vips_hip_image_new_from_jpeg(const char *path, int shrink)
 
 // vips_thumbnail (thumbnail.c:1130-1330 file class + :549-676 open + :678-1067 build) for
 // JPEG and .v files.
-int vips_hip_thumbnail(const char *path, VipsHipImage **out, int width, int height, int size, int linear)
+int vips_hip_thumbnail(const char *path, VipsHipImage **out, int width, int height, int size, int linear,
+	int crop)
 {
 	if (!path || !out) {
 		error("thumbnail", "null argument");
@@ -381,7 +382,7 @@ int vips_hip_thumbnail(const char *path, VipsHipImage **out, int width, int heig
 			error("thumbnail", "\"%s\": CMYK JPEGs need an ICC import: outside the HIP path", path);
 			return -1;
 		}
-		const int factor = vips_hip_thumbnail_find_jpegshrink(h.width, h.height, width, height, size, linear);
+		const int factor = vips_hip_thumbnail_find_jpegshrink(h.width, h.height, width, height, size, linear, crop);
 		if (factor < 0)
 			return -1;
 		loaded = vips_hip_image_new_from_jpeg(path, factor);
@@ -390,7 +391,7 @@ int vips_hip_thumbnail(const char *path, VipsHipImage **out, int width, int heig
 		loaded = vips_hip_image_new_from_vfile(path);
 	if (!loaded)
 		return -1;
-	const int r = vips_hip_thumbnail_image(loaded, out, width, height, size, linear);
+	const int r = vips_hip_thumbnail_image_crop(loaded, out, width, height, size, linear, crop);
 	vips_hip_image_unref(loaded);
 	return r;
 }

@@ -683,12 +683,59 @@ int vips_hip_colourspace(VipsHipImage *in, VipsHipImage **out, int space)
 	return 0;
 }
 
+// vips_extract_area (conversion/extract.c:137-187): a rectangle of the image, as a new image
+int vips_hip_extract_area(VipsHipImage *in, VipsHipImage **out, int left, int top, int width, int height)
+{
+	if (!in || !out) {
+		error("extract_area", "null argument");
+		return -1;
+	}
+	if (width <= 0 || height <= 0 || left < 0 || top < 0 || (long long) left + width > in->width ||
+		(long long) top + height > in->height) {
+		error("extract_area", "bad extract area");
+		return -1;
+	}
+	ImageRef o(vips_hip_image_new(width, height, in->bands, in->format, in->interpretation));
+	if (!o.im)
+		return -1;
+	const size_t pel = (size_t) in->bands * format_sizeof(in->format);
+	const unsigned char *src = (const unsigned char *) in->data + (size_t) top * in->stride + (size_t) left * pel;
+	if (hipMemcpy2DAsync(o.im->data, o.im->stride, src, in->stride, (size_t) width * pel, (size_t) height,
+			hipMemcpyDeviceToDevice, stream()) != hipSuccess) {
+		error("extract_area", "device copy failed");
+		return -1;
+	}
+	*out = o.release();
+	return 0;
+}
+
 // vips_thumbnail_build, resample/thumbnail.c:678-1067, for in-memory images
 // (vips_thumbnail_image: no pre-shrink on load, no pages).
 int vips_hip_thumbnail_image(VipsHipImage *in, VipsHipImage **out, int width, int height, int size,
 	int linear)
 {
+	return vips_hip_thumbnail_image_crop(in, out, width, height, size, linear, 0);
+}
+
+// ... with the crop argument: a VipsInteresting (include/vips/conversion.h:97-107).  The
+// positional modes are here (none 0, centre 1, low 4, high 5, all 6: smartcrop.c:359-400); the
+// content-driven ones (entropy 2, attention 3) are outside the path.
+int vips_hip_thumbnail_image_crop(VipsHipImage *in, VipsHipImage **out, int width, int height, int size,
+	int linear, int crop)
+{
 	const char *domain = "thumbnail";
+	if (!in || !out) {
+		error(domain, "null argument");
+		return -1;
+	}
+	if (crop == 2 || crop == 3) {
+		error(domain, "crop modes 'entropy' and 'attention' are outside the HIP path");
+		return -1;
+	}
+	if (crop < 0 || crop > 6) {
+		error(domain, "bad crop mode %d", crop);
+		return -1;
+	}
 	if (width <= 0) {
 		error(domain, "parameter width not set");
 		return -1;
@@ -725,7 +772,8 @@ int vips_hip_thumbnail_image(VipsHipImage *in, VipsHipImage **out, int width, in
 	// vips_thumbnail_calculate_shrink, thumbnail.c:413-467 (crop NONE, no rotate)
 	double hshrink = (double) cur->width / width;
 	double vshrink = (double) cur->height / height;
-	const bool horizontal = !(hshrink < vshrink);
+	// fit the box (the bigger shrink wins) or, when cropping, fill it (the smaller one)
+	const bool horizontal = crop != 0 ? (hshrink < vshrink) : !(hshrink < vshrink);
 	if (size != 3) { // != VIPS_SIZE_FORCE
 		if (horizontal)
 			vshrink = hshrink;
@@ -774,8 +822,32 @@ int vips_hip_thumbnail_image(VipsHipImage *in, VipsHipImage **out, int width, in
 		resized.im = un.release();
 	}
 
-	if (linear) // thumbnail.c:973-987: back to sRGB
-		return vips_hip_colourspace(resized.im, out, VIPS_HIP_INTERPRETATION_sRGB);
+	if (linear) { // thumbnail.c:973-987: back to sRGB
+		ImageRef back;
+		if (vips_hip_colourspace(resized.im, &back.im, VIPS_HIP_INTERPRETATION_sRGB))
+			return -1;
+		vips_hip_image_unref(resized.im);
+		resized.im = back.release();
+	}
+	if (crop != 0) { // thumbnail.c:1010-1038 -> vips_smartcrop's positional modes
+		const VipsHipImage *r = resized.im;
+		int crop_width = width < r->width ? width : r->width;
+		int crop_height = height < r->height ? height : r->height;
+		int left = 0, top = 0;
+		if (crop == 1) {
+			left = (r->width - crop_width) / 2;
+			top = (r->height - crop_height) / 2;
+		}
+		else if (crop == 5) {
+			left = r->width - crop_width;
+			top = r->height - crop_height;
+		}
+		else if (crop == 6) {
+			crop_width = r->width;
+			crop_height = r->height;
+		}
+		return vips_hip_extract_area(resized.im, out, left, top, crop_width, crop_height);
+	}
 	*out = resized.release();
 	return 0;
 }

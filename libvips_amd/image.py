@@ -56,6 +56,9 @@ KERNELS = {
 }
 # VipsPrecision (include/vips/basic.h:106-110)
 PRECISIONS = {"integer": 0, "float": 1, "approximate": 2}
+# VipsSize (include/vips/resample.h), VipsInteresting (include/vips/conversion.h:97-107)
+SIZES = {"both": 0, "up": 1, "down": 2, "force": 3}
+INTERESTING = {"none": 0, "centre": 1, "entropy": 2, "attention": 3, "low": 4, "high": 5, "all": 6}
 # VipsInterpretation (include/vips/image.h:94-118)
 INTERPRETATIONS = {
     "multiband": 0,
@@ -233,18 +236,21 @@ class Image(object):
         return cls(check_handle(lib.vips_hip_image_new_from_jpeg(os.fsencode(path), int(shrink))))
 
     @classmethod
-    def thumbnail(cls, path, width, height=None, size="both", linear=False):
+    def thumbnail(cls, path, width, height=None, size="both", linear=False, crop="none"):
         """vips_thumbnail() for JPEG and .v files: shrink-on-load, then the thumbnail_image pipeline."""
-        sizes = {"both": 0, "up": 1, "down": 2, "force": 3}
         out = ctypes.c_void_p()
         check(lib.vips_hip_thumbnail(os.fsencode(path), ctypes.byref(out), int(width), int(height) if height else 0,
-                                     sizes[size] if isinstance(size, str) else int(size), int(bool(linear))))
+                                     _enum(SIZES, size, "size"), int(bool(linear)), _enum(INTERESTING, crop, "crop")))
         return cls(out.value)
 
-    def thumbnail_image(self, width, height=None, size="both", linear=False):
-        sizes = {"both": 0, "up": 1, "down": 2, "force": 3}
-        return self._unary(lib.vips_hip_thumbnail_image, int(width), int(height) if height else 0,
-                           sizes[size] if isinstance(size, str) else int(size), int(bool(linear)))
+    def thumbnail_image(self, width, height=None, size="both", linear=False, crop="none"):
+        return self._unary(lib.vips_hip_thumbnail_image_crop, int(width), int(height) if height else 0,
+                           _enum(SIZES, size, "size"), int(bool(linear)), _enum(INTERESTING, crop, "crop"))
+
+    def extract_area(self, left, top, width, height):
+        return self._unary(lib.vips_hip_extract_area, int(left), int(top), int(width), int(height))
+
+    crop = extract_area
 
     @staticmethod
     def _mask(mask):

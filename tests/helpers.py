@@ -636,8 +636,8 @@ class PortCC(object):
         return out
 
     @classmethod
-    def thumbnail_image(cls, array, interpretation, width, height=None, size="both", linear=False):
-        """vips_thumbnail_image (thumbnail.c:678-1067, shrink :413-467), no crop / ICC."""
+    def thumbnail_image(cls, array, interpretation, width, height=None, size="both", linear=False, crop="none"):
+        """vips_thumbnail_image (thumbnail.c:678-1067, shrink :413-467), positional crops, no ICC."""
         space = "scrgb" if linear else "srgb"
         if interpretation == "b-w" and not linear and np.asarray(array).shape[2] == 1:
             a = Port._prep(array)  # B_W is the processing space of one-band images (thumbnail.c:806-820)
@@ -647,7 +647,8 @@ class PortCC(object):
         height = height or width
         hshrink, vshrink = w / width, h / height
         if size != "force":
-            if not (hshrink < vshrink):
+            horizontal = (hshrink < vshrink) if crop != "none" else not (hshrink < vshrink)
+            if horizontal:
                 vshrink = hshrink
             else:
                 hshrink = vshrink
@@ -668,6 +669,14 @@ class PortCC(object):
                 out = cls.cast(cls.premultiply(out, space, inverse=True), fmt)
         if linear:
             out = cls.colourspace(out, "srgb", "scrgb")
+        if crop != "none":  # thumbnail.c:1010-1038 -> smartcrop.c:359-400
+            oh, ow, _ = out.shape
+            cw, ch = min(width, ow), min(height, oh)
+            left, top = {"centre": ((ow - cw) // 2, (oh - ch) // 2), "low": (0, 0),
+                         "high": (ow - cw, oh - ch), "all": (0, 0)}[crop]
+            if crop == "all":
+                cw, ch = ow, oh
+            out = np.ascontiguousarray(out[top:top + ch, left:left + cw])
         return out
 
     @classmethod

@@ -157,14 +157,16 @@ def test_find_jpegshrink_matches_what_the_reference_logs(tmp_path):
     from libvips_amd import _ffi
 
     path = str(tmp_path / "t.jpg")
-    for (w, h, size, args, mode, linear) in ((2000, 1500, "200x200", (), 0, 0), (1801, 1203, "100x100", (), 0, 0),
-                                             (640, 480, "300x300", (), 0, 0), (4000, 3000, "128x128", (), 0, 0),
-                                             (1600, 1200, "100x100", ("--linear",), 0, 1),
-                                             (1600, 400, "100x100!", (), 3, 0), (1000, 800, "125x100", (), 0, 0)):
+    for (w, h, size, args, mode, linear, crop) in (
+            (2000, 1500, "200x200", (), 0, 0, 0), (1801, 1203, "100x100", (), 0, 0, 0),
+            (640, 480, "300x300", (), 0, 0, 0), (4000, 3000, "128x128", (), 0, 0, 0),
+            (1600, 1200, "100x100", ("--linear",), 0, 1, 0), (1600, 400, "100x100!", (), 3, 0, 0),
+            (1000, 800, "125x100", (), 0, 0, 0), (1600, 400, "100x100", ("--smartcrop", "centre"), 0, 0, 1),
+            (900, 2000, "50x100", ("--smartcrop", "high"), 0, 0, 5)):
         make_jpeg(path, w, h, quality=60)
         _, factor = cli_thumbnail(tmp_path, path, size, args)
         tw, th = [int(v) for v in size.rstrip("!").split("x")]
-        assert _ffi.lib.vips_hip_thumbnail_find_jpegshrink(w, h, tw, th, mode, linear) == factor, (w, h, size)
+        assert _ffi.lib.vips_hip_thumbnail_find_jpegshrink(w, h, tw, th, mode, linear, crop) == factor, (w, h, size)
 
 
 @pytest.mark.gpu
@@ -224,9 +226,56 @@ def test_jpeg_pipeline_through_the_port_matches_the_reference_cli(tmp_path, widt
     make_jpeg(path, width, height, grey)
     want, _ = cli_thumbnail(tmp_path, path, size)
     tw, th = [int(v) for v in size.split("x")]
-    factor = _ffi.lib.vips_hip_thumbnail_find_jpegshrink(width, height, tw, th, 0, 0)
+    factor = _ffi.lib.vips_hip_thumbnail_find_jpegshrink(width, height, tw, th, 0, 0, 0)
     pre, _ = product_decode(path, factor)
     from tests.helpers import PortCC
 
     got = PortCC.thumbnail_image(pre, "b-w" if grey else "srgb", tw, th)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@needs_ref_jpeg
+@pytest.mark.parametrize("crop", ["centre", "low", "high", "all"])
+def test_crop_modes_through_the_port_match_the_reference(crop):
+    """thumbnail_image with a positional crop: the port against the compiled reference (the device
+    path is compared with the port in the GPU test below)."""
+    from tests.helpers import PortCC
+
+    src = helpers.lcg_image(517, 389, 3, np.uint8, 99)
+    for (tw, th, size) in ((100, 100, "both"), (60, 200, "both"), (400, 50, "down"), (700, 700, "both")):
+        want = Ref.run("thumbnail_image", src, "width=%d,height=%d,size=%s,crop=%s" % (tw, th, size, crop), 22)
+        got = PortCC.thumbnail_image(src, "srgb", tw, th, size=size, crop=crop)
+        assert got.shape == want.shape and np.array_equal(got, want), (tw, th, size)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("crop", ["centre", "low", "high", "all"])
+def test_hip_crop_modes_match_the_port(crop):
+    import libvips_amd
+    from libvips_amd import Image
+    from tests.helpers import PortCC
+
+    libvips_amd.init(0)
+    src = helpers.lcg_image(517, 389, 4, np.uint8, 99)
+    im = Image.new_from_array(src, interpretation="srgb")
+    for (tw, th, size, linear) in ((100, 100, "both", False), (60, 200, "both", False), (400, 50, "down", False),
+                                   (90, 90, "both", True)):
+        want = PortCC.thumbnail_image(src, "srgb", tw, th, size=size, linear=linear, crop=crop)
+        got = im.thumbnail_image(tw, th, size=size, linear=linear, crop=crop).numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), (tw, th, size, linear)
+    assert np.array_equal(im.extract_area(10, 20, 300, 100).numpy(), src[20:120, 10:310])
+    with pytest.raises(libvips_amd.VipsHipError, match="bad extract area"):
+        im.extract_area(400, 0, 200, 10)
+    with pytest.raises(libvips_amd.VipsHipError, match="attention"):
+        im.thumbnail_image(64, crop="attention")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not helpers.have_module(), reason="oracle/_ref or host/_build missing")
+def test_module_thumbnail_crop_matches_the_reference():
+    Ref.load_module()
+    src = helpers.lcg_image(640, 400, 3, np.uint8, 100)
+    for args in ("width=100,height=100,crop=centre", "width=80,height=200,crop=high", "width=300,height=50,crop=low"):
+        got = Ref.run("thumbnail_image_hip", src, args, 22)
+        want = Ref.run("thumbnail_image", src, args, 22)
+        assert got.shape == want.shape and np.array_equal(got, want), args
