@@ -279,3 +279,40 @@ def test_module_thumbnail_crop_matches_the_reference():
         got = Ref.run("thumbnail_image_hip", src, args, 22)
         want = Ref.run("thumbnail_image", src, args, 22)
         assert got.shape == want.shape and np.array_equal(got, want), args
+
+
+@needs_ref_jpeg
+def test_corrupted_files_behave_like_the_reference(tmp_path):
+    """Random byte damage: wherever the reference's jpegload still produces an image the host
+    decoder produces the same pixels, and wherever it refuses so does the decoder (no crash)."""
+    rng = np.random.RandomState(5)
+    good = str(tmp_path / "good.jpg")
+    make_jpeg(good, 160, 120, quality=75)
+    raw = bytearray(open(good, "rb").read())
+    bad = str(tmp_path / "bad.jpg")
+    agree_ok = agree_fail = 0
+    for trial in range(60):
+        damaged = bytearray(raw)
+        for _ in range(rng.randint(1, 6)):
+            at = rng.randint(2, len(damaged))
+            if trial % 3 == 0:
+                at = rng.randint(2, min(len(damaged), 700))  # the headers and tables
+            damaged[at] = rng.randint(0, 256)
+        if trial % 10 == 9:
+            damaged = damaged[:rng.randint(20, len(damaged))]
+        open(bad, "wb").write(bytes(damaged))
+        try:
+            want, _, _ = Ref.create("jpegload", "filename=%s" % bad)
+        except Exception:
+            want = None
+        try:
+            got, _ = product_decode(bad, 1)
+        except RuntimeError:
+            got = None
+        assert (want is None) == (got is None), trial
+        if want is not None:
+            assert got.shape == want.shape and np.array_equal(got, want), trial
+            agree_ok += 1
+        else:
+            agree_fail += 1
+    assert agree_ok > 5 and agree_fail > 0
