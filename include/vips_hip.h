@@ -469,6 +469,13 @@ VIPS_HIP_API int vips_hip_jpeg_read_to_memory(const char *path, int shrink, void
 VIPS_HIP_API VipsHipImage *vips_hip_image_new_from_jpeg(const char *path, int shrink);
 VIPS_HIP_API int vips_hip_thumbnail(const char *path, VipsHipImage **out,
 	int width, int height, int size, int linear, int crop);
+/* @n files on @n_threads host threads, each with its own stream: decode, upload and device work
+ * of different files overlap (the shape of BASELINE config C4 when the inputs are files).
+ * Returns the number of failures; outs[i] is NULL for those and, when @errors is given
+ * (n x 256 bytes), errors + 256 * i holds the message.
+ */
+VIPS_HIP_API int vips_hip_thumbnail_batch(const char *const *paths, int n, VipsHipImage **outs,
+	char *errors, int width, int height, int size, int linear, int crop, int n_threads);
 
 /* Emulate the reference sink's strip height when seeding the reduce position
  * accumulators (see vips_hip_reducev_gen_tiled); default 16 = vips__fatstrip_height

@@ -203,6 +203,8 @@ _SIGNATURES = {
     "vips_hip_jpeg_read_to_memory": (c_int, [c_char_p, c_int, c_void_p, c_size_t]),
     "vips_hip_image_new_from_jpeg": (c_void_p, [c_char_p, c_int]),
     "vips_hip_thumbnail": (c_int, [c_char_p, P(c_void_p), c_int, c_int, c_int, c_int, c_int]),
+    "vips_hip_thumbnail_batch": (c_int, [P(c_char_p), c_int, P(c_void_p), c_char_p, c_int, c_int, c_int, c_int,
+                                         c_int, c_int]),
     "vips_hip_thumbnail_image_crop": (c_int, [c_void_p, P(c_void_p), c_int, c_int, c_int, c_int, c_int]),
     "vips_hip_extract_area": (c_int, [c_void_p, P(c_void_p), c_int, c_int, c_int, c_int]),
     "vips_hip_conva": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_int, c_double, c_double, c_int, c_int]),

@@ -22,7 +22,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include <dlfcn.h>
@@ -394,6 +396,57 @@ int vips_hip_thumbnail(const char *path, VipsHipImage **out, int width, int heig
 	const int r = vips_hip_thumbnail_image_crop(loaded, out, width, height, size, linear, crop);
 	vips_hip_image_unref(loaded);
 	return r;
+}
+
+// A batch of files on `n_threads` host threads: every thread decodes, uploads and thumbnails on
+// its own stream, so the host cores' entropy decoding (the bottleneck once resize runs at HBM
+// speed) and the device work of different files overlap.  The reference gets the same effect
+// from a caller running vips_thumbnail() on several threads; BASELINE config C4 is this shape.
+// Returns the number of files that failed; outs[i] is NULL and errors[i] (if given, 256 bytes
+// each) holds the message for those.
+int vips_hip_thumbnail_batch(const char *const *paths, int n, VipsHipImage **outs, char *errors, int width,
+	int height, int size, int linear, int crop, int n_threads)
+{
+	if (!paths || !outs || n < 0) {
+		error("thumbnail", "null argument");
+		return -1;
+	}
+	if (n_threads < 1)
+		n_threads = 1;
+	if (n_threads > n)
+		n_threads = n;
+	std::atomic<int> next(0), failed(0);
+	auto worker = [&]() {
+		for (;;) {
+			const int i = next.fetch_add(1);
+			if (i >= n)
+				break;
+			outs[i] = nullptr;
+			if (vips_hip_thumbnail(paths[i], &outs[i], width, height, size, linear, crop)) {
+				outs[i] = nullptr;
+				failed.fetch_add(1);
+				if (errors) {
+					strncpy(errors + (size_t) i * 256, vips_hip_error_buffer(), 255);
+					errors[(size_t) i * 256 + 255] = 0;
+				}
+				vips_hip_error_clear(); // the error buffer is per thread
+			}
+			else if (errors)
+				errors[(size_t) i * 256] = 0;
+		}
+		// results cross to the caller's thread: finish this thread's stream first
+		(void) vips_hip_synchronize();
+	};
+	if (n_threads <= 1)
+		worker();
+	else {
+		std::vector<std::thread> pool;
+		for (int t = 0; t < n_threads; t++)
+			pool.emplace_back(worker);
+		for (std::thread &t : pool)
+			t.join();
+	}
+	return failed.load();
 }
 
 } // extern "C"

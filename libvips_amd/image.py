@@ -243,6 +243,30 @@ class Image(object):
                                      _enum(SIZES, size, "size"), int(bool(linear)), _enum(INTERESTING, crop, "crop")))
         return cls(out.value)
 
+    @classmethod
+    def thumbnail_batch(cls, paths, width, height=None, size="both", linear=False, crop="none", threads=8):
+        """vips_thumbnail() over many files on `threads` host threads (decode and device work of
+        different files overlap).  Returns a list of Images; a failed file gives a VipsHipError
+        instance in its place."""
+        from ._ffi import VipsHipError
+
+        n = len(paths)
+        arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        outs = (ctypes.c_void_p * n)()
+        errors = ctypes.create_string_buffer(256 * max(n, 1))
+        r = lib.vips_hip_thumbnail_batch(arr, n, outs, errors, int(width), int(height) if height else 0,
+                                         _enum(SIZES, size, "size"), int(bool(linear)),
+                                         _enum(INTERESTING, crop, "crop"), int(threads))
+        if r < 0:
+            check(r)
+        result = []
+        for i in range(n):
+            if outs[i]:
+                result.append(cls(outs[i]))
+            else:
+                result.append(VipsHipError(errors.raw[256 * i:256 * i + 256].split(b"\0", 1)[0].decode()))
+        return result
+
     def thumbnail_image(self, width, height=None, size="both", linear=False, crop="none"):
         return self._unary(lib.vips_hip_thumbnail_image_crop, int(width), int(height) if height else 0,
                            _enum(SIZES, size, "size"), int(bool(linear)), _enum(INTERESTING, crop, "crop"))

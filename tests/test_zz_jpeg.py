@@ -316,3 +316,25 @@ def test_corrupted_files_behave_like_the_reference(tmp_path):
         else:
             agree_fail += 1
     assert agree_ok > 5 and agree_fail > 0
+
+
+@pytest.mark.gpu
+def test_thumbnail_batch_on_host_threads(tmp_path):
+    import libvips_amd
+    from libvips_amd import Image
+
+    libvips_amd.init(0)
+    paths = []
+    for i in range(10):
+        p = str(tmp_path / ("b%d.jpg" % i))
+        make_jpeg(p, 400 + 37 * i, 300 + 11 * i, grey=(i == 3), quality=70 + i)
+        paths.append(p)
+    paths.insert(4, str(tmp_path / "missing.jpg"))
+    outs = Image.thumbnail_batch(paths, 96, 96, crop="centre", threads=4)
+    assert len(outs) == len(paths)
+    for p, o in zip(paths, outs):
+        if p.endswith("missing.jpg"):
+            assert isinstance(o, libvips_amd.VipsHipError) and "unable to open" in str(o)
+            continue
+        want = Image.thumbnail(p, 96, 96, crop="centre").numpy()
+        assert np.array_equal(o.numpy(), want), p
