@@ -338,3 +338,19 @@ def test_thumbnail_batch_on_host_threads(tmp_path):
             continue
         want = Image.thumbnail(p, 96, 96, crop="centre").numpy()
         assert np.array_equal(o.numpy(), want), p
+
+
+def test_batch_error_plumbing_without_a_device(tmp_path):
+    """No GPU here: every file must fail loudly (there is no CPU path), each with its own message,
+    from worker threads, without taking the process down."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from libvips_amd import Image, VipsHipError
+
+    good = str(tmp_path / "g.jpg")
+    make_jpeg(good, 80, 60)
+    outs = Image.thumbnail_batch([good, str(tmp_path / "nope.jpg"), good], 32, threads=3)
+    assert all(isinstance(o, VipsHipError) for o in outs)
+    assert "no HIP device" in str(outs[0]) and "unable to open" in str(outs[1])
