@@ -4,7 +4,7 @@
  * iofuncs/init.c:288-330): g_module_check_init() registers VipsOperation subclasses
  *
  *     reduce_hip reduceh_hip reducev_hip shrink_hip shrinkh_hip shrinkv_hip resize_hip
- *     thumbnail_image_hip
+ *     thumbnail_image_hip thumbnail_hip
  *     conv_hip convsep_hip gaussblur_hip sharpen_hip colourspace_hip cast_hip
  *     premultiply_hip unpremultiply_hip
  *
@@ -579,6 +579,151 @@ vips_thumbnail_hip_init(VipsThumbnailHip *thumbnail)
 	thumbnail->crop = VIPS_INTERESTING_NONE;
 }
 
+/* thumbnail_hip: vips_thumbnail() on a file (resample/thumbnail.c:1130-1330, the
+ * VipsThumbnailFile class): JPEG shrink-on-load on the host, everything after it on the
+ * device.  No input image, so this one is a VipsOperation of its own; it serves its result
+ * the way VipsHipOp does.
+ */
+typedef struct _VipsThumbnailFileHip {
+	VipsOperation parent_instance;
+
+	char *filename;
+	VipsImage *out;
+	int width, height;
+	VipsSize size;
+	gboolean linear;
+	VipsInteresting crop;
+
+	VipsHipImage *result;
+	VipsPel *host;
+	GMutex lock;
+} VipsThumbnailFileHip;
+
+typedef VipsOperationClass VipsThumbnailFileHipClass;
+
+G_DEFINE_TYPE(VipsThumbnailFileHip, vips_thumbnail_file_hip, VIPS_TYPE_OPERATION);
+
+static int
+vips_thumbnail_file_hip_gen(VipsRegion *out_region, void *seq, void *a, void *b, gboolean *stop)
+{
+	VipsThumbnailFileHip *thumbnail = (VipsThumbnailFileHip *) b;
+	VipsRect *r = &out_region->valid;
+	VipsImage *out = out_region->im;
+	const size_t ps = VIPS_IMAGE_SIZEOF_PEL(out);
+	const size_t ls = VIPS_IMAGE_SIZEOF_LINE(out);
+
+	if (vips_image_iskilled(out))
+		return -1;
+
+	g_mutex_lock(&thumbnail->lock);
+	if (!thumbnail->host) {
+		VipsPel *host = VIPS_ARRAY(NULL, ls * out->Ysize, VipsPel);
+
+		if (!host || vips_hip_image_write_to_memory(thumbnail->result, host)) {
+			g_mutex_unlock(&thumbnail->lock);
+			VIPS_FREE(host);
+			return hip_fail("thumbnail_hip");
+		}
+		thumbnail->host = host;
+	}
+	g_mutex_unlock(&thumbnail->lock);
+
+	for (int y = 0; y < r->height; y++)
+		memcpy(VIPS_REGION_ADDR(out_region, r->left, r->top + y),
+			thumbnail->host + (size_t) (r->top + y) * ls + (size_t) r->left * ps,
+			(size_t) r->width * ps);
+
+	return 0;
+}
+
+static int
+vips_thumbnail_file_hip_build(VipsObject *object)
+{
+	VipsThumbnailFileHip *thumbnail = (VipsThumbnailFileHip *) object;
+	int height = vips_object_argument_isset(object, "height") ? thumbnail->height : 0;
+
+	if (VIPS_OBJECT_CLASS(vips_thumbnail_file_hip_parent_class)->build(object))
+		return -1;
+
+	if (vips_hip_thumbnail(thumbnail->filename, &thumbnail->result, thumbnail->width, height,
+			thumbnail->size, thumbnail->linear, thumbnail->crop) ||
+		vips_hip_synchronize())
+		return hip_fail("thumbnail_hip");
+
+	g_object_set(object, "out", vips_image_new(), NULL);
+	vips_image_init_fields(thumbnail->out,
+		vips_hip_image_get_width(thumbnail->result), vips_hip_image_get_height(thumbnail->result),
+		vips_hip_image_get_bands(thumbnail->result),
+		(VipsBandFormat) vips_hip_image_get_format(thumbnail->result), VIPS_CODING_NONE,
+		(VipsInterpretation) vips_hip_image_get_interpretation(thumbnail->result), 1.0, 1.0);
+	if (vips_image_pipelinev(thumbnail->out, VIPS_DEMAND_STYLE_ANY, NULL) ||
+		vips_image_generate(thumbnail->out,
+			vips_hip_op_start, vips_thumbnail_file_hip_gen, vips_hip_op_stop, NULL, thumbnail))
+		return -1;
+	hip_link_attach(thumbnail->out,
+		vips_hip_image_new_from_device(vips_hip_image_get_data(thumbnail->result),
+			thumbnail->out->Xsize, thumbnail->out->Ysize, thumbnail->out->Bands,
+			thumbnail->out->BandFmt, thumbnail->out->Type));
+
+	return 0;
+}
+
+static void
+vips_thumbnail_file_hip_dispose(GObject *gobject)
+{
+	VipsThumbnailFileHip *thumbnail = (VipsThumbnailFileHip *) gobject;
+
+	VIPS_FREE(thumbnail->host);
+	if (thumbnail->result) {
+		vips_hip_image_unref(thumbnail->result);
+		thumbnail->result = NULL;
+	}
+
+	G_OBJECT_CLASS(vips_thumbnail_file_hip_parent_class)->dispose(gobject);
+}
+
+static void
+vips_thumbnail_file_hip_class_init(VipsThumbnailFileHipClass *class)
+{
+	GObjectClass *gobject_class = G_OBJECT_CLASS(class);
+	VipsObjectClass *vobject_class = VIPS_OBJECT_CLASS(class);
+
+	gobject_class->dispose = vips_thumbnail_file_hip_dispose;
+	gobject_class->set_property = vips_object_set_property;
+	gobject_class->get_property = vips_object_get_property;
+
+	vobject_class->nickname = "thumbnail_hip";
+	vobject_class->description = "generate thumbnail from file (MI355X)";
+	vobject_class->build = vips_thumbnail_file_hip_build;
+
+	VIPS_ARG_STRING(class, "filename", 1, "Filename", "Filename to read from",
+		VIPS_ARGUMENT_REQUIRED_INPUT, G_STRUCT_OFFSET(VipsThumbnailFileHip, filename), NULL);
+	VIPS_ARG_IMAGE(class, "out", 2, "Output", "Output image",
+		VIPS_ARGUMENT_REQUIRED_OUTPUT, G_STRUCT_OFFSET(VipsThumbnailFileHip, out));
+	VIPS_ARG_INT(class, "width", 3, "Target width", "Size to this width",
+		VIPS_ARGUMENT_REQUIRED_INPUT, G_STRUCT_OFFSET(VipsThumbnailFileHip, width), 1, VIPS_MAX_COORD, 1);
+	VIPS_ARG_INT(class, "height", 113, "Target height", "Size to this height",
+		VIPS_ARGUMENT_OPTIONAL_INPUT, G_STRUCT_OFFSET(VipsThumbnailFileHip, height), 1, VIPS_MAX_COORD, 1);
+	VIPS_ARG_ENUM(class, "size", 114, "Size", "Only upsize, only downsize, or both",
+		VIPS_ARGUMENT_OPTIONAL_INPUT, G_STRUCT_OFFSET(VipsThumbnailFileHip, size),
+		VIPS_TYPE_SIZE, VIPS_SIZE_BOTH);
+	VIPS_ARG_ENUM(class, "crop", 116, "Crop", "Reduce to fill target rectangle, then crop",
+		VIPS_ARGUMENT_OPTIONAL_INPUT, G_STRUCT_OFFSET(VipsThumbnailFileHip, crop),
+		VIPS_TYPE_INTERESTING, VIPS_INTERESTING_NONE);
+	VIPS_ARG_BOOL(class, "linear", 118, "Linear", "Reduce in linear light",
+		VIPS_ARGUMENT_OPTIONAL_INPUT, G_STRUCT_OFFSET(VipsThumbnailFileHip, linear), FALSE);
+}
+
+static void
+vips_thumbnail_file_hip_init(VipsThumbnailFileHip *thumbnail)
+{
+	thumbnail->width = 1;
+	thumbnail->height = 1;
+	thumbnail->size = VIPS_SIZE_BOTH;
+	thumbnail->crop = VIPS_INTERESTING_NONE;
+	g_mutex_init(&thumbnail->lock);
+}
+
 /* conv_hip / convsep_hip: convolution/conv.c:120-175, convsep.c:120-170 */
 typedef struct _VipsConvHip {
 	VipsHipOp parent_instance;
@@ -889,6 +1034,7 @@ g_module_check_init(GModule *module)
 	vips_shrinkv_hip_get_type();
 	vips_resize_hip_get_type();
 	vips_thumbnail_hip_get_type();
+	vips_thumbnail_file_hip_get_type();
 	vips_conv_hip_get_type();
 	vips_convsep_hip_get_type();
 	vips_gaussblur_hip_get_type();

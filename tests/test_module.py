@@ -12,7 +12,7 @@ from tests.helpers import Ref
 needs_module = pytest.mark.skipif(not helpers.have_module(), reason="oracle/_ref or host/_build missing")
 
 HIP_OPS = ["reduce_hip", "reduceh_hip", "reducev_hip", "shrink_hip", "shrinkh_hip", "shrinkv_hip",
-           "resize_hip", "thumbnail_image_hip", "conv_hip", "convsep_hip", "gaussblur_hip", "sharpen_hip", "colourspace_hip",
+           "resize_hip", "thumbnail_image_hip", "thumbnail_hip", "conv_hip", "convsep_hip", "gaussblur_hip", "sharpen_hip", "colourspace_hip",
            "cast_hip", "premultiply_hip", "unpremultiply_hip"]
 
 

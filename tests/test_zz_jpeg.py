@@ -354,3 +354,48 @@ def test_batch_error_plumbing_without_a_device(tmp_path):
     outs = Image.thumbnail_batch([good, str(tmp_path / "nope.jpg"), good], 32, threads=3)
     assert all(isinstance(o, VipsHipError) for o in outs)
     assert "no HIP device" in str(outs[0]) and "unable to open" in str(outs[1])
+
+
+@pytest.mark.skipif(not helpers.have_module(), reason="oracle/_ref or host/_build missing")
+def test_module_thumbnail_hip_without_a_device(tmp_path):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    Ref.load_module()
+    path = str(tmp_path / "t.jpg")
+    make_jpeg(path, 200, 150)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        Ref.create("thumbnail_hip", "filename=%s,width=64" % path)
+
+
+@pytest.mark.gpu
+@needs_ref_jpeg
+@pytest.mark.skipif(not helpers.have_module(), reason="oracle/_ref or host/_build missing")
+def test_module_thumbnail_hip_matches_vips_thumbnail(tmp_path):
+    """`vips thumbnail_hip x.jpg ...` against the reference's own `thumbnail` operation."""
+    Ref.load_module()
+    path = str(tmp_path / "t.jpg")
+    make_jpeg(path, 2400, 1600)
+    for args in ("width=200", "width=128,height=128,crop=centre", "width=300,height=100,size=force"):
+        got, _, _ = Ref.create("thumbnail_hip", "filename=%s,%s" % (path, args))
+        want, _, _ = Ref.create("thumbnail", "filename=%s,%s" % (path, args))
+        assert got.shape == want.shape and np.array_equal(got, want), args
+
+
+@needs_ref_jpeg
+def test_jpeg_crop_pipeline_through_the_port_matches_vips_thumbnail(tmp_path):
+    from libvips_amd import _ffi
+    from tests.helpers import PortCC
+
+    path = str(tmp_path / "t.jpg")
+    make_jpeg(path, 2400, 1600)
+    for (tw, th, size, crop, code) in ((128, 128, "both", "centre", 1), (300, 100, "force", "none", 0),
+                                       (100, 300, "both", "high", 5), (200, 200, "down", "low", 4)):
+        args = "width=%d,height=%d,size=%s,crop=%s" % (tw, th, size, crop)
+        want, _, _ = Ref.create("thumbnail", "filename=%s,%s" % (path, args))
+        mode = {"both": 0, "up": 1, "down": 2, "force": 3}[size]
+        factor = _ffi.lib.vips_hip_thumbnail_find_jpegshrink(2400, 1600, tw, th, mode, 0, code)
+        pre, _ = product_decode(path, factor)
+        got = PortCC.thumbnail_image(pre, "srgb", tw, th, size=size, crop=crop)
+        assert got.shape == want.shape and np.array_equal(got, want), args
