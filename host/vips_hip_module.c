@@ -28,6 +28,7 @@
 #include <string.h>
 
 #include <vips/vips.h>
+#include <vips/vector.h>
 
 #include "vips_hip.h"
 
@@ -202,6 +203,11 @@ vips_hip_op_build(VipsObject *object)
 			return hip_fail(class->nickname);
 		dev = fresh;
 	}
+
+	/* Follow the host library's vector switch (iofuncs/vector.cpp:98-113): in a Highway-built
+	 * libvips this selects the 8-bit-mantissa arithmetic its own convi uses on uchar images,
+	 * so *_hip results keep matching the built-ins; FALSE in a scalar build. */
+	vips_hip_vector_set_enabled(vips_vector_isenabled());
 
 	if (hclass->compute(op, dev, &op->result)) {
 		vips_hip_image_unref(fresh);

@@ -115,6 +115,15 @@ VIPS_HIP_API void vips_hip_error_clear(void);
 VIPS_HIP_API int vips_hip_set_stream(void *stream);
 VIPS_HIP_API void *vips_hip_get_stream(void);
 VIPS_HIP_API int vips_hip_synchronize(void);
+/* vips_vector_set_enabled / vips_vector_isenabled (iofuncs/vector.cpp:98-113).  A Highway-built
+ * libvips computes convi on uchar images with 8-bit mantissas and a shared exponent
+ * (convolution/convi.c:925-1120, convi_hwy.cpp) whenever vectors are enabled and the mask fits;
+ * its other vector paths equal the C paths bit for bit.  Enabling this makes vips_hip_conv /
+ * convsep / gaussblur with precision INTEGER on uchar compute exactly that, so that this
+ * library can stand in for such a build.  Default: disabled (the C path's arithmetic).
+ */
+VIPS_HIP_API void vips_hip_vector_set_enabled(int enabled);
+VIPS_HIP_API int vips_hip_vector_isenabled(void);
 
 /* Device memory comes from a size-bucketed caching pool (hipMalloc is far too
  * slow to sit in a per-tile path); *_host is pinned staging memory.
@@ -299,6 +308,10 @@ VIPS_HIP_API VipsHipConv *vips_hip_conv_new(const double *mask,
 	int mask_width, int mask_height, double scale, double offset, int precision);
 VIPS_HIP_API void vips_hip_conv_free(VipsHipConv *conv);
 VIPS_HIP_API int vips_hip_conv_get_nnz(const VipsHipConv *conv);
+/* The Highway-variant view of an INTEGER plan (vips_convi_intize, convi.c:925-1120): the shared
+ * exponent and the non-zero 8-bit mantissas with their mask positions.  Returns their number,
+ * 0 when the intize refuses the mask (the C path runs even with vectors enabled), -1 on error. */
+VIPS_HIP_API int vips_hip_conv_get_vector(const VipsHipConv *conv, int *exp, int *mant, int *pos, int max);
 /* Output band format for input @format: convf.c:354-355; convi keeps it. */
 VIPS_HIP_API int vips_hip_conv_out_format(const VipsHipConv *conv, int format);
 /* Fill out->valid: vips_convi_gen (convi.c:753-857) or vips_convf_gen

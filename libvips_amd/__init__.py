@@ -15,6 +15,16 @@ def init(device=0):
     check(lib.vips_hip_init(int(device)))
 
 
+def vector_set_enabled(enabled):
+    """vips_vector_set_enabled: select the arithmetic of a Highway-built libvips for convi on
+    uchar images (8-bit mantissas, shared exponent).  Off by default."""
+    lib.vips_hip_vector_set_enabled(1 if enabled else 0)
+
+
+def vector_isenabled():
+    return bool(lib.vips_hip_vector_isenabled())
+
+
 def synchronize():
     from ._ffi import check
 

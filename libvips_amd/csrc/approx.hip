@@ -822,6 +822,7 @@ int fast_plans(_VipsHipConva *c)
 			return -1;
 		}
 		h->rounding = v->rounding = c->lines.rounding;
+		h->no_vector = v->no_vector = true;
 		c->fast[1] = v;
 		c->fast[0] = h;
 	}
@@ -831,6 +832,7 @@ int fast_plans(_VipsHipConva *c)
 		if (!p)
 			return -1;
 		p->rounding = c->boxes.rounding;
+		p->no_vector = true;
 		c->fast[0] = p;
 	}
 	return 0;

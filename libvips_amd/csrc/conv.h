@@ -21,6 +21,14 @@ struct _VipsHipConv {
 	void *d_dense; // int / double [mask_width * mask_height], zeros kept (tiled kernels)
 	double *d_dense8; // convf: rows zero-padded to np8 doubles (grouped kernel)
 	int np8;
+	// the Highway variant of convi on uchar (convi.c:925-1120): 8-bit mantissas sharing one
+	// exponent; hwy_ok is false when vips_convi_intize refuses the mask (the C path then runs)
+	bool hwy_ok;
+	bool no_vector; // internal plans (approx.hip) always want the C path's arithmetic
+	int hwy_exp;
+	std::vector<int> hwy_mant, hwy_pos;
+	void *d_hwy_coeff, *d_hwy_dense;
+	short *d_hwy_dx, *d_hwy_dy;
 	std::mutex mutex;
 };
 

@@ -95,6 +95,17 @@ conv_general(ConvArgs a)
 			sum = ((sum + a.rounding) / a.scale_i) + a.offset_i;
 			dst[e] = (TOUT) ConvClip<TIN>::run(sum);
 		}
+		else if constexpr (MODE == 4) {
+			const int *c = (const int *) a.coeff;
+			int sum = a.rounding;
+			for (int i = 0; i < a.nnz; i++) {
+				const int col = min(max(gx + a.dx[i], 0), a.im_width - 1) - a.in_left;
+				const int row = min(max(gy + a.dy[i], 0), a.im_height - 1) - a.in_top;
+				const TIN *src = (const TIN *) (a.in + row * a.in_stride);
+				sum += c[i] * (int) src[(long long) col * a.epp + b];
+			}
+			dst[e] = (TOUT) ConvClip<TIN>::run((long long) ((sum >> a.scale_i) + a.offset_i));
+		}
 		else if constexpr (MODE == 1) {
 			const int *c = (const int *) a.coeff;
 			double sum = 0;
@@ -179,6 +190,22 @@ struct ConvAcc<TIN, 3> {
 	{
 		s = ((s + a.rounding) / a.scale_i) + a.offset_i;
 		return ConvClip<TIN>::run((long long) s);
+	}
+};
+// MODE 4: the Highway variant of convi on uchar (convi_hwy.cpp:264-273): int32 sum of pixel x
+// 8-bit mantissa seeded with the rounding term, ARITHMETIC shift by the shared exponent (a floor,
+// where the C path's division truncates), offset, clip.  scale_i carries the exponent.
+template <typename TIN>
+struct ConvAcc<TIN, 4> {
+	typedef int acc_t;
+	typedef int coef_t;
+	typedef int win_t;
+	static __device__ __forceinline__ acc_t seed(const ConvArgs &a) { return a.rounding; }
+	static __device__ __forceinline__ win_t widen(TIN v) { return (int) v; }
+	static __device__ __forceinline__ acc_t mac(acc_t s, int c, int v) { return s + __mul24(c, v); }
+	static __device__ __forceinline__ TIN fin(acc_t s, const ConvArgs &a)
+	{
+		return ConvClip<TIN>::run((long long) ((s >> a.scale_i) + a.offset_i));
 	}
 };
 template <typename TIN>
@@ -492,6 +519,73 @@ static int launch_conv_best(const ConvArgs &a, const char *name)
 	return launch_conv<TIN, TOUT, MODE>(a, name);
 }
 
+// vips_convi_intize, convi.c:925-1120 (HAVE_HWY branch).  false: the mask is refused.
+static bool conv_hwy_intize(_VipsHipConv *c, const double *mask, double scale)
+{
+	const int n = c->mask_width * c->mask_height;
+	std::vector<double> scaled(n);
+	for (int i = 0; i < n; i++)
+		scaled[i] = mask[i] / scale;
+	double mx = scaled[0];
+	for (int i = 1; i < n; i++)
+		mx = scaled[i] > mx ? scaled[i] : mx;
+	// the max rounded up to a power of two is the exponent every element shares; + 1 keeps an
+	// exact power of two inside signed 8 bits after the * 128
+	const double fshift = ceil(log2(mx) + 1);
+	if (!(fshift <= 6 && fshift >= -24)) // NaN / -inf (no positive element) lands here too
+		return false;
+	const int shift = (int) fshift;
+	if (ceil(log2((double) n)) > 10)
+		return false;
+	c->hwy_exp = 7 - shift;
+	for (int i = 0; i < n; i++) {
+		const double m = rint(128 * scaled[i] * pow(2, -shift));
+		if (m < -128 || m > 127)
+			return false;
+		if (m != 0) {
+			c->hwy_mant.push_back((int) m);
+			c->hwy_pos.push_back(i);
+		}
+	}
+	if (c->hwy_mant.empty()) {
+		c->hwy_mant.push_back(0);
+		c->hwy_pos.push_back(0);
+	}
+	// refuse masks that come out more than 2 grey levels wrong on a flat image
+	double true_sum = 0;
+	int int_sum = 0;
+	for (size_t i = 0; i < c->hwy_mant.size(); i++) {
+		true_sum += 128 * scaled[c->hwy_pos[i]];
+		int_sum += 128 * c->hwy_mant[i];
+	}
+	const int true_value = (int) (true_sum < 0 ? 0 : (true_sum > 255 ? 255 : true_sum));
+	int int_value = (int_sum + (1 << (c->hwy_exp - 1))) >> c->hwy_exp;
+	int_value = int_value < 0 ? 0 : (int_value > 255 ? 255 : int_value);
+	return abs(true_value - int_value) <= 2;
+}
+
+static int conv_hwy_tables(_VipsHipConv *c)
+{
+	std::lock_guard<std::mutex> lock(c->mutex);
+	if (c->d_hwy_coeff)
+		return 0;
+	const size_t nnz = c->hwy_mant.size();
+	std::vector<short> dx(nnz), dy(nnz);
+	std::vector<int> dense((size_t) c->mask_width * c->mask_height, 0);
+	for (size_t i = 0; i < nnz; i++) {
+		dx[i] = (short) (c->hwy_pos[i] % c->mask_width);
+		dy[i] = (short) (c->hwy_pos[i] / c->mask_width);
+		dense[c->hwy_pos[i]] = c->hwy_mant[i];
+	}
+	c->d_hwy_dx = (short *) upload(dx.data(), dx.size() * sizeof(short));
+	c->d_hwy_dy = (short *) upload(dy.data(), dy.size() * sizeof(short));
+	c->d_hwy_dense = upload(dense.data(), dense.size() * sizeof(int));
+	c->d_hwy_coeff = upload(c->hwy_mant.data(), nnz * sizeof(int));
+	if (!c->d_hwy_dx || !c->d_hwy_dy || !c->d_hwy_dense || !c->d_hwy_coeff)
+		return -1;
+	return 0;
+}
+
 static int conv_tables(_VipsHipConv *c)
 {
 	std::lock_guard<std::mutex> lock(c->mutex);
@@ -573,6 +667,10 @@ VipsHipConv *vips_hip_conv_new(const double *mask, int mask_width, int mask_heig
 	c->d_dense = nullptr;
 	c->d_dense8 = nullptr;
 	c->np8 = 0;
+	c->hwy_ok = c->no_vector = false;
+	c->hwy_exp = 0;
+	c->d_hwy_coeff = c->d_hwy_dense = nullptr;
+	c->d_hwy_dx = c->d_hwy_dy = nullptr;
 	c->scale_i = c->rounding = c->offset_i = 0;
 	const int ne = mask_width * mask_height;
 	if (precision == VIPS_HIP_PRECISION_INTEGER) {
@@ -599,6 +697,7 @@ VipsHipConv *vips_hip_conv_new(const double *mask, int mask_width, int mask_heig
 			c->pos.push_back(0);
 		}
 		c->nnz = (int) c->coeffi.size();
+		c->hwy_ok = conv_hwy_intize(c, mask, scale);
 	}
 	else {
 		// convf.c:300-323: bake the scale into the mask, keep the non-zero elements
@@ -627,12 +726,38 @@ void vips_hip_conv_free(VipsHipConv *c)
 	vips_hip_free(c->d_dy);
 	vips_hip_free(c->d_dense);
 	vips_hip_free(c->d_dense8);
+	vips_hip_free(c->d_hwy_coeff);
+	vips_hip_free(c->d_hwy_dense);
+	vips_hip_free(c->d_hwy_dx);
+	vips_hip_free(c->d_hwy_dy);
 	delete c;
 }
 
 int vips_hip_conv_get_nnz(const VipsHipConv *c)
 {
 	return c ? c->nnz : -1;
+}
+
+// The Highway-variant coefficients of an INTEGER plan, for inspection (host only): returns the
+// number of non-zero mantissas (written to mant[] / pos[] when max allows), or 0 when
+// vips_convi_intize refuses the mask, -1 on error.
+int vips_hip_conv_get_vector(const VipsHipConv *c, int *exp, int *mant, int *pos, int max)
+{
+	if (!c || c->precision != VIPS_HIP_PRECISION_INTEGER) {
+		error("convi", "not an integer conv plan");
+		return -1;
+	}
+	if (!c->hwy_ok)
+		return 0;
+	const int n = (int) c->hwy_mant.size();
+	if (exp)
+		*exp = c->hwy_exp;
+	if (mant && pos && max >= n)
+		for (int i = 0; i < n; i++) {
+			mant[i] = c->hwy_mant[i];
+			pos[i] = c->hwy_pos[i];
+		}
+	return n;
 }
 
 int vips_hip_conv_out_format(const VipsHipConv *c, int format)
@@ -728,6 +853,22 @@ int vips_hip_conv_gen(const VipsHipConv *conv, const VipsHipRegion *in, const Vi
 		const long long off = c->offset_i < 0 ? -(long long) c->offset_i : c->offset_i;
 		const long long rnd = c->rounding < 0 ? -(long long) c->rounding : c->rounding;
 		a.narrow = small && abs_sum * maxval + rnd < (1LL << 30) && off < (1LL << 30);
+	}
+	// convi.c:1150-1158: a Highway build takes its vector path for uchar images when vectors are
+	// enabled and the intize accepts the mask.  Off unless vips_hip_vector_set_enabled(1).
+	if (c->precision == VIPS_HIP_PRECISION_INTEGER && fmt == VIPS_HIP_FORMAT_UCHAR && c->hwy_ok &&
+		!c->no_vector && vips_hip_vector_isenabled()) {
+		if (conv_hwy_tables(c))
+			return -1;
+		a.coeff = c->d_hwy_coeff;
+		a.dense = c->d_hwy_dense;
+		a.dx = c->d_hwy_dx;
+		a.dy = c->d_hwy_dy;
+		a.nnz = (int) c->hwy_mant.size();
+		a.scale_i = c->hwy_exp;
+		a.rounding = 1 << (c->hwy_exp - 1);
+		a.narrow = 0;
+		return launch_conv_best<unsigned char, unsigned char, 4>(a, "convi_vector");
 	}
 	if (c->precision == VIPS_HIP_PRECISION_INTEGER) {
 		switch (fmt) {

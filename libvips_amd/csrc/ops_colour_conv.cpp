@@ -507,8 +507,10 @@ int vips_hip_convsep(VipsHipImage *in, VipsHipImage **out, const double *mask, i
 	}
 	// float images, and uchar / ushort / short with integer precision: both passes in one
 	// streaming kernel (convsep_f32.hip)
+	// (with the Highway variant of convi selected, uchar images take the two plain passes)
+	const bool vector_uchar = in->format == VIPS_HIP_FORMAT_UCHAR && vips_hip_vector_isenabled();
 	if (in->format == VIPS_HIP_FORMAT_FLOAT ||
-		(precision == VIPS_HIP_PRECISION_INTEGER &&
+		(precision == VIPS_HIP_PRECISION_INTEGER && !vector_uchar &&
 			(in->format == VIPS_HIP_FORMAT_UCHAR || in->format == VIPS_HIP_FORMAT_USHORT ||
 				in->format == VIPS_HIP_FORMAT_SHORT))) {
 		ConvPtr c = conv_cached(mask, mask_n, 1, scale, offset, precision);

@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -362,6 +363,21 @@ void *vips_hip_get_stream(void)
 	if (ensure_init())
 		return nullptr;
 	return (void *) stream();
+}
+
+// vips_vector_set_enabled / vips_vector_isenabled (iofuncs/vector.cpp:98-113).  The reference's
+// vector (Highway) paths are bit-identical to its C paths except convi on uchar, so this switch
+// only selects that arithmetic (conv.hip MODE 4).  Off by default: the oracle build has no Highway.
+static std::atomic<int> g_vector_enabled(0);
+
+void vips_hip_vector_set_enabled(int enabled)
+{
+	g_vector_enabled.store(enabled ? 1 : 0);
+}
+
+int vips_hip_vector_isenabled(void)
+{
+	return g_vector_enabled.load();
 }
 
 int vips_hip_synchronize(void)

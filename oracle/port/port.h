@@ -57,6 +57,11 @@ int port_convi(const void *in, int width, int height, int bands, int format,
 	const double *mask, int mw, int mh, double scale, double offset, void *out);
 int port_convf(const void *in, int width, int height, int bands, int format,
 	const double *mask, int mw, int mh, double scale, double offset, void *out);
+/* the Highway variant of convi on uchar (parity unpinned: see port_conv.c) */
+int port_convi_hwy_intize(const double *mask, int n_point, double scale, short *mant, int *pos,
+	int *nnz_out, int *exp_out);
+int port_convi_hwy(const unsigned char *in, int width, int height, int bands, const double *mask, int mw,
+	int mh, double scale, double offset, unsigned char *out);
 int port_gaussmat(double sigma, double min_ampl, int separable, int integer, double *mask,
 	double *scale);
 void port_sharpen_lut(double x1, double y2, double y3, double m1, double m2, int *lut);

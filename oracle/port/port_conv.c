@@ -286,3 +286,120 @@ port_sharpen_apply(const short *in, const short *blur, int n_pixels, int bands, 
 			out[(size_t) i * bands + b] = in[(size_t) i * bands + b];
 	}
 }
+
+/* ------------------------------------------------------------------ convi, Highway variant
+ *
+ * PARITY UNPINNED: the reference's Highway path cannot be built in this image (no libhwy), so
+ * nothing below has been run against it.  It restates
+ *   vips_convi_intize             convolution/convi.c:925-1120 (HAVE_HWY branch): the mask as 8-bit
+ *                                 mantissas with one shared exponent, refused when out of range or
+ *                                 more than 2 grey levels off on a flat image
+ *   vips_convi_uchar_hwy          convolution/convi_hwy.cpp:264-273, the scalar tail that the
+ *                                 vector body has to equal lane for lane: int32 sum seeded with
+ *                                 1 << (exp - 1), arithmetic shift by exp, offset, clip
+ * and is what a Highway-built libvips computes for uchar images with precision=integer when
+ * vips_vector_isenabled().
+ */
+int
+port_convi_hwy_intize(const double *mask, int n_point, double scale, short *mant, int *pos,
+	int *nnz_out, int *exp_out)
+{
+	if (n_point < 1)
+		return -1;
+	double *scaled = malloc(sizeof(double) * n_point);
+	double mx, mn;
+	int shift, exp, nnz;
+
+	for (int i = 0; i < n_point; i++)
+		scaled[i] = mask[i] / scale;
+	mx = mn = scaled[0];
+	for (int i = 1; i < n_point; i++) {
+		if (scaled[i] > mx)
+			mx = scaled[i];
+		if (scaled[i] < mn)
+			mn = scaled[i];
+	}
+	(void) mn;
+	/* +1 so that a max exactly on a power of two still fits signed 8 bits after the * 128 */
+	const double fshift = ceil(log2(mx) + 1);
+	if (!(fshift <= 6 && fshift >= -24)) { /* also catches NaN / -inf from mx <= 0 */
+		free(scaled);
+		return -1;
+	}
+	shift = fshift;
+	if (ceil(log2(n_point)) > 10) {
+		free(scaled);
+		return -1;
+	}
+	exp = 7 - shift;
+
+	nnz = 0;
+	for (int i = 0; i < n_point; i++) {
+		const double m = rint(128 * scaled[i] * pow(2, -shift));
+		if (m < -128 || m > 127) {
+			free(scaled);
+			return -1;
+		}
+		if (m) {
+			mant[nnz] = m;
+			pos[nnz] = i;
+			nnz += 1;
+		}
+	}
+	if (nnz == 0) {
+		mant[0] = 0;
+		pos[0] = 0;
+		nnz = 1;
+	}
+
+	/* accuracy on a flat image */
+	double true_sum = 0.0;
+	int int_sum = 0;
+	for (int i = 0; i < nnz; i++) {
+		true_sum += 128 * scaled[pos[i]];
+		int_sum += 128 * mant[i];
+	}
+	const int true_value = true_sum < 0 ? 0 : (true_sum > 255 ? 255 : true_sum);
+	int int_value = (int_sum + (1 << (exp - 1))) >> exp;
+	int_value = int_value < 0 ? 0 : (int_value > 255 ? 255 : int_value);
+	free(scaled);
+	if (abs(true_value - int_value) > 2)
+		return -1;
+
+	*nnz_out = nnz;
+	*exp_out = exp;
+	return 0;
+}
+
+/* 0 = done, 1 = the mask is refused by the intize (the reference then runs its C path). */
+int
+port_convi_hwy(const unsigned char *in, int width, int height, int bands, const double *mask, int mw,
+	int mh, double scale, double offset, unsigned char *out)
+{
+	const int n = mw * mh;
+	short *mant = malloc(sizeof(short) * n);
+	int *pos = malloc(sizeof(int) * n);
+	int nnz, exp;
+	const int ioffset = rint(offset);
+
+	if (port_convi_hwy_intize(mask, n, scale, mant, pos, &nnz, &exp)) {
+		free(mant);
+		free(pos);
+		return 1;
+	}
+	for (int y = 0; y < height; y++)
+		for (int x = 0; x < width; x++)
+			for (int b = 0; b < bands; b++) {
+				int32_t sum = 1 << (exp - 1);
+				for (int i = 0; i < nnz; i++) {
+					const int xx = clampi(x + pos[i] % mw - mw / 2, 0, width - 1);
+					const int yy = clampi(y + pos[i] / mw - mh / 2, 0, height - 1);
+					sum += in[((size_t) yy * width + xx) * bands + b] * mant[i];
+				}
+				const int v = (sum >> exp) + ioffset;
+				out[((size_t) y * width + x) * bands + b] = v < 0 ? 0 : (v > 255 ? 255 : v);
+			}
+	free(mant);
+	free(pos);
+	return 0;
+}

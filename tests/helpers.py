@@ -425,6 +425,8 @@ def _port_conv_setup(lib):
     lib.port_convasep.argtypes = [vp, ci, ci, ci, ci, pd, ci, cd, cd, ci, vp]
     lib.port_conva_decompose.argtypes = [pd, ci, ci, cd, cd, ci, ci, pi, pi, ci]
     lib.port_convasep_decompose.argtypes = [pd, ci, cd, cd, ci, pi, pi, ci]
+    lib.port_convi_hwy.argtypes = [vp, ci, ci, ci, pd, ci, ci, cd, cd, vp]
+    lib.port_convi_hwy_intize.argtypes = [pd, ci, cd, ctypes.POINTER(ctypes.c_short), pi, pi, pi]
     lib.port_cast.argtypes = [vp, ctypes.c_size_t, ci, ci, vp]
     lib.port_premultiply.argtypes = [vp, ctypes.c_size_t, ci, ci, cd, ci, ci, vp]
     lib._conv_ready = True
@@ -476,6 +478,36 @@ class PortCC(object):
         m = cls._mask(mask).reshape(1, -1)
         t = cls.conv(array, m, scale, offset, precision)
         return cls.conv(t, m.reshape(-1, 1), scale, 0.0, precision)
+
+    @classmethod
+    def convi_vector(cls, array, mask, scale=1.0, offset=0.0):
+        """convi as a Highway-built libvips computes it on uchar (convi.c:925-1120,
+        convi_hwy.cpp:264-273; PARITY UNPINNED: no Highway here).  Falls back to the C path
+        when the intize refuses the mask, as convi.c:1150-1170 does."""
+        a = Port._prep(array)
+        m = cls._mask(mask)
+        if a.dtype != np.uint8:
+            return cls.conv(a, m, scale, offset, "integer")
+        h, w, b = a.shape
+        out = np.empty_like(a)
+        r = cls.lib().port_convi_hwy(a.ctypes.data, w, h, b, m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                     m.shape[1], m.shape[0], scale, offset, out.ctypes.data)
+        if r == 1:
+            return cls.conv(a, m, scale, offset, "integer")
+        return out
+
+    @classmethod
+    def convi_vector_intize(cls, mask, scale=1.0):
+        """(exp, [(mant, pos)...]) or None when refused."""
+        m = cls._mask(mask)
+        n = m.size
+        mant = (ctypes.c_short * n)()
+        pos = (ctypes.c_int * n)()
+        nnz, exp = ctypes.c_int(), ctypes.c_int()
+        if cls.lib().port_convi_hwy_intize(m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n, scale, mant, pos,
+                                           ctypes.byref(nnz), ctypes.byref(exp)) != 0:
+            return None
+        return exp.value, [(mant[i], pos[i]) for i in range(nnz.value)]
 
     @classmethod
     def conva(cls, array, mask, scale=1.0, offset=0.0, layers=5, cluster=1):
