@@ -38,6 +38,8 @@ int hip_failed(hipError_t err, const char *what);
 int ensure_init();
 
 hipStream_t stream();
+// Synchronise and destroy the calling thread's own stream (threads the library starts itself).
+void release_thread_stream();
 
 // Kernel gates: VIPS_GATE_START/STOP analogue around a launch.
 struct Gate {

@@ -434,15 +434,20 @@ int vips_hip_thumbnail_batch(const char *const *paths, int n, VipsHipImage **out
 			else if (errors)
 				errors[(size_t) i * 256] = 0;
 		}
-		// results cross to the caller's thread: finish this thread's stream first
-		(void) vips_hip_synchronize();
 	};
-	if (n_threads <= 1)
+	if (n_threads <= 1) {
 		worker();
+		(void) vips_hip_synchronize();
+	}
 	else {
 		std::vector<std::thread> pool;
+		// results cross to the caller's thread, and a pool thread's cached blocks go to the
+		// global list when it ends: finish (and give back) the thread's stream first
 		for (int t = 0; t < n_threads; t++)
-			pool.emplace_back(worker);
+			pool.emplace_back([&]() {
+				worker();
+				release_thread_stream();
+			});
 		for (std::thread &t : pool)
 			t.join();
 	}

@@ -64,6 +64,19 @@ hipStream_t stream()
 	return tls_stream;
 }
 
+// For threads the library itself starts (vips_hip_thumbnail_batch): finish and destroy the
+// calling thread's own stream before the thread ends -- thread-local streams are otherwise kept
+// for the life of the thread and never destroyed (no HIP calls from thread-exit destructors).
+void release_thread_stream()
+{
+	if (tls_stream && !tls_stream_external) {
+		(void) hipStreamSynchronize(tls_stream);
+		(void) hipStreamDestroy(tls_stream);
+	}
+	tls_stream = nullptr;
+	tls_stream_external = false;
+}
+
 _VipsHipImage *image_share(const _VipsHipImage *in)
 {
 	if (!in || !in->owns || !in->hold)
