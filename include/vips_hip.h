@@ -464,7 +464,8 @@ VIPS_HIP_API int vips_hip_image_write_to_vfile(const VipsHipImage *image, const 
  * at first use.  vips_hip_thumbnail is vips_thumbnail() (resample/thumbnail.c:549-676 open +
  * :678-1067 build) for JPEG and .v files: vips_thumbnail_find_jpegshrink (:488-519) picks the
  * block shrink, the pre-shrunk image is uploaded, the rest is vips_hip_thumbnail_image.  Files
- * that need auto-rotation or ICC colour management are refused.
+ * that need auto-rotation, or ICC colour management (an embedded profile in linear mode), are
+ * refused.
  */
 typedef struct _VipsHipJpegHeader {
 	int width, height;             /* after the shrink */

@@ -14,8 +14,9 @@
 // The entropy decode is libjpeg's and runs on the host (the same IJG library the reference
 // build links, loaded with dlopen so that libvipship.so itself does not depend on it); the
 // pre-shrunk image -- 1/4 to 1/64 of the pixels -- is uploaded and everything after it runs on
-// the device.  Auto-rotation (EXIF orientation other than 1) and ICC colour management are
-// outside the path: such files are refused rather than thumbnailed wrongly.
+// the device.  Auto-rotation (EXIF orientation other than 1) and ICC colour management (an
+// embedded profile in linear mode) are outside the path: such files are refused rather than
+// thumbnailed wrongly.
 #include "internal.h"
 
 #include <csetjmp>
@@ -376,8 +377,12 @@ int vips_hip_thumbnail(const char *path, VipsHipImage **out, int width, int heig
 				h.orientation);
 			return -1;
 		}
-		if (h.has_icc) {
-			error("thumbnail", "\"%s\" carries an ICC profile: colour management is outside the HIP path", path);
+		// an embedded profile only matters when it would be used: in linear mode the reference
+		// imports through it (thumbnail.c:769-790); otherwise, with no export profile asked for,
+		// it is carried as metadata and the pixels are not touched
+		if (h.has_icc && linear) {
+			error("thumbnail", "\"%s\" carries an ICC profile and linear mode would import through it: "
+							   "colour management is outside the HIP path", path);
 			return -1;
 		}
 		if (h.bands != 1 && h.bands != 3) {

@@ -207,7 +207,11 @@ def test_thumbnail_of_a_v_file_and_refusals(tmp_path):
         Image.thumbnail(jpath, 64)
     make_jpeg(jpath, 300, 200, icc_profile=b"\0" * 200)
     with pytest.raises(libvips_amd.VipsHipError, match="ICC"):
-        Image.thumbnail(jpath, 64)
+        Image.thumbnail(jpath, 64, linear=True)
+    # ... but without linear the reference leaves the pixels alone, and so does this path
+    plain = str(tmp_path / "plain.jpg")
+    make_jpeg(plain, 300, 200)
+    assert np.array_equal(Image.thumbnail(jpath, 64).numpy(), Image.thumbnail(plain, 64).numpy())
     # shrink-on-load on its own
     make_jpeg(jpath, 300, 200)
     im = Image.new_from_jpeg(jpath, 2)
@@ -399,3 +403,16 @@ def test_jpeg_crop_pipeline_through_the_port_matches_vips_thumbnail(tmp_path):
         pre, _ = product_decode(path, factor)
         got = PortCC.thumbnail_image(pre, "srgb", tw, th, size=size, crop=crop)
         assert got.shape == want.shape and np.array_equal(got, want), args
+
+
+@needs_ref_jpeg
+def test_embedded_icc_does_not_change_the_reference_pixels(tmp_path):
+    """Why vips_hip_thumbnail only refuses ICC files in linear mode: with no export profile the
+    reference carries the profile as metadata and thumbnails the same pixels."""
+    a, b = str(tmp_path / "a.jpg"), str(tmp_path / "b.jpg")
+    make_jpeg(a, 800, 600)
+    make_jpeg(b, 800, 600, icc_profile=b"\0" * 300)
+    assert product_header(b).has_icc == 1
+    out_a, _ = cli_thumbnail(tmp_path, a, "100x100")
+    out_b, _ = cli_thumbnail(tmp_path, b, "100x100")
+    assert np.array_equal(out_a, out_b)
