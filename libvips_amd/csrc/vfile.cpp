@@ -250,6 +250,12 @@ int vips_hip_image_write_to_vfile(const VipsHipImage *image, const char *path)
 	}
 	if (ensure_init())
 		return -1;
+	const size_t line = (size_t) image->width * image->bands * format_sizeof(image->format);
+	const size_t total = line * image->height;
+	if (image->stride != line) {
+		error("VipsImage", "padded images are outside the .v writer");
+		return -1;
+	}
 	File file(fopen(path, "wb"));
 	if (!file.f) {
 		error("VipsImage", "unable to open \"%s\" for writing: %s", path, strerror(errno));
@@ -278,12 +284,6 @@ int vips_hip_image_write_to_vfile(const VipsHipImage *image, const char *path)
 	Staging st;
 	if (!st.ok) {
 		error("VipsImage", "unable to allocate staging buffers");
-		return -1;
-	}
-	const size_t line = (size_t) image->width * image->bands * format_sizeof(image->format);
-	const size_t total = line * image->height;
-	if (image->stride != line) {
-		error("VipsImage", "padded images are outside the .v writer");
 		return -1;
 	}
 	// chunk k + 1 comes down from the device while chunk k goes to the disc
