@@ -540,6 +540,10 @@ int vips_hip_convsep(VipsHipImage *in, VipsHipImage **out, const double *mask, i
 int vips_hip_gaussblur(VipsHipImage *in, VipsHipImage **out, double sigma, double min_ampl,
 	int precision)
 {
+	if (!in || !out) {
+		error("gaussblur", "null argument");
+		return -1;
+	}
 	if (sigma < 0.2) {
 		ImageRef o(vips_hip_image_new(in->width, in->height, in->bands, in->format,
 			in->interpretation));
@@ -560,11 +564,19 @@ int vips_hip_gaussblur(VipsHipImage *in, VipsHipImage **out, double sigma, doubl
 
 int vips_hip_cast(VipsHipImage *in, VipsHipImage **out, int format)
 {
+	if (!in || !out) {
+		error("cast", "null argument");
+		return -1;
+	}
 	return cast_image(in, out, format);
 }
 
 static int premultiply_image(VipsHipImage *in, VipsHipImage **out, int uchar, int inverse)
 {
+	if (!in || !out) {
+		error("premultiply", "null argument");
+		return -1;
+	}
 	const char *domain = inverse ? "unpremultiply" : "premultiply";
 	if (in->bands == 1) { // "Trivial case: fall back to copy()."
 		return cast_image(in, out, in->format);
@@ -600,6 +612,10 @@ int vips_hip_unpremultiply(VipsHipImage *in, VipsHipImage **out, int uchar)
 // vips_colourspace_build, colour/colourspace.c:551-612
 int vips_hip_colourspace(VipsHipImage *in, VipsHipImage **out, int space)
 {
+	if (!in || !out) {
+		error("colourspace", "null argument");
+		return -1;
+	}
 	int interpretation = guess_interpretation(in);
 	const Route *route = nullptr;
 	for (const Route &r : routes)
@@ -858,6 +874,10 @@ int vips_hip_thumbnail_image_crop(VipsHipImage *in, VipsHipImage **out, int widt
 int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out, double sigma, double x1, double y2,
 	double y3, double m1, double m2)
 {
+	if (!in || !out) {
+		error("sharpen", "null argument");
+		return -1;
+	}
 	const int old_interpretation = in->interpretation;
 	ImageRef labs;
 	if (vips_hip_colourspace(in, &labs.im, VIPS_HIP_INTERPRETATION_LABS))

@@ -230,13 +230,13 @@ void vips_hip_reduce_free(VipsHipReduce *r)
 	delete r;
 }
 
-int vips_hip_reduce_get_n_point(const VipsHipReduce *r) { return r->n_point; }
-int vips_hip_reduce_get_out_size(const VipsHipReduce *r) { return r->out_size; }
-double vips_hip_reduce_get_offset(const VipsHipReduce *r) { return r->offset; }
+int vips_hip_reduce_get_n_point(const VipsHipReduce *r) { return r ? r->n_point : -1; }
+int vips_hip_reduce_get_out_size(const VipsHipReduce *r) { return r ? r->out_size : -1; }
+double vips_hip_reduce_get_offset(const VipsHipReduce *r) { return r ? r->offset : 0.0; }
 
 int vips_hip_reduce_get_matrixs(const VipsHipReduce *r, int phase, short *out)
 {
-	if (phase < 0 || phase > TRANSFORM_SCALE)
+	if (!r || !out || phase < 0 || phase > TRANSFORM_SCALE)
 		return -1;
 	memcpy(out, &r->matrixs[(size_t) phase * r->n_point], sizeof(short) * r->n_point);
 	return 0;
@@ -244,7 +244,7 @@ int vips_hip_reduce_get_matrixs(const VipsHipReduce *r, int phase, short *out)
 
 int vips_hip_reduce_get_matrixf(const VipsHipReduce *r, int phase, double *out)
 {
-	if (phase < 0 || phase > TRANSFORM_SCALE)
+	if (!r || !out || phase < 0 || phase > TRANSFORM_SCALE)
 		return -1;
 	memcpy(out, &r->matrixf[(size_t) phase * r->n_point], sizeof(double) * r->n_point);
 	return 0;
@@ -252,6 +252,13 @@ int vips_hip_reduce_get_matrixf(const VipsHipReduce *r, int phase, double *out)
 
 static void reduce_need(const VipsHipReduce *r, int start, int count, int *in_start, int *in_count)
 {
+	if (!r || !in_start || !in_count) {
+		if (in_start)
+			*in_start = 0;
+		if (in_count)
+			*in_count = 0;
+		return;
+	}
 	// reduceh.cpp:237-240 in embedded coordinates...
 	int s0 = (int) (start * r->shrink - r->offset);
 	int sn = (int) (count * r->shrink + r->n_point);

@@ -537,6 +537,8 @@ void vips_hip_gate_reset(void)
 
 int vips_hip_gate_query(const char *name, double *total_ms)
 {
+	if (!name)
+		name = "";
 	(void) hipDeviceSynchronize();
 	std::lock_guard<std::mutex> lock(g_gate_mutex);
 	int n = 0;
@@ -657,19 +659,30 @@ void vips_hip_image_unref(VipsHipImage *image)
 
 int vips_hip_image_write_to_memory(const VipsHipImage *image, void *host_data)
 {
+	if (!image || !host_data) {
+		error("vips_hip_image_write_to_memory", "null argument");
+		return -1;
+	}
 	return vips_hip_memcpy_d2h(host_data, image->data, image->stride * image->height);
 }
 
-void *vips_hip_image_get_data(const VipsHipImage *image) { return image->data; }
-int vips_hip_image_get_width(const VipsHipImage *image) { return image->width; }
-int vips_hip_image_get_height(const VipsHipImage *image) { return image->height; }
-int vips_hip_image_get_bands(const VipsHipImage *image) { return image->bands; }
-int vips_hip_image_get_format(const VipsHipImage *image) { return image->format; }
-int vips_hip_image_get_interpretation(const VipsHipImage *image) { return image->interpretation; }
-size_t vips_hip_image_get_stride(const VipsHipImage *image) { return image->stride; }
+// the getters of a NULL image answer 0 / NULL instead of crashing
+void *vips_hip_image_get_data(const VipsHipImage *image) { return image ? image->data : nullptr; }
+int vips_hip_image_get_width(const VipsHipImage *image) { return image ? image->width : 0; }
+int vips_hip_image_get_height(const VipsHipImage *image) { return image ? image->height : 0; }
+int vips_hip_image_get_bands(const VipsHipImage *image) { return image ? image->bands : 0; }
+int vips_hip_image_get_format(const VipsHipImage *image) { return image ? image->format : -1; }
+int vips_hip_image_get_interpretation(const VipsHipImage *image) { return image ? image->interpretation : -1; }
+size_t vips_hip_image_get_stride(const VipsHipImage *image) { return image ? image->stride : 0; }
 
 void vips_hip_image_region(const VipsHipImage *image, VipsHipRegion *region)
 {
+	if (!region)
+		return;
+	if (!image) {
+		memset(region, 0, sizeof(*region));
+		return;
+	}
 	region->data = image->data;
 	region->left = 0;
 	region->top = 0;

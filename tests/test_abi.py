@@ -147,3 +147,34 @@ def test_port_affine_vs_ref_mixed():
                 want = Ref.run("resize", src, "scale=%r,vscale=%r,kernel=%s" % (hs, vs, kernel))
                 got = Port.resize(src, hs, vs, kernel=kernel)
                 assert got.shape == want.shape and np.array_equal(got, want), (dtype, kernel, w, h, hs, vs)
+
+
+def test_every_entry_point_survives_null_arguments():
+    """Each C-ABI function called with NULL pointers and zero numbers must return (an error or a
+    neutral value), not crash: run in a child so that a crash is a test failure, not the end of
+    the suite."""
+    import subprocess
+    import sys
+
+    code = r'''
+import ctypes, sys
+sys.path.insert(0, %r)
+from libvips_amd import _ffi
+for name in sorted(_ffi._SIGNATURES):
+    restype, argtypes = _ffi._SIGNATURES[name]
+    args = []
+    for t in argtypes:
+        if t in (ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong):
+            args.append(0)
+        elif t in (ctypes.c_double, ctypes.c_float):
+            args.append(0.0)
+        else:
+            args.append(None)
+    print(name, flush=True)
+    getattr(_ffi.lib, name)(*args)
+    _ffi.lib.vips_hip_error_clear()
+print("ALL-RETURNED", flush=True)
+''' % helpers.ROOT
+    proc = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    tail = proc.stdout.strip().splitlines()[-3:]
+    assert proc.returncode == 0 and "ALL-RETURNED" in proc.stdout, tail
