@@ -1,0 +1,248 @@
+"""CPU: the HOST side of libvipship.so driven end to end against a mock HIP runtime
+(tests/mock_hip/mock_hip.cpp: memory is host memory, copies are memcpy, kernels do nothing).
+
+What this can show without a GPU: every operation's plan building, dispatch, output sizes and
+formats, the file loaders and savers (pixel-exact: they are copies), extract_area (a copy), the
+batch thread pool (and that its streams are given back), the libvips module's build / generate
+plumbing -- and that none of it crashes.  What it cannot show is any pixel a kernel makes; that is
+what the `-m gpu` tests are for.  The child process is LD_PRELOADed with the mock; nothing here
+runs when a real GPU is present."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests import helpers
+
+MOCK_SRC = os.path.join(helpers.ROOT, "tests", "mock_hip", "mock_hip.cpp")
+MOCK_SO = os.path.join(helpers.ROOT, "tests", "mock_hip", "_build", "libmockhip.so")
+
+
+def _build_mock():
+    if os.path.exists(MOCK_SO) and os.path.getmtime(MOCK_SO) >= os.path.getmtime(MOCK_SRC):
+        return True
+    if not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        return False
+    os.makedirs(os.path.dirname(MOCK_SO), exist_ok=True)
+    proc = subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
+                           "-I/opt/rocm/include", "-o", MOCK_SO, MOCK_SRC],
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    return proc.returncode == 0
+
+
+def _gpu_present():
+    import torch
+
+    return torch.cuda.is_available()
+
+
+pytestmark = pytest.mark.skipif(_gpu_present() or not _build_mock(),
+                                reason="a real GPU is present, or the mock runtime cannot be built")
+
+
+def run_child(body, tmp_path):
+    script = os.path.join(str(tmp_path), "child.py")
+    with open(script, "w") as f:
+        f.write("import sys\nsys.path.insert(0, %r)\n" % helpers.ROOT)
+        f.write("TMP = %r\n" % str(tmp_path))
+        f.write(body)
+        f.write("\nprint('CHILD-OK', flush=True)\n")
+    env = dict(os.environ, LD_PRELOAD=MOCK_SO)
+    proc = subprocess.run([sys.executable, script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                          env=env, timeout=600)
+    assert proc.returncode == 0 and "CHILD-OK" in proc.stdout, proc.stdout[-3000:]
+    return proc.stdout
+
+
+def test_files_and_copies_are_pixel_exact(tmp_path):
+    run_child(r'''
+import os, ctypes
+import numpy as np
+import libvips_amd
+from libvips_amd import Image
+from tests import helpers
+
+libvips_amd.init(0)
+# .v: file -> "HBM" -> file, byte for byte, every format family, several staging chunks
+for dtype in (np.uint8, np.uint16, np.float32, np.complex64):
+    if dtype == np.complex64:
+        re = helpers.lcg_image(50, 40, 2, np.float32, 94)
+        src = (re + 1j * re[::-1]).astype(np.complex64)
+    else:
+        src = helpers.lcg_image(123, 77, 3, dtype, 94)
+    a, b = os.path.join(TMP, "a.v"), os.path.join(TMP, "b.v")
+    helpers.write_v(a, src, interpretation=22)
+    im = Image.new_from_file(a)
+    assert np.array_equal(im.numpy(), src)
+    im.write_to_file(b)
+    assert open(a, "rb").read() == open(b, "rb").read()
+big = helpers.lcg_image(4096, 4400, 4, np.uint8, 95)  # 68.75 MiB: three 32 MiB chunks
+a, b = os.path.join(TMP, "big.v"), os.path.join(TMP, "big_out.v")
+helpers.write_v(a, big, interpretation=22)
+im = Image.new_from_file(a)
+im.write_to_file(b)
+assert open(a, "rb").read() == open(b, "rb").read()
+# extract_area is a copy
+src = helpers.lcg_image(300, 200, 4, np.uint16, 96)
+im = Image.new_from_array(src)
+assert np.array_equal(im.extract_area(10, 20, 250, 100).numpy(), src[20:120, 10:260])
+try:
+    im.extract_area(100, 0, 250, 10)
+    raise SystemExit("bad extract area accepted")
+except libvips_amd.VipsHipError as e:
+    assert "bad extract area" in str(e)
+# JPEG: host decode + upload is pixel exact against the host decoder itself
+import tests.test_zz_jpeg as J
+p = os.path.join(TMP, "t.jpg")
+J.make_jpeg(p, 641, 487)
+for shrink in (1, 2, 4, 8):
+    want, _ = J.product_decode(p, shrink)
+    assert np.array_equal(Image.new_from_jpeg(p, shrink).numpy(), want)
+''', tmp_path)
+
+
+def test_sizes_formats_and_refusals(tmp_path):
+    run_child(r'''
+import os
+import numpy as np
+import libvips_amd
+from libvips_amd import Image
+from tests import helpers
+from tests.helpers import PortCC, Port
+import tests.test_zz_jpeg as J
+
+libvips_amd.init(0)
+src = helpers.lcg_image(517, 389, 4, np.uint8, 99)
+im = Image.new_from_array(src, interpretation="srgb")
+# thumbnail geometry (fit, fill + crop, force, down, linear) against the oracle port's
+for crop in ("none", "centre", "low", "high", "all"):
+    for (tw, th, size, linear) in ((100, 100, "both", False), (60, 200, "both", False), (400, 50, "down", False),
+                                   (90, 90, "both", True), (300, 100, "force", False), (700, 700, "both", False)):
+        want = PortCC.thumbnail_image(src, "srgb", tw, th, size=size, linear=linear, crop=crop)
+        got = im.thumbnail_image(tw, th, size=size, linear=linear, crop=crop)
+        assert (got.height, got.width, got.bands) == want.shape, (crop, tw, th, size, linear)
+        assert got.numpy().dtype == want.dtype
+# JPEG thumbnails: geometry against the reference CLI's, grey included; refusals
+class T:  # tmp_path stand-in for the helper
+    def __init__(self, p): self.p = p
+    def __str__(self): return self.p
+p = os.path.join(TMP, "t.jpg")
+for (w, h, grey, size) in ((2000, 1500, False, "200x200"), (1801, 1203, False, "100x100"), (1000, 750, True, "150x150")):
+    J.make_jpeg(p, w, h, grey)
+    tw, th = [int(v) for v in size.split("x")]
+    got = Image.thumbnail(p, tw, th)
+    if os.path.exists(J.VIPSTHUMBNAIL) and J._ref_has_jpeg():
+        want, _ = J.cli_thumbnail(T(TMP), p, size)
+        assert (got.height, got.width, got.bands) == want.shape, (w, h, size)
+exif = J.PIL.Exif()
+exif[0x0112] = 6
+J.make_jpeg(p, 300, 200, exif=exif.tobytes())
+for fn, needle in ((lambda: Image.thumbnail(p, 64), "auto-rotation"),):
+    try:
+        fn()
+        raise SystemExit("accepted")
+    except libvips_amd.VipsHipError as e:
+        assert needle in str(e)
+J.make_jpeg(p, 300, 200, icc_profile=b"\0" * 200)
+try:
+    Image.thumbnail(p, 64, linear=True)
+    raise SystemExit("accepted")
+except libvips_amd.VipsHipError as e:
+    assert "ICC" in str(e)
+assert Image.thumbnail(p, 64).width == 64
+try:
+    im.thumbnail_image(64, crop="attention")
+    raise SystemExit("accepted")
+except libvips_amd.VipsHipError as e:
+    assert "attention" in str(e)
+# every precision of the convolution front doors builds its plan and dispatches, every format
+for dtype in (np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.float32, np.float64):
+    a = helpers.lcg_image(90, 70, 2, dtype, 1)
+    ia = Image.new_from_array(a)
+    for prec in ("integer", "float", "approximate"):
+        o = ia.gaussblur(3.0, precision=prec)
+        assert (o.width, o.height, o.bands) == (90, 70, 2)
+        want = PortCC.gaussblur(a, 3.0, precision=prec)
+        assert o.numpy().dtype == want.dtype, (dtype, prec)
+    m, s = PortCC.gaussmat(2.0, 0.2, False, "integer")
+    assert ia.conv(m, scale=s, precision="approximate", layers=7, cluster=2).numpy().shape == a.shape
+libvips_amd.vector_set_enabled(True)
+assert Image.new_from_array(helpers.lcg_image(64, 48, 3)).gaussblur(2.0).numpy().shape == (48, 64, 3)
+libvips_amd.vector_set_enabled(False)
+# resize / reduce / shrink geometry against the port
+b = helpers.lcg_image(333, 251, 3, np.uint8, 2)
+ib = Image.new_from_array(b)
+for scale in (0.5, 0.123, 0.77, 1.9, 3.0):
+    assert ib.resize(scale).numpy().shape == Port.resize(b, scale).shape, scale
+assert ib.reduce(2.5, 3.3).numpy().shape == Port.reduce(b, 2.5, 3.3).shape
+assert ib.shrink(3, 4).numpy().shape == Port.shrink(b, 3, 4).shape
+''', tmp_path)
+
+
+def test_batch_threads_give_their_streams_back(tmp_path):
+    run_child(r'''
+import ctypes, os
+import numpy as np
+import libvips_amd
+from libvips_amd import Image
+import tests.test_zz_jpeg as J
+
+mock = ctypes.CDLL(os.environ["LD_PRELOAD"])
+mock.mock_hip_launches.restype = ctypes.c_long
+libvips_amd.init(0)
+paths = []
+for i in range(9):
+    p = os.path.join(TMP, "b%d.jpg" % i)
+    J.make_jpeg(p, 400 + 37 * i, 300 + 11 * i, grey=(i == 3))
+    paths.append(p)
+paths.insert(4, os.path.join(TMP, "missing.jpg"))
+Image.thumbnail(paths[0], 64)  # the main thread's own stream exists from here on
+before = mock.mock_hip_live_streams()
+for round in range(3):
+    outs = Image.thumbnail_batch(paths, 96, 96, crop="centre", threads=4)
+    assert len(outs) == len(paths)
+    for p, o in zip(paths, outs):
+        if p.endswith("missing.jpg"):
+            assert isinstance(o, libvips_amd.VipsHipError) and "unable to open" in str(o)
+        else:
+            assert (o.width, o.height) == (96, 96), p
+assert mock.mock_hip_live_streams() == before, (before, mock.mock_hip_live_streams())
+assert mock.mock_hip_launches() > 0
+''', tmp_path)
+
+
+@pytest.mark.skipif(not helpers.have_module(), reason="oracle/_ref or host/_build missing")
+def test_module_plumbing_through_libvips(tmp_path):
+    """The *_hip operations driven through the reference's own operation API: build(), the
+    device-image link between chained ops, generate; geometry against the built-ins."""
+    run_child(r'''
+import os
+import numpy as np
+from tests import helpers
+from tests.helpers import Ref
+import tests.test_zz_jpeg as J
+
+Ref.load_module()
+src = helpers.lcg_image(640, 400, 3, np.uint8, 100)
+for hip, ref, args in (("thumbnail_image_hip", "thumbnail_image", "width=100,height=100,crop=centre"),
+                       ("thumbnail_image_hip", "thumbnail_image", "width=80,height=200,crop=high"),
+                       ("resize_hip", "resize", "scale=0.37"),
+                       ("gaussblur_hip", "gaussblur", "sigma=2,precision=approximate"),
+                       ("reduce_hip", "reduce", "hshrink=2.5,vshrink=3.3"),
+                       ("colourspace_hip", "colourspace", "space=lab"),
+                       ("sharpen_hip", "sharpen", "")):
+    got = Ref.run(hip, src, args, 22)
+    want = Ref.run(ref, src, args, 22)
+    assert got.shape == want.shape and got.dtype == want.dtype, (hip, args)
+got = Ref.run_chain("resize_hip:scale=0.25;sharpen_hip:;cast_hip:format=ushort", src, 22)
+want = Ref.run_chain("resize:scale=0.25;sharpen:;cast:format=ushort", src, 22)
+assert got.shape == want.shape and got.dtype == want.dtype
+if J._ref_has_jpeg():
+    p = os.path.join(TMP, "t.jpg")
+    J.make_jpeg(p, 2400, 1600)
+    for args in ("width=200", "width=128,height=128,crop=centre", "width=300,height=100,size=force"):
+        got, _, _ = Ref.create("thumbnail_hip", "filename=%s,%s" % (p, args))
+        want, _, _ = Ref.create("thumbnail", "filename=%s,%s" % (p, args))
+        assert got.shape == want.shape and got.dtype == want.dtype, args
+''', tmp_path)
