@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvipship.so")
+# VIPS_HIP_LIBRARY: load another build of the same library (e.g. a sanitizer build, tools/asan_mock.sh)
+LIB_PATH = os.environ.get("VIPS_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libvipship.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vips_hip.h")
 
 
