@@ -93,9 +93,13 @@ typedef enum {
 
 /* ------------------------------------------------------------------ runtime */
 
-/* Select the device this thread's calls go to and create the library's
- * streams/pools on it.  Safe to call repeatedly.  Fails (-1) when no gfx950
- * device is visible: there is NO CPU fallback anywhere in this library.
+/* Select the device this PROCESS works on (one process per GPU) and create the
+ * library's streams/pools on it.  Safe to call repeatedly and from every thread
+ * with the same device; a different device than the first call's fails (-1).
+ * Threads that never call it (libvips workers inside the module, the batch
+ * thread pool) use the process's device, or $VIPS_HIP_DEVICE, or 0.  Fails (-1)
+ * when no gfx950 device is visible: there is NO CPU fallback anywhere in this
+ * library.
  */
 VIPS_HIP_API int vips_hip_init(int device);
 VIPS_HIP_API void vips_hip_shutdown(void);

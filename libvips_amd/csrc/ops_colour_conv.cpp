@@ -426,6 +426,10 @@ extern "C" {
 int vips_hip_conv(VipsHipImage *in, VipsHipImage **out, const double *mask, int mask_width,
 	int mask_height, double scale, double offset, int precision)
 {
+	if (!in || !out || !mask) {
+		error("conv", "null argument");
+		return -1;
+	}
 	// conv.c:99-107 with the class defaults layers = 5, cluster = 1 (:159-160)
 	if (precision == VIPS_HIP_PRECISION_APPROXIMATE)
 		return vips_hip_conva(in, out, mask, mask_width, mask_height, scale, offset, 5, 1);
@@ -498,6 +502,10 @@ int vips_hip_convasep(VipsHipImage *in, VipsHipImage **out, const double *mask, 
 int vips_hip_convsep(VipsHipImage *in, VipsHipImage **out, const double *mask, int mask_n,
 	double scale, double offset, int precision)
 {
+	if (!in || !out || !mask) {
+		error("convsep", "null argument");
+		return -1;
+	}
 	// convsep.c:81-87 with the class default layers = 5 (:155)
 	if (precision == VIPS_HIP_PRECISION_APPROXIMATE)
 		return vips_hip_convasep(in, out, mask, mask_n, scale, offset, 5);

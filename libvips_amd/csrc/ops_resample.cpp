@@ -108,6 +108,10 @@ VipsHipImage *copy_image(const VipsHipImage *in)
 int shrink_axis(VipsHipImage *in, VipsHipImage **out, int shrink, int ceil_mode, bool vertical)
 {
 	const char *domain = vertical ? "shrinkv" : "shrinkh";
+	if (!in || !out) {
+		error(domain, "null argument");
+		return -1;
+	}
 	if (shrink < 1) {
 		error(domain, "shrink factors should be >= 1");
 		return -1;
@@ -141,6 +145,10 @@ int reduce_axis(VipsHipImage *in, VipsHipImage **out, double shrink, int kernel,
 	bool vertical)
 {
 	const char *domain = vertical ? "reducev" : "reduceh";
+	if (!in || !out) {
+		error(domain, "null argument");
+		return -1;
+	}
 	if (shrink < 1.0) {
 		error(domain, "reduce factor should be >= 1.0");
 		return -1;
@@ -234,6 +242,10 @@ int vips_hip_reducev(VipsHipImage *in, VipsHipImage **out, double vshrink, int k
 int vips_hip_reduce(VipsHipImage *in, VipsHipImage **out, double hshrink, double vshrink,
 	int kernel, double gap)
 {
+	if (!in || !out) {
+		error("reduce", "null argument");
+		return -1;
+	}
 	// Fused uchar path when neither axis needs an integer pre-shrink.
 	if (in->format == VIPS_HIP_FORMAT_UCHAR && gap <= 0.0 && hshrink > 1.0 && vshrink > 1.0 &&
 		kernel != VIPS_HIP_KERNEL_NEAREST) {
@@ -275,6 +287,10 @@ int vips_hip_reduce(VipsHipImage *in, VipsHipImage **out, double hshrink, double
 int vips_hip_shrink(VipsHipImage *in, VipsHipImage **out, double hshrink, double vshrink,
 	int ceil_mode)
 {
+	if (!in || !out) {
+		error("shrink", "null argument");
+		return -1;
+	}
 	const int hshrink_int = (int) hshrink;
 	const int vshrink_int = (int) vshrink;
 	ImageRef t0;
@@ -292,6 +308,10 @@ int vips_hip_shrink(VipsHipImage *in, VipsHipImage **out, double hshrink, double
 int vips_hip_resize(VipsHipImage *in, VipsHipImage **out, double scale, double vscale_arg,
 	int kernel, double gap)
 {
+	if (!in || !out) {
+		error("resize", "null argument");
+		return -1;
+	}
 	double hscale = scale;
 	double vscale = vscale_arg > 0.0 ? vscale_arg : scale;
 	if (gap < 0.0)

@@ -62,6 +62,8 @@ struct FusedArgs {
 	const unsigned char *in;
 	long long in_stride;
 	int in_left, in_top;   // origin of the input window
+	int in_right;          // in_left + window width
+	int pairs;             // MFMA kernel: every tile can fetch whole pixel pairs (see load_rows)
 	int im_width, im_height;
 	unsigned char *out;
 	long long out_stride;
@@ -72,6 +74,8 @@ struct FusedArgs {
 	int aligned8;           // input base and stride are multiples of 8 bytes
 	int small_window;       // the input window spans < 2 GB: 32-bit byte offsets are safe
 	int debug;              // VIPS_HIP_FUSED_DEBUG ablation bits (profiling only; 0 in production)
+	int xshift;             // MFMA kernel: a tile's lanes start this many columns left of its first tap,
+	                        // so that every wave's 512-byte row segment starts on a 128-byte line
 };
 
 // Coefficients travel BY VALUE in the kernel-argument segment: they are read with
@@ -368,7 +372,7 @@ static constexpr size_t mfma_lds_bytes(int oht)
 	return (size_t) MFMA_PLANES_BYTES + 2 * MFMA_TABLE_ENTRIES * 8 + (size_t) oht * MFMA_STAGE_PITCH * 4;
 }
 
-template <int D>
+template <int D, bool NT = false, int PROF = 0, bool PAIRS = false>
 struct MfmaStep {
 	static constexpr int S = 8;
 
@@ -376,17 +380,37 @@ struct MfmaStep {
 	// windows < 2 GB, so every address is the uniform base (an SGPR pair) plus one 32-bit lane
 	// offset: the saddr form of global_load, no 64-bit VALU address arithmetic.  Interior
 	// tiles fetch their two pixels as one dwordx2; edge tiles clamp each column.
+	//
+	// `interior` is the tile's (block-uniform) load mode:
+	//   1  interior: one dwordx2 per row at column ca
+	//   2  edge tile whose pixel pairs never straddle the clamp (even tile origin, even clamp
+	//      bounds): one dwordx2 per row from the clamped PAIR at column ca, then lanes that lie
+	//      wholly outside duplicate the edge pixel (cb = 1: y = x, left; cb = 2: x = y, right).
+	//      The kernel runs ONE residency round, so it ends when its slowest tile ends: with
+	//      two dword loads per lane and row the edge tiles were that tile.
+	//   0  anything else: clamp each column, two dword loads
 	template <int I0, int N>
 	static __device__ __forceinline__ void load_rows(const FusedArgs &a, uint2 (&px)[S], int first_row,
-		int dir, int ca, int cb, bool interior)
+		int dir, int ca, int cb, int interior)
 	{
 		const unsigned int stride32 = (unsigned int) a.in_stride;
-		if (interior) {
+		if (PAIRS || interior) { // a PAIRS kernel is only launched when every tile is mode 1 or 2
 #pragma unroll
 			for (int i = I0; i < I0 + N; i++) {
 				const int row = min(max(first_row + dir * i, 0), a.im_height - 1) - a.in_top;
 				const unsigned int off = (unsigned int) row * stride32 + (unsigned int) (4 * ca);
-				px[i] = *reinterpret_cast<const uint2 *>(a.in + (size_t) off);
+				typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+				const u32x2 *src = reinterpret_cast<const u32x2 *>(a.in + (size_t) off);
+				const u32x2 v = NT ? __builtin_nontemporal_load(src) : *src;
+				px[i] = make_uint2(v.x, v.y);
+			}
+			if (PAIRS) { // branch-free: interior lanes carry cb = 0 (the compares live in SGPR masks)
+#pragma unroll
+				for (int i = I0; i < I0 + N; i++) {
+					const unsigned int x = px[i].x, y = px[i].y;
+					px[i].y = cb == 1 ? x : y;
+					px[i].x = cb == 2 ? y : x;
+				}
 			}
 		}
 		else {
@@ -432,8 +456,16 @@ struct MfmaStep {
 	template <int ROT, int Q>
 	static __device__ __forceinline__ void quad(const FusedArgs &a, uint2 (&px)[S], float4v (&acc)[8][2],
 		const half4v *lane_a /* &table[lane & 3] */, bool more, int next_row, int dir, int ca, int cb,
-		bool interior)
+		int interior)
 	{
+		if constexpr (PROF == 16) { // profiling: loads only -- consume the rows, refill, no arithmetic
+#pragma unroll
+			for (int i = 4 * Q; i < 4 * Q + 4; i++)
+				asm volatile("" ::"v"(px[i].x), "v"(px[i].y));
+			if (more)
+				load_rows<4 * Q, 4>(a, px, next_row, dir, ca, cb, interior);
+			return;
+		}
 		const half4v a0 = lane_a[((ROT * 2 + Q) * 2 + 0) * 4];
 		const half4v a1 = lane_a[((ROT * 2 + Q) * 2 + 1) * 4];
 #pragma unroll
@@ -447,7 +479,14 @@ struct MfmaStep {
 			b[1] = make_b<1>(r0, r1, r2, r3);
 			b[2] = make_b<2>(r0, r1, r2, r3);
 			b[3] = make_b<3>(r0, r1, r2, r3);
-			if (p == 1 && more)
+			if constexpr (PROF == 8) { // profiling: arithmetic only (rows stay, but opaque to the compiler)
+				if (p == 1) {
+#pragma unroll
+					for (int i = 4 * Q; i < 4 * Q + 4; i++)
+						asm volatile("" : "+v"(px[i].x), "+v"(px[i].y));
+				}
+			}
+			else if (p == 1 && more)
 				load_rows<4 * Q, 4>(a, px, next_row, dir, ca, cb, interior);
 #pragma unroll
 			for (int c = 0; c < 4; c++) {
@@ -517,7 +556,7 @@ struct MfmaStep {
 	template <int ROT, int NB>
 	static __device__ __forceinline__ void batch(const FusedArgs &a, uint2 (&px)[NB][S], int g0, int ngroups,
 		float4v (&acc)[8][2], unsigned char *planes, const half4v *lane_a, int t, int row0, int dir, int ca,
-		int cb, bool interior, int oh)
+		int cb, int interior, int oh)
 	{
 		if constexpr (ROT < MFMA_SLOTS) {
 			const int g = g0 + ROT;
@@ -538,12 +577,12 @@ struct MfmaStep {
 // them, so horizontal neighbours (which read their shared halo columns in lock-step) and
 // most vertical neighbours (which the serpentine walk makes meet at their shared halo rows)
 // share an L2.  Measured on C2: row-major 0.218 ms, column-major 0.221, no serpentine 0.225.
-template <int D, int NB, int OCC>
+template <int D, int NB, int OCC, bool NT, int PROF = 0, bool PAIRS = false>
 __global__ void __launch_bounds__(FUSED_THREADS, OCC)
 reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 {
 	constexpr int S = 8;
-	typedef MfmaStep<D> Step;
+	typedef MfmaStep<D, NT, PROF, PAIRS> Step;
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	// T planes (the horizontal walker over-reads the end of a plane by up to 8 * (D - 1)
 	// samples: into the next plane / the tables -- any byte is a finite f16 denormal), the two
@@ -566,12 +605,21 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 	const int ow = min(a.owt, a.out_width - x0);
 	const int oh = min(a.oht, a.out_height - y0);
 
-	const int tile_col0 = a.fx0 + S * x0;
+	const int tile_col0 = a.fx0 + S * x0 - a.xshift;
 	const int col0 = tile_col0 + 2 * t;
-	const int ca = min(max(col0, 0), a.im_width - 1) - a.in_left;
-	const int cb = min(max(col0 + 1, 0), a.im_width - 1) - a.in_left;
-	const bool interior = a.aligned8 && tile_col0 >= 0 && tile_col0 + FUSED_SPAN <= a.im_width &&
-		(((tile_col0 - a.in_left) & 1) == 0);
+	// Columns clamp to the image (vips_embed COPY) -- and to the window: the window holds every
+	// column an output needs (checked by the host), so this only matters to lanes past the
+	// tile's last tap, whose reads must stay inside the window too.
+	const int lo = max(0, a.in_left), hi = min(a.im_width, a.in_right) - 1;
+	const bool even = a.aligned8 && (((tile_col0 - a.in_left) & 1) == 0);
+	int interior = even && tile_col0 >= lo && tile_col0 + FUSED_SPAN <= hi + 1 ? 1 : 0;
+	int ca = min(max(col0, lo), hi) - a.in_left;
+	int cb = min(max(col0 + 1, lo), hi) - a.in_left;
+	if (PAIRS) {
+		// see load_rows: pairs are whole, so a lane is inside, left of lo (y = x) or right of hi (x = y)
+		ca = min(max(col0, lo), hi - 1) - a.in_left;
+		cb = col0 < lo ? 1 : (col0 > hi ? 2 : 0);
+	}
 	const bool flip = (by & 1) != 0;
 	const int dir = flip ? -1 : 1;
 	const int row0 = flip ? a.fy0 + S * (y0 + oh - 1) + S * D - 1 : a.fy0 + S * y0;
@@ -616,7 +664,7 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 			const half4v *lane_ah = lds_ah + hc;
 			const bool row_ok = hr < nrows;
 			const int lrow = r_lo + (row_ok ? hr : 0);
-			const unsigned char *line = planes + (lrow * 4 + hc) * MFMA_PLANE + 8 * HSEG_OUT * hseg;
+			const unsigned char *line = planes + (lrow * 4 + hc) * MFMA_PLANE + 8 * HSEG_OUT * hseg + a.xshift;
 			float4v hacc[2];
 			hacc[0] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
 			hacc[1] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
@@ -642,348 +690,6 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 					a.out + (long long) (y0 + row) * a.out_stride + (long long) x0 * 4);
 				dst[lane] = stage[row * MFMA_STAGE_PITCH + lane];
 			}
-		}
-	}
-}
-
-// ------------------------------------------------ the persistent variant (experiment, opt-in)
-//
-// reduce_fused_u8x4_mfma_persist<D>: the same tile body, but 1024 resident blocks pull SMALL
-// tiles from per-XCD atomic counters (dynamic balance: in the static one-round kernel the
-// spread of tile finish times costs ~3 %), keep every tile's output rows staged in LDS and
-// write them when the stage is full or the work is gone, i.e. mostly in one burst at the end.
-// VIPS_HIP_MFMA_PERSIST=<resident-tile budget, e.g. 4096>.  Measured on C2: 0.231 ms against the
-// static kernel's 0.219 -- the per-tile pipeline ramp and the extra halo rows of small tiles
-// cost more than the balance gains; kept as the measured counter-example.
-template <int D>
-__global__ void __launch_bounds__(FUSED_THREADS, 4)
-reduce_fused_u8x4_mfma_persist(FusedArgs a, const MfmaTables *__restrict__ tables, int *__restrict__ counters,
-	int stage_rows)
-{
-	constexpr int S = 8;
-	constexpr int NB = 1;
-	constexpr int MAX_STAGED = 16;
-	typedef MfmaStep<D> Step;
-	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-	unsigned char *planes = lds_raw;
-	half4v *lds_a = reinterpret_cast<half4v *>(lds_raw + MFMA_PLANES_BYTES);
-	half4v *lds_ah = lds_a + MFMA_TABLE_ENTRIES;
-	unsigned int *stage = reinterpret_cast<unsigned int *>(lds_ah + MFMA_TABLE_ENTRIES);
-	__shared__ int s_next;
-	__shared__ int s_meta[MAX_STAGED][4]; // x0, y0, ow, oh of the staged tiles
-
-	const int t = threadIdx.x;
-	const int xcd = blockIdx.x % 8;
-	const int per_xcd = (a.tiles + 7) / 8;
-	const half4v *lane_a = lds_a + (t & 3);
-	int staged_rows = 0, staged_tiles = 0;
-
-	auto flush = [&]() {
-		__syncthreads();
-		if (!(a.debug & 2)) {
-			const int lane = t & 63;
-			int base = 0;
-			for (int m = 0; m < staged_tiles; m++) {
-				const int mx0 = s_meta[m][0], my0 = s_meta[m][1], mow = s_meta[m][2], moh = s_meta[m][3];
-				for (int row = t >> 6; row < moh; row += FUSED_THREADS / 64) {
-					if (lane < mow) {
-						unsigned int *dst = reinterpret_cast<unsigned int *>(
-							a.out + (long long) (my0 + row) * a.out_stride + (long long) mx0 * 4);
-						dst[lane] = stage[(base + row) * MFMA_STAGE_PITCH + lane];
-					}
-				}
-				base += moh;
-			}
-		}
-		__syncthreads();
-	};
-
-	for (;;) {
-		__syncthreads();
-		if (t == 0)
-			s_next = atomicAdd(&counters[xcd], 1);
-		__syncthreads();
-		const int local = __builtin_amdgcn_readfirstlane(s_next);
-		const int tile = xcd * per_xcd + local;
-		if (local >= per_xcd || tile >= a.tiles)
-			break;
-
-		const int by = tile / a.tiles_x;
-		const int bx = tile - by * a.tiles_x;
-		const int x0 = bx * a.owt;
-		const int y0 = by * a.oht;
-		const int ow = min(a.owt, a.out_width - x0);
-		const int oh = min(a.oht, a.out_height - y0);
-		if (staged_rows + oh > stage_rows || staged_tiles == MAX_STAGED) {
-			flush();
-			staged_rows = 0;
-			staged_tiles = 0;
-		}
-		unsigned int *stage_t = stage + staged_rows * MFMA_STAGE_PITCH;
-		if (t == 0) {
-			s_meta[staged_tiles][0] = x0;
-			s_meta[staged_tiles][1] = y0;
-			s_meta[staged_tiles][2] = ow;
-			s_meta[staged_tiles][3] = oh;
-		}
-
-		const int tile_col0 = a.fx0 + S * x0;
-		const int col0 = tile_col0 + 2 * t;
-		const int ca = min(max(col0, 0), a.im_width - 1) - a.in_left;
-		const int cb = min(max(col0 + 1, 0), a.im_width - 1) - a.in_left;
-		const bool interior = a.aligned8 && tile_col0 >= 0 && tile_col0 + FUSED_SPAN <= a.im_width &&
-			(((tile_col0 - a.in_left) & 1) == 0);
-		const bool flip = (by & 1) != 0;
-		const int dir = flip ? -1 : 1;
-		const int row0 = flip ? a.fy0 + S * (y0 + oh - 1) + S * D - 1 : a.fy0 + S * y0;
-
-		if (t < MFMA_TABLE_ENTRIES) {
-			reinterpret_cast<uint2 *>(lds_a)[t] = reinterpret_cast<const uint2 *>(tables->a[flip ? 1 : 0])[t];
-			reinterpret_cast<uint2 *>(lds_ah)[t] = reinterpret_cast<const uint2 *>(tables->ah)[t];
-		}
-
-		float4v acc[8][2];
-#pragma unroll
-		for (int o = 0; o < 8; o++)
-#pragma unroll
-			for (int h = 0; h < 2; h++)
-				acc[o][h] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
-
-		const int ngroups = oh + D - 1;
-		uint2 px[NB][S];
-		Step::template load_rows<0, S>(a, px[0], row0, dir, ca, cb, interior);
-		__syncthreads();
-
-		for (int g0 = 0; g0 < ngroups; g0 += MFMA_SLOTS) {
-			Step::template batch<0, NB>(a, px, g0, ngroups, acc, planes, lane_a, t, row0, dir, ca, cb,
-				interior, oh);
-			const int jlo = max(g0 - (D - 1), 0);
-			const int jhi = min(g0 + MFMA_SLOTS - 1 - (D - 1), oh - 1); // inclusive
-			if (jhi < jlo)
-				continue;
-			__syncthreads();
-			const int nrows = jhi - jlo + 1;
-			const int r_lo = jlo - (g0 - (D - 1));
-			if (!(a.debug & 1)) {
-				const int hc = t & 3, hr = (t >> 2) & 7, hseg = t >> 5;
-				const half4v *lane_ah = lds_ah + hc;
-				const bool row_ok = hr < nrows;
-				const int lrow = r_lo + (row_ok ? hr : 0);
-				const unsigned char *line = planes + (lrow * 4 + hc) * MFMA_PLANE + 8 * HSEG_OUT * hseg;
-				float4v hacc[2];
-				hacc[0] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
-				hacc[1] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
-				unsigned int pix[2] = { 0, 0 };
-				Step::template hwalk<0>(hacc, line, lane_ah, hc, pix);
-				const int xo = HSEG_OUT * hseg + 2 * hc;
-				if (row_ok && xo < MFMA_STAGE_PITCH) {
-					const int jj = jlo + hr;
-					unsigned int *srow = stage_t + (flip ? oh - 1 - jj : jj) * MFMA_STAGE_PITCH + xo;
-					*reinterpret_cast<uint2 *>(srow) = make_uint2(pix[0], pix[1]);
-				}
-			}
-			__syncthreads();
-		}
-		staged_rows += oh;
-		staged_tiles++;
-	}
-	flush();
-}
-
-// ------------------------------------------------ the wide variant (experiment, opt-in)
-//
-// reduce_fused_u8x4_mfma_wide<D>: the same kernel with ONE pixel column per lane and 1024
-// threads, i.e. a 1024-pixel span per block, one block per CU (256 tiles of 123 x ~137 for
-// C2 instead of 1015 of 59 x 71).  Halving the per-lane state (32 accumulator registers)
-// pays for a 4-deep ring of row-group buffers, and the bigger tile cuts the re-read traffic
-// from 8.6 % to 2.4 % over algorithmic (PMC).  It is nevertheless SLOWER on C2 -- 0.276 ms
-// against 0.216 -- because a single 16-wave block per CU serialises on its two barriers per
-// 8 rows and leaves half its waves idle in the horizontal pass, where the narrow kernel's
-// four independent blocks per CU overlap each other's phases.  Kept (VIPS_HIP_MFMA_WIDE=1)
-// as the measured counter-example: on this path fewer re-reads do not buy time, overlap does.
-constexpr int WIDE_THREADS = 1024;
-constexpr int WIDE_SPAN = 1024;
-constexpr int WIDE_PLANE = WIDE_SPAN + 4; // bytes per (row, channel) T plane, bank-skewed
-constexpr int WIDE_PLANES_BYTES = MFMA_SLOTS * 4 * WIDE_PLANE;
-constexpr int WIDE_STAGE_PITCH = 124; // dwords per staged output row (owt <= 123)
-constexpr int WIDE_NB = 4;
-constexpr int WIDE_MAX_OHT = 248; // 158 KB - planes - tables
-
-static constexpr size_t wide_lds_bytes(int oht)
-{
-	return (size_t) WIDE_PLANES_BYTES + 2 * MFMA_TABLE_ENTRIES * 8 + (size_t) oht * WIDE_STAGE_PITCH * 4;
-}
-
-template <int D>
-struct MfmaStepW {
-	typedef MfmaStep<D> Base;
-	static constexpr int S = 8;
-
-	// rows first_row + dir * i, I0 <= i < I0 + N, of this lane's (clamped) column
-	template <int I0, int N>
-	static __device__ __forceinline__ void load_rows(const FusedArgs &a, unsigned int (&px)[S], int first_row,
-		int dir, int ca)
-	{
-		const unsigned int stride32 = (unsigned int) a.in_stride;
-#pragma unroll
-		for (int i = I0; i < I0 + N; i++) {
-			const int row = min(max(first_row + dir * i, 0), a.im_height - 1) - a.in_top;
-			const unsigned int off = (unsigned int) row * stride32 + (unsigned int) (4 * ca);
-			px[i] = *reinterpret_cast<const unsigned int *>(a.in + (size_t) off);
-		}
-	}
-
-	template <int ROT, int Q>
-	static __device__ __forceinline__ void quad(const FusedArgs &a, unsigned int (&px)[S], float4v (&acc)[4][2],
-		const half4v *lane_a, bool more, int next_row, int dir, int ca)
-	{
-		const half4v a0 = lane_a[((ROT * 2 + Q) * 2 + 0) * 4];
-		const half4v a1 = lane_a[((ROT * 2 + Q) * 2 + 1) * 4];
-		const unsigned int r0 = px[4 * Q + 0], r1 = px[4 * Q + 1], r2 = px[4 * Q + 2], r3 = px[4 * Q + 3];
-		half4v b[4];
-		b[0] = Base::template make_b<0>(r0, r1, r2, r3);
-		b[1] = Base::template make_b<1>(r0, r1, r2, r3);
-		b[2] = Base::template make_b<2>(r0, r1, r2, r3);
-		b[3] = Base::template make_b<3>(r0, r1, r2, r3);
-		if (more)
-			load_rows<4 * Q, 4>(a, px, next_row, dir, ca);
-#pragma unroll
-		for (int c = 0; c < 4; c++) {
-			acc[c][0] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, b[c], acc[c][0], 0, 0, 0);
-			acc[c][1] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, b[c], acc[c][1], 0, 0, 0);
-		}
-	}
-
-	template <int ROT>
-	static __device__ __forceinline__ void retire(float4v (&acc)[4][2], unsigned char *planes, int lds_row,
-		int t, bool store)
-	{
-		constexpr int SLOT = (ROT - (D - 1) + 2 * MFMA_SLOTS) % MFMA_SLOTS;
-		constexpr int H = SLOT >> 2, I = SLOT & 3;
-		if (store) {
-#pragma unroll
-			for (int c = 0; c < 4; c++)
-				planes[(lds_row * 4 + c) * WIDE_PLANE + t] = (unsigned char) Base::fin_pack(acc[c][H][I], 0, 0);
-		}
-#pragma unroll
-		for (int c = 0; c < 4; c++)
-			acc[c][H][I] = 0.0f;
-	}
-
-	template <int ROT>
-	static __device__ __forceinline__ void batch(const FusedArgs &a, unsigned int (&px)[WIDE_NB][S], int g0,
-		int ngroups, float4v (&acc)[4][2], unsigned char *planes, const half4v *lane_a, int t, int row0,
-		int dir, int ca, int oh)
-	{
-		if constexpr (ROT < MFMA_SLOTS) {
-			const int g = g0 + ROT;
-			if (g < ngroups) {
-				const bool more = g + WIDE_NB < ngroups;
-				const int next_row = row0 + dir * S * (g + WIDE_NB);
-				quad<ROT, 0>(a, px[ROT % WIDE_NB], acc, lane_a, more, next_row, dir, ca);
-				quad<ROT, 1>(a, px[ROT % WIDE_NB], acc, lane_a, more, next_row, dir, ca);
-				const int j = g - (D - 1);
-				retire<ROT>(acc, planes, ROT, t, j >= 0 && j < oh);
-			}
-			batch<ROT + 1>(a, px, g0, ngroups, acc, planes, lane_a, t, row0, dir, ca, oh);
-		}
-	}
-};
-
-template <int D>
-__global__ void __launch_bounds__(WIDE_THREADS)
-reduce_fused_u8x4_mfma_wide(FusedArgs a, const MfmaTables *__restrict__ tables)
-{
-	constexpr int S = 8;
-	typedef MfmaStepW<D> Step;
-	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-	unsigned char *planes = lds_raw;
-	half4v *lds_a = reinterpret_cast<half4v *>(lds_raw + WIDE_PLANES_BYTES);
-	half4v *lds_ah = lds_a + MFMA_TABLE_ENTRIES;
-	unsigned int *stage = reinterpret_cast<unsigned int *>(lds_ah + MFMA_TABLE_ENTRIES);
-
-	const int per_xcd = gridDim.x / 8;
-	const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-	if (tile >= a.tiles)
-		return;
-
-	const int t = threadIdx.x;
-	const int by = tile / a.tiles_x;
-	const int bx = tile - by * a.tiles_x;
-	const int x0 = bx * a.owt;
-	const int y0 = by * a.oht;
-	const int ow = min(a.owt, a.out_width - x0);
-	const int oh = min(a.oht, a.out_height - y0);
-
-	const int col0 = a.fx0 + S * x0 + t;
-	const int ca = min(max(col0, 0), a.im_width - 1) - a.in_left;
-	const bool flip = (by & 1) != 0;
-	const int dir = flip ? -1 : 1;
-	const int row0 = flip ? a.fy0 + S * (y0 + oh - 1) + S * D - 1 : a.fy0 + S * y0;
-
-	if (t < MFMA_TABLE_ENTRIES) {
-		reinterpret_cast<uint2 *>(lds_a)[t] = reinterpret_cast<const uint2 *>(tables->a[flip ? 1 : 0])[t];
-		reinterpret_cast<uint2 *>(lds_ah)[t] = reinterpret_cast<const uint2 *>(tables->ah)[t];
-	}
-	const half4v *lane_a = lds_a + (t & 3);
-
-	float4v acc[4][2];
-#pragma unroll
-	for (int c = 0; c < 4; c++)
-#pragma unroll
-		for (int h = 0; h < 2; h++)
-			acc[c][h] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
-
-	const int ngroups = oh + D - 1;
-	unsigned int px[WIDE_NB][S];
-#pragma unroll
-	for (int b = 0; b < WIDE_NB; b++)
-		if (b < ngroups)
-			Step::template load_rows<0, S>(a, px[b], row0 + dir * S * b, dir, ca);
-	__syncthreads();
-
-	for (int g0 = 0; g0 < ngroups; g0 += MFMA_SLOTS) {
-		Step::template batch<0>(a, px, g0, ngroups, acc, planes, lane_a, t, row0, dir, ca, oh);
-
-		const int jlo = max(g0 - (D - 1), 0);
-		const int jhi = min(g0 + MFMA_SLOTS - 1 - (D - 1), oh - 1); // inclusive
-		if (jhi < jlo)
-			continue;
-		__syncthreads();
-		const int nrows = jhi - jlo + 1;
-		const int r_lo = jlo - (g0 - (D - 1));
-		if (t < 512 && !(a.debug & 1)) {
-			// waves 0..7: thread -> (T row, one of 16 segments of HSEG_OUT outputs, channel)
-			const int hc = t & 3, hr = (t >> 2) & 7, hseg = t >> 5;
-			const half4v *lane_ah = lds_ah + hc;
-			const bool row_ok = hr < nrows;
-			const int lrow = r_lo + (row_ok ? hr : 0);
-			const unsigned char *line = planes + (lrow * 4 + hc) * WIDE_PLANE + 8 * HSEG_OUT * hseg;
-			float4v hacc[2];
-			hacc[0] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
-			hacc[1] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
-			unsigned int pix[2] = { 0, 0 };
-			MfmaStep<D>::template hwalk<0>(hacc, line, lane_ah, hc, pix);
-			const int xo = HSEG_OUT * hseg + 2 * hc;
-			if (row_ok && xo < WIDE_STAGE_PITCH) {
-				const int jj = jlo + hr;
-				unsigned int *srow = stage + (flip ? oh - 1 - jj : jj) * WIDE_STAGE_PITCH + xo;
-				*reinterpret_cast<uint2 *>(srow) = make_uint2(pix[0], pix[1]);
-			}
-		}
-		__syncthreads();
-	}
-
-	// ---- the tile's output, one burst: a wave per row, two pixels per lane
-	if (!(a.debug & 2)) {
-		const int lane = t & 63;
-		for (int row = t >> 6; row < oh; row += WIDE_THREADS / 64) {
-			unsigned int *dst = reinterpret_cast<unsigned int *>(
-				a.out + (long long) (y0 + row) * a.out_stride + (long long) x0 * 4);
-			if (lane < ow)
-				dst[lane] = stage[row * WIDE_STAGE_PITCH + lane];
-			if (lane + 64 < ow)
-				dst[lane + 64] = stage[row * WIDE_STAGE_PITCH + lane + 64];
 		}
 	}
 }
@@ -1225,50 +931,21 @@ static int launch_fused_mfma(const FusedArgs &args, int tiles, const MfmaTables 
 	Gate gate("reduce_fused_u8_mfma");
 	const int grid = (tiles + 7) / 8 * 8; // XCD remap wants a multiple of 8
 	const size_t lds = mfma_lds_bytes(args.oht);
-	const int nb = getenv("VIPS_HIP_MFMA_NB") ? atoi(getenv("VIPS_HIP_MFMA_NB")) : 1;
-	if (nb == 2)
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 2, 3>), dim3(grid), dim3(FUSED_THREADS), lds, stream(),
+	if ((args.debug & 24) == 8) // profiling builds: arithmetic only / loads only
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 8>), dim3(grid), dim3(FUSED_THREADS), lds, stream(),
+			args, d_tables);
+	else if ((args.debug & 24) == 16)
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 16>), dim3(grid), dim3(FUSED_THREADS), lds, stream(),
+			args, d_tables);
+	else if (args.pairs && !(args.debug & 32))
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true>), dim3(grid), dim3(FUSED_THREADS), lds,
+			stream(), args, d_tables);
+	else if (args.debug & 4)
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, false>), dim3(grid), dim3(FUSED_THREADS), lds, stream(),
 			args, d_tables);
 	else
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4>), dim3(grid), dim3(FUSED_THREADS), lds, stream(),
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true>), dim3(grid), dim3(FUSED_THREADS), lds, stream(),
 			args, d_tables);
-	VH_CHECK(hipGetLastError());
-	return 0;
-}
-
-template <int D>
-static int launch_fused_mfma_persist(const FusedArgs &args, int tiles, const MfmaTables *d_tables)
-{
-	int *counters = (int *) vips_hip_malloc(8 * sizeof(int));
-	if (!counters)
-		return -1;
-	if (hipMemsetAsync(counters, 0, 8 * sizeof(int), stream()) != hipSuccess) {
-		vips_hip_free(counters);
-		return hip_failed(hipErrorUnknown, "hipMemsetAsync");
-	}
-	Gate gate("reduce_fused_u8_mfma_persist");
-	const int blocks = tiles < 1024 ? (tiles + 7) / 8 * 8 : 1024;
-	hipLaunchKernelGGL((reduce_fused_u8x4_mfma_persist<D>), dim3(blocks), dim3(FUSED_THREADS),
-		mfma_lds_bytes(MFMA_MAX_OHT), stream(), args, d_tables, counters, MFMA_MAX_OHT);
-	const hipError_t err = hipGetLastError();
-	vips_hip_free(counters);
-	VH_CHECK(err);
-	return 0;
-}
-
-template <int D>
-static int launch_fused_mfma_wide(const FusedArgs &args, int tiles, const MfmaTables *d_tables)
-{
-	static bool attr_done = false;
-	if (!attr_done) {
-		VH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&reduce_fused_u8x4_mfma_wide<D>),
-			hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-		attr_done = true;
-	}
-	Gate gate("reduce_fused_u8_mfma_wide");
-	const int grid = (tiles + 7) / 8 * 8; // XCD remap wants a multiple of 8
-	hipLaunchKernelGGL((reduce_fused_u8x4_mfma_wide<D>), dim3(grid), dim3(WIDE_THREADS),
-		wide_lds_bytes(args.oht), stream(), args, d_tables);
 	VH_CHECK(hipGetLastError());
 	return 0;
 }
@@ -1679,6 +1356,7 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 	args.in = (const unsigned char *) in->data;
 	args.in_stride = (long long) in->stride;
 	args.in_left = in->left;
+	args.in_right = in->left + in->width;
 	args.in_top = in->top;
 	args.im_width = in->im_width;
 	args.im_height = in->im_height;
@@ -1694,6 +1372,8 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 	}
 	args.fx0 = fx0;
 	args.fy0 = fy0;
+	args.xshift = 0;
+	args.pairs = 0;
 	args.owt = FUSED_SPAN / S - D + 1;
 	args.tiles_x = (out->width + args.owt - 1) / args.owt;
 
@@ -1719,33 +1399,49 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 			abs_max = ah > abs_max ? ah : abs_max;
 		}
 		if (abs_max < 2048 && abs_sum * 255 < (1 << 23) && abs_sum_h * 255 < (1 << 23)) {
-			bool persist = false;
-			// the wide kernel (1024-pixel spans, one block per CU) is opt-in: measured slower
-			const char *wide_env = getenv("VIPS_HIP_MFMA_WIDE");
-			const bool wide = wide_env && atoi(wide_env) != 0;
 			// Tile height: ONE residency round (256 CUs x 4 blocks) when the staged rows fit in
 			// LDS -- every tile then ends, and bursts its output, at the same time, and
 			// neighbouring tiles read their shared halos in lock-step (L2 hits); else the
 			// smallest whole number of rounds.
 			{
-				if (wide) {
-					args.owt = WIDE_SPAN / S - D + 1;
-					args.tiles_x = (out->width + args.owt - 1) / args.owt;
+				// Line-aligned tiles: a wave's row segment (64 lanes x 8 bytes) that starts on a
+				// 128-byte line costs the memory pipe 4 line requests instead of 5, and on this
+				// part the requests a CU can issue, not HBM, bound the stream (tools/hbm_probe2:
+				// 2 KB strips at a 1888-byte pitch 5.8 TB/s requested, at a 2048-byte pitch 6.5,
+				// 7.1 with nt loads).  So: tile pitch a whole number of lines (owt a multiple
+				// of 4 -> 32 * owt bytes), lanes start at the line that holds the first tap.
+				const bool no_align = getenv("VIPS_HIP_FUSED_ALIGN") && atoi(getenv("VIPS_HIP_FUSED_ALIGN")) == 0;
+				if (!no_align && !(in->stride & 127)) {
+					const long long addr = (long long) (uintptr_t) in->data + 4LL * ((long long) fx0 - in->left);
+					const int off = (int) (((addr % 128) + 128) % 128); // bytes past a line start
+					const int owt = ((FUSED_SPAN - off / 4) / S - D + 1) & ~3;
+					if (!(off & 15) && owt >= 32) {
+						args.xshift = off / 4;
+						args.owt = owt;
+					}
 				}
-				const char *persist_env = getenv("VIPS_HIP_MFMA_PERSIST");
-				persist = !wide && persist_env && atoi(persist_env) > 0;
-				const int slots = persist ? atoi(persist_env)
-					: getenv("VIPS_HIP_FUSED_CAP")        ? atoi(getenv("VIPS_HIP_FUSED_CAP"))
-					: wide                                  ? 256
-															: 256 * 4;
+				// profiling knob: narrower tiles
+				const int owt_env = getenv("VIPS_HIP_FUSED_OWT") ? atoi(getenv("VIPS_HIP_FUSED_OWT")) : 0;
+				if (owt_env > 0 && owt_env < args.owt)
+					args.owt = owt_env;
+				args.tiles_x = (out->width + args.owt - 1) / args.owt;
+				const int slots = getenv("VIPS_HIP_FUSED_CAP") ? atoi(getenv("VIPS_HIP_FUSED_CAP")) : 256 * 4;
 				const int base = slots / args.tiles_x > 0 ? slots / args.tiles_x : 1;
 				int oht = out->height;
 				for (int k = 1; k <= 4096; k++) {
 					oht = (out->height + base * k - 1) / (base * k);
-					if (oht <= (wide ? WIDE_MAX_OHT : MFMA_MAX_OHT))
+					if (oht <= MFMA_MAX_OHT)
 						break;
 				}
 				args.oht = oht < 1 ? 1 : oht;
+			}
+			{
+				// whole-pair loads for every tile (load_rows): even tile origins and clamp bounds
+				// relative to an 8-byte aligned window, at least one whole pair to clamp to
+				const int lo = in->left > 0 ? in->left : 0;
+				const int hi1 = in->im_width < in->left + in->width ? in->im_width : in->left + in->width;
+				args.pairs = args.aligned8 && !((fx0 - args.xshift - in->left) & 1) && !((lo - in->left) & 1) &&
+					!((hi1 - in->left) & 1) && hi1 - lo >= 2;
 			}
 			const int tiles_y = (out->height + args.oht - 1) / args.oht;
 			const int tiles = args.tiles_x * tiles_y;
@@ -1767,14 +1463,6 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 				else
 					d_tables = (const MfmaTables *) it->second;
 			}
-			if (persist && D == 6)
-				return launch_fused_mfma_persist<6>(args, tiles, d_tables);
-			if (persist && D == 7)
-				return launch_fused_mfma_persist<7>(args, tiles, d_tables);
-			if (wide && D == 6)
-				return launch_fused_mfma_wide<6>(args, tiles, d_tables);
-			if (wide && D == 7)
-				return launch_fused_mfma_wide<7>(args, tiles, d_tables);
 			if (D == 6)
 				return launch_fused_mfma<6>(args, tiles, d_tables);
 			if (D == 7)

@@ -9,6 +9,7 @@
 #include "internal.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
 #include <map>
@@ -26,6 +27,11 @@ static thread_local int tls_device = -1;
 
 static std::mutex g_mutex;
 static bool g_inited = false;
+// One process drives one device (one process per GPU): the first
+// vips_hip_init() -- or $VIPS_HIP_DEVICE for threads that never call it, e.g. libvips
+// workers inside the module -- fixes it, and the pool, the plan caches and every thread
+// the library starts itself (vips_hip_thumbnail_batch) then live on that device.
+static std::atomic<int> g_device{ -1 };
 
 void error(const char *domain, const char *fmt, ...)
 {
@@ -50,7 +56,12 @@ int ensure_init()
 {
 	if (tls_device >= 0)
 		return 0;
-	return vips_hip_init(0);
+	int device = g_device.load();
+	if (device < 0) {
+		const char *env = getenv("VIPS_HIP_DEVICE");
+		device = env && *env ? atoi(env) : 0;
+	}
+	return vips_hip_init(device);
 }
 
 hipStream_t stream()
@@ -312,6 +323,15 @@ int vips_hip_init(int device)
 		error("vips_hip_init", "device %d out of range (have %d)", device, n);
 		return -1;
 	}
+	{
+		std::lock_guard<std::mutex> lock(g_mutex);
+		const int bound = g_device.load();
+		if (bound >= 0 && bound != device) {
+			error("vips_hip_init", "this process is bound to device %d (asked for %d): the device "
+				"pool and plan caches are per process -- run one process per GPU", bound, device);
+			return -1;
+		}
+	}
 	VH_CHECK(hipSetDevice(device));
 	{
 		std::lock_guard<std::mutex> lock(g_mutex);
@@ -325,6 +345,7 @@ int vips_hip_init(int device)
 			}
 			g_inited = true;
 		}
+		g_device.store(device);
 	}
 	tls_device = device;
 	return 0;

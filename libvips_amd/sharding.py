@@ -127,6 +127,24 @@ def exchange_halos(strip, plan, rank, dist=None, group=None):
     return window, w0
 
 
+def _order_after_torch(tensor):
+    """The library launches on its own (non-blocking) per-thread stream; ``exchange_halos``
+    fills the window on torch's current stream (async copies, RCCL receives) and
+    ``torch.empty`` may hand out memory the caching allocator last used there.  Unless the
+    library was put on that very stream (``vips_hip_set_stream``), finish torch's queued work
+    on the tensor's device before a library kernel touches it -- what
+    ``Image.new_from_tensor`` does."""
+    import torch
+
+    from ._ffi import lib
+
+    if not tensor.is_cuda:
+        return
+    cur = torch.cuda.current_stream(tensor.device)
+    if (lib.vips_hip_get_stream() or 0) != cur.cuda_stream:
+        cur.synchronize()
+
+
 def conv_strip(window, window_top, plan, rank, mask, scale=1.0, offset=0.0, precision="float"):
     """Run vips_hip_conv_gen on this rank's window: returns its strip of output rows
     (a torch CUDA tensor).  ``window`` is what exchange_halos returned."""
@@ -153,6 +171,7 @@ def conv_strip(window, window_top, plan, rank, mask, scale=1.0, offset=0.0, prec
                      width * bands * window.element_size())
         rout = Region(out.data_ptr(), 0, o0, width, o1 - o0, width, plan.out_height, bands, out_fmt,
                       width * bands * out.element_size())
+        _order_after_torch(window)
         check(lib.vips_hip_conv_gen(conv, ctypes.byref(rin), ctypes.byref(rout)))
         check(lib.vips_hip_synchronize())
         return out
@@ -187,9 +206,11 @@ def reduce_strip(window, window_top, plan, rank, in_width, hshrink, vshrink, ker
                      width * bands * window.element_size())
         rout = Region(out.data_ptr(), 0, o0, out_width, o1 - o0, out_width, plan.out_height, bands, fmt,
                       out_width * bands * out.element_size())
+        _order_after_torch(window)
         r = lib.vips_hip_reduce_gen(rv, rh, ctypes.byref(rin), ctypes.byref(rout))
         if r == 1:  # not an even-integer RGBA uchar case: the two general passes
             mid = torch.empty((o1 - o0, width, bands), device=window.device, dtype=window.dtype)
+            _order_after_torch(mid)
             rmid = Region(mid.data_ptr(), 0, o0, width, o1 - o0, width, plan.out_height, bands, fmt,
                           width * bands * mid.element_size())
             check(lib.vips_hip_reducev_gen(rv, ctypes.byref(rin), ctypes.byref(rmid)))

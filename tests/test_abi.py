@@ -160,19 +160,24 @@ def test_every_entry_point_survives_null_arguments():
 import ctypes, sys
 sys.path.insert(0, %r)
 from libvips_amd import _ffi
-for name in sorted(_ffi._SIGNATURES):
-    restype, argtypes = _ffi._SIGNATURES[name]
-    args = []
-    for t in argtypes:
-        if t in (ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong):
-            args.append(0)
-        elif t in (ctypes.c_double, ctypes.c_float):
-            args.append(0.0)
-        else:
-            args.append(None)
-    print(name, flush=True)
-    getattr(_ffi.lib, name)(*args)
-    _ffi.lib.vips_hip_error_clear()
+# all-zero numbers, then plausible non-zero numbers (2, 2.0) so that no early "bad factor"
+# error shields a pointer dereference
+for ival, fval in ((0, 0.0), (2, 2.0), (1, 0.5)):
+    for name in sorted(_ffi._SIGNATURES):
+        if ival and name in ("vips_hip_init", "vips_hip_malloc", "vips_hip_malloc_host"):
+            continue  # legitimately act on plain numbers
+        restype, argtypes = _ffi._SIGNATURES[name]
+        args = []
+        for t in argtypes:
+            if t in (ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong):
+                args.append(ival)
+            elif t in (ctypes.c_double, ctypes.c_float):
+                args.append(fval)
+            else:
+                args.append(None)
+        print(name, ival, flush=True)
+        getattr(_ffi.lib, name)(*args)
+        _ffi.lib.vips_hip_error_clear()
 print("ALL-RETURNED", flush=True)
 ''' % helpers.ROOT
     proc = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -216,35 +216,35 @@ def test_fused_reduce_rgba(shrink, size):
 
 @pytest.mark.parametrize("kernel", ["lanczos3"])
 @pytest.mark.parametrize("size", [(4099, 3001), (2048, 1024), (1000, 8), (96, 2600), (9000, 700), (8192, 8197)])
-@pytest.mark.parametrize("wide", [0, 1])
-def test_fused_reduce_mfma_variants(wide, size, kernel):
-    """Both matrix-core kernels on the same inputs: the 256-thread / 2-pixel-per-lane one and the
-    1024-thread / 1-pixel-per-lane wide one (forced either way with VIPS_HIP_MFMA_WIDE), shrink
-    8, sizes with partial tiles on every side, several tiles in both directions, 6 and 7 tap
-    groups (phase 0 and a constant non-zero phase), all edges clamped."""
+@pytest.mark.parametrize("align", [0, 1])
+def test_fused_reduce_mfma_variants(align, size, kernel):
+    """Both tile layouts of the matrix-core kernel on the same inputs: line-aligned tiles (lanes
+    start on the 128-byte line holding the first tap; the default when base and stride allow)
+    and tiles that start at the first tap (VIPS_HIP_FUSED_ALIGN=0: what windows with an odd
+    base get), shrink 8, sizes with partial tiles on every side, several tiles in both
+    directions, 6 and 7 tap groups (phase 0 and a constant non-zero phase), all edges clamped."""
     import os
 
     from libvips_amd import lib
 
     w, h = size
     src = helpers.lcg_image(w, h, 4, np.uint8, 47)
-    os.environ["VIPS_HIP_MFMA_WIDE"] = str(wide)
+    os.environ["VIPS_HIP_FUSED_ALIGN"] = str(align)
     lib.vips_hip_gate_reset()
     lib.vips_hip_gate_enable(1)
     try:
         got = Image.new_from_array(src).reduce(8, 8, kernel=kernel).numpy()
         report = libvips_amd.gate_report()
     finally:
-        del os.environ["VIPS_HIP_MFMA_WIDE"]
+        del os.environ["VIPS_HIP_FUSED_ALIGN"]
         lib.vips_hip_gate_enable(0)
         lib.vips_hip_gate_reset()
-    want_gate = "reduce_fused_u8_mfma_wide" if wide else "reduce_fused_u8_mfma"
-    assert list(report) == [want_gate], report
-    assert_same(got, Port.reduce(src, 8, 8, kernel), str((wide, size, kernel)))
+    assert list(report) == ["reduce_fused_u8_mfma"], report
+    assert_same(got, Port.reduce(src, 8, 8, kernel), str((align, size, kernel)))
 
 
-@pytest.mark.parametrize("wide", [0, 1])
-def test_fused_reduce_region_windows(wide):
+@pytest.mark.parametrize("align", [0, 1])
+def test_fused_reduce_region_windows(align):
     """vips_hip_reduce_gen the way a strip owner (one GPU of several, libvips_amd/sharding.py)
     calls it: an output sub-rect and an input window that only just covers the rows and
     columns vips_hip_reduce{v,h}_need report, at image edges and in the middle; must equal
@@ -256,7 +256,7 @@ def test_fused_reduce_region_windows(wide):
     oh, ow = full.shape[:2]
     rv = _ffi.check_handle(lib.vips_hip_reduce_new(5, 8.0, h, oh, math.nan))
     rh = _ffi.check_handle(lib.vips_hip_reduce_new(5, 8.0, w, ow, math.nan))
-    os.environ["VIPS_HIP_MFMA_WIDE"] = str(wide)
+    os.environ["VIPS_HIP_FUSED_ALIGN"] = str(align)
     try:
         for (left, top, width, height) in ((0, 0, ow, 37), (0, 37, ow, oh - 37), (10, 50, 200, 100),
                                            (ow - 61, oh - 40, 61, 40), (0, 100, 59, 1)):
@@ -274,7 +274,7 @@ def test_fused_reduce_region_windows(wide):
             assert r == 0, (r, _ffi.error_buffer())
             assert np.array_equal(dout.numpy(), full[top:top + height, left:left + width]), (left, top, width, height)
     finally:
-        del os.environ["VIPS_HIP_MFMA_WIDE"]
+        del os.environ["VIPS_HIP_FUSED_ALIGN"]
         lib.vips_hip_reduce_free(rv)
         lib.vips_hip_reduce_free(rh)
 

@@ -16,8 +16,8 @@ import libvips_amd  # noqa: E402
 from bench import lcg_image_device  # noqa: E402
 from libvips_amd import Image, lib  # noqa: E402
 
-KNOBS = ("VIPS_HIP_FUSED_DEBUG", "VIPS_HIP_MFMA_NB", "VIPS_HIP_FUSED_CAP", "VIPS_HIP_NO_MFMA",
-         "VIPS_HIP_MFMA_WIDE", "VIPS_HIP_MFMA_PERSIST")
+KNOBS = ("VIPS_HIP_FUSED_DEBUG", "VIPS_HIP_FUSED_CAP", "VIPS_HIP_NO_MFMA", "VIPS_HIP_FUSED_ALIGN",
+         "VIPS_HIP_FUSED_OWT", "VIPS_HIP_FUSED_V")
 ROUNDS = int(os.environ.get("TUNE_ROUNDS", "5"))
 LAUNCHES = int(os.environ.get("TUNE_LAUNCHES", "15"))
 
