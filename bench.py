@@ -1,25 +1,40 @@
 #!/usr/bin/env python
-"""bench.py -- the BASELINE.json metric: Mpixels/s on the 16k x 16k Lanczos3 reduce.
+"""bench.py -- the BASELINE.json metric (Mpixels/s on the 16k x 16k Lanczos3 reduce) and the
+other BASELINE configurations as parity-checked measurements.
 
-One "step" = one pass of vips_reduce(8, 8, kernel=lanczos3) (BASELINE config 2:
-16384x16384 uchar RGBA -> 2048x2048) over one synthetic image that is already
-resident in HBM when the timed region starts.  Pixels counted are INPUT pixels of
-the first op.
+  python bench.py --gpus 1 --steps K --warmup W [--config c2|c3|c4|c5slab|c5]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ... [--config c2|c4|c5]
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+--config c2 (default): one "step" = one pass of vips_reduce(8, 8, kernel=lanczos3) (BASELINE
+configs[1]: 16384x16384 uchar RGBA -> 2048x2048) over one synthetic image that is already
+resident in HBM when the timed region starts; pixels counted are INPUT pixels of the first op
+(SURVEY.md 8(d)).  The JSON line also carries
 
-N > 1: independent images, one per rank (the batched path of north_star: images
-partition across GPUs, no data-path collective) -> weak scaling; timing is
-barrier + synchronize on both sides, MAX over ranks; value = all ranks' pixels / that.
+  roofline      dominant kernel: algorithmic bytes per launch / mean launch duration, measured
+                with HIP events on the stream the kernel runs on (the library's gates)
+  parity        the timed steps' output compared with the compiled reference (oracle/_ref),
+                after the timed region
+  cpu_baseline  the reference itself (scalar C paths, all host cores) on the same workload
+  configs       C3, C4 and the C5 slab, each run at BASELINE size on this GPU, each with ms per
+                step, algorithmic bytes, fraction of the HBM roofline, per-kernel gate times,
+                a parity check against the compiled reference and a bounded CPU baseline
+                (rank 0, N = 1 only; --no-configs skips them)
 
-Adds to the JSON line:
-  roofline      dominant kernel: algorithmic bytes per launch / mean launch duration,
-                measured with HIP events on the stream the kernel runs on
-  cpu_baseline  the reference itself (oracle/_ref, scalar C paths, all host cores)
-                timed on the same workload on rank 0 at N=1.
+--config c3 | c4 | c5slab | c5 make that configuration the line's own metric:
+  c3      gaussblur(sigma 8) -> colourspace(sRGB -> Lab) on 32768x32768x3 float, one GPU
+  c4      batched thumbnail pipeline resize(1/8) -> sharpen on 8192x8192x3 uchar images
+          generated on the device; N > 1: images round-robin over ranks (libvips_amd.sharding
+          .batch_indices), no data-path collective, weak scaling
+  c5slab  conv 31x31 float mask on one GPU's share of the 65536x65536 ushort image
+          (65536 x 8192 rows + 15-row halos)
+  c5      the whole 65536x65536 image in row strips over the ranks: strip plan -> one halo
+          exchange over RCCL (libvips_amd.sharding.exchange_halos) -> conv on the strip; strong
+          scaling; every rank checks rows of its strip against the reference
+
+N > 1 timing: barrier + synchronize on both sides, MAX over ranks, value = all ranks' pixels / that.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,46 +47,67 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector / matrix peak
+M32 = 0xFFFFFFFF
+_LCG_TABLES = {}
 
 
-def lcg_image_device(torch, width, height, bands, seed, device):
+def _lcg_tables(torch, device):
+    key = str(device)
+    if key not in _LCG_TABLES:
+        B = 1 << 16
+        ak = np.empty(B, dtype=np.uint64)
+        ck = np.empty(B, dtype=np.uint64)
+        aa, cc = 1, 0
+        for k in range(B):
+            aa = (aa * 1664525) & M32
+            cc = (cc * 1664525 + 1013904223) & M32
+            ak[k] = aa
+            ck[k] = cc
+        _LCG_TABLES[key] = (int(ak[-1]), int(ck[-1]), torch.from_numpy(ak.astype(np.int64)).to(device),
+                            torch.from_numpy(ck.astype(np.int64)).to(device))
+    return _LCG_TABLES[key]
+
+
+def lcg_image_device(torch, width, height, bands, seed, device, out=None):
     """The SURVEY.md 8(d) LCG byte stream generated on the device (jump-ahead form):
     s = s*1664525 + 1013904223 mod 2^32, byte = s >> 24.  Bit-identical to
     tests.helpers.lcg_bytes."""
     n = width * height * bands
     B = 1 << 16
-    M = 0xFFFFFFFF
-    ak = np.empty(B, dtype=np.uint64)
-    ck = np.empty(B, dtype=np.uint64)
-    aa, cc = 1, 0
-    for k in range(B):
-        aa = (aa * 1664525) & M
-        cc = (cc * 1664525 + 1013904223) & M
-        ak[k] = aa
-        ck[k] = cc
+    aB, cB, d_ak, d_ck = _lcg_tables(torch, device)
     nblocks = (n + B - 1) // B
     seeds = np.empty(nblocks, dtype=np.uint64)
-    s = seed & M
-    aB, cB = int(ak[-1]), int(ck[-1])
+    s = seed & M32
     for i in range(nblocks):
         seeds[i] = s
-        s = (aB * s + cB) & M
-    d_ak = torch.from_numpy(ak.astype(np.int64)).to(device)
-    d_ck = torch.from_numpy(ck.astype(np.int64)).to(device)
+        s = (aB * s + cB) & M32
     d_seeds = torch.from_numpy(seeds.astype(np.int64)).to(device)
-    out = torch.empty(nblocks * B, dtype=torch.uint8, device=device)
+    flat = torch.empty(nblocks * B, dtype=torch.uint8, device=device)
     chunk = 1024  # blocks per pass: 64 Mi elements of int64 scratch
     for b0 in range(0, nblocks, chunk):
         sd = d_seeds[b0:b0 + chunk]
         # 32x32-bit products overflow int64 only above 2^63; mask keeps the low 32 bits
-        v = (d_ak[None, :] * sd[:, None] + d_ck[None, :]) & M
-        out[b0 * B:(b0 + sd.numel()) * B] = (v >> 24).to(torch.uint8).reshape(-1)
-    return out[:n].reshape(height, width, bands).contiguous()
+        v = (d_ak[None, :] * sd[:, None] + d_ck[None, :]) & M32
+        flat[b0 * B:(b0 + sd.numel()) * B] = (v >> 24).to(torch.uint8).reshape(-1)
+    res = flat[:n].reshape(height, width, bands)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res.contiguous()
+
+
+def file_sha(path):
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except IOError:
+        return None
 
 
 def traffic_for(kernel_name):
-    """HBM bytes per launch for the dominant kernel, from the committed rocprofv3 PMC
-    summary (profiles/traffic.json; PMC passes cannot run inside the timed bench)."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/traffic.json; PMC passes cannot run inside the timed bench).  An entry is only
+    used while the kernel source it was measured on is unchanged (its `source_sha` stamp)."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except (IOError, ValueError):
@@ -79,98 +115,151 @@ def traffic_for(kernel_name):
     keys = [k for k in table if not k.startswith("_") and kernel_name.startswith(k)]
     if not keys:
         return None
-    return table[max(keys, key=len)].get("traffic_bytes")
+    entry = table[max(keys, key=len)]
+    src = entry.get("source")
+    if not src or entry.get("source_sha") != file_sha(os.path.join(ROOT, src)):
+        return None  # stale: the kernel changed since the counters were collected
+    return entry.get("traffic_bytes")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", type=int, default=16384, help="image edge (16384 = BASELINE config 2)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class Ctx(object):
+    """Device, stream, process group."""
 
-    import torch
+    def __init__(self, args):
+        import torch
 
-    import libvips_amd
-    from libvips_amd import Image, lib
+        import libvips_amd
+        from libvips_amd import lib
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+        self.torch = torch
+        self.lib = lib
+        self.vh = libvips_amd
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+            args.gpus = self.world
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device("cuda", self.local_rank)
+        libvips_amd.init(self.local_rank)
+        self.dist = None
+        # BENCH_FORCE_DIST=1 takes the RCCL path with a single rank too (how the N > 1 code is
+        # smoke-tested on a one-GPU box)
+        if self.world > 1 or (os.environ.get("BENCH_FORCE_DIST") and "RANK" in os.environ):
+            import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    libvips_amd.init(local_rank)
-    dist = None
-    # BENCH_FORCE_DIST=1 takes the RCCL path with a single rank too (how the N > 1 code is
-    # smoke-tested on a one-GPU box)
-    if world > 1 or (os.environ.get("BENCH_FORCE_DIST") and "RANK" in os.environ):
-        import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl", device_id=self.device)
+            assert dist.get_world_size() == self.world, "RCCL world size differs from WORLD_SIZE"
+            self.dist = dist
+        # All library work goes to a torch-visible stream so torch.cuda.synchronize and the
+        # barrier bracket exactly the kernels being timed.
+        self.stream = torch.cuda.Stream(device=self.device)
+        lib.vips_hip_set_stream(self.stream.cuda_stream)
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
 
-    # All library work goes to a torch-visible stream so torch.cuda.synchronize and
-    # the barrier bracket exactly the kernels being timed.
-    stream = torch.cuda.Stream(device=device)
-    lib.vips_hip_set_stream(stream.cuda_stream)
+    def timed(self, step, steps, warmup):
+        """warmup untimed steps, then exactly `steps` between fences; MAX over ranks (s)."""
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            out = None
+            for _ in range(warmup):
+                out = step()
+            e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+            self.fence()
+            t0 = time.perf_counter()
+            e0.record(self.stream)  # HIP events on the kernels' own stream, around the timed region
+            for _ in range(steps):
+                out = step()
+            e1.record(self.stream)
+            self.fence()
+            elapsed = time.perf_counter() - t0
+            self.event_ms = e0.elapsed_time(e1)
+        if self.dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, out
+
+    def gates(self, step, n):
+        """Per-kernel launch counts and mean durations (HIP events on the kernels' stream)."""
+        with self.torch.cuda.stream(self.stream):
+            self.lib.vips_hip_gate_reset()
+            self.lib.vips_hip_gate_enable(1)
+            for _ in range(n):
+                step()
+            self.torch.cuda.synchronize()
+            self.lib.vips_hip_gate_enable(0)
+            report = self.vh.gate_report()
+            self.lib.vips_hip_gate_reset()
+        return report
+
+    def trim(self):
+        self.torch.cuda.synchronize()
+        self.torch.cuda.empty_cache()
+        self.lib.vips_hip_pool_trim()
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def kernels_of(report):
+    return {k: {"launches": v[0], "mean_ms": round(v[1] / v[0], 4)} for k, v in report.items()}
+
+
+def ref_or_none():
+    from tests import helpers
+
+    return helpers if helpers.have_ref() else None
+
+
+def same_float(a, b):
+    """Bit-exact, else the largest difference in units in the last place."""
+    if a.shape != b.shape:
+        return False, None
+    ai = np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)
+    bi = np.ascontiguousarray(b, dtype=np.float32).view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai)
+    bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
+    ulp = int(np.abs(ai - bi).max()) if ai.size else 0
+    return ulp == 0, ulp
+
+
+# ------------------------------------------------------------------------------------- C2
+
+def run_c2(ctx, args):
+    torch, lib, vh = ctx.torch, ctx.lib, ctx.vh
+    from libvips_amd import Image
 
     n = args.size
     shrink = 8.0
-    with torch.cuda.stream(stream):
-        src = lcg_image_device(torch, n, n, 4, 12345 + rank, device)
+    with torch.cuda.stream(ctx.stream):
+        src = lcg_image_device(torch, n, n, 4, 12345 + ctx.rank, ctx.device)
     torch.cuda.synchronize()
     im = Image.new_from_tensor(src)
 
     def step():
         return im.reduce(shrink, shrink, kernel="lanczos3")
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    with torch.cuda.stream(stream):
-        out = None
-        for _ in range(args.warmup):
-            out = step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        fence()
-        elapsed = time.perf_counter() - t0
-
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    elapsed, out = ctx.timed(step, args.steps, args.warmup)
+    region_ms = ctx.event_ms / args.steps  # one launch per step: the kernel's average launch duration
     in_pixels = float(n) * n
-    mpix_s = world * in_pixels * args.steps / elapsed / 1e6
+    mpix_s = ctx.world * in_pixels * args.steps / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
 
     # ---- roofline of the dominant kernel: HIP events around every launch, on its stream
     roofline = None
-    with torch.cuda.stream(stream):
-        lib.vips_hip_gate_reset()
-        lib.vips_hip_gate_enable(1)
-        gate_steps = max(3, min(args.steps, 20))
-        for _ in range(gate_steps):
-            out = step()
-        torch.cuda.synchronize()
-        lib.vips_hip_gate_enable(0)
-        report = libvips_amd.gate_report()
-        lib.vips_hip_gate_reset()
+    report = ctx.gates(step, max(3, min(args.steps, 20)))
     oh = ow = int(n / shrink + 0.5)
     # algorithmic bytes per launch (SURVEY.md 8(d): read each input byte once, write each
     # output byte once), per kernel of the pipeline
@@ -181,7 +270,11 @@ def main():
     }
     if report:
         name, (launches, total_ms) = max(report.items(), key=lambda kv: kv[1][1])
-        mean_ms = total_ms / launches
+        isolated_ms = total_ms / launches  # every launch alone between its own pair of events
+        # the fused path is ONE kernel per step, so the events around the timed region give its
+        # average launch duration over exactly the launches that were timed; a multi-kernel
+        # fallback path is priced from its dominant kernel's gate time instead
+        mean_ms = region_ms if len(report) == 1 else isolated_ms
         key = next((k for k in alg_bytes if name.startswith(k)), None)
         if key is not None:
             achieved = alg_bytes[key] / (mean_ms * 1e-3) / 1e9
@@ -194,21 +287,22 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic_for(name),
                 "kernel_ms": round(mean_ms, 4),
+                "kernel_ms_isolated": round(isolated_ms, 4),
                 "algorithmic_bytes": alg_bytes[key],
-                "kernels": {k: {"launches": v[0], "mean_ms": round(v[1] / v[0], 4)} for k, v in report.items()},
+                "kernels": kernels_of(report),
             }
             # also against what this box's HBM delivers -- a device-to-device copy of
             # the same 1 GiB (read + write traffic), timed with events on the same stream
             try:
-                with torch.cuda.stream(stream):
+                with torch.cuda.stream(ctx.stream):
                     dst = torch.empty_like(src)
                     e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
                     dst.copy_(src)
                     best_copy = 1e9
                     for _ in range(5):
-                        e0.record(stream)
+                        e0.record(ctx.stream)
                         dst.copy_(src)
-                        e1.record(stream)
+                        e1.record(ctx.stream)
                         e1.synchronize()
                         best_copy = min(best_copy, e0.elapsed_time(e1))
                     del dst
@@ -217,20 +311,28 @@ def main():
             except Exception:  # the reference rates are a courtesy, never a reason to fail the bench
                 pass
 
-    # ---- CPU baseline: the reference itself on this box's host cores (rank 0, N=1 only)
+    # ---- parity of the timed steps' output + CPU baseline: the reference itself on this box's
+    # host cores (rank 0, N = 1 only)
+    parity = None
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from tests import helpers
+    helpers = ref_or_none()
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
+        from tests import helpers as th
 
         host = src.cpu().numpy()
+        got = out.numpy()
         cores = os.cpu_count() or 1
-        if helpers.have_ref():
-            secs = helpers.Ref.time_chain("reduce:hshrink=8,vshrink=8,kernel=lanczos3", host, repeats=3,
-                                          concurrency=cores)
+        chain = "reduce:hshrink=8,vshrink=8,kernel=lanczos3"
+        if helpers is not None:
+            secs = th.Ref.time_chain(chain, host, repeats=3, concurrency=cores)
+            want = th.Ref.run_chain(chain, host)
+            parity = {"against": "oracle/_ref (compiled reference), whole output",
+                      "bit_exact": bool(got.shape == want.shape and np.array_equal(got, want)),
+                      "checksum": th.checksum(got)}
             cpu_baseline = {
                 "value": round(in_pixels / secs / 1e6, 1),
                 "unit": "Mpixels/s",
-                "cores": helpers.Ref.concurrency(),
+                "cores": th.Ref.concurrency(),
                 "kind": "reference",
                 "sample": "full %dx%dx4 u8 image, vips_reduce(8,8,lanczos3) -> write_to_memory, "
                           "best of 3; libvips 8.19.0 scalar C path (no Highway/ORC)" % (n, n),
@@ -238,8 +340,13 @@ def main():
         else:
             rows = 2048
             t1 = time.perf_counter()
-            helpers.Port.reduce(host[:rows], shrink, shrink, "lanczos3")
+            want = th.Port.reduce(host[:rows], shrink, shrink, "lanczos3")
             secs = time.perf_counter() - t1
+            # rows of the output whose taps all lie in the sample
+            ok_rows = want.shape[0] - 4
+            parity = {"against": "oracle/port, top %d output rows" % ok_rows,
+                      "bit_exact": bool(np.array_equal(got[:ok_rows], want[:ok_rows])),
+                      "checksum": th.checksum(got)}
             cpu_baseline = {
                 "value": round(float(n) * rows / secs / 1e6, 1),
                 "unit": "Mpixels/s",
@@ -247,33 +354,447 @@ def main():
                 "kind": "port",
                 "sample": "top %d rows of the %dx%dx4 image, oracle/port, single thread" % (rows, n, n),
             }
+        if parity and not parity["bit_exact"]:
+            raise SystemExit("bench.py: C2 output differs from the oracle: %r" % (parity,))
+    del im, src, out
+    ctx.trim()
 
-    if rank == 0:
-        line = {
-            "metric": "Mpixels/s, vips_reduce Lanczos3 16384x16384 uchar RGBA -> 2048x2048 (input pixels)",
-            "value": round(mpix_s, 1),
-            "unit": "Mpixels/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic (LCG bytes, seed 12345 + rank, generated on device)",
-            "config": {
-                "workload": "vips_reduce(hshrink=8, vshrink=8, kernel=lanczos3) %dx%dx4 u8 -> %dx%dx4, "
-                            "BASELINE configs[1]" % (n, n, ow, oh),
-                "images_per_step_per_gpu": 1,
-                "partition": "one independent image per GPU, no data-path collective",
-            },
-            "roofline": roofline,
-            "cpu_baseline": cpu_baseline,
-        }
+    return {
+        "metric": "Mpixels/s, vips_reduce Lanczos3 16384x16384 uchar RGBA -> 2048x2048 (input pixels)",
+        "value": round(mpix_s, 1),
+        "unit": "Mpixels/s",
+        "n_gpus": ctx.world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic (LCG bytes, seed 12345 + rank, generated on device)",
+        "config": {
+            "workload": "vips_reduce(hshrink=8, vshrink=8, kernel=lanczos3) %dx%dx4 u8 -> %dx%dx4, "
+                        "BASELINE configs[1]" % (n, n, ow, oh),
+            "images_per_step_per_gpu": 1,
+            "partition": "one independent image per GPU, no data-path collective",
+        },
+        "roofline": roofline,
+        "parity": parity,
+        "cpu_baseline": cpu_baseline,
+    }
+
+
+# ------------------------------------------------------------------------------------- C3
+
+def run_c3(ctx, steps, warmup, verify=True, cpu=True, size=32768):
+    """BASELINE configs[2]: vips_gaussblur(sigma 8) + vips_colourspace(sRGB -> Lab) on
+    size x size x 3 float.  One step = the whole pipeline over the image."""
+    torch = ctx.torch
+    from libvips_amd import Image
+
+    n = size
+    with torch.cuda.stream(ctx.stream):
+        u8 = lcg_image_device(torch, n, n, 3, 12345, ctx.device)
+        src = u8.float()
+        del u8
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    im = Image.new_from_tensor(src, interpretation="srgb")
+
+    def step():
+        return im.gaussblur(8.0).colourspace("lab")
+
+    elapsed, out = ctx.timed(step, steps, warmup)
+    ms = elapsed / steps * 1e3
+    report = ctx.gates(step, 2)
+    alg = 2 * n * n * 12
+    entry = {
+        "name": "c3",
+        "workload": "vips_gaussblur(sigma=8) + vips_colourspace(sRGB->Lab) %dx%dx3 f32, BASELINE configs[2]" % (n, n),
+        "ms": round(ms, 3),
+        "steps": steps,
+        "mpixels_per_s": round(float(n) * n / (ms * 1e-3) / 1e6, 1),
+        "algorithmic_bytes": alg,
+        "bound": "hbm",
+        "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "dtype": "f32 (f64 sums)",
+        "kernels": kernels_of(report),
+    }
+    helpers = ref_or_none()
+    if helpers is not None and (verify or cpu):
+        chain = "gaussblur:sigma=8;colourspace:space=lab"
+        interp = helpers.INTERP["srgb"]
+        halo = 14  # 29-tap mask
+        worst = 0
+        exact = True
+        checked = []
+        rows = 96
+        # strips at the top edge, across the middle (several row segments of the fused kernel)
+        # and at the bottom edge; full width (every column strip of the kernel)
+        for r0 in ((0, n // 2 - rows // 2, n - rows) if verify else ()):
+            i0, i1 = max(r0 - halo, 0), min(r0 + rows + halo, n)
+            host = src[i0:i1].cpu().numpy()
+            want = helpers.Ref.run_chain(chain, host, interp)[r0 - i0:r0 - i0 + rows]
+            got = out.extract_area(0, r0, n, rows).numpy()
+            ok, ulp = same_float(got, want)
+            exact = exact and ok
+            worst = max(worst, ulp if ulp is not None else 1 << 30)
+            checked.append([r0, r0 + rows])
+        if verify:
+            entry["parity"] = {"against": "oracle/_ref (compiled reference)", "rows": checked,
+                               "bit_exact": exact, "max_ulp": worst, "tolerance_ulp": 1}
+            if worst > 1:
+                raise SystemExit("bench.py: C3 output differs from the reference by %d ULP" % worst)
+        if cpu:
+            srows = 512
+            host = src[n // 2:n // 2 + srows].cpu().numpy()
+            secs = helpers.Ref.time_chain(chain, host, repeats=1, interpretation=interp,
+                                          concurrency=os.cpu_count() or 1)
+            entry["cpu_baseline"] = {
+                "value": round(float(n) * srows / secs / 1e6, 1), "unit": "Mpixels/s",
+                "cores": helpers.Ref.concurrency(), "kind": "reference",
+                "sample": "%d rows x %d x 3 f32 of the same image, whole pipeline, one run" % (srows, n)}
+    del im, src, out
+    ctx.trim()
+    return entry
+
+
+# ------------------------------------------------------------------------------------- C4
+
+def run_c4(ctx, steps, warmup, images, verify=True, cpu=True, size=8192):
+    """BASELINE configs[3]: batched thumbnail pipeline.  `images` images per rank of
+    size x size x 3 uchar (sRGB) generated on the device, each through vips_resize(1/8)
+    (= shrinkv 4, reducev 2, shrinkh 4, reduceh 2) -> vips_sharpen() -> sRGB uchar.  One
+    step = the whole per-rank batch."""
+    torch = ctx.torch
+    from libvips_amd import Image, sharding
+
+    n = size
+    total = images * ctx.world
+    mine = sharding.batch_indices(total, ctx.world, ctx.rank)  # round-robin over ranks
+    store = torch.empty((len(mine), n, n, 3), dtype=torch.uint8, device=ctx.device)
+    with torch.cuda.stream(ctx.stream):
+        for k, idx in enumerate(mine):
+            lcg_image_device(torch, n, n, 3, 12345 + idx, ctx.device, out=store[k])
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    ims = [Image.new_from_tensor(store[k], interpretation="srgb") for k in range(len(mine))]
+    outs = [None] * len(ims)
+
+    def step():
+        for k, im in enumerate(ims):
+            outs[k] = im.resize(0.125).sharpen()
+        return outs
+
+    elapsed, _ = ctx.timed(step, steps, warmup)
+    ms = elapsed / steps * 1e3
+    report = ctx.gates(lambda: ims[0].resize(0.125).sharpen(), 8)
+    t = n // 8
+    alg_image = n * n * 3 + t * t * 3
+    alg = alg_image * len(ims)
+    entry = {
+        "name": "c4",
+        "workload": "%d x (vips_resize(1/8) + vips_sharpen on %dx%dx3 u8 sRGB -> %dx%dx3), BASELINE configs[3]"
+                    % (total, n, n, t, t),
+        "images_per_gpu": len(ims),
+        "ms": round(ms, 3),
+        "ms_per_image": round(ms / len(ims), 4),
+        "steps": steps,
+        "images_per_s": round(total / (ms * 1e-3), 1),
+        "mpixels_per_s": round(float(n) * n * total / (ms * 1e-3) / 1e6, 1),
+        "algorithmic_bytes": alg,
+        "bound": "hbm",
+        "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "dtype": "u8",
+        "kernels_per_image": kernels_of(report),
+    }
+    helpers = ref_or_none()
+    if helpers is not None and (verify or cpu):
+        chain = "resize:scale=0.125;sharpen:"
+        interp = helpers.INTERP["srgb"]
+        if verify:
+            checked = []
+            exact = True
+            for k in sorted(set((0, len(ims) - 1))):
+                host = store[k].cpu().numpy()
+                want = helpers.Ref.run_chain(chain, host, interp)
+                got = outs[k].numpy()
+                exact = exact and got.shape == want.shape and bool(np.array_equal(got, want))
+                checked.append(int(mine[k]))
+            entry["parity"] = {"against": "oracle/_ref (compiled reference), whole thumbnails",
+                               "images": checked, "bit_exact": exact}
+            if not exact:
+                raise SystemExit("bench.py: C4 thumbnails differ from the reference")
+        if cpu and ctx.rank == 0:
+            host = store[0].cpu().numpy()
+            secs = helpers.Ref.time_chain(chain, host, repeats=2, interpretation=interp,
+                                          concurrency=os.cpu_count() or 1)
+            entry["cpu_baseline"] = {
+                "value": round(float(n) * n / secs / 1e6, 1), "unit": "Mpixels/s",
+                "images_per_s": round(1.0 / secs, 2),
+                "cores": helpers.Ref.concurrency(), "kind": "reference",
+                "sample": "one %dx%dx3 image through the same pipeline, best of 2" % (n, n)}
+    del ims, outs, store
+    ctx.trim()
+    return entry
+
+
+# ------------------------------------------------------------------------------------- C5
+
+def c5_mask(vh):
+    return vh.gaussmat(5, 0.01, False, "float")  # 31 x 31 doubles (SURVEY.md 8(d))
+
+
+def c5_rows_device(torch, width, row0, rows, device):
+    """Rows [row0, row0 + rows) of the 65536-wide ushort LCG image (seed 12345): the byte
+    stream position of a row is known, so any strip is generated without the rest."""
+    # jump the LCG ahead by row0 * width * 2 bytes
+    skip = row0 * width * 2
+    a, c, s = 1664525, 1013904223, 12345
+    # (a, c)^skip by squaring
+    ra, rc = 1, 0
+    pa, pc = a, c
+    k = skip
+    while k:
+        if k & 1:
+            ra, rc = (pa * ra) & M32, (pa * rc + pc) & M32
+        pa, pc = (pa * pa) & M32, (pa * pc + pc) & M32
+        k >>= 1
+    seed = (ra * s + rc) & M32
+    img = lcg_image_device(torch, width, rows, 2, seed, device)
+    return img.view(torch.uint16).reshape(rows, width, 1)
+
+
+def run_c5slab(ctx, steps, warmup, verify=True, cpu=True, width=65536, rows=8192, im_height=65536):
+    """One GPU's share of BASELINE configs[4]: vips_conv with the 31x31 float mask on rows
+    [top, top + rows) of the width x im_height ushort image, its input window carrying the
+    15-row halos a neighbour would send (libvips_amd.sharding)."""
+    torch, vh = ctx.torch, ctx.vh
+    from libvips_amd import sharding
+
+    mask, scale = c5_mask(vh)
+    plan = sharding.StripPlan(im_height, im_height, im_height // rows, sharding.conv_need(31, im_height))
+    slab = (im_height // rows) // 2  # a slab from the middle: halos on both sides
+    w0, w1 = plan.windows[slab]
+    with torch.cuda.stream(ctx.stream):
+        window = c5_rows_device(torch, width, w0, w1 - w0, ctx.device)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+    def step():
+        return sharding.conv_strip(window, w0, plan, slab, mask, scale=scale, precision="float")
+
+    elapsed, out = ctx.timed(step, steps, warmup)
+    ms = elapsed / steps * 1e3
+    report = ctx.gates(step, 1)
+    o0, o1 = plan.out_bounds[slab]
+    alg = width * (o1 - o0) * (2 + 4)
+    flops = 2.0 * 961 * width * (o1 - o0)
+    entry = {
+        "name": "c5slab",
+        "workload": "vips_conv 31x31 float mask, rows %d..%d of the %dx%d u16 image (+15-row halos) -> f32: "
+                    "one GPU's share of BASELINE configs[4]" % (o0, o1, width, im_height),
+        "ms": round(ms, 3),
+        "steps": steps,
+        "mpixels_per_s": round(float(width) * (o1 - o0) / (ms * 1e-3) / 1e6, 1),
+        "algorithmic_bytes": alg,
+        "bound": "fp64",
+        "tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+        "frac": round(flops / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
+        "frac_hbm": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "dtype": "f64 sums -> f32",
+        "kernels": kernels_of(report),
+    }
+    helpers = ref_or_none()
+    if helpers is not None and (verify or cpu):
+        if verify:
+            worst, exact, checked = 0, True, []
+            nrows = 8
+            for r0 in (o0, (o0 + o1) // 2, o1 - nrows):
+                host = window[r0 - 15 - w0:r0 + nrows + 15 - w0].cpu().numpy()
+                want = helpers.Ref.run_mask("conv", host, mask, scale, 0.0, "precision=float")[15:15 + nrows]
+                got = out[r0 - o0:r0 - o0 + nrows].cpu().numpy()
+                ok, ulp = same_float(got, want)
+                exact = exact and ok
+                worst = max(worst, ulp if ulp is not None else 1 << 30)
+                checked.append([r0, r0 + nrows])
+            entry["parity"] = {"against": "oracle/_ref (compiled reference)", "rows": checked,
+                               "bit_exact": exact, "max_ulp": worst, "tolerance_ulp": 1}
+            if worst > 1:
+                raise SystemExit("bench.py: C5 slab differs from the reference by %d ULP" % worst)
+        if cpu:
+            srows = 64
+            host = window[:srows + 30].cpu().numpy()
+            t1 = time.perf_counter()
+            helpers.Ref.run_mask("conv", host, mask, scale, 0.0, "precision=float")
+            secs = time.perf_counter() - t1
+            entry["cpu_baseline"] = {
+                "value": round(float(width) * (srows + 30) / secs / 1e6, 1), "unit": "Mpixels/s",
+                "cores": helpers.Ref.concurrency(), "kind": "reference",
+                "sample": "%d rows x %d u16 of the same window, one run" % (srows + 30, width)}
+    del window, out
+    ctx.trim()
+    return entry
+
+
+def run_c5(ctx, steps, warmup, verify=True, width=65536, im_height=65536):
+    """BASELINE configs[4] across the ranks: the image is cut into one row strip per rank,
+    every rank generates ITS strip, gets its 15-row halos from its neighbours in one exchange
+    (RCCL send/recv) and convolves its strip; strong scaling.  The halo exchange is inside the
+    timed step."""
+    torch, vh = ctx.torch, ctx.vh
+    from libvips_amd import sharding
+
+    mask, scale = c5_mask(vh)
+    plan = sharding.StripPlan(im_height, im_height, ctx.world, sharding.conv_need(31, im_height))
+    s0, s1 = plan.in_bounds[ctx.rank]  # conv: output rows = input rows
+    with torch.cuda.stream(ctx.stream):
+        strip = c5_rows_device(torch, width, s0, s1 - s0, ctx.device)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+    def step():
+        if ctx.dist is not None:
+            window, w0 = sharding.exchange_halos(strip, plan, ctx.rank, ctx.dist)
+        else:
+            window, w0 = strip, s0
+        return sharding.conv_strip(window, w0, plan, ctx.rank, mask, scale=scale, precision="float")
+
+    elapsed, out = ctx.timed(step, steps, warmup)
+    ms = elapsed / steps * 1e3
+    parity = None
+    helpers = ref_or_none()
+    if verify and helpers is not None:
+        # every rank checks rows at both ends of its strip (the rows that depend on the halos)
+        worst, exact, checked = 0, True, []
+        nrows = 4
+        for r0 in (s0, s1 - nrows):
+            i0, i1 = max(r0 - 15, 0), min(r0 + nrows + 15, im_height)
+            host = c5_rows_device(torch, width, i0, i1 - i0, ctx.device).cpu().numpy()
+            want = helpers.Ref.run_mask("conv", host, mask, scale, 0.0, "precision=float")[r0 - i0:r0 - i0 + nrows]
+            got = out[r0 - s0:r0 - s0 + nrows].cpu().numpy()
+            ok, ulp = same_float(got, want)
+            exact = exact and ok
+            worst = max(worst, ulp if ulp is not None else 1 << 30)
+            checked.append([r0, r0 + nrows])
+        flag = torch.tensor([worst], dtype=torch.int64, device=ctx.device)
+        if ctx.dist is not None:
+            ctx.dist.all_reduce(flag, op=ctx.dist.ReduceOp.MAX)
+        worst = int(flag.item())
+        parity = {"against": "oracle/_ref (compiled reference), first and last %d rows of every rank's strip" % nrows,
+                  "rank0_rows": checked, "max_ulp_all_ranks": worst, "tolerance_ulp": 1}
+        if worst > 1:
+            raise SystemExit("bench.py: C5 strips differ from the reference by %d ULP" % worst)
+    flops = 2.0 * 961 * width * im_height
+    alg = width * im_height * 6
+    line = {
+        "metric": "Mpixels/s, vips_conv 31x31 float mask on %dx%d ushort in row strips over the GPUs" % (width, im_height),
+        "value": round(float(width) * im_height / (ms * 1e-3) / 1e6, 1),
+        "unit": "Mpixels/s",
+        "n_gpus": ctx.world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(ms, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic (LCG ushorts, seed 12345, every rank generates its strip on its device)",
+        "config": {"workload": "vips_conv(31x31 gaussmat sigma 5, precision=float) %dx%dx1 u16 -> f32, "
+                               "BASELINE configs[4]" % (width, im_height),
+                   "partition": "%d row strips, one 15-row halo exchange per step over RCCL send/recv" % ctx.world},
+        "roofline": {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": FP64_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
+                     "traffic": None, "algorithmic_bytes": alg,
+                     "note": "FP64 compute bound (961 taps per pixel); peak = the 78.6 TFLOP/s FP64 rate"},
+        "parity": parity,
+        "cpu_baseline": None,
+    }
+    del strip, out
+    ctx.trim()
+    return line
+
+
+def entry_as_line(entry, ctx, steps, warmup, metric, scaling="weak"):
+    """A configs[] entry promoted to the bench line (--config c3 / c4 / c5slab)."""
+    bound = entry.get("bound", "hbm")
+    ms = entry["ms"]
+    if bound == "hbm":
+        roof = {"bound": "hbm", "achieved": round(entry["algorithmic_bytes"] / (ms * 1e-3) / 1e9, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": entry["frac"], "traffic": None,
+                "algorithmic_bytes": entry["algorithmic_bytes"],
+                "kernels": entry.get("kernels") or entry.get("kernels_per_image")}
+    else:
+        roof = {"bound": "mfma", "achieved": entry["tflops"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": entry["frac"], "traffic": None, "algorithmic_bytes": entry["algorithmic_bytes"],
+                "kernels": entry.get("kernels"),
+                "note": "FP64 compute bound (961 taps per pixel); peak = the 78.6 TFLOP/s FP64 rate"}
+    return {
+        "metric": metric,
+        "value": entry["mpixels_per_s"],
+        "unit": "Mpixels/s",
+        "n_gpus": ctx.world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": ms,
+        "higher_is_better": True,
+        "scaling": scaling,
+        "vs_baseline": None,
+        "dtype": entry["dtype"],
+        "data": "synthetic (LCG bytes, seed 12345 + image index, generated on device)",
+        "config": {k: entry[k] for k in ("workload", "images_per_gpu", "ms_per_image", "images_per_s") if k in entry},
+        "roofline": roof,
+        "parity": entry.get("parity"),
+        "cpu_baseline": entry.get("cpu_baseline"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5slab", "c5"])
+    ap.add_argument("--size", type=int, default=None, help="image edge (default: the BASELINE size of the config)")
+    ap.add_argument("--images", type=int, default=None, help="c4: images per GPU (default 256 at N=1, 128 at N>1: "
+                                                             "1024 images on 8 GPUs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="c2: leave the C3/C4/C5 entries out")
+    ap.add_argument("--no-verify", action="store_true", help="skip the comparisons with the reference")
+    args = ap.parse_args()
+
+    ctx = Ctx(args)
+    verify = not args.no_verify
+    cpu = not args.no_cpu_baseline and ctx.rank == 0 and ctx.world == 1
+    line = None
+    if args.config == "c2":
+        args.size = args.size or 16384
+        line = run_c2(ctx, args)
+        if ctx.rank == 0 and ctx.world == 1 and not args.no_configs and args.size == 16384:
+            k = max(2, min(args.steps, 5))
+            line["configs"] = [
+                run_c3(ctx, k, 2, verify, cpu),
+                run_c4(ctx, max(1, min(args.steps, 3)), 1, args.images or 256, verify, cpu),
+                run_c5slab(ctx, max(1, min(args.steps, 3)), 1, verify, cpu),
+            ]
+    elif args.config == "c3":
+        e = run_c3(ctx, args.steps, args.warmup, verify, cpu, args.size or 32768)
+        line = entry_as_line(e, ctx, args.steps, args.warmup,
+                             "Mpixels/s, vips_gaussblur(sigma 8) + sRGB->Lab on 32768x32768x3 float")
+    elif args.config == "c4":
+        images = args.images or (256 if ctx.world == 1 else 128)
+        e = run_c4(ctx, args.steps, args.warmup, images, verify, cpu, args.size or 8192)
+        line = entry_as_line(e, ctx, args.steps, args.warmup,
+                             "Mpixels/s (input), batched thumbnail pipeline resize(1/8)+sharpen over 8192x8192x3 uchar images")
+    elif args.config == "c5slab":
+        e = run_c5slab(ctx, args.steps, args.warmup, verify, cpu)
+        line = entry_as_line(e, ctx, args.steps, args.warmup,
+                             "Mpixels/s, vips_conv 31x31 float mask on a 65536x8192 ushort slab (+halos)")
+    else:
+        line = run_c5(ctx, args.steps, args.warmup, verify)
+    if ctx.rank == 0:
         print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+    ctx.close()
 
 
 if __name__ == "__main__":

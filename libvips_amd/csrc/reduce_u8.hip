@@ -64,6 +64,8 @@ struct FusedArgs {
 	int in_left, in_top;   // origin of the input window
 	int in_right;          // in_left + window width
 	int pairs;             // MFMA kernel: every tile can fetch whole pixel pairs (see load_rows)
+	int stagger;           // MFMA kernel: groups of phase shift between the 4 blocks of a CU
+	int burst_rows;        // MFMA kernel: staged output rows per burst (a multiple of 8)
 	int im_width, im_height;
 	unsigned char *out;
 	long long out_stride;
@@ -367,9 +369,11 @@ constexpr int MFMA_PLANES_BYTES = MFMA_SLOTS * 4 * MFMA_PLANE;
 constexpr int MFMA_STAGE_PITCH = 60; // dwords per staged output row (owt <= 59)
 constexpr int MFMA_MAX_OHT = 88;     // 4 blocks per CU: (160 KB / 4) - planes - tables
 
-static constexpr size_t mfma_lds_bytes(int oht)
+// stage_rows = rows the stage must hold: a burst leaves as soon as burst_rows are complete, and a
+// horizontal pass completes at most 8 more
+static constexpr size_t mfma_lds_bytes(int stage_rows)
 {
-	return (size_t) MFMA_PLANES_BYTES + 2 * MFMA_TABLE_ENTRIES * 8 + (size_t) oht * MFMA_STAGE_PITCH * 4;
+	return (size_t) MFMA_PLANES_BYTES + 2 * MFMA_TABLE_ENTRIES * 8 + (size_t) stage_rows * MFMA_STAGE_PITCH * 4;
 }
 
 template <int D, bool NT = false, int PROF = 0, bool PAIRS = false>
@@ -560,7 +564,7 @@ struct MfmaStep {
 	{
 		if constexpr (ROT < MFMA_SLOTS) {
 			const int g = g0 + ROT;
-			if (g < ngroups) {
+			if (g >= 0 && g < ngroups) {
 				const bool more = g + NB < ngroups;
 				const int next_row = row0 + dir * S * (g + NB);
 				quad<ROT, 0>(a, px[ROT % NB], acc, lane_a, more, next_row, dir, ca, cb, interior);
@@ -616,9 +620,11 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 	int ca = min(max(col0, lo), hi) - a.in_left;
 	int cb = min(max(col0 + 1, lo), hi) - a.in_left;
 	if (PAIRS) {
-		// see load_rows: pairs are whole, so a lane is inside, left of lo (y = x) or right of hi (x = y)
+		// see load_rows: the pair is fetched from columns clamped to [lo, hi - 1]; a lane whose
+		// first column is left of lo needs pixel lo twice (y = x), one whose second column is
+		// right of hi needs pixel hi twice (x = y); dwordx2 loads only need dword alignment
 		ca = min(max(col0, lo), hi - 1) - a.in_left;
-		cb = col0 < lo ? 1 : (col0 > hi ? 2 : 0);
+		cb = col0 < lo ? 1 : (col0 + 1 > hi ? 2 : 0);
 	}
 	const bool flip = (by & 1) != 0;
 	const int dir = flip ? -1 : 1;
@@ -646,7 +652,14 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 			Step::template load_rows<0, S>(a, px[b], row0 + dir * S * b, dir, ca, cb, interior);
 	__syncthreads();
 
-	for (int g0 = 0; g0 < ngroups; g0 += MFMA_SLOTS) {
+	// The tile's groups are numbered from `off` instead of 0 (ROT = (g + off) mod 8): the blocks
+	// sharing a CU get different offsets, so their horizontal passes -- which issue no loads --
+	// and their output bursts fall at different times instead of all at once (every tile of the
+	// single residency round starts at the same moment and advances at the same rate).
+	const int off = a.stagger ? (((int) blockIdx.x / 256) * a.stagger) & 7 : 0;
+	int flushed = 0; // rows of the tile already written out
+	for (int v0 = 0; v0 < ngroups + off; v0 += MFMA_SLOTS) {
+		const int g0 = v0 - off;
 		Step::template batch<0, NB>(a, px, g0, ngroups, acc, planes, lane_a, t, row0, dir, ca, cb, interior,
 			oh);
 
@@ -674,23 +687,38 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 			const int xo = HSEG_OUT * hseg + 2 * hc;
 			if (row_ok && xo < MFMA_STAGE_PITCH) {
 				const int jj = jlo + hr;
-				unsigned int *srow = stage + (flip ? oh - 1 - jj : jj) * MFMA_STAGE_PITCH + xo;
+				unsigned int *srow = stage + (jj - flushed) * MFMA_STAGE_PITCH + xo;
 				*reinterpret_cast<uint2 *>(srow) = make_uint2(pix[0], pix[1]);
 			}
 		}
 		__syncthreads();
-	}
 
-	// ---- the tile's output, one burst: a wave per row, a lane per pixel
-	if (!(a.debug & 2)) {
-		const int lane = t & 63;
-		for (int row = t >> 6; row < oh; row += FUSED_THREADS / 64) {
-			if (lane < ow) {
+		// ---- output: staged rows leave in bursts of burst_rows (and at the tile's end), a wave
+		// per row, a lane per pixel; the next write into the stage is behind the next barrier
+		const int done = jhi + 1;
+		if ((done - flushed >= a.burst_rows || done == oh) && !(a.debug & 2)) {
+			// 16 lanes per row, 4 pixels (one dwordx4 store, dword aligned) per lane: the burst is
+			// the kernel's tail, so it wants few, wide store instructions
+			const int part = t & 15;
+			for (int r = t >> 4; r < done - flushed; r += FUSED_THREADS / 16) {
+				const int jj = flushed + r;
 				unsigned int *dst = reinterpret_cast<unsigned int *>(
-					a.out + (long long) (y0 + row) * a.out_stride + (long long) x0 * 4);
-				dst[lane] = stage[row * MFMA_STAGE_PITCH + lane];
+					a.out + (long long) (y0 + (flip ? oh - 1 - jj : jj)) * a.out_stride + (long long) x0 * 4);
+				const unsigned int *src = stage + r * MFMA_STAGE_PITCH;
+				if (4 * part + 4 <= ow) {
+					typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+					typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
+					*reinterpret_cast<u32x4_a4 *>(dst + 4 * part) = *reinterpret_cast<const u32x4 *>(src + 4 * part);
+				}
+				else {
+					for (int x = 4 * part; x < ow; x++)
+						dst[x] = src[x];
+				}
 			}
+			flushed = done;
 		}
+		else if (done - flushed >= a.burst_rows || done == oh)
+			flushed = done;
 	}
 }
 
@@ -930,22 +958,20 @@ static int launch_fused_mfma(const FusedArgs &args, int tiles, const MfmaTables 
 {
 	Gate gate("reduce_fused_u8_mfma");
 	const int grid = (tiles + 7) / 8 * 8; // XCD remap wants a multiple of 8
-	const size_t lds = mfma_lds_bytes(args.oht);
+	const int stage_rows = args.burst_rows + 7 < args.oht ? args.burst_rows + 7 : args.oht;
+	const size_t lds = mfma_lds_bytes(stage_rows);
 	if ((args.debug & 24) == 8) // profiling builds: arithmetic only / loads only
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 8>), dim3(grid), dim3(FUSED_THREADS), lds, stream(),
-			args, d_tables);
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 8, true>), dim3(grid), dim3(FUSED_THREADS), lds,
+			stream(), args, d_tables);
 	else if ((args.debug & 24) == 16)
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 16>), dim3(grid), dim3(FUSED_THREADS), lds, stream(),
-			args, d_tables);
-	else if (args.pairs && !(args.debug & 32))
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 16, true>), dim3(grid), dim3(FUSED_THREADS), lds,
+			stream(), args, d_tables);
+	else if (args.debug & 4) // profiling: plain (not nt) loads
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, false, 0, true>), dim3(grid), dim3(FUSED_THREADS), lds,
+			stream(), args, d_tables);
+	else
 		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true>), dim3(grid), dim3(FUSED_THREADS), lds,
 			stream(), args, d_tables);
-	else if (args.debug & 4)
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, false>), dim3(grid), dim3(FUSED_THREADS), lds, stream(),
-			args, d_tables);
-	else
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true>), dim3(grid), dim3(FUSED_THREADS), lds, stream(),
-			args, d_tables);
 	VH_CHECK(hipGetLastError());
 	return 0;
 }
@@ -1373,14 +1399,21 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 	args.fx0 = fx0;
 	args.fy0 = fy0;
 	args.xshift = 0;
-	args.pairs = 0;
+	{
+		// the MFMA kernel's whole-pair loads (load_rows) need two columns to clamp a pair to
+		const int lo = in->left > 0 ? in->left : 0;
+		const int hi1 = in->im_width < in->left + in->width ? in->im_width : in->left + in->width;
+		args.pairs = hi1 - lo >= 2;
+	}
+	args.stagger = 0;
+	args.burst_rows = 1 << 20;
 	args.owt = FUSED_SPAN / S - D + 1;
 	args.tiles_x = (out->width + args.owt - 1) / args.owt;
 
 	_VipsHipReduce *rv = const_cast<_VipsHipReduce *>(reducev);
 	// S = 8: both passes on the matrix cores when the exactness bounds hold
 	// (|c| < 2048 is an exact half, sum |c| * 255 < 2^23 keeps 2n + 1 in 24 bits)
-	if (S == 8 && args.small_window && !getenv("VIPS_HIP_NO_MFMA")) {
+	if (S == 8 && args.small_window && args.pairs && !getenv("VIPS_HIP_NO_MFMA")) {
 		const short *c = &rv->matrixs[(size_t) phase_y * rv->n_point];
 		const short *ch = &reduceh->matrixs[(size_t) phase_x * reduceh->n_point];
 		std::vector<int> taps(8 * D, 0), taps_h(8 * D, 0);
@@ -1410,8 +1443,11 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 				// 2 KB strips at a 1888-byte pitch 5.8 TB/s requested, at a 2048-byte pitch 6.5,
 				// 7.1 with nt loads).  So: tile pitch a whole number of lines (owt a multiple
 				// of 4 -> 32 * owt bytes), lanes start at the line that holds the first tap.
-				const bool no_align = getenv("VIPS_HIP_FUSED_ALIGN") && atoi(getenv("VIPS_HIP_FUSED_ALIGN")) == 0;
-				if (!no_align && !(in->stride & 127)) {
+				// Measured on C2 with whole-pair edge loads: 0.1936 ms aligned (999 tiles of 56
+				// columns: more halo), 0.1902 ms with tiles that start at their first tap (1015
+				// tiles of 59) -- so alignment is opt-in (VIPS_HIP_FUSED_ALIGN=1).
+				const bool align = getenv("VIPS_HIP_FUSED_ALIGN") && atoi(getenv("VIPS_HIP_FUSED_ALIGN")) == 1;
+				if (align && !(in->stride & 127)) {
 					const long long addr = (long long) (uintptr_t) in->data + 4LL * ((long long) fx0 - in->left);
 					const int off = (int) (((addr % 128) + 128) % 128); // bytes past a line start
 					const int owt = ((FUSED_SPAN - off / 4) / S - D + 1) & ~3;
@@ -1436,12 +1472,11 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 				args.oht = oht < 1 ? 1 : oht;
 			}
 			{
-				// whole-pair loads for every tile (load_rows): even tile origins and clamp bounds
-				// relative to an 8-byte aligned window, at least one whole pair to clamp to
-				const int lo = in->left > 0 ? in->left : 0;
-				const int hi1 = in->im_width < in->left + in->width ? in->im_width : in->left + in->width;
-				args.pairs = args.aligned8 && !((fx0 - args.xshift - in->left) & 1) && !((lo - in->left) & 1) &&
-					!((hi1 - in->left) & 1) && hi1 - lo >= 2;
+				const char *e = getenv("VIPS_HIP_FUSED_STAGGER");
+				args.stagger = e ? atoi(e) & 7 : 0;
+				e = getenv("VIPS_HIP_FUSED_BURST");
+				const int burst = e ? atoi(e) : 0;
+				args.burst_rows = burst > 0 ? (burst + 7) & ~7 : MFMA_MAX_OHT + 8;
 			}
 			const int tiles_y = (out->height + args.oht - 1) / args.oht;
 			const int tiles = args.tiles_x * tiles_y;

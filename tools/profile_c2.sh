@@ -5,9 +5,9 @@ tag=$1
 repo=$(pwd)
 out=$repo/gpurun_out
 mkdir -p $out
-python bench.py --steps 50 --warmup 5 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+python bench.py --steps 50 --warmup 5 --no-configs > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 cd /tmp && export TMPDIR=/tmp
-cmd="python $repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+cmd="python $repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs"
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $cmd > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_f -o f -- $cmd > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_w -o w -- $cmd > /dev/null 2>&1
