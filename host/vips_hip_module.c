@@ -24,7 +24,9 @@
  *
  * Host code is C (the reference's language); nothing here knows about HIP.
  */
+#include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vips/vips.h>
@@ -33,51 +35,6 @@
 #include "vips_hip.h"
 
 #define HIP_META "vips-hip-image"
-
-/* ------------------------------------------------------------------ device link */
-
-/* The device-resident twin of a VipsImage, attached to it as a VipsArea. */
-typedef struct _HipLink {
-	VipsHipImage *dev;
-	VipsImage *owner; /* metadata is copied down pipelines: only valid on its owner */
-} HipLink;
-
-static int
-hip_link_free(void *data, void *unused)
-{
-	HipLink *link = (HipLink *) data;
-
-	vips_hip_image_unref(link->dev);
-	g_free(link);
-
-	return 0;
-}
-
-static void
-hip_link_attach(VipsImage *image, VipsHipImage *dev)
-{
-	HipLink *link = g_new(HipLink, 1);
-
-	link->dev = dev;
-	link->owner = image;
-	vips_image_set_area(image, HIP_META, (VipsCallbackFn) hip_link_free, link);
-}
-
-static VipsHipImage *
-hip_link_find(VipsImage *image)
-{
-	const void *data;
-
-	if (vips_image_get_typeof(image, HIP_META) &&
-		!vips_image_get_area(image, HIP_META, &data)) {
-		const HipLink *link = (const HipLink *) data;
-
-		if (link->owner == image)
-			return link->dev;
-	}
-
-	return NULL;
-}
 
 static int
 hip_fail(const char *domain)
@@ -88,7 +45,96 @@ hip_fail(const char *domain)
 	return -1;
 }
 
+/* ------------------------------------------------------------------ device link */
+
+/* How a *_hip operation finds the device-resident result of the *_hip operation that makes
+ * its input: the producer hangs a link on its `out` image as a VipsArea.  libvips copies
+ * metadata down pipelines (and into vips_image_copy_memory() descendants), so a link is only
+ * honoured on the image it was made for, and it names its operation through a GWeakRef: a
+ * link that outlives its operation resolves to NULL instead of to a recycled address.
+ * Nothing is computed to make a link -- `device` is called when (if) a consumer evaluates.
+ */
+typedef VipsHipImage *(*HipDeviceFn)(GObject *producer);
+
+typedef struct _HipLink {
+	GWeakRef producer;  /* the operation that owns the pixels */
+	HipDeviceFn device; /* evaluate (if need be) and return its device image, or NULL */
+	VipsImage *owner;   /* the producer's `out`: the only image this link is valid on */
+} HipLink;
+
+static int
+hip_link_free(void *data, void *unused)
+{
+	HipLink *link = (HipLink *) data;
+
+	g_weak_ref_clear(&link->producer);
+	g_free(link);
+
+	return 0;
+}
+
+static void
+hip_link_attach(VipsImage *image, GObject *producer, HipDeviceFn device)
+{
+	HipLink *link = g_new(HipLink, 1);
+
+	g_weak_ref_init(&link->producer, producer);
+	link->device = device;
+	link->owner = image;
+	vips_image_set_area(image, HIP_META, (VipsCallbackFn) hip_link_free, link);
+}
+
+/* The *_hip operation that makes @image, with a new reference, or NULL. */
+static GObject *
+hip_link_producer(VipsImage *image, HipDeviceFn *device)
+{
+	const void *data;
+
+	if (vips_image_get_typeof(image, HIP_META) &&
+		!vips_image_get_area(image, HIP_META, &data)) {
+		HipLink *link = (HipLink *) data;
+
+		if (link->owner == image) {
+			GObject *producer = g_weak_ref_get(&link->producer);
+
+			if (producer) {
+				*device = link->device;
+				return producer;
+			}
+		}
+	}
+
+	return NULL;
+}
+
 /* ------------------------------------------------------------------ base class */
+
+/* HBM budget (bytes of input + output an operation may hold on the device at once) above
+ * which strip-capable operations work through the image in row strips.
+ * $VIPS_HIP_BUDGET, with an optional k / m / g suffix; default 64 GiB.
+ */
+static guint64
+hip_budget(void)
+{
+	const char *env = g_getenv("VIPS_HIP_BUDGET");
+	guint64 budget = (guint64) 64 << 30;
+
+	if (env && *env) {
+		char *end = NULL;
+		guint64 v = g_ascii_strtoull(env, &end, 10);
+
+		if (end && (*end == 'k' || *end == 'K'))
+			v <<= 10;
+		else if (end && (*end == 'm' || *end == 'M'))
+			v <<= 20;
+		else if (end && (*end == 'g' || *end == 'G'))
+			v <<= 30;
+		if (v > 0)
+			budget = v;
+	}
+
+	return budget;
+}
 
 typedef struct _VipsHipOp {
 	VipsOperation parent_instance;
@@ -96,10 +142,18 @@ typedef struct _VipsHipOp {
 	VipsImage *in;
 	VipsImage *out;
 
-	/* The result: on the device, and (lazily) on the host for generate. */
-	VipsHipImage *result;
-	VipsPel *host;
+	/* build() only records these: no pixel is touched until somebody asks for one
+	 * (iofuncs/generate.c:679-728 stores the callbacks; doc/how-it-works.md:57-80). */
+	VipsImage *ready;       /* `in` after vips_image_decode() */
+	GObject *upstream;      /* the *_hip operation that makes `in`, if one does */
+	HipDeviceFn upstream_device;
+
+	/* Evaluation state, all under `lock`. */
 	GMutex lock;
+	gboolean evaluated;
+	char *eval_error;       /* non-NULL: evaluation failed, with this message */
+	VipsHipImage *result;   /* the result on the device (NULL after a strip-mined run) */
+	VipsPel *host;          /* the result on the host, for generate */
 } VipsHipOp;
 
 typedef struct _VipsHipOpClass {
@@ -107,6 +161,16 @@ typedef struct _VipsHipOpClass {
 
 	/* Run the operation on a device-resident image. */
 	int (*compute)(struct _VipsHipOp *op, VipsHipImage *in, VipsHipImage **out);
+
+	/* Optional: the region-level form, for images over the HBM budget.  strip_open makes the
+	 * plan (returns 1 when this instance cannot be strip-mined, e.g. a reducing gap);
+	 * strip_need maps output rows to the input rows they read; strip_run makes output region
+	 * @out (rows of the whole output image) from input window @in.
+	 */
+	int (*strip_open)(struct _VipsHipOp *op, VipsImage *in, void **plan);
+	void (*strip_need)(struct _VipsHipOp *op, void *plan, int out_top, int out_rows, int *in_top, int *in_rows);
+	int (*strip_run)(struct _VipsHipOp *op, void *plan, const VipsHipRegion *in, const VipsHipRegion *out);
+	void (*strip_close)(struct _VipsHipOp *op, void *plan);
 } VipsHipOpClass;
 
 #define VIPS_TYPE_HIP_OP (vips_hip_op_get_type())
@@ -119,13 +183,6 @@ G_DEFINE_ABSTRACT_TYPE(VipsHipOp, vips_hip_op, VIPS_TYPE_OPERATION);
 static void *
 vips_hip_op_start(VipsImage *out, void *a, void *b)
 {
-	/* NULL selects the library's own per-thread stream; creating it here and dropping it
-	 * in stop matches the sequence contract (one per worker, under image->sslock). */
-	if (vips_hip_set_stream(NULL)) {
-		hip_fail("vips_hip");
-		return NULL;
-	}
-
 	return (void *) out;
 }
 
@@ -133,6 +190,238 @@ static int
 vips_hip_op_stop(void *seq, void *a, void *b)
 {
 	return 0;
+}
+
+static void
+hip_eval_fail(VipsHipOp *op, const char *domain)
+{
+	if (vips_hip_error_buffer()[0])
+		hip_fail(domain);
+	VIPS_FREE(op->eval_error);
+	op->eval_error = g_strdup(vips_error_buffer());
+}
+
+/* Does the result have the header build() promised?  (The promise came from the built-in
+ * operation's own build; a mismatch is a bug in this module, reported, never papered over.) */
+static int
+hip_check_header(VipsHipOp *op, int width, int height, int bands, int format)
+{
+	VipsImage *out = op->out;
+
+	if (width != out->Xsize || height != out->Ysize || bands != out->Bands || format != (int) out->BandFmt) {
+		vips_error(VIPS_OBJECT_GET_CLASS(op)->nickname,
+			"device result is %dx%dx%d format %d, the operation's header says %dx%dx%d format %d",
+			width, height, bands, format, out->Xsize, out->Ysize, out->Bands, (int) out->BandFmt);
+		return -1;
+	}
+
+	return 0;
+}
+
+/* The image in row strips: pull the input rows a strip needs from upstream (a threaded
+ * vips_sink_memory() of a vips_crop()), upload, run the region form, download into the host
+ * result.  Returns 1 when this operation cannot be strip-mined.
+ */
+static int
+hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
+{
+	VipsHipOpClass *hclass = VIPS_HIP_OP_GET_CLASS(op);
+	const char *nick = VIPS_OBJECT_GET_CLASS(op)->nickname;
+	VipsImage *out = op->out;
+	const size_t ls = VIPS_IMAGE_SIZEOF_LINE(out);
+	const size_t in_ls = VIPS_IMAGE_SIZEOF_LINE(in);
+	void *plan = NULL;
+	VipsPel *host;
+	int rows;
+	int result;
+
+	if (!hclass->strip_open || !hclass->strip_need || !hclass->strip_run)
+		return 1;
+	if ((result = hclass->strip_open(op, in, &plan)))
+		return result;
+
+	/* the tallest strip (a multiple of 16 lines: the reference's fat-strip height, which the
+	 * vertical reduce re-seeds its position on) whose input rows + output rows fit */
+	for (rows = VIPS_ROUND_UP(out->Ysize, 16); rows > 16; rows = VIPS_ROUND_UP(rows / 2, 16)) {
+		int in_top, in_rows;
+
+		hclass->strip_need(op, plan, 0, VIPS_MIN(rows, out->Ysize), &in_top, &in_rows);
+		if ((guint64) in_rows * in_ls + (guint64) rows * ls <= budget)
+			break;
+	}
+
+	if (!(host = (VipsPel *) g_try_malloc(ls * out->Ysize))) {
+		vips_error(nick, "%s", "out of memory for the result");
+		if (hclass->strip_close)
+			hclass->strip_close(op, plan);
+		return -1;
+	}
+
+	result = 0;
+	for (int top = 0; top < out->Ysize && !result; top += rows) {
+		const int n = VIPS_MIN(rows, out->Ysize - top);
+		VipsImage *crop = NULL, *mem = NULL;
+		VipsHipImage *dev_in = NULL, *dev_out = NULL;
+		VipsHipRegion ri, ro;
+		int in_top, in_rows;
+
+		hclass->strip_need(op, plan, top, n, &in_top, &in_rows);
+		if (in_top < 0) {
+			in_rows += in_top;
+			in_top = 0;
+		}
+		in_rows = VIPS_MIN(in_rows, in->Ysize - in_top);
+
+		if (vips_image_iskilled(out)) {
+			vips_error(nick, "%s", "killed");
+			result = -1;
+		}
+		else if (vips_crop(in, &crop, 0, in_top, in->Xsize, in_rows, NULL) ||
+			!(mem = vips_image_copy_memory(crop)))
+			result = -1;
+		else if (!(dev_in = vips_hip_image_new_from_memory(VIPS_IMAGE_ADDR(mem, 0, 0),
+					   mem->Xsize, mem->Ysize, mem->Bands, mem->BandFmt, mem->Type)) ||
+			!(dev_out = vips_hip_image_new(out->Xsize, n, out->Bands, out->BandFmt, out->Type)))
+			result = hip_fail(nick);
+		else {
+			vips_hip_image_region(dev_in, &ri);
+			ri.top = in_top;
+			ri.im_width = in->Xsize;
+			ri.im_height = in->Ysize;
+			vips_hip_image_region(dev_out, &ro);
+			ro.top = top;
+			ro.im_width = out->Xsize;
+			ro.im_height = out->Ysize;
+			if (hclass->strip_run(op, plan, &ri, &ro) ||
+				vips_hip_image_write_to_memory(dev_out, host + (size_t) top * ls))
+				result = hip_fail(nick);
+		}
+
+		vips_hip_image_unref(dev_out);
+		vips_hip_image_unref(dev_in);
+		VIPS_UNREF(mem);
+		VIPS_UNREF(crop);
+	}
+
+	if (hclass->strip_close)
+		hclass->strip_close(op, plan);
+	if (result) {
+		g_free(host);
+		return -1;
+	}
+	op->host = host;
+
+	return 0;
+}
+
+/* Evaluate, once.  Called with the lock held, from the first generate or from a downstream
+ * *_hip operation that wants the device image.
+ */
+static void
+hip_eval(VipsHipOp *op)
+{
+	VipsObjectClass *class = VIPS_OBJECT_GET_CLASS(op);
+	VipsHipOpClass *hclass = VIPS_HIP_OP_GET_CLASS(op);
+	VipsImage *in = op->ready;
+	VipsImage *mem = NULL;
+	VipsHipImage *dev = NULL;
+	VipsHipImage *fresh = NULL;
+
+	op->evaluated = TRUE;
+
+	/* NULL selects the library's own per-thread stream for this (worker) thread. */
+	if (vips_hip_set_stream(NULL)) {
+		hip_eval_fail(op, class->nickname);
+		return;
+	}
+
+	/* A device-resident input (made by another *_hip op, evaluated now if it has not been)
+	 * is used as it is ... */
+	if (op->upstream)
+		dev = op->upstream_device(op->upstream);
+
+	if (!dev) {
+		/* ... anything else is pulled from upstream -- in strips when the image is over the
+		 * HBM budget and the operation has a region form, else in one piece -- and uploaded. */
+		const guint64 bytes = (guint64) VIPS_IMAGE_SIZEOF_IMAGE(in) + (guint64) VIPS_IMAGE_SIZEOF_IMAGE(op->out);
+		const guint64 budget = hip_budget();
+
+		if (bytes > budget) {
+			const int r = hip_eval_strips(op, in, budget);
+
+			if (r < 0)
+				hip_eval_fail(op, class->nickname);
+			if (r <= 0)
+				return;
+			/* r == 1: no region form -- try the whole image (fails loudly if HBM runs out) */
+		}
+		if (!(mem = vips_image_copy_memory(in))) {
+			hip_eval_fail(op, class->nickname);
+			return;
+		}
+		if (!(fresh = vips_hip_image_new_from_memory(VIPS_IMAGE_ADDR(mem, 0, 0),
+				  mem->Xsize, mem->Ysize, mem->Bands, mem->BandFmt, mem->Type))) {
+			VIPS_UNREF(mem);
+			hip_eval_fail(op, class->nickname);
+			return;
+		}
+		VIPS_UNREF(mem);
+		dev = fresh;
+	}
+
+	/* The Highway variant of convi on uchar (8-bit mantissas, shared exponent: convi.c:932-1120,
+	 * convi_hwy.cpp) is PARITY UNPINNED -- no Highway build of the reference exists to compare
+	 * with -- so it is never selected silently: only with VIPS_HIP_HWY_CONVI=1 does the module
+	 * follow the host library's vector switch (iofuncs/vector.cpp:98-113).  Otherwise uchar
+	 * convolutions use the C path's exact integer arithmetic (convi.c:698-716), whatever the
+	 * host libvips was built with. */
+	{
+		const char *hwy = g_getenv("VIPS_HIP_HWY_CONVI");
+
+		vips_hip_vector_set_enabled(hwy && atoi(hwy) == 1 && vips_vector_isenabled());
+	}
+
+	/* The kernels are queued on THIS thread's stream; other generates run on other worker
+	 * threads with their own (non-blocking) streams, and a downstream *_hip op may evaluate
+	 * on yet another thread: finish the work before anyone else can see the result, and
+	 * before the uploaded input goes back to the pool. */
+	if (hclass->compute(op, dev, &op->result) ||
+		vips_hip_synchronize()) {
+		if (op->result) {
+			vips_hip_image_unref(op->result);
+			op->result = NULL;
+		}
+		vips_hip_image_unref(fresh);
+		hip_eval_fail(op, class->nickname);
+		return;
+	}
+	vips_hip_image_unref(fresh);
+
+	if (hip_check_header(op, vips_hip_image_get_width(op->result), vips_hip_image_get_height(op->result),
+			vips_hip_image_get_bands(op->result), vips_hip_image_get_format(op->result))) {
+		vips_hip_image_unref(op->result);
+		op->result = NULL;
+		hip_eval_fail(op, class->nickname);
+	}
+}
+
+/* For consumers: the device image (borrowed: it lives as long as the operation), or NULL when
+ * there is none (evaluation failed -- the consumer's own pull of `in` will then report it --
+ * or the result was strip-mined to the host).
+ */
+static VipsHipImage *
+vips_hip_op_device(GObject *producer)
+{
+	VipsHipOp *op = VIPS_HIP_OP(producer);
+	VipsHipImage *result;
+
+	g_mutex_lock(&op->lock);
+	if (!op->evaluated)
+		hip_eval(op);
+	result = op->result;
+	g_mutex_unlock(&op->lock);
+
+	return result;
 }
 
 static int
@@ -147,8 +436,15 @@ vips_hip_op_gen(VipsRegion *out_region, void *seq, void *a, void *b, gboolean *s
 	if (vips_image_iskilled(out))
 		return -1;
 
-	/* First demand: bring the device result to the host, once. */
+	/* First demand: evaluate, then bring the device result to the host, once. */
 	g_mutex_lock(&op->lock);
+	if (!op->evaluated)
+		hip_eval(op);
+	if (op->eval_error) {
+		vips_error(VIPS_OBJECT_GET_CLASS(op)->nickname, "%s", op->eval_error);
+		g_mutex_unlock(&op->lock);
+		return -1;
+	}
 	if (!op->host) {
 		VipsPel *host = VIPS_ARRAY(NULL, ls * out->Ysize, VipsPel);
 
@@ -169,17 +465,82 @@ vips_hip_op_gen(VipsRegion *out_region, void *seq, void *a, void *b, gboolean *s
 	return 0;
 }
 
+/* Copy every assigned input argument of @object to the same-named property of the twin. */
+static void *
+hip_copy_argument(VipsObject *object, GParamSpec *pspec, VipsArgumentClass *argument_class,
+	VipsArgumentInstance *argument_instance, void *a, void *b)
+{
+	GObject *twin = G_OBJECT(a);
+	const char *name = g_param_spec_get_name(pspec);
+
+	if ((argument_class->flags & VIPS_ARGUMENT_INPUT) && argument_instance->assigned &&
+		g_object_class_find_property(G_OBJECT_GET_CLASS(twin), name)) {
+		GValue value = G_VALUE_INIT;
+
+		g_value_init(&value, G_PARAM_SPEC_VALUE_TYPE(pspec));
+		g_object_get_property(G_OBJECT(object), name, &value);
+		g_object_set_property(twin, name, &value);
+		g_value_unset(&value);
+	}
+
+	return NULL;
+}
+
+/* What will `out` look like?  A drop-in has, by definition, the header the original would
+ * produce, and a libvips build() moves no pixels: so build the ORIGINAL operation (the
+ * nickname less "_hip") with the same arguments, copy its output's header, drop it.  Exact by
+ * construction, costs microseconds, and needs no device.
+ */
+static int
+hip_twin_header(VipsHipOp *op, VipsImage *out)
+{
+	const char *nick = VIPS_OBJECT_GET_CLASS(op)->nickname;
+	const size_t len = strlen(nick);
+	char base[64];
+	VipsOperation *twin;
+	VipsImage *twin_out = NULL;
+
+	if (len < 5 || len >= sizeof(base) || strcmp(nick + len - 4, "_hip") != 0) {
+		vips_error(nick, "%s", "not a *_hip nickname");
+		return -1;
+	}
+	memcpy(base, nick, len - 4);
+	base[len - 4] = '\0';
+
+	if (!(twin = vips_operation_new(base)))
+		return -1;
+	vips_argument_map(VIPS_OBJECT(op), hip_copy_argument, twin, NULL);
+	if (vips_object_build(VIPS_OBJECT(twin))) {
+		vips_object_unref_outputs(VIPS_OBJECT(twin));
+		g_object_unref(twin);
+		return -1;
+	}
+	g_object_get(twin, "out", &twin_out, NULL);
+	out->Xsize = twin_out->Xsize;
+	out->Ysize = twin_out->Ysize;
+	out->Bands = twin_out->Bands;
+	out->BandFmt = twin_out->BandFmt;
+	out->Coding = twin_out->Coding;
+	out->Type = twin_out->Type;
+	out->Xres = twin_out->Xres;
+	out->Yres = twin_out->Yres;
+	out->Xoffset = twin_out->Xoffset;
+	out->Yoffset = twin_out->Yoffset;
+	g_object_unref(twin_out);
+	vips_object_unref_outputs(VIPS_OBJECT(twin));
+	g_object_unref(twin);
+
+	return 0;
+}
+
 static int
 vips_hip_op_build(VipsObject *object)
 {
 	VipsObjectClass *class = VIPS_OBJECT_GET_CLASS(object);
 	VipsHipOp *op = VIPS_HIP_OP(object);
-	VipsHipOpClass *hclass = VIPS_HIP_OP_GET_CLASS(op);
 	VipsImage **t = (VipsImage **) vips_object_local_array(object, 2);
 
 	VipsImage *in;
-	VipsHipImage *dev;
-	VipsHipImage *fresh = NULL;
 
 	if (VIPS_OBJECT_CLASS(vips_hip_op_parent_class)->build(object))
 		return -1;
@@ -192,55 +553,23 @@ vips_hip_op_build(VipsObject *object)
 		vips_error(class->nickname, "%s", "complex images are outside the HIP path");
 		return -1;
 	}
+	op->ready = in;
+	op->upstream = hip_link_producer(op->in, &op->upstream_device);
 
-	/* A device-resident input (made by another *_hip op) is used as it is; anything
-	 * else is rendered to memory and uploaded once. */
-	if (!(dev = hip_link_find(op->in))) {
-		if (!(t[1] = vips_image_copy_memory(in)))
-			return -1;
-		if (!(fresh = vips_hip_image_new_from_memory(VIPS_IMAGE_ADDR(t[1], 0, 0),
-				  t[1]->Xsize, t[1]->Ysize, t[1]->Bands, t[1]->BandFmt, t[1]->Type)))
-			return hip_fail(class->nickname);
-		dev = fresh;
-	}
-
-	/* Follow the host library's vector switch (iofuncs/vector.cpp:98-113): in a Highway-built
-	 * libvips this selects the 8-bit-mantissa arithmetic its own convi uses on uchar images,
-	 * so *_hip results keep matching the built-ins; FALSE in a scalar build. */
-	vips_hip_vector_set_enabled(vips_vector_isenabled());
-
-	if (hclass->compute(op, dev, &op->result)) {
-		vips_hip_image_unref(fresh);
-		return hip_fail(class->nickname);
-	}
-	/* The kernels were queued on THIS thread's stream; generate runs on libvips worker
-	 * threads with their own (non-blocking) streams, and a downstream *_hip op may build on
-	 * yet another thread: finish the work before anyone else can see the result, and before
-	 * the uploaded input goes back to the pool. */
-	if (vips_hip_synchronize()) {
-		vips_hip_image_unref(fresh);
-		return hip_fail(class->nickname);
-	}
-	vips_hip_image_unref(fresh);
-
+	/* No pixel work here (iofuncs/generate.c:705-728: a partial image only stores its
+	 * callbacks): the header comes from the original operation's build, the pixels are made
+	 * when the first one is asked for. */
 	g_object_set(object, "out", vips_image_new(), NULL);
-	if (vips_image_pipelinev(op->out, VIPS_DEMAND_STYLE_ANY, in, NULL))
+	if (vips_image_pipelinev(op->out, VIPS_DEMAND_STYLE_ANY, in, NULL) ||
+		hip_twin_header(op, op->out))
 		return -1;
-	op->out->Xsize = vips_hip_image_get_width(op->result);
-	op->out->Ysize = vips_hip_image_get_height(op->result);
-	op->out->Bands = vips_hip_image_get_bands(op->result);
-	op->out->BandFmt = (VipsBandFormat) vips_hip_image_get_format(op->result);
-	op->out->Type = (VipsInterpretation) vips_hip_image_get_interpretation(op->result);
 
 	if (vips_image_generate(op->out,
 			vips_hip_op_start, vips_hip_op_gen, vips_hip_op_stop, in, op))
 		return -1;
 
-	/* Downstream *_hip ops pick the device copy up from here. The link holds its own
-	 * handle on the same pixels. */
-	hip_link_attach(op->out,
-		vips_hip_image_new_from_device(vips_hip_image_get_data(op->result),
-			op->out->Xsize, op->out->Ysize, op->out->Bands, op->out->BandFmt, op->out->Type));
+	/* Downstream *_hip ops reach the device copy through this. */
+	hip_link_attach(op->out, G_OBJECT(op), vips_hip_op_device);
 
 	return 0;
 }
@@ -251,10 +580,12 @@ vips_hip_op_dispose(GObject *gobject)
 	VipsHipOp *op = VIPS_HIP_OP(gobject);
 
 	VIPS_FREE(op->host);
+	VIPS_FREE(op->eval_error);
 	if (op->result) {
 		vips_hip_image_unref(op->result);
 		op->result = NULL;
 	}
+	VIPS_UNREF(op->upstream);
 
 	G_OBJECT_CLASS(vips_hip_op_parent_class)->dispose(gobject);
 }
@@ -287,7 +618,7 @@ vips_hip_op_init(VipsHipOp *op)
 
 /* ------------------------------------------------------------------ subclasses */
 
-#define HIP_SUBCLASS(TypeName, type_name, nick, desc) \
+#define HIP_SUBCLASS_FULL(TypeName, type_name, nick, desc, STRIP_HOOKS) \
 	typedef VipsHipOpClass TypeName##Class; \
 	G_DEFINE_TYPE(TypeName, type_name, VIPS_TYPE_HIP_OP); \
 	static void type_name##_args(TypeName##Class *class); \
@@ -301,8 +632,18 @@ vips_hip_op_init(VipsHipOp *op)
 		vobject_class->nickname = nick; \
 		vobject_class->description = desc; \
 		class->compute = type_name##_compute; \
+		STRIP_HOOKS \
 		type_name##_args(class); \
 	}
+
+#define HIP_SUBCLASS(TypeName, type_name, nick, desc) HIP_SUBCLASS_FULL(TypeName, type_name, nick, desc, )
+
+/* For operations with a region form: images over the HBM budget go through in row strips. */
+#define HIP_STRIPS(type_name) \
+	class->strip_open = type_name##_strip_open; \
+	class->strip_need = type_name##_strip_need; \
+	class->strip_run = type_name##_strip_run; \
+	class->strip_close = type_name##_strip_close;
 
 /* reduce_hip: resample/reduce.c:98-200 */
 typedef struct _VipsReduceHip {
@@ -319,7 +660,83 @@ vips_reduce_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
 	return vips_hip_reduce(in, out, reduce->hshrink, reduce->vshrink, reduce->kernel, reduce->gap);
 }
 
-HIP_SUBCLASS(VipsReduceHip, vips_reduce_hip, "reduce_hip", "reduce an image (MI355X)")
+/* The region form of reduce_hip: the plans the whole-image operation would make
+ * (ops_resample.cpp vips_hip_reduce), run per strip through the generate replacements. */
+typedef struct _ReduceStrip {
+	VipsHipReduce *rv, *rh;
+	int in_width, out_height;
+} ReduceStrip;
+
+static void
+vips_reduce_hip_strip_close(VipsHipOp *op, void *plan)
+{
+	ReduceStrip *p = (ReduceStrip *) plan;
+
+	if (p) {
+		vips_hip_reduce_free(p->rv);
+		vips_hip_reduce_free(p->rh);
+		g_free(p);
+	}
+}
+
+static int
+vips_reduce_hip_strip_open(VipsHipOp *op, VipsImage *in, void **plan)
+{
+	VipsReduceHip *reduce = (VipsReduceHip *) op;
+	ReduceStrip *p;
+
+	/* a reducing gap puts integer pre-shrinks in front; factor 1 is a copy: whole image only */
+	if (reduce->gap > 0.0 || reduce->hshrink == 1.0 || reduce->vshrink == 1.0 ||
+		reduce->kernel == VIPS_KERNEL_NEAREST)
+		return 1;
+	p = g_new0(ReduceStrip, 1);
+	p->in_width = in->Xsize;
+	p->out_height = op->out->Ysize;
+	p->rv = vips_hip_reduce_new(reduce->kernel, reduce->vshrink, in->Ysize, op->out->Ysize, NAN);
+	p->rh = vips_hip_reduce_new(reduce->kernel, reduce->hshrink, in->Xsize, op->out->Xsize, NAN);
+	if (!p->rv || !p->rh) {
+		vips_reduce_hip_strip_close(op, p);
+		return hip_fail("reduce_hip");
+	}
+	*plan = p;
+
+	return 0;
+}
+
+static void
+vips_reduce_hip_strip_need(VipsHipOp *op, void *plan, int out_top, int out_rows, int *in_top, int *in_rows)
+{
+	vips_hip_reducev_need(((ReduceStrip *) plan)->rv, out_top, out_rows, in_top, in_rows);
+}
+
+static int
+vips_reduce_hip_strip_run(VipsHipOp *op, void *plan, const VipsHipRegion *in, const VipsHipRegion *out)
+{
+	ReduceStrip *p = (ReduceStrip *) plan;
+	VipsHipImage *mid;
+	VipsHipRegion rmid;
+	int r;
+
+	/* 16: the fat-strip height the reference's sink evaluates reducev in (thread.c:301-325),
+	 * what the whole-image path uses */
+	if ((r = vips_hip_reduce_gen_tiled(p->rv, p->rh, in, out, 16)) <= 0)
+		return r;
+	/* not the fused uchar RGBA case: the two passes, the rows between them on the device */
+	if (!(mid = vips_hip_image_new(p->in_width, out->height, in->bands, in->format, 0)))
+		return -1;
+	vips_hip_image_region(mid, &rmid);
+	rmid.top = out->top;
+	rmid.im_width = p->in_width;
+	rmid.im_height = p->out_height;
+	r = vips_hip_reducev_gen_tiled(p->rv, in, &rmid, 16) || vips_hip_reduceh_gen(p->rh, &rmid, out);
+	/* the pool orders reuse of mid's block behind these kernels (same thread, same stream) */
+	vips_hip_image_unref(mid);
+
+	return r ? -1 : 0;
+}
+
+HIP_SUBCLASS_FULL(VipsReduceHip, vips_reduce_hip, "reduce_hip", "reduce an image (MI355X)",
+	HIP_STRIPS(vips_reduce_hip))
 
 static void
 vips_reduce_hip_args(VipsReduceHipClass *class)
@@ -642,6 +1059,12 @@ vips_thumbnail_file_hip_gen(VipsRegion *out_region, void *seq, void *a, void *b,
 	return 0;
 }
 
+static VipsHipImage *
+vips_thumbnail_file_hip_device(GObject *producer)
+{
+	return ((VipsThumbnailFileHip *) producer)->result;
+}
+
 static int
 vips_thumbnail_file_hip_build(VipsObject *object)
 {
@@ -666,10 +1089,7 @@ vips_thumbnail_file_hip_build(VipsObject *object)
 		vips_image_generate(thumbnail->out,
 			vips_hip_op_start, vips_thumbnail_file_hip_gen, vips_hip_op_stop, NULL, thumbnail))
 		return -1;
-	hip_link_attach(thumbnail->out,
-		vips_hip_image_new_from_device(vips_hip_image_get_data(thumbnail->result),
-			thumbnail->out->Xsize, thumbnail->out->Ysize, thumbnail->out->Bands,
-			thumbnail->out->BandFmt, thumbnail->out->Type));
+	hip_link_attach(thumbnail->out, G_OBJECT(thumbnail), vips_thumbnail_file_hip_device);
 
 	return 0;
 }
@@ -790,7 +1210,66 @@ vips_convsep_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
 	return vips_conv_hip_run(op, in, out, TRUE);
 }
 
-HIP_SUBCLASS(VipsConvHip, vips_conv_hip, "conv_hip", "convolution operation (MI355X)")
+/* The region form of conv_hip (integer and float precision): one plan, vips_hip_conv_gen per
+ * strip; a strip reads mask_height / 2 rows above and the rest below (convi.c:778-782). */
+typedef struct _ConvStrip {
+	VipsHipConv *conv;
+	int mask_height;
+} ConvStrip;
+
+static void
+vips_conv_hip_strip_close(VipsHipOp *op, void *plan)
+{
+	ConvStrip *p = (ConvStrip *) plan;
+
+	if (p) {
+		vips_hip_conv_free(p->conv);
+		g_free(p);
+	}
+}
+
+static int
+vips_conv_hip_strip_open(VipsHipOp *op, VipsImage *in, void **plan)
+{
+	VipsConvHip *conv = (VipsConvHip *) op;
+	ConvStrip *p;
+	VipsImage *M;
+
+	if (conv->precision == VIPS_PRECISION_APPROXIMATE)
+		return 1;
+	if (vips_check_matrix("conv_hip", conv->mask, &M))
+		return -1;
+	p = g_new0(ConvStrip, 1);
+	p->mask_height = M->Ysize;
+	p->conv = vips_hip_conv_new(VIPS_MATRIX(M, 0, 0), M->Xsize, M->Ysize,
+		vips_image_get_scale(M), vips_image_get_offset(M), conv->precision);
+	g_object_unref(M);
+	if (!p->conv) {
+		g_free(p);
+		return hip_fail("conv_hip");
+	}
+	*plan = p;
+
+	return 0;
+}
+
+static void
+vips_conv_hip_strip_need(VipsHipOp *op, void *plan, int out_top, int out_rows, int *in_top, int *in_rows)
+{
+	const int mask_height = ((ConvStrip *) plan)->mask_height;
+
+	*in_top = out_top - mask_height / 2;
+	*in_rows = out_rows + mask_height - 1;
+}
+
+static int
+vips_conv_hip_strip_run(VipsHipOp *op, void *plan, const VipsHipRegion *in, const VipsHipRegion *out)
+{
+	return vips_hip_conv_gen(((ConvStrip *) plan)->conv, in, out);
+}
+
+HIP_SUBCLASS_FULL(VipsConvHip, vips_conv_hip, "conv_hip", "convolution operation (MI355X)",
+	HIP_STRIPS(vips_conv_hip))
 HIP_SUBCLASS(VipsConvsepHip, vips_convsep_hip, "convsep_hip", "separable convolution operation (MI355X)")
 
 #define CONV_ARGS(class) \

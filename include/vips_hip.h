@@ -129,6 +129,17 @@ VIPS_HIP_API int vips_hip_synchronize(void);
 VIPS_HIP_API void vips_hip_vector_set_enabled(int enabled);
 VIPS_HIP_API int vips_hip_vector_isenabled(void);
 
+/* Float arithmetic mode.  The reference is baseline x86-64 C: a double sum is a chain of
+ * separately rounded multiplies and adds (convolution/convf.c:163-181).  By default the large
+ * float convolutions on integer images (masks 8 or more wide: BASELINE config 5) accumulate
+ * with fused multiply-adds instead -- twice the FP64 rate, and the float result differs from the
+ * reference's by at most 1 ULP (the tolerance BASELINE.json's north_star grants float paths;
+ * measured: a handful of pixels per million).  Enabled (or $VIPS_HIP_EXACT_FLOAT=1 at first use)
+ * every float path reproduces the reference bit for bit.  Integer paths are always exact.
+ */
+VIPS_HIP_API void vips_hip_set_exact_float(int enabled);
+VIPS_HIP_API int vips_hip_get_exact_float(void);
+
 /* Device memory comes from a size-bucketed caching pool (hipMalloc is far too
  * slow to sit in a per-tile path); *_host is pinned staging memory.
  */

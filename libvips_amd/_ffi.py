@@ -160,6 +160,8 @@ _SIGNATURES = {
     "vips_hip_conv_gen": (c_int, [c_void_p, RegionP, RegionP]),
     "vips_hip_vector_set_enabled": (None, [c_int]),
     "vips_hip_vector_isenabled": (c_int, []),
+    "vips_hip_set_exact_float": (None, [c_int]),
+    "vips_hip_get_exact_float": (c_int, []),
     "vips_hip_conva_new": (c_void_p, [P(c_double), c_int, c_int, c_double, c_double, c_int, c_int]),
     "vips_hip_convasep_new": (c_void_p, [P(c_double), c_int, c_double, c_double, c_int]),
     "vips_hip_conva_free": (None, [c_void_p]),

@@ -384,7 +384,7 @@ struct ConvGroupLoad {
 	}
 };
 
-template <typename TIN, int EPP, bool INTERIOR>
+template <typename TIN, int EPP, bool INTERIOR, bool FUSED>
 static __device__ __forceinline__ void convf_grouped_rows(const ConvArgs &a, double (&acc)[CONV_TILE], int b,
 	int gx, int gy, int last, int e_base)
 {
@@ -419,7 +419,8 @@ static __device__ __forceinline__ void convf_grouped_rows(const ConvArgs &a, dou
 			for (int ii = 0; ii < 8; ii++)
 #pragma unroll
 				for (int k = 0; k < T; k++)
-					acc[k] = __dadd_rn(acc[k], __dmul_rn(c0[ii], ii + k < 8 ? g0[ii + k] : g1[ii + k - 8]));
+					acc[k] = FUSED ? __fma_rn(c0[ii], ii + k < 8 ? g0[ii + k] : g1[ii + k - 8], acc[k])
+								   : __dadd_rn(acc[k], __dmul_rn(c0[ii], ii + k < 8 ? g0[ii + k] : g1[ii + k - 8]));
 #pragma unroll
 			for (int m = 0; m < 8; m++)
 				g0[m] = (double) raw[m];
@@ -433,7 +434,8 @@ static __device__ __forceinline__ void convf_grouped_rows(const ConvArgs &a, dou
 			for (int ii = 0; ii < 8; ii++)
 #pragma unroll
 				for (int k = 0; k < T; k++)
-					acc[k] = __dadd_rn(acc[k], __dmul_rn(c1[ii], ii + k < 8 ? g1[ii + k] : g0[ii + k - 8]));
+					acc[k] = FUSED ? __fma_rn(c1[ii], ii + k < 8 ? g1[ii + k] : g0[ii + k - 8], acc[k])
+								   : __dadd_rn(acc[k], __dmul_rn(c1[ii], ii + k < 8 ? g1[ii + k] : g0[ii + k - 8]));
 #pragma unroll
 			for (int m = 0; m < 8; m++)
 				g1[m] = (double) raw[m];
@@ -441,7 +443,10 @@ static __device__ __forceinline__ void convf_grouped_rows(const ConvArgs &a, dou
 	}
 }
 
-template <typename TIN, typename TOUT, int EPP>
+// FUSED: v_fma_f64 instead of v_mul_f64 + v_add_f64 -- one rounding per tap instead of two, twice
+// the DP instruction rate; the float output then differs from the reference's by at most 1 ULP
+// (vips_hip_set_exact_float, include/vips_hip.h).
+template <typename TIN, typename TOUT, int EPP, bool FUSED>
 __global__ void __launch_bounds__(256)
 convf_grouped(ConvArgs a)
 {
@@ -470,9 +475,9 @@ convf_grouped(ConvArgs a)
 	// to 16 elements past the last tap's window.
 	const bool mine = gx >= a.in_left && gx >= 0 && last + 16 < a.in_right && last + 16 < a.im_width;
 	if (__all(mine))
-		convf_grouped_rows<TIN, EPP, true>(a, acc, b, gx, gy, last, e_base);
+		convf_grouped_rows<TIN, EPP, true, FUSED>(a, acc, b, gx, gy, last, e_base);
 	else
-		convf_grouped_rows<TIN, EPP, false>(a, acc, b, gx, gy, last, e_base);
+		convf_grouped_rows<TIN, EPP, false, FUSED>(a, acc, b, gx, gy, last, e_base);
 
 #pragma unroll
 	for (int k = 0; k < T; k++) {
@@ -484,22 +489,175 @@ convf_grouped(ConvArgs a)
 	}
 }
 
+
+// convf on a one-band 8/16-bit image, masks 8..64 wide (BASELINE config 5: 31x31 on ushort):
+// a thread makes 8 x R outputs (8 along x, R rows), a block 2048 x R.  Input rows stream
+// through LDS one at a time (staged once per block with clamped columns, double-buffered, one
+// barrier per row): a thread reads its window for a group of 8 taps as two aligned
+// ds_read_b128 instead of eight scattered global loads, converts it once and uses it for the
+// R output rows the input row belongs to (mask row j = q - i for output row i), so
+// per input row a thread issues ~8 global loads and ~60 converts for up to 256 * R double
+// multiply-adds.  The taps of (mask row, group) are 8 scalar operands fetched a step ahead.
+// Every output still sums its taps in row-major mask order (zero taps multiplied through: exact
+// for integer pixels), so with FUSED = false the result is the reference's bit for bit
+// (convf.c:163-181); FUSED = true uses v_fma_f64 (see convf_grouped).
+constexpr int CONVF_LDS_SPAN = 256 * 8;   // output columns per block
+constexpr int CONVF_LDS_MAXW = 64;        // widest mask
+constexpr int CONVF_LDS_WIN = CONVF_LDS_SPAN + CONVF_LDS_MAXW + 16; // staged elements per row
+
+template <typename TIN, int R, bool FUSED>
+__global__ void __launch_bounds__(256)
+convf_rows_lds(ConvArgs a)
+{
+	constexpr int T = 8;
+	__shared__ __attribute__((aligned(16))) TIN rows[2][CONVF_LDS_WIN];
+	const int t = threadIdx.x;
+	const int bx0 = blockIdx.x * CONVF_LDS_SPAN; // first output column of the block (region coords)
+	const int y0 = blockIdx.y * R;
+	const int gx = a.out_left + bx0 - a.half_w; // image column of staged element 0
+	const int gy = a.out_top + y0 - a.half_h;   // image row of step q = 0
+	const int groups = (a.mask_width + 7) / 8;
+	const int win = CONVF_LDS_SPAN + 8 * groups + 8; // staged elements a row needs (incl. group over-read)
+	const int steps = a.mask_height + R - 1;
+
+	double acc[R][T];
+#pragma unroll
+	for (int i = 0; i < R; i++)
+#pragma unroll
+		for (int k = 0; k < T; k++)
+			acc[i][k] = a.offset;
+
+	// this thread's share of a staged row: elements 8t .. 8t+7, and (t < 16) 2048 + 8t .. + 7
+	int col[8], colx[8];
+#pragma unroll
+	for (int m = 0; m < 8; m++) {
+		col[m] = min(max(gx + 8 * t + m, 0), a.im_width - 1) - a.in_left;
+		colx[m] = min(max(gx + CONVF_LDS_SPAN + 8 * t + m, 0), a.im_width - 1) - a.in_left;
+		// never outside the window (elements past the last tap multiply zero coefficients)
+		col[m] = min(max(col[m], 0), a.in_right - a.in_left - 1);
+		colx[m] = min(max(colx[m], 0), a.in_right - a.in_left - 1);
+	}
+	const bool extra = CONVF_LDS_SPAN + 8 * t < win;
+	TIN stage[8], stagex[8];
+	auto fetch = [&](int q) {
+		const int rr = min(max(gy + q, 0), a.im_height - 1) - a.in_top;
+		const TIN *row = (const TIN *) (a.in + (long long) rr * a.in_stride);
+#pragma unroll
+		for (int m = 0; m < 8; m++)
+			stage[m] = row[col[m]];
+		if (extra) {
+#pragma unroll
+			for (int m = 0; m < 8; m++)
+				stagex[m] = row[colx[m]];
+		}
+	};
+	fetch(0);
+	for (int q = 0; q < steps; q++) {
+		TIN *buf = rows[q & 1];
+#pragma unroll
+		for (int m = 0; m < 8; m++)
+			buf[8 * t + m] = stage[m];
+		if (extra) {
+#pragma unroll
+			for (int m = 0; m < 8; m++)
+				buf[CONVF_LDS_SPAN + 8 * t + m] = stagex[m];
+		}
+		__syncthreads();
+		if (q + 1 < steps)
+			fetch(q + 1);
+		for (int tg = 0; tg < groups; tg++) {
+			// window elements 8t + 8tg .. + 15 (two aligned 16-byte reads for 16-bit pixels)
+			double d[16];
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				d[m] = (double) buf[8 * t + 8 * tg + m];
+#pragma unroll
+			for (int i = 0; i < R; i++) {
+				const int j = q - i; // mask row this input row is for output row i
+				if (j >= 0 && j < a.mask_height) {
+					const double *crow = a.dense8 + (size_t) j * a.np8 + 8 * tg;
+					double c[8];
+#pragma unroll
+					for (int m = 0; m < 8; m++)
+						c[m] = crow[m];
+#pragma unroll
+					for (int ii = 0; ii < 8; ii++)
+#pragma unroll
+						for (int k = 0; k < T; k++)
+							acc[i][k] = FUSED ? __fma_rn(c[ii], d[ii + k], acc[i][k])
+											  : __dadd_rn(acc[i][k], __dmul_rn(c[ii], d[ii + k]));
+				}
+			}
+		}
+	}
+
+#pragma unroll
+	for (int i = 0; i < R; i++) {
+		const int oy = y0 + i;
+		if (oy >= a.out_height)
+			break;
+		float *dst = (float *) (a.out + (long long) oy * a.out_stride) + bx0 + 8 * t;
+#pragma unroll
+		for (int k = 0; k < T; k++)
+			if (bx0 + 8 * t + k < a.out_width)
+				dst[k] = (float) acc[i][k];
+	}
+}
+
+template <typename TIN>
+static int launch_convf_rows_lds(const ConvArgs &a, const char *name)
+{
+	constexpr int R = 4;
+	dim3 grid((a.out_width + CONVF_LDS_SPAN - 1) / CONVF_LDS_SPAN, (a.out_height + R - 1) / R, 1);
+	if (grid.y > 65535)
+		return 1;
+	Gate gate(name);
+	if (vips_hip_get_exact_float())
+		hipLaunchKernelGGL((convf_rows_lds<TIN, R, false>), grid, dim3(256, 1, 1), 0, stream(), a);
+	else
+		hipLaunchKernelGGL((convf_rows_lds<TIN, R, true>), grid, dim3(256, 1, 1), 0, stream(), a);
+	VH_CHECK(hipGetLastError());
+	return 0;
+}
+
 // The tiled kernel wins whenever a thread's TILE outputs share taps; masks that are a
 // single element (or tiny images) keep the general kernel.
 template <typename TIN, typename TOUT, int MODE>
 static int launch_conv_best(const ConvArgs &a, const char *name)
 {
+	if constexpr (MODE == 2 && std::is_integral<TIN>::value && sizeof(TIN) <= 2 && std::is_same<TOUT, float>::value) {
+		// one band, masks 8..64 wide, images wide enough to fill blocks: the LDS row-streaming kernel
+		if (a.epp == 1 && a.mask_width >= 8 && a.mask_width <= CONVF_LDS_MAXW && a.mask_height >= 4 &&
+			a.out_width >= 512 && a.dense8 && !getenv("VIPS_HIP_NO_GROUPED_CONV") && !getenv("VIPS_HIP_NO_LDS_CONV")) {
+			const int r = launch_convf_rows_lds<TIN>(a, name);
+			if (r <= 0)
+				return r;
+		}
+	}
 	if constexpr (MODE == 2 && std::is_integral<TIN>::value) {
 		if (a.mask_width >= 8 && a.out_height <= 65535 && a.dense8 && !getenv("VIPS_HIP_NO_GROUPED_CONV")) {
 			const int ids = ((a.out_width + CONV_TILE - 1) / CONV_TILE) * a.epp;
 			dim3 grid((ids + 255) / 256, a.out_height, 1);
 			Gate gate(name);
-			switch (a.epp) {
-			case 1: hipLaunchKernelGGL((convf_grouped<TIN, TOUT, 1>), grid, dim3(256, 1, 1), 0, stream(), a); break;
-			case 3: hipLaunchKernelGGL((convf_grouped<TIN, TOUT, 3>), grid, dim3(256, 1, 1), 0, stream(), a); break;
-			case 4: hipLaunchKernelGGL((convf_grouped<TIN, TOUT, 4>), grid, dim3(256, 1, 1), 0, stream(), a); break;
-			default: hipLaunchKernelGGL((convf_grouped<TIN, TOUT, 0>), grid, dim3(256, 1, 1), 0, stream(), a); break;
+#define GROUPED(EPP, FUSED) \
+	hipLaunchKernelGGL((convf_grouped<TIN, TOUT, EPP, FUSED>), grid, dim3(256, 1, 1), 0, stream(), a)
+			if (vips_hip_get_exact_float()) {
+				switch (a.epp) {
+				case 1: GROUPED(1, false); break;
+				case 3: GROUPED(3, false); break;
+				case 4: GROUPED(4, false); break;
+				default: GROUPED(0, false); break;
+				}
 			}
+			else {
+				switch (a.epp) {
+				case 1: GROUPED(1, true); break;
+				case 3: GROUPED(3, true); break;
+				case 4: GROUPED(4, true); break;
+				default: GROUPED(0, true); break;
+				}
+			}
+#undef GROUPED
 			VH_CHECK(hipGetLastError());
 			return 0;
 		}

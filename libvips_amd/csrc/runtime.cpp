@@ -414,6 +414,25 @@ int vips_hip_vector_isenabled(void)
 	return g_vector_enabled.load();
 }
 
+// Float arithmetic mode.  -1 = not decided yet (first use reads $VIPS_HIP_EXACT_FLOAT).
+static std::atomic<int> g_exact_float(-1);
+
+void vips_hip_set_exact_float(int enabled)
+{
+	g_exact_float.store(enabled ? 1 : 0);
+}
+
+int vips_hip_get_exact_float(void)
+{
+	int v = g_exact_float.load();
+	if (v < 0) {
+		const char *env = getenv("VIPS_HIP_EXACT_FLOAT");
+		v = env && atoi(env) != 0 ? 1 : 0;
+		g_exact_float.store(v);
+	}
+	return v;
+}
+
 int vips_hip_synchronize(void)
 {
 	if (ensure_init())
@@ -608,6 +627,16 @@ int vips_hip_gate_report(char *buf, int size)
 
 // ------------------------------------------------------------------ images
 
+// width * height * bands * element size must fit comfortably (1 TiB cap): every kernel does
+// its address arithmetic in size_t / long long from these four numbers
+static bool image_bytes_overflow(int width, int height, int bands, int es)
+{
+	long long size = 0;
+	return __builtin_mul_overflow((long long) width, (long long) height, &size) ||
+		__builtin_mul_overflow(size, (long long) bands, &size) ||
+		__builtin_mul_overflow(size, (long long) es, &size) || size > (1LL << 40);
+}
+
 VipsHipImage *vips_hip_image_new(int width, int height, int bands, int format,
 	int interpretation)
 {
@@ -617,6 +646,10 @@ VipsHipImage *vips_hip_image_new(int width, int height, int bands, int format,
 	if (width <= 0 || height <= 0 || bands <= 0 || es == 0) {
 		error("vips_hip_image_new", "bad image parameters %dx%dx%d format %d",
 			width, height, bands, format);
+		return nullptr;
+	}
+	if (image_bytes_overflow(width, height, bands, es)) {
+		error("vips_hip_image_new", "image %dx%dx%d is too large", width, height, bands);
 		return nullptr;
 	}
 	VipsHipImage *im = new VipsHipImage;
@@ -657,6 +690,10 @@ VipsHipImage *vips_hip_image_new_from_device(void *device_data, int width, int h
 	int es = format_sizeof(format);
 	if (!device_data || width <= 0 || height <= 0 || bands <= 0 || es == 0) {
 		error("vips_hip_image_new_from_device", "bad image parameters");
+		return nullptr;
+	}
+	if (image_bytes_overflow(width, height, bands, es)) {
+		error("vips_hip_image_new_from_device", "image %dx%dx%d is too large", width, height, bands);
 		return nullptr;
 	}
 	VipsHipImage *im = new VipsHipImage;

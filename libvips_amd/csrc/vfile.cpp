@@ -108,7 +108,17 @@ int parse_header(const char *path, const unsigned char *h, VipsHipVHeader *out)
 		return -1;
 	}
 	out->data_offset = (long long) HEADER_BYTES;
-	out->data_size = (long long) out->width * out->height * out->bands * format_sizeof(out->format);
+	// The header is untrusted: 1e7 x 1e7 x 1e7 x 16 bytes wraps a long long.  Checked products, and
+	// nothing the device could hold anyway (1 TiB) gets past here.
+	long long size = 0;
+	if (__builtin_mul_overflow((long long) out->width, (long long) out->height, &size) ||
+		__builtin_mul_overflow(size, (long long) out->bands, &size) ||
+		__builtin_mul_overflow(size, (long long) format_sizeof(out->format), &size) ||
+		size <= 0 || size > (1LL << 40)) {
+		error("VipsImage", "image dimensions %d x %d x %d are too large", out->width, out->height, out->bands);
+		return -1;
+	}
+	out->data_size = size;
 	return 0;
 }
 

@@ -314,6 +314,48 @@ ref_time_chain(const char *chain, const RefImage *in, int repeats)
 	return best;
 }
 
+/* Build operation @nick on a width x height x bands uchar vips_black() WITHOUT evaluating it:
+ * the output header and the seconds build took.  What "a libvips build() moves no pixels"
+ * (doc/how-it-works.md:57-80) is checked with, for the built-ins and for the *_hip module.
+ * @header: Xsize, Ysize, Bands, BandFmt, Type.
+ */
+int
+ref_build_probe(const char *nick, int width, int height, int bands, int interpretation, const char *args,
+	int *header, double *seconds)
+{
+	VipsImage *x, *y;
+	GTimer *timer;
+
+	if (ref_init(0))
+		return -1;
+	if (vips_black(&x, width, height, "bands", bands, NULL))
+		return -1;
+	if (interpretation > 0) {
+		if (vips_copy(x, &y, "interpretation", interpretation, NULL)) {
+			g_object_unref(x);
+			return -1;
+		}
+		g_object_unref(x);
+		x = y;
+	}
+	timer = g_timer_new();
+	if (ref_build(nick, "in", x, NULL, NULL, args, "out", &y)) {
+		g_timer_destroy(timer);
+		g_object_unref(x);
+		return -1;
+	}
+	*seconds = g_timer_elapsed(timer, NULL);
+	g_timer_destroy(timer);
+	header[0] = y->Xsize;
+	header[1] = y->Ysize;
+	header[2] = y->Bands;
+	header[3] = y->BandFmt;
+	header[4] = y->Type;
+	g_object_unref(y);
+	g_object_unref(x);
+	return 0;
+}
+
 /* Known-answer helpers from the reference's public colour API
  * (include/vips/colour.h), used to pin the colour port.
  */

@@ -19,3 +19,17 @@ def _built():
     import __graft_entry__
 
     __graft_entry__.build()
+
+
+@pytest.fixture(autouse=True)
+def _exact_float(_built):
+    """The parity suite pins kernels bit for bit, so it runs the library in its exact float mode
+    (every double sum a chain of separately rounded multiplies and adds, as the reference's C);
+    the default mode -- fused multiply-adds in the large float convolutions, at most 1 ULP from
+    the reference -- is covered by the tests that switch it back on themselves
+    (test_conv_colour_gpu.py::test_c5_*_default_mode, bench.py's parity checks, smoke())."""
+    from libvips_amd import lib
+
+    lib.vips_hip_set_exact_float(1)
+    yield
+    lib.vips_hip_set_exact_float(1)

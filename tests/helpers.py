@@ -205,6 +205,20 @@ class Ref(object):
     def concurrency(cls):
         return cls.lib().ref_concurrency()
 
+    @classmethod
+    def build_probe(cls, nick, width, height, bands=4, args="", interpretation=0):
+        """Build (never evaluate) @nick on a black uchar image: ((Xsize, Ysize, Bands, BandFmt,
+        Type), seconds)."""
+        lib = cls.lib()
+        lib.ref_build_probe.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
+        header = (ctypes.c_int * 5)()
+        seconds = ctypes.c_double()
+        if lib.ref_build_probe(nick.encode(), width, height, bands, interpretation, args.encode(), header,
+                               ctypes.byref(seconds)) != 0:
+            cls._fail(nick)
+        return tuple(header), seconds.value
+
     _module_loaded = False
 
     @classmethod

@@ -169,6 +169,39 @@ def test_c5_conv31_reduced():
     assert_same(got, want)
 
 
+def ulp_distance(a, b):
+    """Largest distance between two float32 arrays in units in the last place."""
+    ai = np.ascontiguousarray(a).view(np.int32).astype(np.int64)
+    bi = np.ascontiguousarray(b).view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai)
+    bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
+    return int(np.abs(ai - bi).max())
+
+
+@pytest.mark.parametrize("bands", [1, 3])
+def test_c5_conv31_default_mode(bands):
+    """The library's DEFAULT float mode on BASELINE config 5's kernel: fused multiply-adds in the
+    double sums (twice the FP64 rate).  north_star grants float paths 1 ULP: asserted here against
+    the compiled reference / the port, with the exact mode (bit for bit) right next to it."""
+    src = helpers.lcg_image(900, 400, bands, np.uint16, 66)
+    mask, scale = libvips_amd.gaussmat(5, 0.01, False, "float")
+    lib = _ffi.lib
+    if helpers.have_ref():
+        want = Ref.run_mask("conv", src, mask, scale, 0.0, "precision=float")
+    else:
+        want = PortCC.conv(src, mask, scale, 0.0, "float")
+    assert lib.vips_hip_get_exact_float() == 1
+    exact = Image.new_from_array(src).conv(mask, scale=scale, precision="float").numpy()
+    assert_same(exact, want)
+    lib.vips_hip_set_exact_float(0)
+    try:
+        fast = Image.new_from_array(src).conv(mask, scale=scale, precision="float").numpy()
+    finally:
+        lib.vips_hip_set_exact_float(1)
+    assert fast.dtype == np.float32 and fast.shape == want.shape
+    assert ulp_distance(fast, want) <= 1  # tolerance: 1 ULP (BASELINE.json north_star)
+
+
 @pytest.mark.parametrize("precision", ["integer", "float"])
 @pytest.mark.parametrize("shape", [(700, 300, 3), (1500, 90, 1), (37, 411, 4), (2300, 140, 2), (5, 3, 3)])
 @pytest.mark.parametrize("sigma", [0.6, 2.0, 8.0])

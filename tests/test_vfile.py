@@ -98,6 +98,13 @@ def test_header_errors(tmp_path):
     h = read_header(be)
     assert (h.width, h.height, h.bands, h.msb_first, h.xres, h.xoffset, h.yoffset) == (16, 8, 1, 1, 2.0, 3, 4)
 
+    # a hostile header: 2^23 x 2^23 x 2^14 dpcomplex (16 bytes) wraps a 64-bit byte count to 0 --
+    # refused, instead of passing the length check and describing a 256-byte image
+    huge = str(tmp_path / "huge.v")
+    open(huge, "wb").write(raw[:4] + struct.pack("<iiiii", 1 << 23, 1 << 23, 1 << 14, 128, 9) + raw[24:])
+    with pytest.raises(RuntimeError, match="too large"):
+        read_header(huge)
+
     # unknown interpretation value -> VIPS_INTERPRETATION_ERROR, out-of-range sizes are clipped
     odd = str(tmp_path / "odd.v")
     open(odd, "wb").write(raw[:28] + struct.pack("<i", 14) + raw[32:])
