@@ -774,8 +774,8 @@ def main():
             k = max(2, min(args.steps, 5))
             line["configs"] = [
                 run_c3(ctx, k, 2, verify, cpu),
-                run_c4(ctx, max(1, min(args.steps, 3)), 1, args.images or 256, verify, cpu),
-                run_c5slab(ctx, max(1, min(args.steps, 3)), 1, verify, cpu),
+                run_c4(ctx, max(1, min(args.steps, 3)), 2, args.images or 256, verify, cpu),
+                run_c5slab(ctx, max(2, min(args.steps, 4)), 2, verify, cpu),
             ]
     elif args.config == "c3":
         e = run_c3(ctx, args.steps, args.warmup, verify, cpu, args.size or 32768)
