@@ -567,6 +567,15 @@ VIPS_HIP_API int vips_hip_gaussblur(VipsHipImage *in, VipsHipImage **out,
 VIPS_HIP_API int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out,
 	double sigma, double x1, double y2, double y3, double m1, double m2);
 VIPS_HIP_API int vips_hip_colourspace(VipsHipImage *in, VipsHipImage **out, int space);
+/* vips_gaussblur() then vips_colourspace() (convolution/gaussblur.c:71-116,
+ * colour/colourspace.c:551-612) as one call: on 3-band float images both blur passes and
+ * the colour route run in one streaming kernel and the blurred image never reaches HBM
+ * (BASELINE config 3); other images take the two operations.  Same pixels either way.
+ * The libvips module calls this when a colourspace_hip consumes a gaussblur_hip that nobody
+ * has evaluated yet.
+ */
+VIPS_HIP_API int vips_hip_gaussblur_colourspace(VipsHipImage *in, VipsHipImage **out,
+	double sigma, double min_ampl, int precision, int space);
 VIPS_HIP_API int vips_hip_cast(VipsHipImage *in, VipsHipImage **out, int format);
 /* vips_premultiply / vips_unpremultiply with max_alpha from the interpretation
  * (premultiply.c:246-250) and alpha = the last band. */

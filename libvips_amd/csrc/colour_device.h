@@ -1,0 +1,401 @@
+// Device side of the colour routes, shared by colour.hip (the pointwise route kernels) and
+// convsep_stream.hip (the colourspace epilogue fused behind a separable convolution): the
+// per-pixel steps with the reference's intermediate types and operation order, and the chain
+// for one pixel.  Host side: colour.hip.
+#pragma once
+
+#include "colour.h"
+
+namespace vh {
+
+struct ColourTables {
+	float *v2Y_8;   // 256     sRGB2scRGB, 8 bit    LabQ2sRGB.c:151-159
+	float *v2Y_16;  // 65536
+	int *Y2v_8;     // 257     scRGB2sRGB           LabQ2sRGB.c:134-149
+	int *Y2v_16;    // 65537
+	float *cbrt;    // 100000  XYZ2Lab              XYZ2Lab.c:92-106
+};
+
+// ---------------------------------------------------------------- the steps
+
+struct Px {
+	float a, b, c;
+};
+
+// scRGB2XYZ.c:58-82
+static __device__ __forceinline__ Px step_scRGB2XYZ(Px p)
+{
+	// p * VIPS_D65_Y0: float * double(100.0), rounded to float == float multiply
+	const float R = __fmul_rn(p.a, 100.0f);
+	const float G = __fmul_rn(p.b, 100.0f);
+	const float B = __fmul_rn(p.c, 100.0f);
+	Px q;
+	q.a = __fadd_rn(__fadd_rn(__fmul_rn(0.4124F, R), __fmul_rn(0.3576F, G)), __fmul_rn(0.1805F, B));
+	q.b = __fadd_rn(__fadd_rn(__fmul_rn(0.2126F, R), __fmul_rn(0.7152F, G)), __fmul_rn(0.0722F, B));
+	q.c = __fadd_rn(__fadd_rn(__fmul_rn(0.0193F, R), __fmul_rn(0.1192F, G)), __fmul_rn(0.9505F, B));
+	return q;
+}
+
+// a / y for a compile-time constant y, correctly rounded: q0 = a * RN(1/y), one FMA
+// residual, one FMA correction (Markstein's theorem: with r = RN(1/y) and q0 within an ulp
+// of a/y, RN(q0 + (a - y*q0) * r) = RN(a/y)).  Three DP ops instead of the ~12 of the
+// generic IEEE division expansion; the FMAs are the exact-division device, not a fused
+// version of reference arithmetic.
+static __device__ __forceinline__ double div_const(double a, double y, double r)
+{
+	const double q0 = __dmul_rn(a, r);
+	const double e = __fma_rn(-y, q0, a);
+	const double q1 = __fma_rn(e, r, q0);
+	// an infinite quotient has no finite residual: keep it (the reference gets inf too)
+	return isinf(q0) ? q0 : q1;
+}
+#define DIV_CONST(A, Y) div_const((A), (Y), 1.0 / (Y))
+
+// vips_col_XYZ2Lab_helper, XYZ2Lab.c:109-138 (D65: include/vips/colour.h:58-60)
+template <int WHICH>
+static __device__ __forceinline__ float cbrt_lerp(const float *__restrict__ table, float v)
+{
+	// nX = QUANT_ELEMENTS * X / X0: (int * float) in float, then / double, back to float
+	const double num = (double) __fmul_rn(100000.0f, v);
+	const float n = (float) (WHICH == 0 ? DIV_CONST(num, 95.0470)
+							 : WHICH == 1 ? DIV_CONST(num, 100.0)
+										  : DIV_CONST(num, 108.8827));
+	// VIPS_CLIP(0, (int) nX, QUANT_ELEMENTS - 2); (int) of NaN / overflow is the x86
+	// "integer indefinite" INT_MIN, which the clip turns into 0
+	int i;
+	if (!(n > -2147483904.0f && n < 2147483648.0f))
+		i = INT_MIN;
+	else
+		i = (int) n;
+	i = min(max(i, 0), 100000 - 2);
+	const float f = __fsub_rn(n, (float) i);
+	const float t0 = table[i];
+	return __fadd_rn(t0, __fmul_rn(f, __fsub_rn(table[i + 1], t0)));
+}
+
+static __device__ __forceinline__ Px step_XYZ2Lab(Px p, const float *__restrict__ table)
+{
+	const float cbx = cbrt_lerp<0>(table, p.a);
+	const float cby = cbrt_lerp<1>(table, p.b);
+	const float cbz = cbrt_lerp<2>(table, p.c);
+	Px q;
+	q.a = __fsub_rn(__fmul_rn(116.0F, cby), 16.0F);
+	q.b = __fmul_rn(500.0F, __fsub_rn(cbx, cby));
+	q.c = __fmul_rn(200.0F, __fsub_rn(cby, cbz));
+	return q;
+}
+
+// vips_col_Lab2XYZ_helper, Lab2XYZ.c:84-109 -- double arithmetic
+static __device__ __forceinline__ Px step_Lab2XYZ(Px p)
+{
+	const double X0 = 95.0470, Y0 = 100.0, Z0 = 108.8827;
+	const float L = p.a, a = p.b, b = p.c;
+	double cby, tmp;
+	Px q;
+
+	if (L < 8.0) {
+		q.b = (float) __ddiv_rn(__dmul_rn((double) L, Y0), 903.3);
+		cby = __dadd_rn(__dmul_rn(7.787, __ddiv_rn((double) q.b, Y0)), 16.0 / 116.0);
+	}
+	else {
+		cby = __ddiv_rn(__dadd_rn((double) L, 16.0), 116.0);
+		q.b = (float) __dmul_rn(__dmul_rn(__dmul_rn(Y0, cby), cby), cby);
+	}
+
+	tmp = __dadd_rn(__ddiv_rn((double) a, 500.0), cby);
+	if (tmp < 0.2069)
+		q.a = (float) __ddiv_rn(__dmul_rn(X0, __dsub_rn(tmp, 0.13793)), 7.787);
+	else
+		q.a = (float) __dmul_rn(__dmul_rn(__dmul_rn(X0, tmp), tmp), tmp);
+
+	tmp = __dsub_rn(cby, __ddiv_rn((double) b, 200.0));
+	if (tmp < 0.2069)
+		q.c = (float) __ddiv_rn(__dmul_rn(Z0, __dsub_rn(tmp, 0.13793)), 7.787);
+	else
+		q.c = (float) __dmul_rn(__dmul_rn(__dmul_rn(Z0, tmp), tmp), tmp);
+	return q;
+}
+
+// vips_col_XYZ2scRGB, LabQ2sRGB.c:263-283
+static __device__ __forceinline__ Px step_XYZ2scRGB(Px p)
+{
+	// X /= SCALE with SCALE = VIPS_D65_Y0 (double)
+	const float X = (float) DIV_CONST((double) p.a, 100.0);
+	const float Y = (float) DIV_CONST((double) p.b, 100.0);
+	const float Z = (float) DIV_CONST((double) p.c, 100.0);
+	Px q;
+	q.a = __fadd_rn(__fadd_rn(__fmul_rn(3.240625F, X), __fmul_rn(-1.537208F, Y)), __fmul_rn(-0.498629F, Z));
+	q.b = __fadd_rn(__fadd_rn(__fmul_rn(-0.968931F, X), __fmul_rn(1.875756F, Y)), __fmul_rn(0.041518F, Z));
+	q.c = __fadd_rn(__fadd_rn(__fmul_rn(0.055710F, X), __fmul_rn(-0.204021F, Y)), __fmul_rn(1.056996F, Z));
+	return q;
+}
+
+// one channel of vips_col_scRGB2sRGB, LabQ2sRGB.c:290-360
+static __device__ __forceinline__ int scRGB2sRGB_channel(const int *__restrict__ lut, float v, int maxval)
+{
+	float Yf = __fmul_rn(v, (float) maxval);
+	if (Yf < 0)
+		Yf = 0;
+	else if (Yf > maxval)
+		Yf = maxval;
+	const int Yi = (int) Yf;
+	const int l0 = lut[Yi];
+	const float r =
+		__fadd_rn((float) l0, __fmul_rn((float) (lut[Yi + 1] - l0), __fsub_rn(Yf, (float) Yi)));
+	return (int) rintf(r);
+}
+
+// vips_Lab2LabS_line, Lab2LabS.c:59-73: double multiply, clip, truncate
+static __device__ __forceinline__ short lab2labs(float v, double scale, double lo)
+{
+	double d = __dmul_rn((double) v, scale);
+	d = d > 32767.0 ? 32767.0 : d; // VIPS_MIN(B, V)
+	d = lo > d ? lo : d;           // VIPS_MAX(A, ...)
+	return (short) d;
+}
+
+// ------------------------------------------------------------- pixel IO
+
+// vips_cast semantics (conversion/cast.c:120-330, no shift) from any real format to the
+// format a chain's first step wants, one band element at a time.
+template <typename T>
+static __device__ __forceinline__ int load_as_uchar_like(T v, int maxv)
+{
+	// CAST_INT_INT with TEMP = int: wraps through int first
+	int t = (int) v;
+	return min(max(t, 0), maxv);
+}
+template <>
+__device__ __forceinline__ int load_as_uchar_like<float>(float v, int maxv)
+{
+	// CAST_FLOAT_INT: clip as double, then C truncation
+	double d = (double) v;
+	d = (double) maxv < d ? (double) maxv : d;
+	d = 0.0 > d ? 0.0 : d;
+	return (int) d;
+}
+template <>
+__device__ __forceinline__ int load_as_uchar_like<double>(double v, int maxv)
+{
+	double d = v;
+	d = (double) maxv < d ? (double) maxv : d;
+	d = 0.0 > d ? 0.0 : d;
+	return (int) d;
+}
+
+template <typename T>
+static __device__ __forceinline__ int load_as_short(T v)
+{
+	int t = (int) v;
+	return min(max(t, (int) SHRT_MIN), (int) SHRT_MAX);
+}
+template <>
+__device__ __forceinline__ int load_as_short<float>(float v)
+{
+	double d = (double) v;
+	d = 32767.0 < d ? 32767.0 : d;
+	d = -32768.0 > d ? -32768.0 : d;
+	return (int) d;
+}
+template <>
+__device__ __forceinline__ int load_as_short<double>(double v)
+{
+	double d = v;
+	d = 32767.0 < d ? 32767.0 : d;
+	d = -32768.0 > d ? -32768.0 : d;
+	return (int) d;
+}
+
+struct RouteArgs {
+	const unsigned char *in;
+	unsigned char *out;
+	long long in_stride, out_stride;
+	int width, height;
+	int in_bands, out_bands; // bands per pel in memory (3 colour + extra)
+	int n_steps;
+	int steps[8];
+	int extra_bands;      // bands carried through after the 3 colour bands
+	double alpha_scale;   // max_alpha_after / max_alpha_before (colour.c:257-273), 1.0 = none
+	ColourTables tables;
+};
+
+// Extra bands: [vips_linear1(scale) ->] vips_cast(out format) (colour.c:249-296).
+template <typename TOUT>
+static __device__ __forceinline__ TOUT cast_from_double(double d);
+template <>
+__device__ __forceinline__ unsigned char cast_from_double<unsigned char>(double d)
+{
+	d = 255.0 < d ? 255.0 : d;
+	d = 0.0 > d ? 0.0 : d;
+	return (unsigned char) d;
+}
+template <>
+__device__ __forceinline__ unsigned short cast_from_double<unsigned short>(double d)
+{
+	d = 65535.0 < d ? 65535.0 : d;
+	d = 0.0 > d ? 0.0 : d;
+	return (unsigned short) d;
+}
+template <>
+__device__ __forceinline__ short cast_from_double<short>(double d)
+{
+	d = 32767.0 < d ? 32767.0 : d;
+	d = -32768.0 > d ? -32768.0 : d;
+	return (short) d;
+}
+template <>
+__device__ __forceinline__ float cast_from_double<float>(double d)
+{
+	return (float) d;
+}
+
+template <typename TOUT, typename TIN>
+static __device__ __forceinline__ TOUT cast_int_to(TIN v);
+// CAST_INT_INT through TEMP = int
+#define CAST_INT_TO(TOUT, LO, HI) \
+	template <> \
+	__device__ __forceinline__ TOUT cast_int_to<TOUT, unsigned char>(unsigned char v) \
+	{ \
+		int t = (int) v; \
+		return (TOUT) min(max(t, LO), HI); \
+	} \
+	template <> \
+	__device__ __forceinline__ TOUT cast_int_to<TOUT, unsigned short>(unsigned short v) \
+	{ \
+		int t = (int) v; \
+		return (TOUT) min(max(t, LO), HI); \
+	} \
+	template <> \
+	__device__ __forceinline__ TOUT cast_int_to<TOUT, short>(short v) \
+	{ \
+		int t = (int) v; \
+		return (TOUT) min(max(t, LO), HI); \
+	}
+CAST_INT_TO(unsigned char, 0, 255)
+CAST_INT_TO(unsigned short, 0, 65535)
+CAST_INT_TO(short, -32768, 32767)
+#undef CAST_INT_TO
+
+template <typename TIN, typename TOUT>
+struct Carry {
+	static __device__ __forceinline__ TOUT run(TIN v, double scale)
+	{
+		if (scale != 1.0) {
+			// vips_linear1, LOOP1 (arithmetic/linear.c:213-223): float a1 = a,
+			// q = a1 * (float) p + b1 in float; then vips_cast from float
+			const float f = __fadd_rn(__fmul_rn((float) scale, (float) v), 0.0f);
+			return cast_from_double<TOUT>((double) f);
+		}
+		return cast_from_double<TOUT>((double) v);
+	}
+};
+
+// int -> int carries go through CAST_INT_INT rather than the double clip (same result for
+// the in-range values these formats hold, but keep the reference's path)
+#define CARRY_INT(TIN, TOUT) \
+	template <> \
+	struct Carry<TIN, TOUT> { \
+		static __device__ __forceinline__ TOUT run(TIN v, double scale) \
+		{ \
+			if (scale != 1.0) { \
+				const float f = __fadd_rn(__fmul_rn((float) scale, (float) v), 0.0f); \
+				return cast_from_double<TOUT>((double) f); \
+			} \
+			return cast_int_to<TOUT, TIN>(v); \
+		} \
+	};
+CARRY_INT(unsigned char, unsigned char)
+CARRY_INT(unsigned char, unsigned short)
+CARRY_INT(unsigned char, short)
+CARRY_INT(unsigned short, unsigned char)
+CARRY_INT(unsigned short, unsigned short)
+CARRY_INT(unsigned short, short)
+CARRY_INT(short, unsigned char)
+CARRY_INT(short, unsigned short)
+CARRY_INT(short, short)
+#undef CARRY_INT
+
+// The chain for one pixel: stored bands in, stored bands out.
+template <typename TIN, typename TOUT>
+static __device__ __forceinline__ void route_pixel(const RouteArgs &a, TIN i0, TIN i1, TIN i2,
+	TOUT &o0, TOUT &o1, TOUT &o2)
+{
+	Px v;
+	const int first = a.steps[0];
+	int s = 0;
+	// ---- the first step fixes how the stored bands are interpreted
+	if (first == VIPS_HIP_COLOUR_sRGB2scRGB) {
+		// vips_colour_code_build casts to uchar (colour.c:428-434), sRGB2scRGB.c:72-90
+		v.a = a.tables.v2Y_8[load_as_uchar_like<TIN>(i0, 255)];
+		v.b = a.tables.v2Y_8[load_as_uchar_like<TIN>(i1, 255)];
+		v.c = a.tables.v2Y_8[load_as_uchar_like<TIN>(i2, 255)];
+		s = 1;
+	}
+	else if (first == VIPS_HIP_COLOUR_sRGB2scRGB16) {
+		v.a = a.tables.v2Y_16[load_as_uchar_like<TIN>(i0, 65535)];
+		v.b = a.tables.v2Y_16[load_as_uchar_like<TIN>(i1, 65535)];
+		v.c = a.tables.v2Y_16[load_as_uchar_like<TIN>(i2, 65535)];
+		s = 1;
+	}
+	else if (first == VIPS_HIP_COLOUR_LabS2Lab) {
+		// LabS2Lab.c:55-69 on the vips_cast_short'ed input
+		v.a = (float) __ddiv_rn((double) load_as_short<TIN>(i0), 32767.0 / 100.0);
+		v.b = (float) __ddiv_rn((double) load_as_short<TIN>(i1), 32768.0 / 128.0);
+		v.c = (float) __ddiv_rn((double) load_as_short<TIN>(i2), 32768.0 / 128.0);
+		s = 1;
+	}
+	else {
+		// colour transforms see vips_cast_float'ed input (colour.c:343-348)
+		v.a = (float) i0;
+		v.b = (float) i1;
+		v.c = (float) i2;
+	}
+
+	// ---- float -> float steps
+	int last = -1;
+	for (; s < a.n_steps; s++) {
+		const int st = a.steps[s];
+		if (st == VIPS_HIP_COLOUR_scRGB2XYZ)
+			v = step_scRGB2XYZ(v);
+		else if (st == VIPS_HIP_COLOUR_XYZ2Lab)
+			v = step_XYZ2Lab(v, a.tables.cbrt);
+		else if (st == VIPS_HIP_COLOUR_Lab2XYZ)
+			v = step_Lab2XYZ(v);
+		else if (st == VIPS_HIP_COLOUR_XYZ2scRGB)
+			v = step_XYZ2scRGB(v);
+		else
+			last = st; // a coding step: must be the final one
+	}
+
+	// ---- the last step fixes the stored format
+	if (last == VIPS_HIP_COLOUR_scRGB2sRGB || last == VIPS_HIP_COLOUR_scRGB2sRGB16) {
+		const bool wide = last == VIPS_HIP_COLOUR_scRGB2sRGB16;
+		const int *lut = wide ? a.tables.Y2v_16 : a.tables.Y2v_8;
+		const int maxval = wide ? 65535 : 255;
+		int r = 0, g = 0, b = 0;
+		if (!(isnan(v.a) || isnan(v.b) || isnan(v.c))) {
+			r = scRGB2sRGB_channel(lut, v.a, maxval);
+			g = scRGB2sRGB_channel(lut, v.b, maxval);
+			b = scRGB2sRGB_channel(lut, v.c, maxval);
+		}
+		o0 = (TOUT) r;
+		o1 = (TOUT) g;
+		o2 = (TOUT) b;
+	}
+	else if (last == VIPS_HIP_COLOUR_Lab2LabS) {
+		o0 = (TOUT) lab2labs(v.a, 32767.0 / 100.0, 0.0);
+		o1 = (TOUT) lab2labs(v.b, 32768.0 / 128.0, -32768.0);
+		o2 = (TOUT) lab2labs(v.c, 32768.0 / 128.0, -32768.0);
+	}
+	else {
+		o0 = (TOUT) v.a;
+		o1 = (TOUT) v.b;
+		o2 = (TOUT) v.c;
+	}
+}
+
+// Fill the steps and table pointers of a RouteArgs (tables are built and uploaded on first use);
+// 0 on success.  Defined in colour.hip.
+int colour_route_prepare(const int *steps, int n_steps, RouteArgs *a);
+
+} // namespace vh

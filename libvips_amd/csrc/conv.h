@@ -39,6 +39,12 @@ namespace vh {
 int convsep_f32_fused(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConv *pass1,
 	double offset2);
 
+// convsep_stream.hip: the float cases of the above with the vertical sums in registers, and
+// (route_steps != NULL, 3-band images) the colour route that follows fused behind it: `out`
+// then holds the converted image.  Returns 1 when the case is not covered.
+int convsep_stream_fused(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConv *pass1,
+	double offset2, const int *route_steps, int n_route);
+
 // approx.hip: both passes of a convasep plan through the fused kernel above; 1 when not covered.
 int convasep_fused(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConva *plan);
 

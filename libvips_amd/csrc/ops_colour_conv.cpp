@@ -527,7 +527,9 @@ int vips_hip_convsep(VipsHipImage *in, VipsHipImage **out, const double *mask, i
 		ImageRef o(vips_hip_image_new(in->width, in->height, in->bands, in->format, in->interpretation));
 		if (!o.im)
 			return -1;
-		const int r = vh::convsep_f32_fused(in, o.im, c.get(), 0.0);
+		int r = vh::convsep_stream_fused(in, o.im, c.get(), 0.0, nullptr, 0);
+		if (r == 1)
+			r = vh::convsep_f32_fused(in, o.im, c.get(), 0.0);
 		if (r < 0)
 			return -1;
 		if (r == 0) {
@@ -707,6 +709,57 @@ int vips_hip_colourspace(VipsHipImage *in, VipsHipImage **out, int space)
 	}
 	*out = hold.release();
 	return 0;
+}
+
+// vips_gaussblur() followed by vips_colourspace() (gaussblur.c:71-116, colourspace.c:551-612):
+// BASELINE config 3.  On a 3-band float image whose route has float colour steps only, both
+// convolution passes and the route run in ONE streaming kernel (convsep_stream.hip): the
+// blurred image is never written.  Every other case is the two operations, one after the
+// other.  The pixels are the same either way.
+int vips_hip_gaussblur_colourspace(VipsHipImage *in, VipsHipImage **out, double sigma, double min_ampl,
+	int precision, int space)
+{
+	if (!in || !out) {
+		error("gaussblur", "null argument");
+		return -1;
+	}
+	if (in->format == VIPS_HIP_FORMAT_FLOAT && in->bands == 3 && sigma >= 0.2 &&
+		precision != VIPS_HIP_PRECISION_APPROXIMATE) {
+		const int interpretation = guess_interpretation(in); // gaussblur keeps the interpretation
+		const Route *route = nullptr;
+		for (const Route &r : routes)
+			if (r.from == interpretation && r.to == space) {
+				route = &r;
+				break;
+			}
+		if (route && route->n > 0 && step_out_format(route->steps[route->n - 1]) == VIPS_HIP_FORMAT_FLOAT) {
+			const int width = vips_hip_gaussmat(sigma, min_ampl, 1, precision, nullptr, 0, nullptr);
+			if (width < 0)
+				return -1;
+			std::vector<double> mask(width);
+			double scale = 1.0;
+			if (vips_hip_gaussmat(sigma, min_ampl, 1, precision, mask.data(), width, &scale) < 0)
+				return -1;
+			ConvPtr c = conv_cached(mask.data(), width, 1, scale, 0.0, precision);
+			if (!c)
+				return -1;
+			ImageRef o(vips_hip_image_new(in->width, in->height, 3, VIPS_HIP_FORMAT_FLOAT,
+				step_out_interpretation(route->steps[route->n - 1])));
+			if (!o.im)
+				return -1;
+			const int r = vh::convsep_stream_fused(in, o.im, c.get(), 0.0, route->steps, route->n);
+			if (r < 0)
+				return -1;
+			if (r == 0) {
+				*out = o.release();
+				return 0;
+			}
+		}
+	}
+	ImageRef blurred;
+	if (vips_hip_gaussblur(in, &blurred.im, sigma, min_ampl, precision))
+		return -1;
+	return vips_hip_colourspace(blurred.im, out, space);
 }
 
 // vips_extract_area (conversion/extract.c:137-187): a rectangle of the image, as a new image

@@ -346,6 +346,12 @@ class Image(object):
             lib.vips_hip_sharpen, float(sigma), float(x1), float(y2), float(y3), float(m1), float(m2)
         )
 
+    def gaussblur_colourspace(self, sigma, space, min_ampl=0.2, precision="integer"):
+        """vips_gaussblur() then vips_colourspace(), one kernel where the image allows it
+        (vips_hip_gaussblur_colourspace); the same pixels as ``.gaussblur().colourspace()``."""
+        return self._unary(lib.vips_hip_gaussblur_colourspace, float(sigma), float(min_ampl),
+                           _enum(PRECISIONS, precision, "precision"), _enum(INTERPRETATIONS, space, "space"))
+
     def colourspace(self, space):
         return self._unary(lib.vips_hip_colourspace, _enum(INTERPRETATIONS, space, "interpretation"))
 

@@ -169,6 +169,59 @@ def test_c5_conv31_reduced():
     assert_same(got, want)
 
 
+@pytest.mark.parametrize("precision", ["integer", "float"])
+@pytest.mark.parametrize("shape", [(700, 300), (2300, 140), (37, 411), (256, 64), (5, 3), (1030, 77)])
+@pytest.mark.parametrize("sigma,space", [(8.0, "lab"), (2.0, "xyz"), (0.6, "scrgb"), (3.1, "lab")])
+def test_gaussblur_colourspace_fused(shape, sigma, space, precision):
+    """vips_hip_gaussblur_colourspace (convsep_stream.hip with the colour epilogue: BASELINE
+    config 3 in one kernel) against the same two operations run one after the other on the older
+    kernels, and against the port: several strips wide, several row segments, narrow / tiny
+    images (all four edges clamped), 3..29 taps, both precisions; bit for bit."""
+    w, h = shape
+    src = helpers.lcg_image(w, h, 3, np.float32, 68)
+    src[3 % h, 5 % w] = [300.0, -7.5, 128.25]  # out of the 0..255 range: clipped by the sRGB decode
+    lib = _ffi.lib
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    try:
+        im = Image.new_from_array(src, interpretation="srgb")
+        got = im.gaussblur_colourspace(sigma, space, precision=precision).numpy()
+        report = libvips_amd.gate_report()
+    finally:
+        lib.vips_hip_gate_enable(0)
+        lib.vips_hip_gate_reset()
+    assert any(k.startswith("convsep_stream") and k.endswith("_colour") for k in report) and len(report) == 1, report
+    os.environ["VIPS_HIP_NO_STREAM_CONVSEP"] = "1"
+    try:
+        two_ops = Image.new_from_array(src, interpretation="srgb").gaussblur(sigma, precision=precision).colourspace(space).numpy()
+    finally:
+        del os.environ["VIPS_HIP_NO_STREAM_CONVSEP"]
+    assert got.dtype == np.float32 and got.shape == two_ops.shape
+    assert np.array_equal(got.view(np.int32), two_ops.view(np.int32))
+    want = PortCC.colourspace(PortCC.gaussblur(src, sigma, precision=precision), space, "srgb")
+    assert np.array_equal(got.view(np.int32), want.view(np.int32))
+    # and the unfused call of the new kernel (blur only)
+    blur = Image.new_from_array(src, interpretation="srgb").gaussblur(sigma, precision=precision).numpy()
+    assert np.array_equal(blur.view(np.int32), PortCC.gaussblur(src, sigma, precision=precision).view(np.int32))
+
+
+def test_gaussblur_colourspace_fallbacks():
+    """Images the fused kernel does not take (uchar, 4 bands, a route that ends in a coding
+    step) go through the two operations and give the same pixels as calling them."""
+    u8 = helpers.lcg_image(300, 200, 3, np.uint8, 69)
+    a = Image.new_from_array(u8, interpretation="srgb").gaussblur_colourspace(2.0, "lab").numpy()
+    b = Image.new_from_array(u8, interpretation="srgb").gaussblur(2.0).colourspace("lab").numpy()
+    assert np.array_equal(a.view(np.int32), b.view(np.int32))
+    f4 = helpers.lcg_image(120, 90, 4, np.float32, 70)
+    a = Image.new_from_array(f4, interpretation="srgb").gaussblur_colourspace(2.0, "lab").numpy()
+    b = Image.new_from_array(f4, interpretation="srgb").gaussblur(2.0).colourspace("lab").numpy()
+    assert np.array_equal(a.view(np.int32), b.view(np.int32))
+    f3 = helpers.lcg_image(120, 90, 3, np.float32, 71)
+    a = Image.new_from_array(f3, interpretation="srgb").gaussblur_colourspace(2.0, "labs").numpy()
+    b = Image.new_from_array(f3, interpretation="srgb").gaussblur(2.0).colourspace("labs").numpy()
+    assert a.dtype == np.int16 and np.array_equal(a, b)
+
+
 def ulp_distance(a, b):
     """Largest distance between two float32 arrays in units in the last place."""
     ai = np.ascontiguousarray(a).view(np.int32).astype(np.int64)
@@ -221,7 +274,7 @@ def test_fused_convsep_float(shape, sigma, precision):
     finally:
         lib.vips_hip_gate_enable(0)
         lib.vips_hip_gate_reset()
-    assert any(k.startswith("convsep_f32") for k in report), report
+    assert any(k.startswith("convsep_stream") for k in report), report
     want = PortCC.gaussblur(src, sigma, precision=precision)
     assert got.dtype == np.float32 and np.array_equal(got, want)
     os.environ["VIPS_HIP_NO_FUSED_CONVSEP"] = "1"
