@@ -566,6 +566,16 @@ VIPS_HIP_API int vips_hip_gaussblur(VipsHipImage *in, VipsHipImage **out,
 	double sigma, double min_ampl, int precision);
 VIPS_HIP_API int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out,
 	double sigma, double x1, double y2, double y3, double m1, double m2);
+/* BASELINE config 4: vips_resize(scale, kernel, gap) [then vips_sharpen(sigma, x1, y2, y3, m1,
+ * m2)] on n independent images, as libvips would run n pipelines over its thread pool
+ * (iofuncs/threadpool.c:625): n_threads host threads take images in turn, each on its own
+ * stream, so one image's small kernels overlap another's streaming ones.  sigma < 0: no
+ * sharpen.  Returns the number of images that failed (out[i] NULL); everything is complete
+ * on return.
+ */
+VIPS_HIP_API int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage **out,
+	double scale, int kernel, double gap,
+	double sigma, double x1, double y2, double y3, double m1, double m2, int n_threads);
 VIPS_HIP_API int vips_hip_colourspace(VipsHipImage *in, VipsHipImage **out, int space);
 /* vips_gaussblur() then vips_colourspace() (convolution/gaussblur.c:71-116,
  * colour/colourspace.c:551-612) as one call: on 3-band float images both blur passes and

@@ -6,7 +6,7 @@ mirror used by tests and bench.py.  Importing it requires the built library --
 there is no CPU fallback.
 """
 from ._ffi import VipsHipError, lib, LIB_PATH, HEADER_PATH  # noqa: F401
-from .image import Image, gaussmat, FORMATS, KERNELS, PRECISIONS, INTERPRETATIONS  # noqa: F401
+from .image import Image, gaussmat, resize_sharpen_batch, FORMATS, KERNELS, PRECISIONS, INTERPRETATIONS  # noqa: F401
 
 
 def init(device=0):

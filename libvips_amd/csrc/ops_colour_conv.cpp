@@ -5,6 +5,9 @@
 #include "colour.h"
 #include "conv.h"
 
+#include <atomic>
+#include <thread>
+#include <string>
 #include <cmath>
 #include <cstring>
 #include <list>
@@ -760,6 +763,76 @@ int vips_hip_gaussblur_colourspace(VipsHipImage *in, VipsHipImage **out, double 
 	if (vips_hip_gaussblur(in, &blurred.im, sigma, min_ampl, precision))
 		return -1;
 	return vips_hip_colourspace(blurred.im, out, space);
+}
+
+// BASELINE config 4, the batched thumbnail pipeline: vips_resize(scale) [then vips_sharpen()] on
+// n independent images.  libvips runs such a batch as n pipelines over its thread pool
+// (iofuncs/threadpool.c:625); here n_threads host threads each take the next image, every thread
+// on its own stream: the many small kernels of one image's sharpen stage overlap the two big
+// streaming kernels of the next images' resize instead of each paying its launch latency alone.
+// sigma < 0 skips the sharpen.  Returns the number of images that failed (their outs[] are
+// NULL; the first error message is left in the caller's error buffer); all work is complete
+// on return.
+int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel,
+	double gap, double sigma, double x1, double y2, double y3, double m1, double m2, int n_threads)
+{
+	if (!in || !out || n < 0) {
+		error("resize_sharpen_batch", "null argument");
+		return -1;
+	}
+	if (ensure_init())
+		return -1;
+	if (n_threads < 1)
+		n_threads = 1;
+	if (n_threads > n)
+		n_threads = n;
+	std::atomic<int> next(0), failed(0);
+	std::mutex err_mutex;
+	std::string first_error;
+	auto worker = [&]() {
+		for (;;) {
+			const int i = next.fetch_add(1);
+			if (i >= n)
+				break;
+			out[i] = nullptr;
+			ImageRef small;
+			int r = in[i] ? vips_hip_resize(in[i], &small.im, scale, -1.0, kernel, gap) : -1;
+			if (!r) {
+				if (sigma >= 0.0)
+					r = vips_hip_sharpen(small.im, &out[i], sigma, x1, y2, y3, m1, m2);
+				else
+					out[i] = small.release();
+			}
+			if (r) {
+				out[i] = nullptr;
+				failed.fetch_add(1);
+				std::lock_guard<std::mutex> lock(err_mutex);
+				if (first_error.empty())
+					first_error = in[i] ? vips_hip_error_buffer() : "resize_sharpen_batch: null image\n";
+				vips_hip_error_clear(); // the error buffer is per thread
+			}
+		}
+	};
+	if (n_threads <= 1) {
+		worker();
+		if (vips_hip_synchronize())
+			return -1;
+	}
+	else {
+		std::vector<std::thread> pool;
+		// results cross to the caller's thread: every pool thread finishes its stream (and gives
+		// it back) before it ends
+		for (int t = 0; t < n_threads; t++)
+			pool.emplace_back([&]() {
+				worker();
+				release_thread_stream();
+			});
+		for (std::thread &t : pool)
+			t.join();
+	}
+	if (!first_error.empty())
+		error("resize_sharpen_batch", "%s", first_error.c_str());
+	return failed.load();
 }
 
 // vips_extract_area (conversion/extract.c:137-187): a rectangle of the image, as a new image

@@ -174,11 +174,11 @@ int reduce_axis(VipsHipImage *in, VipsHipImage **out, double shrink, int kernel,
 		if (int_shrink < 1)
 			int_shrink = 1;
 		if (int_shrink > 1) {
+			residual /= int_shrink;
+			extra_pixels /= int_shrink;
 			if (shrink_axis(in, &pre.im, int_shrink, 1, vertical))
 				return -1;
 			cur = pre.im;
-			residual /= int_shrink;
-			extra_pixels /= int_shrink;
 		}
 	}
 

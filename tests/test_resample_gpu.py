@@ -360,3 +360,33 @@ def test_reducev_mfma_any_bands(bands):
         assert "reducev_u8_mfma" in report or bands == 4, report
         assert_same(got_v, Port.reducev(src, 8.0, "lanczos3"), str((bands, w, h)))
         assert_same(got, Port.reduce(src, 8.0, 8.0, "lanczos3"), str((bands, w, h)))
+
+
+@pytest.mark.parametrize("bands", [1, 3, 4])
+@pytest.mark.parametrize("size", [(2048, 1536), (1000, 1203), (4099, 2051), (256, 64), (8192, 520)])
+@pytest.mark.parametrize("scale,kernel", [(0.125, "lanczos3"), (0.1, "lanczos3"), (0.125, "cubic"), (1.0 / 6.0, "lanczos3")])
+def test_resize_uchar_gap_shrinks(bands, size, scale, kernel):
+    """vips_resize on uchar with its default gap (an integer box shrink in front of the residual
+    reduce on both axes): heights that are / are not multiples of the shrink, rows of 16-byte
+    and of odd length, 9 and 13 taps; bit-exact against the port."""
+    w, h = size
+    src = helpers.lcg_image(w, h, bands, np.uint8, 51)
+    got = Image.new_from_array(src).resize(scale, kernel=kernel).numpy()
+    assert_same(got, Port.resize(src, scale, kernel=kernel), str((bands, size, scale, kernel)))
+
+
+def test_resize_sharpen_batch():
+    """vips_hip_resize_sharpen_batch (BASELINE config 4's batch entry point): every image of the
+    batch equals the same pipeline run on it alone; also without the sharpen, and with a failing
+    image in the batch."""
+    srcs = [helpers.lcg_image(1024, 768, 3, np.uint8, 60 + k) for k in range(7)]
+    ims = [Image.new_from_array(s, interpretation="srgb") for s in srcs]
+    outs = libvips_amd.resize_sharpen_batch(ims, 0.125, threads=4)
+    for im, out in zip(ims, outs):
+        assert np.array_equal(out.numpy(), im.resize(0.125).sharpen().numpy())
+    outs = libvips_amd.resize_sharpen_batch(ims, 0.25, sharpen=False, threads=3)
+    for im, out in zip(ims, outs):
+        assert np.array_equal(out.numpy(), im.resize(0.25).numpy())
+    bad = ims[:2] + [Image.new_from_array(helpers.lcg_image(64, 48, 2, np.uint8, 70))] + ims[2:4]
+    with pytest.raises(libvips_amd.VipsHipError):
+        libvips_amd.resize_sharpen_batch(bad, 0.125, threads=2)  # a 2-band image has no route to LabS
