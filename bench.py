@@ -791,11 +791,13 @@ def main():
         line = entry_as_line(e, ctx, args.steps, args.warmup,
                              "Mpixels/s (input), batched thumbnail pipeline resize(1/8)+sharpen over 8192x8192x3 uchar images")
     elif args.config == "c5slab":
-        e = run_c5slab(ctx, args.steps, args.warmup, verify, cpu)
+        size = args.size or 65536
+        e = run_c5slab(ctx, args.steps, args.warmup, verify, cpu, width=size, rows=max(size // 8, 64), im_height=size)
         line = entry_as_line(e, ctx, args.steps, args.warmup,
                              "Mpixels/s, vips_conv 31x31 float mask on a 65536x8192 ushort slab (+halos)")
     else:
-        line = run_c5(ctx, args.steps, args.warmup, verify)
+        size = args.size or 65536
+        line = run_c5(ctx, args.steps, args.warmup, verify, width=size, im_height=size)
     if ctx.rank == 0:
         print(json.dumps(line))
     ctx.close()

@@ -171,6 +171,12 @@ typedef struct _VipsHipOpClass {
 	void (*strip_need)(struct _VipsHipOp *op, void *plan, int out_top, int out_rows, int *in_top, int *in_rows);
 	int (*strip_run)(struct _VipsHipOp *op, void *plan, const VipsHipRegion *in, const VipsHipRegion *out);
 	void (*strip_close)(struct _VipsHipOp *op, void *plan);
+
+	/* Optional: this operation and the not-yet-evaluated *_hip operation that makes its input
+	 * as ONE device call (colourspace_hip after gaussblur_hip: BASELINE config 3 in one kernel).
+	 * @up_in is the upstream operation's input on the device.  Returns 1 when the pair is not
+	 * one this hook fuses. */
+	int (*fuse)(struct _VipsHipOp *op, struct _VipsHipOp *up, VipsHipImage *up_in, VipsHipImage **out);
 } VipsHipOpClass;
 
 #define VIPS_TYPE_HIP_OP (vips_hip_op_get_type())
@@ -190,6 +196,14 @@ static int
 vips_hip_op_stop(void *seq, void *a, void *b)
 {
 	return 0;
+}
+
+static VipsHipImage *vips_hip_op_device(GObject *producer);
+
+static HipDeviceFn
+vips_hip_op_device_fn(void)
+{
+	return vips_hip_op_device;
 }
 
 static void
@@ -314,6 +328,77 @@ hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
 	return 0;
 }
 
+/* The operation's whole input on the device: the upstream *_hip operation's result (evaluated
+ * now if it has not been), else the image pulled from upstream (a threaded vips_sink_memory())
+ * and uploaded -- then *fresh is what the caller unrefs when it is done.  NULL on failure.
+ */
+static VipsHipImage *
+hip_input(VipsHipOp *op, VipsHipImage **fresh)
+{
+	VipsImage *in = op->ready;
+	VipsHipImage *dev = NULL;
+	VipsImage *mem;
+
+	*fresh = NULL;
+	if (op->upstream)
+		dev = op->upstream_device(op->upstream);
+	if (dev)
+		return dev;
+	if (!(mem = vips_image_copy_memory(in)))
+		return NULL;
+	*fresh = vips_hip_image_new_from_memory(VIPS_IMAGE_ADDR(mem, 0, 0),
+		mem->Xsize, mem->Ysize, mem->Bands, mem->BandFmt, mem->Type);
+	VIPS_UNREF(mem);
+	if (!*fresh)
+		hip_fail(VIPS_OBJECT_GET_CLASS(op)->nickname);
+
+	return *fresh;
+}
+
+static void hip_eval(VipsHipOp *op);
+
+/* This operation fused with the one that makes its input, when the class has a hook for the
+ * pair and nobody has evaluated the upstream operation yet (if somebody asks for it later it
+ * is simply evaluated then).  TRUE when the result is in place.
+ */
+static gboolean
+hip_eval_fused(VipsHipOp *op)
+{
+	VipsHipOpClass *hclass = VIPS_HIP_OP_GET_CLASS(op);
+	const char *nick = VIPS_OBJECT_GET_CLASS(op)->nickname;
+	gboolean done = FALSE;
+	VipsHipOp *up;
+
+	if (!hclass->fuse || !op->upstream || op->upstream_device != vips_hip_op_device_fn())
+		return FALSE;
+	up = VIPS_HIP_OP(op->upstream);
+
+	g_mutex_lock(&up->lock); /* downstream lock, then upstream lock: the order every evaluation takes */
+	if (!up->evaluated) {
+		VipsHipImage *fresh = NULL;
+		VipsHipImage *up_in = hip_input(up, &fresh);
+
+		if (up_in) {
+			const int r = hclass->fuse(op, up, up_in, &op->result);
+
+			if (r == 0 && !vips_hip_synchronize())
+				done = TRUE;
+			else if (r != 1) {
+				if (op->result) {
+					vips_hip_image_unref(op->result);
+					op->result = NULL;
+				}
+				hip_fail(nick);
+			}
+			vips_hip_image_unref(fresh);
+		}
+	}
+	g_mutex_unlock(&up->lock);
+	vips_error_clear(); /* a failed attempt falls back to the two operations, which report for themselves */
+
+	return done;
+}
+
 /* Evaluate, once.  Called with the lock held, from the first generate or from a downstream
  * *_hip operation that wants the device image.
  */
@@ -332,6 +417,16 @@ hip_eval(VipsHipOp *op)
 	/* NULL selects the library's own per-thread stream for this (worker) thread. */
 	if (vips_hip_set_stream(NULL)) {
 		hip_eval_fail(op, class->nickname);
+		return;
+	}
+
+	if (hip_eval_fused(op)) {
+		if (hip_check_header(op, vips_hip_image_get_width(op->result), vips_hip_image_get_height(op->result),
+				vips_hip_image_get_bands(op->result), vips_hip_image_get_format(op->result))) {
+			vips_hip_image_unref(op->result);
+			op->result = NULL;
+			hip_eval_fail(op, class->nickname);
+		}
 		return;
 	}
 
@@ -1406,8 +1501,24 @@ vips_colourspace_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out
 	return vips_hip_colourspace(in, out, c->space);
 }
 
-HIP_SUBCLASS(VipsColourspaceHip, vips_colourspace_hip, "colourspace_hip",
-	"convert to a new colorspace (MI355X)")
+/* gaussblur_hip -> colourspace_hip as one call: vips_hip_gaussblur_colourspace runs both blur
+ * passes and the colour route in one kernel on 3-band float images (BASELINE config 3), and
+ * the two operations otherwise. */
+static int
+vips_colourspace_hip_fuse(VipsHipOp *op, VipsHipOp *up, VipsHipImage *up_in, VipsHipImage **out)
+{
+	VipsColourspaceHip *c = (VipsColourspaceHip *) op;
+	VipsGaussblurHip *g;
+
+	if (!G_TYPE_CHECK_INSTANCE_TYPE(up, vips_gaussblur_hip_get_type()))
+		return 1;
+	g = (VipsGaussblurHip *) up;
+
+	return vips_hip_gaussblur_colourspace(up_in, out, g->sigma, g->min_ampl, g->precision, c->space);
+}
+
+HIP_SUBCLASS_FULL(VipsColourspaceHip, vips_colourspace_hip, "colourspace_hip",
+	"convert to a new colorspace (MI355X)", class->fuse = vips_colourspace_hip_fuse;)
 
 static void
 vips_colourspace_hip_args(VipsColourspaceHipClass *class)

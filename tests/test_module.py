@@ -222,3 +222,31 @@ class TestModuleOnGpu(object):
         header, secs = Ref.build_probe("reduce_hip", 20000, 20000, 4, "hshrink=8,vshrink=8")
         assert header[:2] == (2500, 2500)
         assert vh.vips_hip_pool_bytes() == before
+
+    def test_gaussblur_then_colourspace_is_one_kernel(self):
+        """colourspace_hip on top of a gaussblur_hip nobody has evaluated: the module evaluates
+        the pair as one device call (vips_hip_gaussblur_colourspace: BASELINE config 3 in one
+        kernel); same pixels as the built-in chain; and a consumer of the blurred image alone
+        still gets it."""
+        import ctypes
+
+        vh = ctypes.CDLL(helpers.ROOT + "/libvips_amd/lib/libvipship.so")
+        srgb = cases.INTERP["srgb"]
+        src = helpers.lcg_image(700, 300, 3, np.float32, 85)
+        vh.vips_hip_gate_reset()
+        vh.vips_hip_gate_enable(1)
+        try:
+            got = Ref.run_chain("gaussblur_hip:sigma=8;colourspace_hip:space=lab", src, srgb)
+            buf = ctypes.create_string_buffer(1 << 14)
+            vh.vips_hip_gate_report(buf, len(buf))
+        finally:
+            vh.vips_hip_gate_enable(0)
+            vh.vips_hip_gate_reset()
+        want = Ref.run_chain("gaussblur:sigma=8;colourspace:space=lab", src, srgb)
+        assert np.array_equal(got.view(np.int32), want.view(np.int32))
+        names = [line.rsplit(" ", 2)[0] for line in buf.value.decode().splitlines()]
+        assert names == ["convsep_stream_convi_colour"], names
+        # uchar input: not the fused kernel's case, the hook falls back to the two operations
+        u8 = helpers.lcg_image(300, 200, 3, np.uint8, 86)
+        assert np.array_equal(Ref.run_chain("gaussblur_hip:sigma=2;colourspace_hip:space=lab", u8, srgb),
+                              Ref.run_chain("gaussblur:sigma=2;colourspace:space=lab", u8, srgb))

@@ -163,3 +163,85 @@ def test_reduce_strips_on_gpu_match_whole_image():
             assert np.array_equal(out.cpu().numpy(), whole[o0:o1]), rank
     finally:
         lib.vips_hip_reduce_free(rv)
+
+
+def _bench_c5_worker(rank, world, port, size, out_dir):
+    """What bench.py --config c5 does per rank up to the kernel call, on CPU tensors over gloo:
+    strip plan -> this rank generates ITS rows with the jump-ahead LCG -> one halo exchange."""
+    import torch.distributed as dist
+
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert dist.get_world_size() == world
+        plan = sharding.StripPlan(size, size, world, sharding.conv_need(31, size))
+        s0, s1 = plan.in_bounds[rank]
+        strip = bench.c5_rows_device(torch, size, s0, s1 - s0, torch.device("cpu"))
+        window, w0 = sharding.exchange_halos(strip.view(torch.int16), plan, rank, dist)
+        np.save(os.path.join(out_dir, "w%d.npy" % rank), window.numpy().view(np.uint16))
+        np.save(os.path.join(out_dir, "t%d.npy" % rank), np.array([w0]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_c5_program_gloo(world, tmp_path):
+    """bench.py --config c5 (BASELINE config 4... configs[4]: the 65536^2 conv in row strips with
+    one RCCL halo exchange), its multi-rank part on CPU: every rank's window -- own strip from
+    the jump-ahead generator plus the rows its neighbours sent -- is exactly those rows of the
+    one-piece image, and a conv of the window gives the rank's rows of the whole-image conv."""
+    size = 192
+    port = _free_port()
+    mp.spawn(_bench_c5_worker, args=(world, port, size, str(tmp_path)), nprocs=world, join=True)
+    full = helpers.lcg_bytes(size * size * 2, 12345).view(np.uint16).reshape(size, size, 1)
+    plan = sharding.StripPlan(size, size, world, sharding.conv_need(31, size))
+    mask, scale = PortCC.gaussmat(5, 0.01, False, "float")
+    want = PortCC.conv(full, mask, scale, 0.0, "float")
+    for rank in range(world):
+        window = np.load(os.path.join(str(tmp_path), "w%d.npy" % rank))
+        w0, w1 = plan.windows[rank]
+        assert int(np.load(os.path.join(str(tmp_path), "t%d.npy" % rank))[0]) == w0
+        assert np.array_equal(window, full[w0:w1])
+        o0, o1 = plan.out_bounds[rank]
+        local = PortCC.conv(np.ascontiguousarray(window), mask, scale, 0.0, "float")
+        assert np.array_equal(local[o0 - w0:o1 - w0].view(np.uint8), want[o0:o1].view(np.uint8)), rank
+
+
+def test_bench_c4_partition():
+    """bench.py --config c4 deals the batch round-robin (sharding.batch_indices): every image
+    goes to exactly one rank, ranks differ by at most one image, seeds follow the image index."""
+    for world in (1, 2, 3, 8):
+        total = 128 * world + (3 if world == 3 else 0)
+        seen = []
+        for rank in range(world):
+            mine = sharding.batch_indices(total, world, rank)
+            assert all(i % world == rank for i in mine)
+            seen += mine
+        assert sorted(seen) == list(range(total))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,extra", [("c5", ["--size", "2048"]), ("c4", ["--size", "1024", "--images", "6"]),
+                                          ("c2", ["--size", "2048", "--no-configs"])])
+def test_bench_programs_under_torchrun(config, extra):
+    """The commands the driver launches for N > 1 (python -m torch.distributed.run ... bench.py
+    --gpus N --config ...), here with one rank and BENCH_FORCE_DIST=1 so that the RCCL process
+    group, the barrier / all-reduce timing and (c5) the halo-exchange call are really taken."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, BENCH_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(helpers.ROOT, "bench.py"), "--gpus", "1",
+           "--steps", "2", "--warmup", "1", "--config", config, "--no-cpu-baseline"] + extra
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    if config == "c5":
+        assert line["scaling"] == "strong" and line["parity"]["max_ulp_all_ranks"] <= 1
