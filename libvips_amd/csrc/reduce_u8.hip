@@ -966,11 +966,14 @@ static int launch_fused_mfma(const FusedArgs &args, int tiles, const MfmaTables 
 	else if ((args.debug & 24) == 16)
 		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 16, true>), dim3(grid), dim3(FUSED_THREADS), lds,
 			stream(), args, d_tables);
-	else if (args.debug & 4) // profiling: plain (not nt) loads
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, false, 0, true>), dim3(grid), dim3(FUSED_THREADS), lds,
+	else if (args.debug & 4) // profiling: nt (streaming) loads
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true>), dim3(grid), dim3(FUSED_THREADS), lds,
 			stream(), args, d_tables);
 	else
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true>), dim3(grid), dim3(FUSED_THREADS), lds,
+		// plain loads: nt loads run within noise of them (+-1.5 % either way between boxes) but
+		// fetch 9 % more from the fabric (rocprofv3 FETCH_SIZE 1 221 MB against 1 120 MB per
+		// launch: the halo lines a neighbouring tile just read are not kept in L2)
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, false, 0, true>), dim3(grid), dim3(FUSED_THREADS), lds,
 			stream(), args, d_tables);
 	VH_CHECK(hipGetLastError());
 	return 0;
