@@ -32,6 +32,9 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     libvips_amd.init(0)
+    # bit-for-bit comparisons: the library's exact float mode (the default lets the large float
+    # convolutions on integer images use fused multiply-adds, <= 1 ULP from the reference)
+    libvips_amd.lib.vips_hip_set_exact_float(1)
     t0 = time.time()
     n = bad = 0
     while time.time() - t0 < budget:
