@@ -1013,6 +1013,50 @@ int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out, double sigma, double 
 		return -1;
 	}
 	const int old_interpretation = in->interpretation;
+	// 3-band uchar sRGB (every thumbnail): the LabS round trip, the blur of L and the LUT in
+	// one kernel (colour.hip sharpen_fused_u8) when the blur mask has at most 5 taps
+	if (in->format == VIPS_HIP_FORMAT_UCHAR && in->bands == 3 && guess_interpretation(in) == VIPS_HIP_INTERPRETATION_sRGB &&
+		old_interpretation == VIPS_HIP_INTERPRETATION_sRGB) {
+		const Route *to = nullptr, *from = nullptr;
+		for (const Route &r : routes) {
+			if (r.from == VIPS_HIP_INTERPRETATION_sRGB && r.to == VIPS_HIP_INTERPRETATION_LABS)
+				to = &r;
+			if (r.from == VIPS_HIP_INTERPRETATION_LABS && r.to == VIPS_HIP_INTERPRETATION_sRGB)
+				from = &r;
+		}
+		const int n = vips_hip_gaussmat(sigma, 0.1, 1, VIPS_HIP_PRECISION_INTEGER, nullptr, 0, nullptr);
+		if (to && from && to->n > 0 && from->n > 0 && n >= 1 && n <= 5) {
+			std::vector<double> mask(n);
+			double scale = 1.0;
+			if (vips_hip_gaussmat(sigma, 0.1, 1, VIPS_HIP_PRECISION_INTEGER, mask.data(), n, &scale) < 0)
+				return -1;
+			// the convi C path's integers: rint of the mask and of its scale (convi.c:886-915)
+			std::vector<int> coef(n);
+			bool whole = true;
+			for (int k = 0; k < n; k++) {
+				coef[k] = (int) rint(mask[k]);
+				whole = whole && coef[k] != 0; // zero taps are squeezed out by the reference: same sums
+			}
+			LutPtr lut = sharpen_lut_cached(x1, y2, y3, m1, m2);
+			if (!lut)
+				return -1;
+			ImageRef o(vips_hip_image_new(in->width, in->height, 3, VIPS_HIP_FORMAT_UCHAR, VIPS_HIP_INTERPRETATION_sRGB));
+			if (!o.im)
+				return -1;
+			VipsHipRegion ri, ro;
+			vips_hip_image_region(in, &ri);
+			vips_hip_image_region(o.im, &ro);
+			(void) whole;
+			const int r = vh::sharpen_fused_u8(&ri, &ro, to->steps, to->n, from->steps, from->n, coef.data(), n,
+				(int) rint(scale), lut.get());
+			if (r < 0)
+				return -1;
+			if (r == 0) {
+				*out = o.release();
+				return 0;
+			}
+		}
+	}
 	ImageRef labs;
 	if (vips_hip_colourspace(in, &labs.im, VIPS_HIP_INTERPRETATION_LABS))
 		return -1;

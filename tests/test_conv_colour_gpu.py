@@ -222,6 +222,41 @@ def test_gaussblur_colourspace_fallbacks():
     assert a.dtype == np.int16 and np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("size", [(1024, 768), (67, 19), (64, 16), (130, 33), (5, 3), (1000, 1)])
+@pytest.mark.parametrize("params", [dict(), dict(sigma=1.0), dict(sigma=0.3), dict(sigma=2.0),
+                                    dict(sigma=0.8, x1=1.0, y2=20.0, y3=30.0, m1=0.5, m2=2.0)])
+def test_sharpen_fused_uchar_srgb(size, params):
+    """vips_sharpen on 3-band uchar sRGB in one kernel (colour.hip sharpen_fused_u8: the LabS round
+    trip, the integer blur of L in LDS and the LUT step): tiles with partial edges, images smaller
+    than a tile, 1..5-tap masks in the kernel and longer ones on the operation chain; against the
+    port / the compiled reference and against the chain of six kernels."""
+    w, h = size
+    src = helpers.lcg_image(w, h, 3, np.uint8, 72)
+    lib = _ffi.lib
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    try:
+        got = Image.new_from_array(src, interpretation="srgb").sharpen(**params).numpy()
+        report = libvips_amd.gate_report()
+    finally:
+        lib.vips_hip_gate_enable(0)
+        lib.vips_hip_gate_reset()
+    os.environ["VIPS_HIP_NO_FUSED_SHARPEN"] = "1"
+    try:
+        chain = Image.new_from_array(src, interpretation="srgb").sharpen(**params).numpy()
+    finally:
+        del os.environ["VIPS_HIP_NO_FUSED_SHARPEN"]
+    assert got.dtype == np.uint8 and np.array_equal(got, chain)
+    if helpers.have_ref():
+        args = ",".join("%s=%s" % kv for kv in params.items())
+        want = Ref.run("sharpen", src, args, cases.INTERP["srgb"])
+    else:
+        want = PortCC.sharpen(src, "srgb", **params)
+    assert np.array_equal(got, want)
+    if params.get("sigma", 0.5) <= 1.0:
+        assert list(report) == ["sharpen_fused_u8"], report
+
+
 def ulp_distance(a, b):
     """Largest distance between two float32 arrays in units in the last place."""
     ai = np.ascontiguousarray(a).view(np.int32).astype(np.int64)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""C4 per-image kernels and the batched rate for variants of the vertical half of resize.
+usage: python tools/time_c4.py "NAME:VAR=val,..." ..."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import libvips_amd  # noqa: E402
+from libvips_amd import Image, lib  # noqa: E402
+
+KNOBS = ("VIPS_HIP_SRV_BAND", "VIPS_HIP_NO_FUSED_SHRINKV", "VIPS_HIP_SRV_NARROW", "VIPS_HIP_NO_FUSED_SHARPEN")
+n, count = 8192, int(os.environ.get("C4_IMAGES", "64"))
+libvips_amd.init(0)
+dev = torch.device("cuda", 0)
+store = torch.empty((count, n, n, 3), dtype=torch.uint8, device=dev)
+for k in range(count):
+    bench.lcg_image_device(torch, n, n, 3, 12345 + k, dev, out=store[k])
+torch.cuda.synchronize()
+ims = [Image.new_from_tensor(store[k], interpretation="srgb") for k in range(count)]
+ref = None
+for spec in sys.argv[1:] or ["default:"]:
+    name, _, rest = spec.partition(":")
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    os.environ.update(dict(kv.split("=") for kv in rest.split(",") if kv))
+    one = ims[0].resize(0.125).sharpen().numpy()
+    if ref is None:
+        ref = one
+    same = bool((one == ref).all())
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    for _ in range(4):
+        ims[0].resize(0.125)
+    libvips_amd.synchronize()
+    lib.vips_hip_gate_enable(0)
+    rep = {k: round(v[1] / v[0], 4) for k, v in libvips_amd.gate_report().items()}
+    lib.vips_hip_gate_reset()
+    libvips_amd.resize_sharpen_batch(ims, 0.125, threads=8)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        libvips_amd.resize_sharpen_batch(ims, 0.125, threads=8)
+        best = min(best, (time.perf_counter() - t0) / count * 1e3)
+    print("%-14s same=%s batch %.4f ms/image  resize kernels alone %s" % (name, same, best, rep), flush=True)
