@@ -121,7 +121,10 @@ static __device__ __forceinline__ void ss_dma_dword(const char *src, unsigned in
 typedef const double __attribute__((address_space(4))) *SsCoefs;
 typedef float float4v __attribute__((ext_vector_type(4)));
 
-// ---- horizontal pass: 8 same-band outputs from a sliding window of 12 doubles
+// ---- horizontal pass: 8 same-band outputs from a window of 12 doubles.  The window is
+// circular with static indices (the groups are unrolled): element e of the staged row lives in
+// win[e mod 12], the quad that arrives during group g replaces the quad group g has just
+// finished with -- no register moves.
 template <int MODE, int NG>
 static __device__ __forceinline__ void ss_hpass(const StreamArgs &a, const double *kc, const float *base, float *xd)
 {
@@ -159,16 +162,14 @@ static __device__ __forceinline__ void ss_hpass(const StreamArgs &a, const doubl
 				const double c = cg[ii];
 #pragma unroll
 				for (int k = 0; k < SS_T; k++)
-					hacc[k] = ss_mac<MODE>(hacc[k], c, win[ii + k]);
+					hacc[k] = ss_mac<MODE>(hacc[k], c, win[(4 * g + ii + k) % 12]);
 			}
 		}
 		if (g + 1 < NG) {
-#pragma unroll
-			for (int m = 0; m < 8; m++)
-				win[m] = win[m + 4];
+			// elements 4g + 12 .. 4g + 15 take the places of 4g .. 4g + 3
 #pragma unroll
 			for (int m = 0; m < 4; m++)
-				win[8 + m] = (double) nx[m];
+				win[(4 * g + m) % 12] = (double) nx[m];
 		}
 		// one group's LDS read in flight at a time: left alone the scheduler hoists all ten
 		// reads (40 registers) above the first multiply-add and the accumulators spill
@@ -185,7 +186,7 @@ static __device__ __forceinline__ void ss_hpass(const StreamArgs &a, const doubl
 // complete since row m - 32 + n - 1) is rounded and stored right before the slot is seeded
 // again, so the slot to retire is the static ROT whatever the mask length (a segment simply
 // runs 32 rows past its last output row instead of n - 1).
-template <int MODE, int NG, bool EPI, int Q4>
+template <int MODE, int NG, int EPI, int Q4>
 static __device__ __forceinline__ void ss_vpass(const StreamArgs &a, const double *kc, double (&acc)[SS_SLOTS],
 	const float *xs, float *os, int q, int rows_out, int y0, int e0, int t, bool store)
 {
@@ -230,7 +231,7 @@ static __device__ __forceinline__ void ss_vpass(const StreamArgs &a, const doubl
 	}
 }
 
-template <int MODE, int NG, bool EPI, int SS_NT>
+template <int MODE, int NG, int EPI, int SS_NT>
 __global__ void __launch_bounds__(SS_NT)
 convsep_stream(StreamArgs a, RouteArgs route)
 {
@@ -393,7 +394,20 @@ convsep_stream(StreamArgs a, RouteArgs route)
 					if (j >= 0 && j < rows_out && px < a.width) {
 						const float *src = os + r * a.w + 3 * x;
 						float o0, o1, o2;
-						route_pixel<float, float>(route, src[0], src[1], src[2], o0, o1, o2);
+						if constexpr (EPI == 2) {
+							// sRGB -> scRGB -> XYZ -> Lab spelled out (what route_pixel does for these
+							// steps, without its step loop and the scalars that loop keeps live)
+							Px v;
+							v.a = route.tables.v2Y_8[load_as_uchar_like<float>(src[0], 255)];
+							v.b = route.tables.v2Y_8[load_as_uchar_like<float>(src[1], 255)];
+							v.c = route.tables.v2Y_8[load_as_uchar_like<float>(src[2], 255)];
+							v = step_XYZ2Lab(step_scRGB2XYZ(v), route.tables.cbrt);
+							o0 = v.a;
+							o1 = v.b;
+							o2 = v.c;
+						}
+						else
+							route_pixel<float, float>(route, src[0], src[1], src[2], o0, o1, o2);
 						float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(a.out) + (long long) (y0 + j) * a.out_stride) + 3LL * px;
 						dst[0] = o0;
 						dst[1] = o1;
@@ -418,7 +432,7 @@ convsep_stream(StreamArgs a, RouteArgs route)
 	}
 }
 
-template <int MODE, int NG, bool EPI, int NT>
+template <int MODE, int NG, int EPI, int NT>
 static int ss_launch(const StreamArgs &a, const RouteArgs &route, size_t lds, int grid, const char *gate_name)
 {
 	static bool attr_done = false; // one attribute per instantiation
@@ -433,7 +447,7 @@ static int ss_launch(const StreamArgs &a, const RouteArgs &route, size_t lds, in
 	return 0;
 }
 
-template <int MODE, bool EPI, int NT>
+template <int MODE, int EPI, int NT>
 static int ss_launch_ng(int ng, const StreamArgs &a, const RouteArgs &route, size_t lds, int grid, const char *gate_name)
 {
 	switch (ng) {
@@ -449,13 +463,18 @@ static int ss_launch_ng(int ng, const StreamArgs &a, const RouteArgs &route, siz
 }
 
 template <int NT>
-static int ss_launch_mode(bool integer, bool epi, int ng, const StreamArgs &a, const RouteArgs &route, size_t lds, int grid)
+static int ss_launch_mode(bool integer, int epi, int ng, const StreamArgs &a, const RouteArgs &route, size_t lds, int grid)
 {
-	if (integer)
-		return epi ? ss_launch_ng<1, true, NT>(ng, a, route, lds, grid, "convsep_stream_convi_colour")
-				   : ss_launch_ng<1, false, NT>(ng, a, route, lds, grid, "convsep_stream_convi");
-	return epi ? ss_launch_ng<2, true, NT>(ng, a, route, lds, grid, "convsep_stream_convf_colour")
-			   : ss_launch_ng<2, false, NT>(ng, a, route, lds, grid, "convsep_stream_convf");
+	if (integer) {
+		if (epi == 2)
+			return ss_launch_ng<1, 2, NT>(ng, a, route, lds, grid, "convsep_stream_convi_colour");
+		return epi ? ss_launch_ng<1, 1, NT>(ng, a, route, lds, grid, "convsep_stream_convi_colour")
+				   : ss_launch_ng<1, 0, NT>(ng, a, route, lds, grid, "convsep_stream_convi");
+	}
+	if (epi == 2)
+		return ss_launch_ng<2, 2, NT>(ng, a, route, lds, grid, "convsep_stream_convf_colour");
+	return epi ? ss_launch_ng<2, 1, NT>(ng, a, route, lds, grid, "convsep_stream_convf_colour")
+			   : ss_launch_ng<2, 0, NT>(ng, a, route, lds, grid, "convsep_stream_convf");
 }
 
 // Both passes of a separable convolution on a float image (and, with route_steps, the colour
@@ -512,13 +531,12 @@ int convsep_stream_fused(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 	a.offset2 = integer ? (double) (int) rint(offset2) : offset2;
 
 	// threads per block = widest strip: 768 (168 registers per thread, 3 waves per SIMD; the
-	// compiler spills ~130 registers outside the hot loops) or 512 (256 registers, 2 waves per
-	// SIMD, no spills).  Measured on 16384^2 x 3 float, sigma 8: blur 3.31 ms against 4.25,
-	// blur + sRGB->Lab 5.03 against 7.5: the kernel hides its LDS and issue stalls behind other
-	// waves, so the third wave per SIMD is worth more than the spills cost.
-	// Profiling knob: VIPS_HIP_STREAM_NT=512.
-	const char *nt_env = getenv("VIPS_HIP_STREAM_NT");
-	const int nt = nt_env && atoi(nt_env) == 512 ? 512 : 768;
+	// compiler spills ~130 registers outside the hot loops).  A 512-thread build (256 registers,
+	// 2 waves per SIMD, no spills) measured 30-50 % slower (16384^2 x 3 float, sigma 8: blur 4.25
+	// ms against 3.31, blur + sRGB->Lab 7.5 against 5.03): the kernel is bound by VALU issue and
+	// hides its LDS and barrier stalls behind other waves, so the third wave per SIMD is worth
+	// more than the spills cost.  Only the 768 build is instantiated.
+	const int nt = 768;
 	const int unit = SS_T * a.bands;
 	const long long E = (long long) a.width * a.bands;
 	long long w = nt / unit * unit;
@@ -569,8 +587,13 @@ int convsep_stream_fused(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 		return hip_failed(hipErrorUnknown, "hipMemsetAsync");
 	}
 	const int grid = items < 256 ? items : 256;
-	const int r = nt == 768 ? ss_launch_mode<768>(integer, epi, ng, a, route, lds, grid)
-							: ss_launch_mode<512>(integer, epi, ng, a, route, lds, grid);
+	// the route of BASELINE config 3 has its own build of the epilogue
+	const int epi_kind = !epi ? 0
+		: (n_route == 3 && route_steps[0] == VIPS_HIP_COLOUR_sRGB2scRGB && route_steps[1] == VIPS_HIP_COLOUR_scRGB2XYZ &&
+			  route_steps[2] == VIPS_HIP_COLOUR_XYZ2Lab)
+		? 2
+		: 1;
+	const int r = ss_launch_mode<768>(integer, epi_kind, ng, a, route, lds, grid);
 	vips_hip_free(counter);
 	return r;
 }

@@ -40,9 +40,7 @@ scale = (32768.0 / n) ** 2
 print("image %d^2 (x%.0f for 32768^2)" % (n, scale))
 run("blur old kernel", {"VIPS_HIP_NO_STREAM_CONVSEP": "1"}, lambda: im.gaussblur(8.0))
 run("blur stream 768", {}, lambda: im.gaussblur(8.0))
-run("blur stream 512", {"VIPS_HIP_STREAM_NT": "512"}, lambda: im.gaussblur(8.0))
 run("blur+lab stream 768", {}, lambda: im.gaussblur_colourspace(8.0, "lab"))
-run("blur+lab stream 512", {"VIPS_HIP_STREAM_NT": "512"}, lambda: im.gaussblur_colourspace(8.0, "lab"))
 run("blur+xyz stream 768", {}, lambda: im.gaussblur_colourspace(8.0, "xyz"))
 run("blur sigma 2 stream 768", {}, lambda: im.gaussblur(2.0))
 run("blur sigma 2 old", {"VIPS_HIP_NO_STREAM_CONVSEP": "1"}, lambda: im.gaussblur(2.0))
