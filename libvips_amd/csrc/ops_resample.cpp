@@ -5,6 +5,7 @@
 // on a 288 GB device the natural "tile" is the image.
 #include "internal.h"
 #include "resample.h"
+#include "reduce_u8.h"
 
 #include <cmath>
 #include <cstring>
@@ -140,63 +141,63 @@ int shrink_axis(VipsHipImage *in, VipsHipImage **out, int shrink, int ceil_mode,
 }
 
 // vips_reduceh_build / vips_reducev_build up to the generate:
-// reduceh.cpp:396-481, reducev.cpp:859-941.
-int reduce_axis(VipsHipImage *in, VipsHipImage **out, double shrink, int kernel, double gap,
-	bool vertical)
+// reduceh.cpp:396-481, reducev.cpp:859-941.  The decisions first (sizes, the integer pre-shrink
+// of `gap`, the residual factor), then the pre-shrink, then the residual reduce.
+struct AxisPlan {
+	int size;            // output size
+	int int_shrink;      // box shrink ahead of the reduce (1 = none)
+	double residual;     // what the reduce does
+	double extra_pixels;
+};
+
+int plan_axis(const char *domain, int in_size, double shrink, int kernel, double gap, AxisPlan *p)
 {
-	const char *domain = vertical ? "reducev" : "reduceh";
-	if (!in || !out) {
-		error(domain, "null argument");
-		return -1;
-	}
 	if (shrink < 1.0) {
 		error(domain, "reduce factor should be >= 1.0");
 		return -1;
 	}
-	const int in_size = vertical ? in->height : in->width;
 	// "We need to always round to nearest, so round(), not rint()."
-	const int size = (int) ((double) in_size / shrink + 0.5);
-	double extra_pixels = size * shrink - in_size;
-	double residual = shrink;
-
-	ImageRef pre;
-	VipsHipImage *cur = in;
+	p->size = (int) ((double) in_size / shrink + 0.5);
+	p->extra_pixels = p->size * shrink - in_size;
+	p->residual = shrink;
+	p->int_shrink = 1;
 	if (gap > 0.0 && kernel != VIPS_HIP_KERNEL_NEAREST) {
 		if (gap < 1.0) {
 			error(domain, "reduce gap should be >= 1.0");
 			return -1;
 		}
-		if (size <= 0) {
+		if (p->size <= 0) {
 			error(domain, "image has shrunk to nothing");
 			return -1;
 		}
-		int int_shrink = (int) floor((double) in_size / size / gap);
-		if (int_shrink < 1)
-			int_shrink = 1;
+		int int_shrink = (int) floor((double) in_size / p->size / gap);
 		if (int_shrink > 1) {
-			residual /= int_shrink;
-			extra_pixels /= int_shrink;
-			if (shrink_axis(in, &pre.im, int_shrink, 1, vertical))
-				return -1;
-			cur = pre.im;
+			p->int_shrink = int_shrink;
+			p->residual /= int_shrink;
+			p->extra_pixels /= int_shrink;
 		}
 	}
+	return 0;
+}
 
-	if (residual == 1.0) {
+// the residual reduce of an axis whose pre-shrink (if any) has run: `cur` is its result
+int residual_axis(const char *domain, VipsHipImage *cur, VipsHipImage **out, const AxisPlan &p, int kernel,
+	bool vertical)
+{
+	if (p.residual == 1.0) {
 		*out = copy_image(cur);
 		return *out ? 0 : -1;
 	}
-
-	if (size <= 0) {
+	if (p.size <= 0) {
 		error(domain, "image has shrunk to nothing");
 		return -1;
 	}
-	ReducePtr rp = reduce_cached(kernel, residual, vertical ? cur->height : cur->width, size,
-		extra_pixels);
+	ReducePtr rp = reduce_cached(kernel, p.residual, vertical ? cur->height : cur->width, p.size,
+		p.extra_pixels);
 	if (!rp)
 		return -1;
 	VipsHipReduce *r = rp.get();
-	ImageRef o(vertical ? like(cur, cur->width, size) : like(cur, size, cur->height));
+	ImageRef o(vertical ? like(cur, cur->width, p.size) : like(cur, p.size, cur->height));
 	int result = -1;
 	if (o.im) {
 		VipsHipRegion ri, ro;
@@ -212,6 +213,72 @@ int reduce_axis(VipsHipImage *in, VipsHipImage **out, double shrink, int kernel,
 		return -1;
 	*out = o.release();
 	return 0;
+}
+
+int reduce_axis(VipsHipImage *in, VipsHipImage **out, double shrink, int kernel, double gap,
+	bool vertical)
+{
+	const char *domain = vertical ? "reducev" : "reduceh";
+	if (!in || !out) {
+		error(domain, "null argument");
+		return -1;
+	}
+	AxisPlan p;
+	if (plan_axis(domain, vertical ? in->height : in->width, shrink, kernel, gap, &p))
+		return -1;
+	ImageRef pre;
+	VipsHipImage *cur = in;
+	if (p.int_shrink > 1) {
+		if (shrink_axis(in, &pre.im, p.int_shrink, 1, vertical))
+			return -1;
+		cur = pre.im;
+	}
+	return residual_axis(domain, cur, out, p, kernel, vertical);
+}
+
+// vips_resize's downsizing of a uchar image on both axes (resize.c:207-228: reducev with its
+// box pre-shrink, then reduceh with its own): the vertical box shrink, then everything else in
+// one kernel (resize_tail.hip) when the geometry fits it.  1 = not this function's case.
+int resize_down_u8(VipsHipImage *in, VipsHipImage **out, double vshrink, double hshrink, int kernel, double gap)
+{
+	AxisPlan pv, ph;
+	if (plan_axis("reducev", in->height, vshrink, kernel, gap, &pv) ||
+		plan_axis("reduceh", in->width, hshrink, kernel, gap, &ph))
+		return -1;
+	if (pv.residual == 1.0 || ph.residual == 1.0 || pv.size <= 0 || ph.size <= 0)
+		return 1;
+	const int shrunk_width = ph.int_shrink > 1 ? vips_hip_shrink_out_size(in->width, ph.int_shrink, 1) : in->width;
+	if (shrunk_width <= 0)
+		return 1;
+	ImageRef pre;
+	VipsHipImage *cur = in;
+	if (pv.int_shrink > 1) {
+		if (shrink_axis(in, &pre.im, pv.int_shrink, 1, true))
+			return -1;
+		cur = pre.im;
+	}
+	ReducePtr rv = reduce_cached(kernel, pv.residual, cur->height, pv.size, pv.extra_pixels);
+	ReducePtr rh = rv ? reduce_cached(kernel, ph.residual, shrunk_width, ph.size, ph.extra_pixels) : ReducePtr();
+	if (!rv || !rh)
+		return -1;
+	ImageRef o(like(cur, ph.size, pv.size));
+	if (!o.im)
+		return -1;
+	VipsHipRegion ri, ro;
+	vips_hip_image_region(cur, &ri);
+	vips_hip_image_region(o.im, &ro);
+	const int done = resize_tail_u8_try(rv.get(), ph.int_shrink, shrunk_width, rh.get(), &ri, &ro, g_fatstrip_height);
+	if (done < 0)
+		return -1;
+	if (done > 0) {
+		*out = o.release();
+		return 0;
+	}
+	// not the kernel's geometry: the separate operations, from the pre-shrunk image on
+	ImageRef t;
+	if (residual_axis("reducev", cur, &t.im, pv, kernel, true))
+		return -1;
+	return reduce_axis(t.im, out, hshrink, kernel, gap, false);
 }
 
 } // namespace
@@ -367,6 +434,15 @@ int vips_hip_resize(VipsHipImage *in, VipsHipImage **out, double scale, double v
 		vscale = 1.0 / cur->height;
 
 	// any residual downsizing (the integer pre-shrink of the other kernels lives in reduce_axis)
+	if (vscale < 1.0 && hscale < 1.0 && cur->format == VIPS_HIP_FORMAT_UCHAR && kernel != VIPS_HIP_KERNEL_NEAREST) {
+		const int done = resize_down_u8(cur, &t2.im, 1.0 / vscale, 1.0 / hscale, kernel, gap);
+		if (done < 0)
+			return -1;
+		if (done == 0) {
+			*out = t2.release();
+			return 0;
+		}
+	}
 	if (vscale < 1.0) {
 		if (reduce_axis(cur, &t2.im, 1.0 / vscale, kernel, gap, true))
 			return -1;

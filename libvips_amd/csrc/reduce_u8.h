@@ -16,5 +16,11 @@ int reducev_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsH
 int shrinkv_u8_try(int vshrink, const VipsHipRegion *in, const VipsHipRegion *out);
 
 const ReducePos *reduce_device_positions(_VipsHipReduce *r, int start, int count, int tile);
+// device-resident coefficient table of a reduce (short or double), created on first use
+int reduce_tables(_VipsHipReduce *r, bool want_float, const void **table);
+
+// vips_resize's tail (reducev -> shrinkh -> reduceh) on a whole uchar image, resize_tail.hip
+int resize_tail_u8_try(_VipsHipReduce *rv, int hshrink, int shrunk_width, _VipsHipReduce *rh,
+	const VipsHipRegion *in, const VipsHipRegion *out, int tile);
 
 } // namespace vh

@@ -386,7 +386,7 @@ static int launch_reduceh(const _VipsHipReduce *r, const VipsHipRegion *in,
 }
 
 // Device-resident tables / position arrays, created on first use.
-static int reduce_tables(_VipsHipReduce *r, bool want_float, const void **table)
+int reduce_tables(_VipsHipReduce *r, bool want_float, const void **table)
 {
 	std::lock_guard<std::mutex> lock(r->mutex);
 	if (want_float) {

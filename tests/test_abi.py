@@ -2,6 +2,7 @@
 declares; the host-side table builders agree with the oracle; error behaviour."""
 import ctypes
 import math
+import os
 import re
 
 import numpy as np
@@ -183,3 +184,26 @@ print("ALL-RETURNED", flush=True)
     proc = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     tail = proc.stdout.strip().splitlines()[-3:]
     assert proc.returncode == 0 and "ALL-RETURNED" in proc.stdout, tail
+
+
+def test_device_code_has_no_ashr_pk(tmp_path):
+    """ROCm 7.2's clang folds "arithmetic shift, saturate to u8, pack" into v_ashr_pk_u8_i32 and
+    then ORs more bytes on top as if the instruction zeroed the upper half of its destination;
+    on gfx950 it does not (measured in resize_tail.hip: wrong byte 2).  The kernels that clip
+    and pack make the shifted value opaque first -- check that no code object of the library
+    holds the instruction."""
+    import glob
+    import shutil
+    import subprocess
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    so = shutil.copy(_ffi.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", os.path.basename(so)], cwd=tmp_path, check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    objects = glob.glob(str(tmp_path / "lib.so.*gfx950"))
+    assert objects, "no gfx950 code objects in the library"
+    for path in objects:
+        text = subprocess.run([objdump, "-d", path], check=True, capture_output=True, text=True).stdout
+        assert "v_ashr_pk_u8_i32" not in text, path

@@ -375,6 +375,35 @@ def test_resize_uchar_gap_shrinks(bands, size, scale, kernel):
     assert_same(got, Port.resize(src, scale, kernel=kernel), str((bands, size, scale, kernel)))
 
 
+@pytest.mark.parametrize("bands", [1, 2, 3, 4])
+@pytest.mark.parametrize("size,scale,vscale", [
+    ((2048, 1536), 0.125, None), ((1531, 1203), 0.3, None), ((4099, 1051), 0.07, 0.19),
+    ((640, 480), 0.45, 0.26), ((3000, 700), 0.021, 0.3), ((1024, 1024), 1.0 / 3.0, 0.125),
+    ((517, 2049), 0.26, 0.031), ((200, 100), 0.2, None), ((8192, 300), 0.0125, 0.4)])
+def test_resize_tail_fused(bands, size, scale, vscale, monkeypatch):
+    """The fused tail of vips_resize on uchar (reducev -> shrinkh -> reduceh in one kernel,
+    resize_tail.hip): ran, and bit-exact against the port and against the separate kernels;
+    scales with and without box pre-shrinks on either axis, irregular tap positions, all
+    band counts, narrow outputs."""
+    w, h = size
+    src = helpers.lcg_image(w, h, bands, np.uint8, 77)
+    kw = {} if vscale is None else {"vscale": vscale}
+    im = Image.new_from_array(src)
+    libvips_amd.lib.vips_hip_gate_reset()
+    libvips_amd.lib.vips_hip_gate_enable(1)
+    try:
+        got = im.resize(scale, **kw).numpy()
+        report = libvips_amd.gate_report()
+    finally:
+        libvips_amd.lib.vips_hip_gate_enable(0)
+        libvips_amd.lib.vips_hip_gate_reset()
+    assert "resize_tail_u8" in report, report
+    assert not any(k.startswith("reduceh") or k.startswith("shrinkh") for k in report), report
+    assert_same(got, Port.resize(src, scale, **kw), str((bands, size, scale, vscale)))
+    monkeypatch.setenv("VIPS_HIP_NO_RESIZE_TAIL", "1")
+    assert np.array_equal(got, im.resize(scale, **kw).numpy())
+
+
 def test_resize_sharpen_batch():
     """vips_hip_resize_sharpen_batch (BASELINE config 4's batch entry point): every image of the
     batch equals the same pipeline run on it alone; also without the sharpen, and with a failing

@@ -12,7 +12,7 @@ import bench  # noqa: E402
 import libvips_amd  # noqa: E402
 from libvips_amd import Image, lib  # noqa: E402
 
-KNOBS = ("VIPS_HIP_SRV_BAND", "VIPS_HIP_NO_FUSED_SHRINKV", "VIPS_HIP_SRV_NARROW", "VIPS_HIP_NO_FUSED_SHARPEN")
+KNOBS = ("VIPS_HIP_NO_RESIZE_TAIL", "VIPS_HIP_NO_FUSED_SHARPEN", "VIPS_HIP_TAIL_TH", "VIPS_HIP_TAIL_TW")
 n, count = 8192, int(os.environ.get("C4_IMAGES", "64"))
 libvips_amd.init(0)
 dev = torch.device("cuda", 0)
