@@ -383,10 +383,13 @@ TailPlan tail_plan(const _VipsHipReduce *rv, int hs, int W3, const _VipsHipReduc
 		if (ph[x].first < ph[x - 1].first)
 			return plan;
 	auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; };
+	// experiments: $VIPS_HIP_TAIL_TH = tallest tile tried, $VIPS_HIP_TAIL_LDS = LDS budget in KiB
+	const int th_max = getenv("VIPS_HIP_TAIL_TH") ? atoi(getenv("VIPS_HIP_TAIL_TH")) : 16;
+	const long long budget = getenv("VIPS_HIP_TAIL_LDS") ? atoi(getenv("VIPS_HIP_TAIL_LDS")) * 1024LL : TAIL_LDS_BUDGET;
 	for (int pass = 0; pass < 2 && !plan.ok; pass++) {
 		const int max_pitch = pass == 0 ? TAIL_NT : 8 * TAIL_NT;
 		const int min_tw = pass == 0 ? 12 : 2;
-		for (int th = 16; th >= 2 && !plan.ok; th /= 2) {
+		for (int th = th_max; th >= 2 && !plan.ok; th /= 2) {
 			int rows = 0;
 			for (int y0 = 0; y0 < out_height; y0 += th) {
 				const int ny = std::min(th, out_height - y0);
@@ -407,7 +410,7 @@ TailPlan tail_plan(const _VipsHipReduce *rv, int hs, int W3, const _VipsHipReduc
 				if (pitch > max_pitch)
 					continue;
 				const int s_pitch = (ncol_max * bands + 3) & ~3;
-				if (tail_lds_bytes(rows, pitch, th, s_pitch, tw, rv->n_point, rh->n_point, nullptr) > TAIL_LDS_BUDGET)
+				if (tail_lds_bytes(rows, pitch, th, s_pitch, tw, rv->n_point, rh->n_point, nullptr) > budget)
 					continue;
 				plan.ok = true;
 				plan.tw = tw;
@@ -459,6 +462,10 @@ int resize_tail_u8_try(_VipsHipReduce *rv, int hs, int W3, _VipsHipReduce *rh, c
 			rh->in_size, rh->out_size, rh->offset, in->width, in->bands, tile, rh->kernel);
 		std::lock_guard<std::mutex> lock(g_tail_mutex);
 		auto it = g_tail_plans.find(key);
+		if (getenv("VIPS_HIP_TAIL_TH") || getenv("VIPS_HIP_TAIL_LDS")) {
+			g_tail_plans.clear();
+			it = g_tail_plans.end();
+		}
 		if (it == g_tail_plans.end()) {
 			if (g_tail_plans.size() > 256)
 				g_tail_plans.clear();
