@@ -17,8 +17,9 @@ int colour_route(const int *steps, int n_steps, double alpha_scale, const VipsHi
 	const VipsHipRegion *out);
 
 // vips_sharpen on a whole 3-band uchar sRGB image in one kernel (colour.hip); 1 = not its case
-int sharpen_fused_u8(const VipsHipRegion *in, const VipsHipRegion *out, const int *to_steps, int n_to,
-	const int *from_steps, int n_from, const int *coef, int n, int scale, const int *lut);
+int sharpen_fused_u8(const VipsHipRegion *const *in, const VipsHipRegion *const *out, int n_images,
+	const int *to_steps, int n_to, const int *from_steps, int n_from, const int *coef, int n, int scale,
+	const int *lut);
 
 int premultiply_region(const VipsHipRegion *in, const VipsHipRegion *out, double max_alpha, int uchar,
 	int inverse);

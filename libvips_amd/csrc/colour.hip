@@ -416,42 +416,86 @@ sharpen_kernel(SharpenArgs a)
 constexpr int SF_TW = 64, SF_TH = 16, SF_MAXHALF = 2;
 constexpr int SF_RW = SF_TW + 2 * SF_MAXHALF, SF_RH = SF_TH + 2 * SF_MAXHALF;
 
+constexpr int SF_MAXB = 64; // images per launch
+
+// the images of a launch (blockIdx.z), read where they lie in the kernarg segment
+struct SharpenFusedPtrs {
+	const unsigned char *in[SF_MAXB];
+	unsigned char *out[SF_MAXB];
+};
+
 struct SharpenFusedArgs {
-	const unsigned char *in;
-	unsigned char *out;
 	long long in_stride, out_stride;
 	int width, height;
 	int n, half;          // blur taps, n / 2
 	int coef[2 * SF_MAXHALF + 1];
 	int scale, rounding;
+	unsigned int magic;   // n / scale = (t + ((n - t) >> 1)) >> shift with t = mulhi(magic, n), 0 <= n < 2^32
+	int shift;            // (Granlund & Montgomery's round-up multiplier; scale > 1)
 	const int *lut;       // 65536 ints (sharpen.c:230-257)
+	ColourTables tables;
 };
 
 static __device__ __forceinline__ int sf_convi_fin(int sum, const SharpenFusedArgs &a)
 {
-	// ((sum + rounding) / scale) with C (truncating) division, offset 0, clip to short
-	int q = (sum + a.rounding) / a.scale;
+	// ((sum + rounding) / scale) with C (truncating) division, offset 0, clip to short.  The
+	// divisor is the same for the whole launch: a multiply-high and two shifts on the magnitude
+	// instead of the ~30 instructions of a 32-bit division
+	const int x = sum + a.rounding;
+	const unsigned int n = (unsigned int) (x < 0 ? -x : x);
+	unsigned int m = n;
+	if (a.scale != 1) {
+		const unsigned int t = __umulhi(a.magic, n);
+		m = (t + ((n - t) >> 1)) >> a.shift;
+	}
+	const int q = x < 0 ? -(int) m : (int) m;
 	return min(max(q, -32768), 32767);
 }
 
 __global__ void __launch_bounds__(256)
-sharpen_fused_u8_kernel(SharpenFusedArgs a, RouteArgs to_labs, RouteArgs from_labs)
+sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 {
 	__shared__ short s_lab[SF_RH][SF_RW][3];
 	__shared__ short s_h[SF_RH][SF_TW];
+	// the two 8-bit colour tables in LDS: six of a pixel's table reads stay off the vector memory path
+	__shared__ float s_v2Y[256];
+	__shared__ int s_Y2v[260];
+	(void) ptrs_by_value;
+	s_v2Y[threadIdx.x] = a.tables.v2Y_8[threadIdx.x];
+	s_Y2v[threadIdx.x] = a.tables.Y2v_8[threadIdx.x];
+	if (threadIdx.x == 0)
+		s_Y2v[256] = a.tables.Y2v_8[256];
+	__syncthreads();
+	typedef const unsigned long long __attribute__((address_space(4))) *KernargPtrs;
+	const KernargPtrs kp = (KernargPtrs) __builtin_amdgcn_kernarg_segment_ptr();
+	// (pointers made from integers are generic to the compiler: say they are global)
+	typedef const unsigned char __attribute__((address_space(1))) *GlobalIn;
+	typedef unsigned char __attribute__((address_space(1))) *GlobalOut;
+	const GlobalIn in = (GlobalIn) kp[blockIdx.z];
+	const GlobalOut out = (GlobalOut) kp[SF_MAXB + blockIdx.z];
 	const int t = threadIdx.x;
 	const int x0 = blockIdx.x * SF_TW, y0 = blockIdx.y * SF_TH;
 	const int h = a.half;
 	const int rw = SF_TW + 2 * h, rh = SF_TH + 2 * h;
 
 	// 1. the tile and its halo: sRGB uchar -> LabS
-	for (int idx = t; idx < rw * rh; idx += 256) {
-		const int ry = idx / rw, rx = idx - ry * rw;
+	// (region coordinates advance by 256 elements per turn: no division per pixel)
+	const int step_y = 256 / rw, step_x = 256 - step_y * rw;
+	int ry = t / rw, rx = t - ry * rw;
+	for (int idx = t; idx < rw * rh; idx += 256, ry += step_y, rx += step_x) {
+		if (rx >= rw) {
+			rx -= rw;
+			ry++;
+		}
 		const int x = min(max(x0 + rx - h, 0), a.width - 1);
 		const int y = min(max(y0 + ry - h, 0), a.height - 1);
-		const unsigned char *p = a.in + (long long) y * a.in_stride + 3LL * x;
-		short L, A, B;
-		route_pixel<unsigned char, short>(to_labs, p[0], p[1], p[2], L, A, B);
+		const GlobalIn p = in + (long long) y * a.in_stride + 3LL * x;
+		short L, A = 0, B = 0;
+		// only L is blurred: the halo needs no a, b
+		if (ry >= h && ry < rh - h && rx >= h && rx < rw - h)
+			srgb8_to_labs<true>(a.tables, s_v2Y, p[0], p[1], p[2], L, A, B);
+		else
+			srgb8_to_labs<false>(a.tables, s_v2Y, p[0], p[1], p[2], L, A, B);
 		s_lab[ry][rx][0] = L;
 		s_lab[ry][rx][1] = A;
 		s_lab[ry][rx][2] = B;
@@ -483,13 +527,13 @@ sharpen_fused_u8_kernel(SharpenFusedArgs a, RouteArgs to_labs, RouteArgs from_la
 				const int diff = (v1 & 0x7fff) - (blur & 0x7fff);
 				int sharp = v1 + a.lut[diff + 32768];
 				sharp = min(max(sharp, 0), 32767);
-				route_pixel<short, unsigned char>(from_labs, (short) sharp, s_lab[row + h][cx + h][1],
-					s_lab[row + h][cx + h][2], o[3 * m], o[3 * m + 1], o[3 * m + 2]);
+				labs_to_srgb8(s_Y2v, sharp, s_lab[row + h][cx + h][1], s_lab[row + h][cx + h][2], o[3 * m],
+					o[3 * m + 1], o[3 * m + 2]);
 			}
 			const int x = x0 + 4 * quad;
-			unsigned char *dst = a.out + (long long) y * a.out_stride + 3LL * x;
+			const GlobalOut dst = out + (long long) y * a.out_stride + 3LL * x;
 			if (x + 4 <= a.width && !(((uintptr_t) dst) & 3)) {
-				unsigned int *d4 = reinterpret_cast<unsigned int *>(dst);
+				unsigned int __attribute__((address_space(1))) *d4 = (unsigned int __attribute__((address_space(1))) *) dst;
 #pragma unroll
 				for (int w = 0; w < 3; w++)
 					d4[w] = (unsigned) o[4 * w] | ((unsigned) o[4 * w + 1] << 8) | ((unsigned) o[4 * w + 2] << 16) |
@@ -503,29 +547,46 @@ sharpen_fused_u8_kernel(SharpenFusedArgs a, RouteArgs to_labs, RouteArgs from_la
 	}
 }
 
-// 0 done, 1 not this kernel's case, -1 error
-int sharpen_fused_u8(const VipsHipRegion *in, const VipsHipRegion *out, const int *to_steps, int n_to,
-	const int *from_steps, int n_from, const int *coef, int n, int scale, const int *lut)
+// n images of one geometry (one launch per SF_MAXB of them).  0 done, 1 not this kernel's case, -1 error
+int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const *outs, int n_images,
+	const int *to_steps, int n_to, const int *from_steps, int n_from, const int *coef, int n, int scale,
+	const int *lut)
 {
-	if (getenv("VIPS_HIP_NO_FUSED_SHARPEN"))
+	if (getenv("VIPS_HIP_NO_FUSED_SHARPEN") || n_images < 1)
 		return 1;
-	if (in->format != VIPS_HIP_FORMAT_UCHAR || out->format != VIPS_HIP_FORMAT_UCHAR || in->bands != 3 ||
-		out->bands != 3 || n < 1 || n > 2 * SF_MAXHALF + 1 || !(n & 1) || scale <= 0)
-		return 1;
-	if (in->left != 0 || in->top != 0 || out->left != 0 || out->top != 0 || in->width != in->im_width ||
-		in->height != in->im_height || out->width != in->width || out->height != in->height)
+	const VipsHipRegion *in = ins[0], *out = outs[0];
+	for (int i = 0; i < n_images; i++) {
+		const VipsHipRegion *ri = ins[i], *ro = outs[i];
+		if (ri->format != VIPS_HIP_FORMAT_UCHAR || ro->format != VIPS_HIP_FORMAT_UCHAR || ri->bands != 3 ||
+			ro->bands != 3)
+			return 1;
+		if (ri->left != 0 || ri->top != 0 || ro->left != 0 || ro->top != 0 || ri->width != ri->im_width ||
+			ri->height != ri->im_height || ro->width != ri->width || ro->height != ri->height)
+			return 1;
+		if (ri->width != in->width || ri->height != in->height || ri->stride != in->stride ||
+			ro->stride != out->stride)
+			return 1;
+	}
+	if (n < 1 || n > 2 * SF_MAXHALF + 1 || !(n & 1) || scale <= 0)
 		return 1;
 	long long abs_sum = 0;
 	for (int k = 0; k < n; k++)
 		abs_sum += coef[k] < 0 ? -(long long) coef[k] : coef[k];
 	if (abs_sum * 32768 + scale >= (1LL << 31)) // 32-bit sums
 		return 1;
+	// the kernel runs the two chains vips_sharpen uses on sRGB, spelled out
+	static const int want_to[4] = { VIPS_HIP_COLOUR_sRGB2scRGB, VIPS_HIP_COLOUR_scRGB2XYZ, VIPS_HIP_COLOUR_XYZ2Lab,
+		VIPS_HIP_COLOUR_Lab2LabS };
+	static const int want_from[4] = { VIPS_HIP_COLOUR_LabS2Lab, VIPS_HIP_COLOUR_Lab2XYZ, VIPS_HIP_COLOUR_XYZ2scRGB,
+		VIPS_HIP_COLOUR_scRGB2sRGB };
+	if (n_to != 4 || n_from != 4 || memcmp(to_steps, want_to, sizeof(want_to)) ||
+		memcmp(from_steps, want_from, sizeof(want_from)))
+		return 1;
 	SharpenFusedArgs a;
-	RouteArgs to_labs, from_labs;
-	if (colour_route_prepare(to_steps, n_to, &to_labs) || colour_route_prepare(from_steps, n_from, &from_labs))
+	RouteArgs to_labs;
+	if (colour_route_prepare(to_steps, n_to, &to_labs))
 		return -1;
-	a.in = (const unsigned char *) in->data;
-	a.out = (unsigned char *) out->data;
+	a.tables = to_labs.tables;
 	a.in_stride = (long long) in->stride;
 	a.out_stride = (long long) out->stride;
 	a.width = in->width;
@@ -536,11 +597,29 @@ int sharpen_fused_u8(const VipsHipRegion *in, const VipsHipRegion *out, const in
 		a.coef[k] = k < n ? coef[k] : 0;
 	a.scale = scale;
 	a.rounding = scale / 2;
+	a.magic = 0;
+	a.shift = 0;
+	if (scale > 1) {
+		int l = 0;
+		while ((1LL << l) < scale)
+			l++;
+		a.magic = (unsigned int) ((((1ULL << 32) * ((1ULL << l) - (unsigned long long) scale)) / (unsigned long long) scale) + 1);
+		a.shift = l - 1;
+	}
 	a.lut = lut;
-	dim3 grid((a.width + SF_TW - 1) / SF_TW, (a.height + SF_TH - 1) / SF_TH, 1);
 	Gate gate("sharpen_fused_u8");
-	hipLaunchKernelGGL(sharpen_fused_u8_kernel, grid, dim3(256, 1, 1), 0, stream(), a, to_labs, from_labs);
-	VH_CHECK(hipGetLastError());
+	for (int base = 0; base < n_images; base += SF_MAXB) {
+		const int count = n_images - base < SF_MAXB ? n_images - base : SF_MAXB;
+		SharpenFusedPtrs p;
+		memset(&p, 0, sizeof(p));
+		for (int i = 0; i < count; i++) {
+			p.in[i] = (const unsigned char *) ins[base + i]->data;
+			p.out[i] = (unsigned char *) outs[base + i]->data;
+		}
+		dim3 grid((a.width + SF_TW - 1) / SF_TW, (a.height + SF_TH - 1) / SF_TH, count);
+		hipLaunchKernelGGL(sharpen_fused_u8_kernel, grid, dim3(256, 1, 1), 0, stream(), p, a);
+		VH_CHECK(hipGetLastError());
+	}
 	return 0;
 }
 

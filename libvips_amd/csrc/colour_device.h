@@ -69,8 +69,10 @@ static __device__ __forceinline__ float cbrt_lerp(const float *__restrict__ tabl
 		i = (int) n;
 	i = min(max(i, 0), 100000 - 2);
 	const float f = __fsub_rn(n, (float) i);
-	const float t0 = table[i];
-	return __fadd_rn(t0, __fmul_rn(f, __fsub_rn(table[i + 1], t0)));
+	// table[i] and table[i + 1] in one 8-byte access (dword aligned is enough for global memory)
+	float2 pair;
+	__builtin_memcpy(&pair, table + i, sizeof(pair));
+	return __fadd_rn(pair.x, __fmul_rn(f, __fsub_rn(pair.y, pair.x)));
 }
 
 static __device__ __forceinline__ Px step_XYZ2Lab(Px p, const float *__restrict__ table)
@@ -111,6 +113,41 @@ static __device__ __forceinline__ Px step_Lab2XYZ(Px p)
 	tmp = __dsub_rn(cby, __ddiv_rn((double) b, 200.0));
 	if (tmp < 0.2069)
 		q.c = (float) __ddiv_rn(__dmul_rn(Z0, __dsub_rn(tmp, 0.13793)), 7.787);
+	else
+		q.c = (float) __dmul_rn(__dmul_rn(__dmul_rn(Z0, tmp), tmp), tmp);
+	return q;
+}
+
+// The same with every division by a constant done as the correctly rounded three-operation
+// quotient (div_const) instead of the ~25-instruction IEEE expansion of `/`: five divisions per
+// pixel.  Used where the input is LabS-coded (vips_sharpen's way back to sRGB); there it equals
+// step_Lab2XYZ for EVERY (L, a, b) the coding can hold -- tools/div_probe.hip compares the two on
+// the device over all 2^15 x 2^16 (L, a) and (L, b) pairs (profiles/r02_probes.txt).
+static __device__ __forceinline__ Px step_Lab2XYZ_c(Px p)
+{
+	const double X0 = 95.0470, Y0 = 100.0, Z0 = 108.8827;
+	const float L = p.a, a = p.b, b = p.c;
+	double cby, tmp;
+	Px q;
+
+	if (L < 8.0) {
+		q.b = (float) DIV_CONST(__dmul_rn((double) L, Y0), 903.3);
+		cby = __dadd_rn(__dmul_rn(7.787, DIV_CONST((double) q.b, 100.0)), 16.0 / 116.0);
+	}
+	else {
+		cby = DIV_CONST(__dadd_rn((double) L, 16.0), 116.0);
+		q.b = (float) __dmul_rn(__dmul_rn(__dmul_rn(Y0, cby), cby), cby);
+	}
+
+	tmp = __dadd_rn(DIV_CONST((double) a, 500.0), cby);
+	if (tmp < 0.2069)
+		q.a = (float) DIV_CONST(__dmul_rn(X0, __dsub_rn(tmp, 0.13793)), 7.787);
+	else
+		q.a = (float) __dmul_rn(__dmul_rn(__dmul_rn(X0, tmp), tmp), tmp);
+
+	tmp = __dsub_rn(cby, DIV_CONST((double) b, 200.0));
+	if (tmp < 0.2069)
+		q.c = (float) DIV_CONST(__dmul_rn(Z0, __dsub_rn(tmp, 0.13793)), 7.787);
 	else
 		q.c = (float) __dmul_rn(__dmul_rn(__dmul_rn(Z0, tmp), tmp), tmp);
 	return q;
@@ -392,6 +429,50 @@ static __device__ __forceinline__ void route_pixel(const RouteArgs &a, TIN i0, T
 		o1 = (TOUT) v.b;
 		o2 = (TOUT) v.c;
 	}
+}
+
+// The two fixed chains of vips_sharpen on uchar sRGB (sharpen.c:214, 285), without the step
+// interpreter of route_pixel: sRGB2scRGB -> scRGB2XYZ -> XYZ2Lab -> Lab2LabS and
+// LabS2Lab -> Lab2XYZ -> XYZ2scRGB -> scRGB2sRGB.  Same steps, same roundings.
+// (v2Y / Y2v: the 8-bit tables, wherever the caller keeps them -- LDS in the sharpen kernel)
+template <bool WANT_AB>
+static __device__ __forceinline__ void srgb8_to_labs(const ColourTables &tb, const float *v2Y, int r, int g, int b,
+	short &L, short &A, short &B)
+{
+	Px v;
+	v.a = v2Y[r];
+	v.b = v2Y[g];
+	v.c = v2Y[b];
+	v = step_scRGB2XYZ(v);
+	const float cby = cbrt_lerp<1>(tb.cbrt, v.b);
+	L = lab2labs(__fsub_rn(__fmul_rn(116.0F, cby), 16.0F), 32767.0 / 100.0, 0.0);
+	if (WANT_AB) {
+		const float cbx = cbrt_lerp<0>(tb.cbrt, v.a);
+		const float cbz = cbrt_lerp<2>(tb.cbrt, v.c);
+		A = lab2labs(__fmul_rn(500.0F, __fsub_rn(cbx, cby)), 32768.0 / 128.0, -32768.0);
+		B = lab2labs(__fmul_rn(200.0F, __fsub_rn(cby, cbz)), 32768.0 / 128.0, -32768.0);
+	}
+}
+
+static __device__ __forceinline__ void labs_to_srgb8(const int *Y2v, int L, int A, int B, unsigned char &r,
+	unsigned char &g, unsigned char &b)
+{
+	Px v;
+	// LabS2Lab.c:55-69: / (32767 / 100) correctly rounded; / 256 is exact
+	v.a = (float) DIV_CONST((double) L, 32767.0 / 100.0);
+	v.b = __fmul_rn((float) A, 0.00390625f);
+	v.c = __fmul_rn((float) B, 0.00390625f);
+	v = step_Lab2XYZ_c(v);
+	v = step_XYZ2scRGB(v);
+	int ri = 0, gi = 0, bi = 0;
+	if (!(isnan(v.a) || isnan(v.b) || isnan(v.c))) {
+		ri = scRGB2sRGB_channel(Y2v, v.a, 255);
+		gi = scRGB2sRGB_channel(Y2v, v.b, 255);
+		bi = scRGB2sRGB_channel(Y2v, v.c, 255);
+	}
+	r = (unsigned char) ri;
+	g = (unsigned char) gi;
+	b = (unsigned char) bi;
 }
 
 // Fill the steps and table pointers of a RouteArgs (tables are built and uploaded on first use);

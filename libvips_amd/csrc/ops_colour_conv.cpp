@@ -4,6 +4,7 @@
 // region ops once over the whole (device-resident) image.
 #include "colour.h"
 #include "conv.h"
+#include "reduce_u8.h"
 
 #include <atomic>
 #include <thread>
@@ -765,6 +766,8 @@ int vips_hip_gaussblur_colourspace(VipsHipImage *in, VipsHipImage **out, double 
 	return vips_hip_colourspace(blurred.im, out, space);
 }
 
+static int sharpen_fused_images(VipsHipImage *const *in, int n_images, VipsHipImage **out, double sigma, double x1,
+	double y2, double y3, double m1, double m2);
 // BASELINE config 4, the batched thumbnail pipeline: vips_resize(scale) [then vips_sharpen()] on
 // n independent images.  libvips runs such a batch as n pipelines over its thread pool
 // (iofuncs/threadpool.c:625); here n_threads host threads each take the next image, every thread
@@ -786,6 +789,40 @@ int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage *
 		n_threads = 1;
 	if (n_threads > n)
 		n_threads = n;
+	// a batch of uchar images of one size whose resize is the streaming kernel's case: one launch
+	// per 64 images for the whole resize chain and one for the sharpen (resize_stream.hip)
+	if (n > 0 && !getenv("VIPS_HIP_NO_BATCH_LAUNCH")) {
+		std::vector<ImageRef> small(n);
+		std::vector<VipsHipImage *> ps(n, nullptr);
+		const int r = vh::resize_batch_u8(in, n, ps.data(), scale, kernel, gap);
+		if (r < 0)
+			return -1;
+		if (r == 0) {
+			for (int i = 0; i < n; i++)
+				small[i].im = ps[i];
+			int done = 1;
+			if (sigma >= 0.0) {
+				done = sharpen_fused_images(ps.data(), n, out, sigma, x1, y2, y3, m1, m2);
+				if (done < 0)
+					return -1;
+				if (done > 0)
+					for (int i = 0; i < n && done > 0; i++)
+						if (vips_hip_sharpen(ps[i], &out[i], sigma, x1, y2, y3, m1, m2)) {
+							for (int k = 0; k < i; k++) {
+								vips_hip_image_unref(out[k]);
+								out[k] = nullptr;
+							}
+							return -1;
+						}
+			}
+			else
+				for (int i = 0; i < n; i++)
+					out[i] = small[i].release();
+			if (vips_hip_synchronize())
+				return -1;
+			return 0;
+		}
+	}
 	std::atomic<int> next(0), failed(0);
 	std::mutex err_mutex;
 	std::string first_error;
@@ -1005,6 +1042,61 @@ int vips_hip_thumbnail_image_crop(VipsHipImage *in, VipsHipImage **out, int widt
 }
 
 // vips_sharpen_build, convolution/sharpen.c:171-302
+// vips_sharpen on n 3-band uchar sRGB images of one size (every thumbnail): the LabS round trip,
+// the blur of L and the LUT in one kernel (colour.hip sharpen_fused_u8) when the blur mask has at
+// most 5 taps.  0 = done (out[] filled), 1 = not that kernel's case, -1 = error
+static int sharpen_fused_images(VipsHipImage *const *in, int n_images, VipsHipImage **out, double sigma, double x1,
+	double y2, double y3, double m1, double m2)
+{
+	for (int i = 0; i < n_images; i++)
+		if (!in[i] || in[i]->format != VIPS_HIP_FORMAT_UCHAR || in[i]->bands != 3 ||
+			in[i]->interpretation != VIPS_HIP_INTERPRETATION_sRGB ||
+			guess_interpretation(in[i]) != VIPS_HIP_INTERPRETATION_sRGB || in[i]->width != in[0]->width ||
+			in[i]->height != in[0]->height)
+			return 1;
+	const Route *to = nullptr, *from = nullptr;
+	for (const Route &r : routes) {
+		if (r.from == VIPS_HIP_INTERPRETATION_sRGB && r.to == VIPS_HIP_INTERPRETATION_LABS)
+			to = &r;
+		if (r.from == VIPS_HIP_INTERPRETATION_LABS && r.to == VIPS_HIP_INTERPRETATION_sRGB)
+			from = &r;
+	}
+	const int n = vips_hip_gaussmat(sigma, 0.1, 1, VIPS_HIP_PRECISION_INTEGER, nullptr, 0, nullptr);
+	if (!(to && from && to->n > 0 && from->n > 0 && n >= 1 && n <= 5))
+		return 1;
+	std::vector<double> mask(n);
+	double scale = 1.0;
+	if (vips_hip_gaussmat(sigma, 0.1, 1, VIPS_HIP_PRECISION_INTEGER, mask.data(), n, &scale) < 0)
+		return -1;
+	// the convi C path's integers: rint of the mask and of its scale (convi.c:886-915); zero taps
+	// are squeezed out by the reference: same sums
+	std::vector<int> coef(n);
+	for (int k = 0; k < n; k++)
+		coef[k] = (int) rint(mask[k]);
+	LutPtr lut = sharpen_lut_cached(x1, y2, y3, m1, m2);
+	if (!lut)
+		return -1;
+	std::vector<ImageRef> o(n_images);
+	std::vector<VipsHipRegion> ri(n_images), ro(n_images);
+	std::vector<const VipsHipRegion *> pi(n_images), po(n_images);
+	for (int i = 0; i < n_images; i++) {
+		o[i].im = vips_hip_image_new(in[i]->width, in[i]->height, 3, VIPS_HIP_FORMAT_UCHAR, VIPS_HIP_INTERPRETATION_sRGB);
+		if (!o[i].im)
+			return -1;
+		vips_hip_image_region(in[i], &ri[i]);
+		vips_hip_image_region(o[i].im, &ro[i]);
+		pi[i] = &ri[i];
+		po[i] = &ro[i];
+	}
+	const int r = vh::sharpen_fused_u8(pi.data(), po.data(), n_images, to->steps, to->n, from->steps, from->n,
+		coef.data(), n, (int) rint(scale), lut.get());
+	if (r)
+		return r;
+	for (int i = 0; i < n_images; i++)
+		out[i] = o[i].release();
+	return 0;
+}
+
 int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out, double sigma, double x1, double y2,
 	double y3, double m1, double m2)
 {
@@ -1013,49 +1105,10 @@ int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out, double sigma, double 
 		return -1;
 	}
 	const int old_interpretation = in->interpretation;
-	// 3-band uchar sRGB (every thumbnail): the LabS round trip, the blur of L and the LUT in
-	// one kernel (colour.hip sharpen_fused_u8) when the blur mask has at most 5 taps
-	if (in->format == VIPS_HIP_FORMAT_UCHAR && in->bands == 3 && guess_interpretation(in) == VIPS_HIP_INTERPRETATION_sRGB &&
-		old_interpretation == VIPS_HIP_INTERPRETATION_sRGB) {
-		const Route *to = nullptr, *from = nullptr;
-		for (const Route &r : routes) {
-			if (r.from == VIPS_HIP_INTERPRETATION_sRGB && r.to == VIPS_HIP_INTERPRETATION_LABS)
-				to = &r;
-			if (r.from == VIPS_HIP_INTERPRETATION_LABS && r.to == VIPS_HIP_INTERPRETATION_sRGB)
-				from = &r;
-		}
-		const int n = vips_hip_gaussmat(sigma, 0.1, 1, VIPS_HIP_PRECISION_INTEGER, nullptr, 0, nullptr);
-		if (to && from && to->n > 0 && from->n > 0 && n >= 1 && n <= 5) {
-			std::vector<double> mask(n);
-			double scale = 1.0;
-			if (vips_hip_gaussmat(sigma, 0.1, 1, VIPS_HIP_PRECISION_INTEGER, mask.data(), n, &scale) < 0)
-				return -1;
-			// the convi C path's integers: rint of the mask and of its scale (convi.c:886-915)
-			std::vector<int> coef(n);
-			bool whole = true;
-			for (int k = 0; k < n; k++) {
-				coef[k] = (int) rint(mask[k]);
-				whole = whole && coef[k] != 0; // zero taps are squeezed out by the reference: same sums
-			}
-			LutPtr lut = sharpen_lut_cached(x1, y2, y3, m1, m2);
-			if (!lut)
-				return -1;
-			ImageRef o(vips_hip_image_new(in->width, in->height, 3, VIPS_HIP_FORMAT_UCHAR, VIPS_HIP_INTERPRETATION_sRGB));
-			if (!o.im)
-				return -1;
-			VipsHipRegion ri, ro;
-			vips_hip_image_region(in, &ri);
-			vips_hip_image_region(o.im, &ro);
-			(void) whole;
-			const int r = vh::sharpen_fused_u8(&ri, &ro, to->steps, to->n, from->steps, from->n, coef.data(), n,
-				(int) rint(scale), lut.get());
-			if (r < 0)
-				return -1;
-			if (r == 0) {
-				*out = o.release();
-				return 0;
-			}
-		}
+	{
+		const int r = sharpen_fused_images(&in, 1, out, sigma, x1, y2, y3, m1, m2);
+		if (r <= 0)
+			return r;
 	}
 	ImageRef labs;
 	if (vips_hip_colourspace(in, &labs.im, VIPS_HIP_INTERPRETATION_LABS))

@@ -236,6 +236,47 @@ int reduce_axis(VipsHipImage *in, VipsHipImage **out, double shrink, int kernel,
 	return residual_axis(domain, cur, out, p, kernel, vertical);
 }
 
+// n uchar images of one size through vips_resize's whole downsizing chain in one launch
+// (resize_stream.hip): 0 = done (out[] filled), 1 = not that kernel's case (nothing done), -1 = error
+int resize_down_u8_stream(VipsHipImage *const *in, int n, VipsHipImage **out, const AxisPlan &pv, const AxisPlan &ph,
+	int shrunk_width, int kernel)
+{
+	if (pv.residual != 2.0 || ph.residual != 2.0 || kernel != VIPS_HIP_KERNEL_LANCZOS3 || n < 1)
+		return 1;
+	const int shrunk_height =
+		pv.int_shrink > 1 ? vips_hip_shrink_out_size(in[0]->height, pv.int_shrink, 1) : in[0]->height;
+	if (shrunk_height <= 0)
+		return 1;
+	ReducePtr rv = reduce_cached(kernel, pv.residual, shrunk_height, pv.size, pv.extra_pixels);
+	ReducePtr rh = rv ? reduce_cached(kernel, ph.residual, shrunk_width, ph.size, ph.extra_pixels) : ReducePtr();
+	if (!rv || !rh)
+		return -1;
+	std::vector<ImageRef> o(n);
+	std::vector<VipsHipRegion> ri(n), ro(n);
+	std::vector<const VipsHipRegion *> pi(n), po(n);
+	for (int i = 0; i < n; i++) {
+		if (in[i]->width != in[0]->width || in[i]->height != in[0]->height || in[i]->bands != in[0]->bands ||
+			in[i]->format != VIPS_HIP_FORMAT_UCHAR)
+			return 1;
+		o[i].im = like(in[i], ph.size, pv.size);
+		if (!o[i].im)
+			return -1;
+		vips_hip_image_region(in[i], &ri[i]);
+		vips_hip_image_region(o[i].im, &ro[i]);
+		pi[i] = &ri[i];
+		po[i] = &ro[i];
+	}
+	const int done = resize_stream_u8_try(rv.get(), pv.int_shrink, rh.get(), ph.int_shrink, shrunk_height,
+		shrunk_width, pi.data(), po.data(), n, g_fatstrip_height);
+	if (done < 0)
+		return -1;
+	if (done == 0)
+		return 1;
+	for (int i = 0; i < n; i++)
+		out[i] = o[i].release();
+	return 0;
+}
+
 // vips_resize's downsizing of a uchar image on both axes (resize.c:207-228: reducev with its
 // box pre-shrink, then reduceh with its own): the vertical box shrink, then everything else in
 // one kernel (resize_tail.hip) when the geometry fits it.  1 = not this function's case.
@@ -250,6 +291,12 @@ int resize_down_u8(VipsHipImage *in, VipsHipImage **out, double vshrink, double 
 	const int shrunk_width = ph.int_shrink > 1 ? vips_hip_shrink_out_size(in->width, ph.int_shrink, 1) : in->width;
 	if (shrunk_width <= 0)
 		return 1;
+	{
+		// all four operations in one kernel when both residuals are exactly 2 (resize_stream.hip)
+		const int done = resize_down_u8_stream(&in, 1, out, pv, ph, shrunk_width, kernel);
+		if (done <= 0)
+			return done;
+	}
 	ImageRef pre;
 	VipsHipImage *cur = in;
 	if (pv.int_shrink > 1) {
@@ -282,6 +329,36 @@ int resize_down_u8(VipsHipImage *in, VipsHipImage **out, double vshrink, double 
 }
 
 } // namespace
+
+namespace vh {
+
+// vips_resize(scale) of n uchar images of one size in one launch, for the batch entry point:
+// 0 = done, 1 = not the streaming kernel's case (the caller resizes image by image), -1 = error
+int resize_batch_u8(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel, double gap)
+{
+	if (n < 1 || !in[0] || in[0]->format != VIPS_HIP_FORMAT_UCHAR || kernel == VIPS_HIP_KERNEL_NEAREST)
+		return 1;
+	if (gap < 0.0)
+		gap = 2.0; // resize.c:397
+	if (!(scale > 0.0) || scale >= 1.0 || scale < 1.0 / in[0]->width || scale < 1.0 / in[0]->height)
+		return 1;
+	for (int i = 1; i < n; i++)
+		if (!in[i])
+			return 1;
+	AxisPlan pv, ph;
+	if (plan_axis("reducev", in[0]->height, 1.0 / scale, kernel, gap, &pv) ||
+		plan_axis("reduceh", in[0]->width, 1.0 / scale, kernel, gap, &ph))
+		return -1;
+	if (pv.size <= 0 || ph.size <= 0)
+		return 1;
+	const int shrunk_width =
+		ph.int_shrink > 1 ? vips_hip_shrink_out_size(in[0]->width, ph.int_shrink, 1) : in[0]->width;
+	if (shrunk_width <= 0)
+		return 1;
+	return resize_down_u8_stream(in, n, out, pv, ph, shrunk_width, kernel);
+}
+
+} // namespace vh
 
 extern "C" {
 

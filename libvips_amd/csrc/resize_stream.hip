@@ -1,0 +1,481 @@
+// vips_resize() of uchar images by an even integer factor, ALL FOUR operations in one streaming
+// kernel, and a batch of same-sized images in one launch (BASELINE configs 1 and 4):
+//
+//   vips_shrinkv(vs, ceil) -> vips_reducev(2.0) -> vips_shrinkh(hs, ceil) -> vips_reduceh(2.0)
+//   (resample/resize.c:207-228 chains shrinkv.c:158-268, reducev.cpp:418-459, shrinkh.c:78-156 and
+//   reduceh.cpp:216-255 through three intermediate images; each rounds to uchar).
+//
+// With `gap` = 2 a resize by 1/(2k) runs a box shrink of k and a residual reduce of exactly 2 on
+// each axis: the reduce then steps two pixels per output with ONE coefficient phase, and the
+// whole chain streams.  A 256-thread block owns a strip of output columns and a segment of output
+// rows of one image and walks down the input rows; lane t owns bytes [8t, 8t + 8) of the strip's
+// span of every row (one global_load_dwordx2 per row: a wave reads 512 contiguous bytes; a
+// scanline is a byte array to the two vertical operations, so any band count works).
+//
+//   vertical: the vs rows of a box are summed as two 16-bit lanes per dword and rounded the way
+//   shrinkv does; two shrunk rows make one i16 pair per byte column and feed the 7 reducev sums
+//   they are taps (2q, 2q + 1) of with v_dot2_i32_i16 (7 accumulator rows per column rotate
+//   statically through the unrolled body of 7 pairs); one row of the vertically resized image
+//   retires per pair into LDS.  Row registers are refilled in place with the next pair's rows, so
+//   2 vs loads per lane are always in flight.  Nothing is read twice within a segment.
+//   horizontal, every 7 retired rows: shrinkh box sums from that LDS slab into a second one, then
+//   the 13 reduceh taps from there, bytes stored straight to the output image.
+//
+// The 1/vs-size and the two further intermediate images of the chain never exist: an 8192 x 8192 x 3
+// image is read once (201 MB) and 3 MB are written.  Every rounding is the separate operations'
+// own, so the result is theirs bit for bit (tests/test_resample_gpu.py compares it with the
+// compiled reference and with the unfused kernels).
+#include "resample.h"
+#include "reduce_u8.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace vh {
+
+constexpr int RS_SPAN = 2048; // bytes of a row a strip covers
+constexpr int RS_NT = 256;    // a strip's outputs are at most this many band elements wide
+constexpr int RS_MAXB = 64;        // images per launch
+constexpr int RS_NP = 7;           // coefficient pairs of the 13-tap vertical reduce = rows per slab
+
+struct StreamArgs {
+	long long in_stride, out_stride;
+	int width, height, bands; // input images
+	int h1, w3;               // height after shrinkv, width after shrinkh
+	int out_width, out_height;
+	int hs;
+	unsigned int mult_v, mult_h; // 2^32 / (256 * shrink), shrinkv.c:201 / shrinkh.c:141
+	int fv, fh;                  // first tap of output row 0 / output column 0
+	int n_h;                     // horizontal taps (<= 13)
+	int tw, seg;                 // output columns per strip, output rows per segment
+	int s_pitch;                 // bytes per row of the shrinkh slab
+	int debug;                   // $VIPS_HIP_STREAM_DEBUG: 1 skip the horizontal pass (timing only)
+	unsigned int cv[RS_NP];      // vertical taps (2q, 2q + 1) as i16 pairs
+	short ch[16];                // horizontal taps
+};
+
+struct StreamPtrs {
+	const unsigned char *in[RS_MAXB];
+	unsigned char *out[RS_MAXB];
+};
+
+typedef short rs_short2 __attribute__((ext_vector_type(2)));
+
+static __device__ __forceinline__ int rs_dot2(unsigned int pix, unsigned int coef, int acc)
+{
+	return __builtin_amdgcn_sdot2(__builtin_bit_cast(rs_short2, pix), __builtin_bit_cast(rs_short2, coef), acc, false);
+}
+
+// (sum + 2048) >> 12, clip (templates.h:152-157); see fin_u8 in reduce_u8.hip for the asm
+static __device__ __forceinline__ unsigned int rs_fin(int s)
+{
+	s = (s + (INTERPOLATE_SCALE >> 1)) >> INTERPOLATE_SHIFT;
+	asm volatile("" : "+v"(s));
+	return (unsigned int) min(max(s, 0), 255);
+}
+
+// two i32 sums, already shifted, as one dword of two saturated bytes: {0, 0, sat_u8(hi), sat_u8(lo)}
+static __device__ __forceinline__ unsigned int rs_sat2(int lo, int hi)
+{
+	// the low halves of the two sums side by side (|sum >> 12| < 2^15), then v_sat_pk_u8_i16
+	const unsigned int both = __builtin_amdgcn_perm((unsigned int) hi, (unsigned int) lo, 0x05040100u);
+	unsigned int r;
+	asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(both));
+	return r;
+}
+
+// The box rounding of shrinkv on two 16-bit sums held in one dword (bytes 0 and 2 of a dword
+// column, or 1 and 3): ((sum + vs/2) * (2^32 / (256 vs))) >> 24, shrinkv.c:158-165; the result
+// again as two 16-bit lanes.
+template <int VS>
+static __device__ __forceinline__ unsigned int rs_box2(unsigned int sums, unsigned int mult)
+{
+	if constexpr ((VS & (VS - 1)) == 0) {
+		// a power of two: the multiplier is 2^(24 - log2 vs), both lanes shift at once
+		constexpr int SH = VS == 1 ? 0 : VS == 2 ? 1 : VS == 4 ? 2 : VS == 8 ? 3 : 4;
+		constexpr unsigned int RND = (unsigned int) (VS / 2) * 0x00010001u;
+		return ((sums + RND) >> SH) & 0x00ff00ffu;
+	}
+	else {
+		const unsigned int lo = (((sums & 0xffffu) + VS / 2) * mult) >> 24;
+		const unsigned int hi = (((sums >> 16) + VS / 2) * mult) >> 24;
+		return lo | (hi << 16);
+	}
+}
+
+// DW = dwords of a row per lane (2: 256 threads with 7 x 8 sums each; 1: 512 threads, half the
+// registers, twice the waves)
+template <int VS, int DW>
+__global__ void __launch_bounds__(RS_SPAN / (4 * DW))
+resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
+{
+	constexpr int NT = RS_SPAN / (4 * DW);
+	constexpr int NB = 4 * DW; // byte columns per lane
+	extern __shared__ __attribute__((aligned(16))) unsigned int rs_lds[];
+	unsigned char *T = reinterpret_cast<unsigned char *>(rs_lds); // RS_NP rows of RS_SPAN bytes
+	unsigned char *S = T + RS_NP * RS_SPAN;                        // RS_NP rows of s_pitch bytes
+	(void) ptrs_by_value;
+	// the image pointers where they lie in the kernarg segment (a by-value array indexed
+	// dynamically would be copied to scratch)
+	typedef const unsigned long long __attribute__((address_space(4))) *KernargPtrs;
+	static_assert(sizeof(StreamArgs) % 8 == 0, "kernarg layout");
+	const KernargPtrs kp = (KernargPtrs) ((const char __attribute__((address_space(4))) *)
+											  __builtin_amdgcn_kernarg_segment_ptr() +
+		sizeof(StreamArgs));
+	// (pointers made from integers are generic to the compiler: say they are global, or every
+	// access is a flat_load)
+	typedef const unsigned char __attribute__((address_space(1))) *GlobalIn;
+	typedef unsigned char __attribute__((address_space(1))) *GlobalOut;
+	typedef const unsigned int __attribute__((address_space(1))) *GlobalIn1;
+	typedef unsigned int rs_uint2 __attribute__((ext_vector_type(2)));
+	typedef const rs_uint2 __attribute__((address_space(1))) *GlobalIn2;
+	const GlobalIn in = (GlobalIn) kp[blockIdx.z];
+	const GlobalOut out = (GlobalOut) kp[RS_MAXB + blockIdx.z];
+
+	const int t = threadIdx.x;
+	const int B = a.bands;
+	const int x0 = blockIdx.x * a.tw, nx = min(a.tw, a.out_width - x0);
+	const int y0 = blockIdx.y * a.seg, ny = min(a.seg, a.out_height - y0);
+	// columns of the shrinkh image the strip's taps touch, and the input bytes under them
+	const int c_lo = min(max(2 * x0 + a.fh, 0), a.w3 - 1);
+	const int c_hi = min(max(2 * (x0 + nx - 1) + a.fh + a.n_h - 1, 0), a.w3 - 1);
+	const int ncol = c_hi - c_lo + 1;
+	const int row_bytes = a.width * B;
+	// the strip's span starts at the dword holding its first byte, or earlier when it would run
+	// over the end of the row (the host checked row_bytes >= RS_SPAN and row_bytes % 4 == 0)
+	const int start_al = min((c_lo * a.hs * B) & ~3, row_bytes - RS_SPAN);
+	const GlobalIn span = in + start_al; // uniform: rows load as scalar base + lane offset
+	const unsigned int lane_off = (unsigned int) (4 * DW * t);
+
+	struct Row {
+		unsigned int w[DW];
+	};
+	// input row k of shrunk row `r` (any integer: rows clamp to the shrunk image, boxes to the input)
+	auto load = [&](int r, int k) -> Row {
+		const int rc = min(max(r, 0), a.h1 - 1);
+		const int row = min(rc * VS + k, a.height - 1);
+		// (the host checked height * stride < 2^32: a 32-bit scalar multiply)
+		const unsigned int row_off = (unsigned int) row * (unsigned int) a.in_stride;
+		// global_load_dword(x2) v, v_off, s[span]: one 32-bit add per load (as span + row_off +
+		// lane_off the compiler keeps a 64-bit vector address per row instead)
+		const unsigned int off = row_off + lane_off;
+		Row v;
+		if constexpr (DW == 2) {
+			const rs_uint2 x = *(GlobalIn2) (span + off);
+			v.w[0] = x.x;
+			v.w[DW - 1] = x.y;
+		}
+		else
+			v.w[0] = *(GlobalIn1) (span + off);
+		return v;
+	};
+
+	// 7 output rows in flight per byte column; a sum starts at the rounding term of its final
+	// (sum + 2048) >> 12 (templates.h:152-157)
+	int acc[RS_NP][NB];
+	int half = INTERPOLATE_SCALE >> 1;
+	asm volatile("" : "+v"(half)); // one register for all sums to start from
+#pragma unroll
+	for (int s = 0; s < RS_NP; s++)
+#pragma unroll
+		for (int b = 0; b < NB; b++)
+			acc[s][b] = 0;
+
+	// pair j of the segment = shrunk rows r0 + 2j, r0 + 2j + 1; it is tap pair q of output row
+	// y0 + j - q.  Pair -1 is a dummy that lets a slab of 7 output rows end with a body.
+	const int r0 = 2 * y0 + a.fv;
+	Row ring[2][VS];
+#pragma unroll
+	for (int h = 0; h < 2; h++)
+#pragma unroll
+		for (int k = 0; k < VS; k++)
+			ring[h][k] = load(r0 - 2 + h, k);
+
+	const int nbody = (ny + RS_NP - 1) / RS_NP + 1;
+	for (int n = 0; n < nbody; n++) {
+#pragma unroll
+		for (int p = 0; p < RS_NP; p++) {
+			const int j = RS_NP * n + p - 1;
+			// the two shrunk rows: per dword column the even bytes (0, 2) and the odd bytes (1, 3)
+			// as 16-bit lanes: [h][2 d] even, [h][2 d + 1] odd
+			unsigned int sb[2][2 * DW];
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				unsigned int e[DW], o[DW];
+#pragma unroll
+				for (int d = 0; d < DW; d++)
+					e[d] = o[d] = 0;
+#pragma unroll
+				for (int k = 0; k < VS; k++) {
+					const Row w = ring[h][k];
+#pragma unroll
+					for (int d = 0; d < DW; d++) {
+						e[d] += w.w[d] & 0x00ff00ffu;
+						o[d] += __builtin_amdgcn_perm(0u, w.w[d], 0x0c030c01u);
+					}
+					ring[h][k] = load(r0 + 2 * (j + 1) + h, k);
+				}
+#pragma unroll
+				for (int d = 0; d < DW; d++) {
+					sb[h][2 * d] = rs_box2<VS>(e[d], a.mult_v);
+					sb[h][2 * d + 1] = rs_box2<VS>(o[d], a.mult_v);
+				}
+			}
+			// byte column b of the lane: dword b / 4, lane (b % 4) / 2 of its even / odd sums
+#pragma unroll
+			for (int b = 0; b < NB; b++) {
+				const int w = (b >> 2) * 2 + (b & 1);
+				const unsigned int pk = __builtin_amdgcn_perm(sb[1][w], sb[0][w], (b & 2) ? 0x07060302u : 0x05040100u);
+#pragma unroll
+				for (int q = 0; q < RS_NP; q++) {
+					const int slot = (p - 1 - q + 2 * RS_NP) % RS_NP;
+					if (q == 0)
+						asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(acc[slot][b]) : "v"(pk), "s"(a.cv[0]), "v"(half));
+					else
+						acc[slot][b] = rs_dot2(pk, a.cv[q], acc[slot][b]);
+				}
+			}
+			// output row y0 + j - 6 is complete: slab row p
+			unsigned int packed[DW];
+#pragma unroll
+			for (int d = 0; d < DW; d++)
+				packed[d] = rs_sat2(acc[p][4 * d] >> INTERPOLATE_SHIFT, acc[p][4 * d + 1] >> INTERPOLATE_SHIFT) |
+					(rs_sat2(acc[p][4 * d + 2] >> INTERPOLATE_SHIFT, acc[p][4 * d + 3] >> INTERPOLATE_SHIFT) << 16);
+			if constexpr (DW == 2)
+				*reinterpret_cast<uint2 *>(T + p * RS_SPAN + 8 * t) = make_uint2(packed[0], packed[DW - 1]);
+			else
+				*reinterpret_cast<unsigned int *>(T + p * RS_SPAN + 4 * t) = packed[0];
+			// keep the pairs apart: left alone the scheduler hoists the loads of several pairs to
+			// the top of the body and holds their destinations (50 more registers)
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		if (n == 0 || (a.debug & 1))
+			continue;
+
+		// ---- the slab: output rows y0 + 7 (n - 1) ...
+		const int yb = RS_NP * (n - 1);
+		const int nr = min(RS_NP, ny - yb);
+		__syncthreads();
+		// (everything the horizontal pass derives from the thread index is made anew per slab:
+		// hoisted out of the row loop it would sit in ~30 registers through the vertical pass)
+		int th = t;
+		asm volatile("" : "+v"(th));
+		// shrinkh: thread = one band element of the shrunk rows, all slab rows
+		{
+			const int per_row = ncol * B;
+			const unsigned int magic = (65536u + B - 1) / B;
+			for (int e = th; e < per_row; e += NT) {
+				const int c = (int) ((e * magic) >> 16);
+				const int b = e - c * B;
+				const int px0 = (c_lo + c) * a.hs;
+				const unsigned char *src = T + b - start_al;
+				unsigned int sum[RS_NP];
+#pragma unroll
+				for (int r = 0; r < RS_NP; r++)
+					sum[r] = (unsigned int) (a.hs / 2);
+#pragma unroll 4
+				for (int k = 0; k < a.hs; k++) {
+					const int off = min(px0 + k, a.width - 1) * B;
+#pragma unroll
+					for (int r = 0; r < RS_NP; r++)
+						sum[r] += src[r * RS_SPAN + off];
+				}
+#pragma unroll
+				for (int r = 0; r < RS_NP; r++)
+					S[r * a.s_pitch + e] = (unsigned char) ((sum[r] * a.mult_h) >> 24);
+			}
+		}
+		__syncthreads();
+		// reduceh: thread = one band element of the output rows (nx * B <= 256), all slab rows
+		if (th < nx * B) {
+			const unsigned int magic = (65536u + B - 1) / B;
+			const int x = (int) ((th * magic) >> 16);
+			const int b = th - x * B;
+			const int f = 2 * (x0 + x) + a.fh;
+			int sum[RS_NP];
+#pragma unroll
+			for (int r = 0; r < RS_NP; r++)
+				sum[r] = 0;
+#pragma unroll
+			for (int k = 0; k < 13; k++) {
+				if (k < a.n_h) {
+					const int off = (min(max(f + k, 0), a.w3 - 1) - c_lo) * B + b;
+					const int ck = a.ch[k];
+#pragma unroll
+					for (int r = 0; r < RS_NP; r++)
+						sum[r] += ck * (int) S[r * a.s_pitch + off];
+				}
+			}
+			const GlobalOut dst = out + (long long) (y0 + yb) * a.out_stride + (long long) x0 * B + th;
+#pragma unroll
+			for (int r = 0; r < RS_NP; r++)
+				if (r < nr)
+					dst[(long long) r * a.out_stride] = (unsigned char) rs_fin(sum[r]);
+		}
+	}
+}
+
+namespace {
+
+// positions 2 k + first0 with one phase
+bool stream_regular(const std::vector<ReducePos> &pos, int *first0, int *phase)
+{
+	if (pos.empty())
+		return false;
+	*first0 = pos[0].first;
+	*phase = pos[0].phase;
+	for (size_t k = 0; k < pos.size(); k++)
+		if (pos[k].first != *first0 + 2 * (int) k || pos[k].phase != *phase)
+			return false;
+	return true;
+}
+
+template <int VS>
+void stream_launch(const StreamArgs &a, const StreamPtrs &p, dim3 grid, size_t lds, int dw)
+{
+	if (dw == 1)
+		hipLaunchKernelGGL((resize_stream_u8<VS, 1>), grid, dim3(RS_SPAN / 4, 1, 1), lds, stream(), a, p);
+	else
+		hipLaunchKernelGGL((resize_stream_u8<VS, 2>), grid, dim3(RS_SPAN / 8, 1, 1), lds, stream(), a, p);
+}
+
+} // namespace
+
+// The whole downsizing chain of vips_resize on n uchar images of one geometry.  `rv` was built
+// for the image after shrinkv(vs) (height h1), `rh` for the one after shrinkh(hs) (width w3).
+// 1 = handled, 0 = not this kernel's case (nothing launched), -1 = error.
+int resize_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh, int hs, int h1, int w3,
+	const VipsHipRegion *const *in, const VipsHipRegion *const *out, int n, int tile)
+{
+	if (getenv("VIPS_HIP_NO_RESIZE_STREAM") || n < 1)
+		return 0;
+	const VipsHipRegion *i0 = in[0], *o0 = out[0];
+	for (int i = 0; i < n; i++) {
+		const VipsHipRegion *ri = in[i], *ro = out[i];
+		if (ri->format != VIPS_HIP_FORMAT_UCHAR || ro->format != VIPS_HIP_FORMAT_UCHAR || ri->bands != ro->bands ||
+			ri->bands < 1 || ri->bands > 4)
+			return 0;
+		if (ri->left != 0 || ri->top != 0 || ri->width != ri->im_width || ri->height != ri->im_height ||
+			ro->left != 0 || ro->top != 0 || ro->width != ro->im_width || ro->height != ro->im_height)
+			return 0;
+		if (ri->width != i0->width || ri->height != i0->height || ri->bands != i0->bands || ri->stride != i0->stride ||
+			ro->width != o0->width || ro->height != o0->height || ro->stride != o0->stride)
+			return 0;
+		if (((uintptr_t) ri->data & 3) || (ri->stride & 3))
+			return 0;
+	}
+	const int B = i0->bands;
+	const long long row_bytes = (long long) i0->width * B;
+	if ((row_bytes & 3) || row_bytes < RS_SPAN || row_bytes > 0x3fffffffLL)
+		return 0;
+	if ((unsigned long long) i0->stride * (unsigned long long) i0->height > 0xffffffffULL)
+		return 0;
+	if (vs != 1 && vs != 2 && vs != 3 && vs != 4 && vs != 5 && vs != 6 && vs != 8)
+		return 0;
+	if (hs < 1 || hs > 64)
+		return 0;
+	if (rv->in_size != h1 || rv->out_size != o0->height || rh->in_size != w3 || rh->out_size != o0->width)
+		return 0;
+	if (rv->n_point != 13 || rh->n_point > 13 || rh->n_point < 1)
+		return 0;
+	std::vector<ReducePos> pv, ph;
+	reduce_positions(rv, 0, o0->height, tile, pv);
+	reduce_positions(rh, 0, o0->width, 0, ph);
+	int fv, fh, phase_v, phase_h;
+	if (!stream_regular(pv, &fv, &phase_v) || !stream_regular(ph, &fh, &phase_h))
+		return 0;
+
+	StreamArgs a;
+	memset(&a, 0, sizeof(a));
+	a.in_stride = (long long) i0->stride;
+	a.out_stride = (long long) o0->stride;
+	a.width = i0->width;
+	a.height = i0->height;
+	a.bands = B;
+	a.h1 = h1;
+	a.w3 = w3;
+	a.out_width = o0->width;
+	a.out_height = o0->height;
+	a.hs = hs;
+	a.mult_v = (unsigned int) ((1LL << 32) / ((1 << 8) * (long long) vs));
+	a.mult_h = (unsigned int) ((1LL << 32) / ((1 << 8) * (long long) hs));
+	a.fv = fv;
+	a.fh = fh;
+	a.n_h = rh->n_point;
+	// the widest strip whose span fits: (2 tw + n_h - 1) shrunk columns of hs pixels, + 3 bytes of alignment
+	int tw = (int) (((RS_SPAN - 3) / ((long long) hs * B) - (a.n_h - 1)) / 2);
+	if (tw > RS_NT / B)
+		tw = RS_NT / B;
+	if (tw > o0->width)
+		tw = o0->width;
+	if (tw < 4)
+		return 0;
+	a.tw = tw;
+	a.s_pitch = ((2 * tw + a.n_h - 1) * B + 3) & ~3;
+	const int nstrips = (o0->width + tw - 1) / tw;
+	// segments: enough blocks to fill the chip several times, but tall (a segment re-reads 6 pairs)
+	long long want = getenv("VIPS_HIP_STREAM_BLOCKS") ? atoll(getenv("VIPS_HIP_STREAM_BLOCKS")) : 2048;
+	int nsegs = (int) ((want + (long long) nstrips * n - 1) / ((long long) nstrips * n));
+	int seg = (o0->height + nsegs - 1) / nsegs;
+	const int seg_min = getenv("VIPS_HIP_STREAM_SEG") ? atoi(getenv("VIPS_HIP_STREAM_SEG")) : 28;
+	if (seg < seg_min)
+		seg = seg_min;
+	seg = (seg + RS_NP - 1) / RS_NP * RS_NP;
+	nsegs = (o0->height + seg - 1) / seg;
+	a.seg = seg;
+	a.debug = getenv("VIPS_HIP_STREAM_DEBUG") ? atoi(getenv("VIPS_HIP_STREAM_DEBUG")) : 0;
+	const short *cvs = &rv->matrixs[(size_t) phase_v * rv->n_point];
+	for (int q = 0; q < RS_NP; q++) {
+		const unsigned int lo = (unsigned short) cvs[2 * q];
+		const unsigned int hi = 2 * q + 1 < rv->n_point ? (unsigned short) cvs[2 * q + 1] : 0u;
+		a.cv[q] = lo | (hi << 16);
+	}
+	const short *chs = &rh->matrixs[(size_t) phase_h * rh->n_point];
+	for (int k = 0; k < rh->n_point; k++)
+		a.ch[k] = chs[k];
+	const size_t lds = (size_t) RS_NP * RS_SPAN + (size_t) RS_NP * a.s_pitch;
+	const int dw = getenv("VIPS_HIP_STREAM_DW") ? atoi(getenv("VIPS_HIP_STREAM_DW")) : 2;
+
+	Gate gate("resize_stream_u8");
+	for (int base = 0; base < n; base += RS_MAXB) {
+		const int count = n - base < RS_MAXB ? n - base : RS_MAXB;
+		StreamPtrs p;
+		memset(&p, 0, sizeof(p));
+		for (int i = 0; i < count; i++) {
+			p.in[i] = (const unsigned char *) in[base + i]->data;
+			p.out[i] = (unsigned char *) out[base + i]->data;
+		}
+		const dim3 grid(nstrips, nsegs, count);
+		switch (vs) {
+		case 1:
+			stream_launch<1>(a, p, grid, lds, dw);
+			break;
+		case 2:
+			stream_launch<2>(a, p, grid, lds, dw);
+			break;
+		case 3:
+			stream_launch<3>(a, p, grid, lds, dw);
+			break;
+		case 4:
+			stream_launch<4>(a, p, grid, lds, dw);
+			break;
+		case 5:
+			stream_launch<5>(a, p, grid, lds, dw);
+			break;
+		case 6:
+			stream_launch<6>(a, p, grid, lds, dw);
+			break;
+		default:
+			stream_launch<8>(a, p, grid, lds, dw);
+			break;
+		}
+		if (hipGetLastError() != hipSuccess) {
+			error("resize", "kernel launch failed");
+			return -1;
+		}
+	}
+	return 1;
+}
+
+} // namespace vh

@@ -389,6 +389,7 @@ def test_resize_tail_fused(bands, size, scale, vscale, monkeypatch):
     src = helpers.lcg_image(w, h, bands, np.uint8, 77)
     kw = {} if vscale is None else {"vscale": vscale}
     im = Image.new_from_array(src)
+    monkeypatch.setenv("VIPS_HIP_NO_RESIZE_STREAM", "1")  # the whole-chain kernel takes 1 / (2 k) scales first
     libvips_amd.lib.vips_hip_gate_reset()
     libvips_amd.lib.vips_hip_gate_enable(1)
     try:
@@ -402,6 +403,57 @@ def test_resize_tail_fused(bands, size, scale, vscale, monkeypatch):
     assert_same(got, Port.resize(src, scale, **kw), str((bands, size, scale, vscale)))
     monkeypatch.setenv("VIPS_HIP_NO_RESIZE_TAIL", "1")
     assert np.array_equal(got, im.resize(scale, **kw).numpy())
+
+
+@pytest.mark.parametrize("bands", [1, 2, 3, 4])
+@pytest.mark.parametrize("size,scale,vscale", [
+    ((2048, 1536), 0.125, None), ((4104, 1203), 0.125, None), ((2048, 1537), 0.25, None),
+    ((2052, 1202), 1.0 / 6.0, None), ((2560, 1004), 0.1, None), ((3072, 1205), 1.0 / 12.0, None),
+    ((4096, 1607), 1.0 / 16.0, None), ((2048, 1001), 0.5, None), ((4096, 900), 0.125, 0.25),
+    ((8192, 2563), 0.125, None), ((2048, 40), 0.25, None)])
+def test_resize_stream_fused(bands, size, scale, vscale, monkeypatch):
+    """vips_resize by 1 / (2 k) on uchar in ONE kernel (resize_stream.hip: shrinkv -> reducev ->
+    shrinkh -> reduceh streaming down column strips): ran alone, and bit-exact against the port
+    and against the separate kernels; box shrinks 1..8 on either axis, heights the box does not
+    divide (ceil mode), several strips and segments, every band count."""
+    w, h = size
+    src = helpers.lcg_image(w, h, bands, np.uint8, 78)
+    kw = {} if vscale is None else {"vscale": vscale}
+    im = Image.new_from_array(src)
+    monkeypatch.setenv("VIPS_HIP_STREAM_BLOCKS", "4096")  # short segments: several per image
+    libvips_amd.lib.vips_hip_gate_reset()
+    libvips_amd.lib.vips_hip_gate_enable(1)
+    try:
+        got = im.resize(scale, **kw).numpy()
+        report = libvips_amd.gate_report()
+    finally:
+        libvips_amd.lib.vips_hip_gate_enable(0)
+        libvips_amd.lib.vips_hip_gate_reset()
+    assert list(report) == ["resize_stream_u8"], report
+    assert_same(got, Port.resize(src, scale, **kw), str((bands, size, scale, vscale)))
+    monkeypatch.delenv("VIPS_HIP_STREAM_BLOCKS")
+    assert np.array_equal(got, im.resize(scale, **kw).numpy())  # one tall segment per strip
+    monkeypatch.setenv("VIPS_HIP_NO_RESIZE_STREAM", "1")
+    assert np.array_equal(got, im.resize(scale, **kw).numpy())
+
+
+def test_resize_stream_batch_chunks():
+    """More images than one launch of the streaming resize / the one-kernel sharpen holds (64):
+    every image of the batch equals the pipeline run on it alone."""
+    srcs = [helpers.lcg_image(688, 96, 3, np.uint8, 900 + k) for k in range(70)]
+    ims = [Image.new_from_array(s, interpretation="srgb") for s in srcs]
+    libvips_amd.lib.vips_hip_gate_reset()
+    libvips_amd.lib.vips_hip_gate_enable(1)
+    try:
+        outs = libvips_amd.resize_sharpen_batch(ims, 0.125, threads=4)
+        report = libvips_amd.gate_report()
+    finally:
+        libvips_amd.lib.vips_hip_gate_enable(0)
+        libvips_amd.lib.vips_hip_gate_reset()
+    assert sorted(report) == ["resize_stream_u8", "sharpen_fused_u8"], report
+    for k in (0, 1, 63, 64, 69):
+        assert np.array_equal(outs[k].numpy(), ims[k].resize(0.125).sharpen().numpy()), k
+        assert np.array_equal(outs[k].numpy(), helpers.PortCC.sharpen(Port.resize(srcs[k], 0.125)))
 
 
 def test_resize_sharpen_batch():

@@ -12,7 +12,9 @@ import bench  # noqa: E402
 import libvips_amd  # noqa: E402
 from libvips_amd import Image, lib  # noqa: E402
 
-KNOBS = ("VIPS_HIP_NO_RESIZE_TAIL", "VIPS_HIP_NO_FUSED_SHARPEN", "VIPS_HIP_TAIL_TH", "VIPS_HIP_TAIL_TW")
+KNOBS = ("VIPS_HIP_NO_RESIZE_TAIL", "VIPS_HIP_NO_FUSED_SHARPEN", "VIPS_HIP_TAIL_TH", "VIPS_HIP_TAIL_TW",
+         "VIPS_HIP_NO_RESIZE_STREAM", "VIPS_HIP_NO_BATCH_LAUNCH", "VIPS_HIP_STREAM_BLOCKS", "VIPS_HIP_STREAM_SEG",
+         "VIPS_HIP_STREAM_DEBUG")
 n, count = 8192, int(os.environ.get("C4_IMAGES", "64"))
 libvips_amd.init(0)
 dev = torch.device("cuda", 0)
@@ -45,4 +47,11 @@ for spec in sys.argv[1:] or ["default:"]:
         t0 = time.perf_counter()
         libvips_amd.resize_sharpen_batch(ims, 0.125, threads=8)
         best = min(best, (time.perf_counter() - t0) / count * 1e3)
-    print("%-14s same=%s batch %.4f ms/image  resize kernels alone %s" % (name, same, best, rep), flush=True)
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    libvips_amd.resize_sharpen_batch(ims, 0.125, threads=8)
+    lib.vips_hip_gate_enable(0)
+    inb = {k: round(v[1] / count, 4) for k, v in libvips_amd.gate_report().items()}
+    lib.vips_hip_gate_reset()
+    print("%-14s same=%s batch %.4f ms/image  resize kernels alone %s  in the batch, per image %s" %
+          (name, same, best, rep, inb), flush=True)
