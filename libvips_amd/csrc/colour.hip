@@ -478,34 +478,79 @@ sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 	const int h = a.half;
 	const int rw = SF_TW + 2 * h, rh = SF_TH + 2 * h;
 
-	// 1. the tile and its halo: sRGB uchar -> LabS
-	// (region coordinates advance by 256 elements per turn: no division per pixel)
-	const int step_y = 256 / rw, step_x = 256 - step_y * rw;
-	int ry = t / rw, rx = t - ry * rw;
-	for (int idx = t; idx < rw * rh; idx += 256, ry += step_y, rx += step_x) {
-		if (rx >= rw) {
-			rx -= rw;
-			ry++;
+	// 1. the tile and its halo: sRGB uchar -> LabS.
+	// 1a. the tile itself, 4 pixels per thread (the mapping of step 3): 12 bytes as three dwords
+	// when the row allows it, the four conversions side by side (their table reads overlap)
+	{
+		const int row = t >> 4, quad = t & 15;
+		const int y = min(y0 + row, a.height - 1);
+		const int x = x0 + 4 * quad;
+		const GlobalIn line = in + (long long) y * a.in_stride;
+		unsigned char px[12];
+		if (x + 4 <= a.width && !((((unsigned long long) in) | (unsigned long long) a.in_stride) & 3)) {
+			const unsigned int __attribute__((address_space(1))) *p4 =
+				(const unsigned int __attribute__((address_space(1))) *) (line + 3LL * x);
+#pragma unroll
+			for (int w = 0; w < 3; w++) {
+				const unsigned int v = p4[w];
+				px[4 * w] = (unsigned char) v;
+				px[4 * w + 1] = (unsigned char) (v >> 8);
+				px[4 * w + 2] = (unsigned char) (v >> 16);
+				px[4 * w + 3] = (unsigned char) (v >> 24);
+			}
 		}
-		const int x = min(max(x0 + rx - h, 0), a.width - 1);
-		const int y = min(max(y0 + ry - h, 0), a.height - 1);
-		const GlobalIn p = in + (long long) y * a.in_stride + 3LL * x;
-		short L, A = 0, B = 0;
-		// only L is blurred: the halo needs no a, b
-		if (ry >= h && ry < rh - h && rx >= h && rx < rw - h)
-			srgb8_to_labs<true>(a.tables, s_v2Y, p[0], p[1], p[2], L, A, B);
-		else
+		else {
+#pragma unroll
+			for (int m = 0; m < 4; m++) {
+				const GlobalIn p = line + 3LL * min(x + m, a.width - 1);
+				px[3 * m] = p[0];
+				px[3 * m + 1] = p[1];
+				px[3 * m + 2] = p[2];
+			}
+		}
+#pragma unroll
+		for (int m = 0; m < 4; m++) {
+			short L, A, B;
+			srgb8_to_labs<true>(a.tables, s_v2Y, px[3 * m], px[3 * m + 1], px[3 * m + 2], L, A, B);
+			s_lab[row + h][4 * quad + m + h][0] = L;
+			s_lab[row + h][4 * quad + m + h][1] = A;
+			s_lab[row + h][4 * quad + m + h][2] = B;
+		}
+	}
+	// 1b. the ring of h pixels around it (image edges clamped): only L is blurred, so only L
+	{
+		const int ring = rw * rh - SF_TW * SF_TH;
+		for (int idx = t; idx < ring; idx += 256) {
+			int ry, rx;
+			if (idx < 2 * rw * h) {
+				// rows above and below
+				const int r = idx / rw;
+				rx = idx - r * rw;
+				ry = r < h ? r : SF_TH + r;
+			}
+			else {
+				// columns left and right of the tile's rows
+				const int k = idx - 2 * rw * h;
+				const int r = k / (2 * h), c = k - r * 2 * h;
+				ry = h + r;
+				rx = c < h ? c : SF_TW + c;
+			}
+			const int x = min(max(x0 + rx - h, 0), a.width - 1);
+			const int y = min(max(y0 + ry - h, 0), a.height - 1);
+			const GlobalIn p = in + (long long) y * a.in_stride + 3LL * x;
+			short L, A = 0, B = 0;
 			srgb8_to_labs<false>(a.tables, s_v2Y, p[0], p[1], p[2], L, A, B);
-		s_lab[ry][rx][0] = L;
-		s_lab[ry][rx][1] = A;
-		s_lab[ry][rx][2] = B;
+			s_lab[ry][rx][0] = L;
+		}
 	}
 	__syncthreads();
 	// 2. horizontal pass on L (all rows of the region, the tile's columns)
 	for (int idx = t; idx < rh * SF_TW; idx += 256) {
 		const int ry = idx / SF_TW, cx = idx - ry * SF_TW;
+		// always five taps (coefficients beyond the mask are zero, the reads stay inside the arrays)
 		int sum = 0;
-		for (int k = 0; k < a.n; k++)
+#pragma unroll
+		for (int k = 0; k < 2 * SF_MAXHALF + 1; k++)
 			sum += a.coef[k] * (int) s_lab[ry][cx + k][0];
 		s_h[ry][cx] = (short) sf_convi_fin(sum, a);
 	}
@@ -520,7 +565,8 @@ sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 			for (int m = 0; m < 4; m++) {
 				const int cx = 4 * quad + m;
 				int sum = 0;
-				for (int k = 0; k < a.n; k++)
+#pragma unroll
+				for (int k = 0; k < 2 * SF_MAXHALF + 1; k++)
 					sum += a.coef[k] * (int) s_h[row + k][cx];
 				const int blur = sf_convi_fin(sum, a);
 				const int v1 = s_lab[row + h][cx + h][0];

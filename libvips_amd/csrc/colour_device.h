@@ -51,19 +51,33 @@ static __device__ __forceinline__ double div_const(double a, double y, double r)
 }
 #define DIV_CONST(A, Y) div_const((A), (Y), 1.0 / (Y))
 
+// the same for a dividend known to be finite and far from overflow (no infinite quotient to keep)
+static __device__ __forceinline__ double div_const_finite(double a, double y, double r)
+{
+	const double q0 = __dmul_rn(a, r);
+	const double e = __fma_rn(-y, q0, a);
+	return __fma_rn(e, r, q0);
+}
+#define DIV_CONST_F(A, Y) div_const_finite((A), (Y), 1.0 / (Y))
+
 // vips_col_XYZ2Lab_helper, XYZ2Lab.c:109-138 (D65: include/vips/colour.h:58-60)
-template <int WHICH>
+// FINITE: v is known to be a small finite number (XYZ of a uchar pixel): no inf / NaN handling
+template <int WHICH, bool FINITE = false>
 static __device__ __forceinline__ float cbrt_lerp(const float *__restrict__ table, float v)
 {
 	// nX = QUANT_ELEMENTS * X / X0: (int * float) in float, then / double, back to float
 	const double num = (double) __fmul_rn(100000.0f, v);
-	const float n = (float) (WHICH == 0 ? DIV_CONST(num, 95.0470)
-							 : WHICH == 1 ? DIV_CONST(num, 100.0)
-										  : DIV_CONST(num, 108.8827));
+	float n;
+	if (FINITE)
+		n = (float) (WHICH == 0 ? DIV_CONST_F(num, 95.0470) : WHICH == 1 ? DIV_CONST_F(num, 100.0)
+																	 : DIV_CONST_F(num, 108.8827));
+	else
+		n = (float) (WHICH == 0 ? DIV_CONST(num, 95.0470) : WHICH == 1 ? DIV_CONST(num, 100.0)
+																   : DIV_CONST(num, 108.8827));
 	// VIPS_CLIP(0, (int) nX, QUANT_ELEMENTS - 2); (int) of NaN / overflow is the x86
 	// "integer indefinite" INT_MIN, which the clip turns into 0
 	int i;
-	if (!(n > -2147483904.0f && n < 2147483648.0f))
+	if (!FINITE && !(n > -2147483904.0f && n < 2147483648.0f))
 		i = INT_MIN;
 	else
 		i = (int) n;
@@ -118,38 +132,37 @@ static __device__ __forceinline__ Px step_Lab2XYZ(Px p)
 	return q;
 }
 
-// The same with every division by a constant done as the correctly rounded three-operation
-// quotient (div_const) instead of the ~25-instruction IEEE expansion of `/`: five divisions per
-// pixel.  Used where the input is LabS-coded (vips_sharpen's way back to sRGB); there it equals
-// step_Lab2XYZ for EVERY (L, a, b) the coding can hold -- tools/div_probe.hip compares the two on
-// the device over all 2^15 x 2^16 (L, a) and (L, b) pairs (profiles/r02_probes.txt).
+// The same for LabS-coded input (vips_sharpen's way back to sRGB): every division by a constant
+// is the correctly rounded three-operation quotient (div_const_finite) instead of the
+// ~25-instruction IEEE expansion of `/` -- five divisions per pixel -- and the dark-pixel arms
+// (L < 8, f < 0.2069) are only executed by waves that hold such a pixel.  It equals step_Lab2XYZ
+// for EVERY (L, a, b) the coding can hold: tools/div_probe.hip compares the two on the device
+// over all 2^15 x 2^16 (L, a) and (L, b) pairs (profiles/r02_probes.txt).
 static __device__ __forceinline__ Px step_Lab2XYZ_c(Px p)
 {
 	const double X0 = 95.0470, Y0 = 100.0, Z0 = 108.8827;
 	const float L = p.a, a = p.b, b = p.c;
-	double cby, tmp;
 	Px q;
 
-	if (L < 8.0) {
-		q.b = (float) DIV_CONST(__dmul_rn((double) L, Y0), 903.3);
-		cby = __dadd_rn(__dmul_rn(7.787, DIV_CONST((double) q.b, 100.0)), 16.0 / 116.0);
-	}
-	else {
-		cby = DIV_CONST(__dadd_rn((double) L, 16.0), 116.0);
-		q.b = (float) __dmul_rn(__dmul_rn(__dmul_rn(Y0, cby), cby), cby);
+	double cby = DIV_CONST_F(__dadd_rn((double) L, 16.0), 116.0);
+	q.b = (float) __dmul_rn(__dmul_rn(__dmul_rn(Y0, cby), cby), cby);
+	if (__builtin_amdgcn_ballot_w64(L < 8.0f)) {
+		if (L < 8.0f) {
+			q.b = (float) DIV_CONST_F(__dmul_rn((double) L, Y0), 903.3);
+			cby = __dadd_rn(__dmul_rn(7.787, DIV_CONST_F((double) q.b, 100.0)), 16.0 / 116.0);
+		}
 	}
 
-	tmp = __dadd_rn(DIV_CONST((double) a, 500.0), cby);
-	if (tmp < 0.2069)
-		q.a = (float) DIV_CONST(__dmul_rn(X0, __dsub_rn(tmp, 0.13793)), 7.787);
-	else
-		q.a = (float) __dmul_rn(__dmul_rn(__dmul_rn(X0, tmp), tmp), tmp);
-
-	tmp = __dsub_rn(cby, DIV_CONST((double) b, 200.0));
-	if (tmp < 0.2069)
-		q.c = (float) DIV_CONST(__dmul_rn(Z0, __dsub_rn(tmp, 0.13793)), 7.787);
-	else
-		q.c = (float) __dmul_rn(__dmul_rn(__dmul_rn(Z0, tmp), tmp), tmp);
+	const double fx = __dadd_rn(DIV_CONST_F((double) a, 500.0), cby);
+	const double fz = __dsub_rn(cby, DIV_CONST_F((double) b, 200.0));
+	q.a = (float) __dmul_rn(__dmul_rn(__dmul_rn(X0, fx), fx), fx);
+	q.c = (float) __dmul_rn(__dmul_rn(__dmul_rn(Z0, fz), fz), fz);
+	if (__builtin_amdgcn_ballot_w64(fx < 0.2069 || fz < 0.2069)) {
+		if (fx < 0.2069)
+			q.a = (float) DIV_CONST_F(__dmul_rn(X0, __dsub_rn(fx, 0.13793)), 7.787);
+		if (fz < 0.2069)
+			q.c = (float) DIV_CONST_F(__dmul_rn(Z0, __dsub_rn(fz, 0.13793)), 7.787);
+	}
 	return q;
 }
 
@@ -435,6 +448,26 @@ static __device__ __forceinline__ void route_pixel(const RouteArgs &a, TIN i0, T
 // interpreter of route_pixel: sRGB2scRGB -> scRGB2XYZ -> XYZ2Lab -> Lab2LabS and
 // LabS2Lab -> Lab2XYZ -> XYZ2scRGB -> scRGB2sRGB.  Same steps, same roundings.
 // (v2Y / Y2v: the 8-bit tables, wherever the caller keeps them -- LDS in the sharpen kernel)
+// lab2labs for a finite value: the same clip with v_min_f64 / v_max_f64
+static __device__ __forceinline__ short lab2labs_finite(float v, double scale, double lo)
+{
+	const double d = __dmul_rn((double) v, scale);
+	return (short) __builtin_fmax(lo, __builtin_fmin(d, 32767.0));
+}
+
+// step_XYZ2scRGB for finite input
+static __device__ __forceinline__ Px step_XYZ2scRGB_finite(Px p)
+{
+	const float X = (float) DIV_CONST_F((double) p.a, 100.0);
+	const float Y = (float) DIV_CONST_F((double) p.b, 100.0);
+	const float Z = (float) DIV_CONST_F((double) p.c, 100.0);
+	Px q;
+	q.a = __fadd_rn(__fadd_rn(__fmul_rn(3.240625F, X), __fmul_rn(-1.537208F, Y)), __fmul_rn(-0.498629F, Z));
+	q.b = __fadd_rn(__fadd_rn(__fmul_rn(-0.968931F, X), __fmul_rn(1.875756F, Y)), __fmul_rn(0.041518F, Z));
+	q.c = __fadd_rn(__fadd_rn(__fmul_rn(0.055710F, X), __fmul_rn(-0.204021F, Y)), __fmul_rn(1.056996F, Z));
+	return q;
+}
+
 template <bool WANT_AB>
 static __device__ __forceinline__ void srgb8_to_labs(const ColourTables &tb, const float *v2Y, int r, int g, int b,
 	short &L, short &A, short &B)
@@ -444,13 +477,13 @@ static __device__ __forceinline__ void srgb8_to_labs(const ColourTables &tb, con
 	v.b = v2Y[g];
 	v.c = v2Y[b];
 	v = step_scRGB2XYZ(v);
-	const float cby = cbrt_lerp<1>(tb.cbrt, v.b);
-	L = lab2labs(__fsub_rn(__fmul_rn(116.0F, cby), 16.0F), 32767.0 / 100.0, 0.0);
+	const float cby = cbrt_lerp<1, true>(tb.cbrt, v.b);
+	L = lab2labs_finite(__fsub_rn(__fmul_rn(116.0F, cby), 16.0F), 32767.0 / 100.0, 0.0);
 	if (WANT_AB) {
-		const float cbx = cbrt_lerp<0>(tb.cbrt, v.a);
-		const float cbz = cbrt_lerp<2>(tb.cbrt, v.c);
-		A = lab2labs(__fmul_rn(500.0F, __fsub_rn(cbx, cby)), 32768.0 / 128.0, -32768.0);
-		B = lab2labs(__fmul_rn(200.0F, __fsub_rn(cby, cbz)), 32768.0 / 128.0, -32768.0);
+		const float cbx = cbrt_lerp<0, true>(tb.cbrt, v.a);
+		const float cbz = cbrt_lerp<2, true>(tb.cbrt, v.c);
+		A = lab2labs_finite(__fmul_rn(500.0F, __fsub_rn(cbx, cby)), 32768.0 / 128.0, -32768.0);
+		B = lab2labs_finite(__fmul_rn(200.0F, __fsub_rn(cby, cbz)), 32768.0 / 128.0, -32768.0);
 	}
 }
 
@@ -459,20 +492,15 @@ static __device__ __forceinline__ void labs_to_srgb8(const int *Y2v, int L, int 
 {
 	Px v;
 	// LabS2Lab.c:55-69: / (32767 / 100) correctly rounded; / 256 is exact
-	v.a = (float) DIV_CONST((double) L, 32767.0 / 100.0);
+	v.a = (float) DIV_CONST_F((double) L, 32767.0 / 100.0);
 	v.b = __fmul_rn((float) A, 0.00390625f);
 	v.c = __fmul_rn((float) B, 0.00390625f);
 	v = step_Lab2XYZ_c(v);
-	v = step_XYZ2scRGB(v);
-	int ri = 0, gi = 0, bi = 0;
-	if (!(isnan(v.a) || isnan(v.b) || isnan(v.c))) {
-		ri = scRGB2sRGB_channel(Y2v, v.a, 255);
-		gi = scRGB2sRGB_channel(Y2v, v.b, 255);
-		bi = scRGB2sRGB_channel(Y2v, v.c, 255);
-	}
-	r = (unsigned char) ri;
-	g = (unsigned char) gi;
-	b = (unsigned char) bi;
+	v = step_XYZ2scRGB_finite(v);
+	// (finite: the NaN test of vips_col_scRGB2sRGB cannot fire)
+	r = (unsigned char) scRGB2sRGB_channel(Y2v, v.a, 255);
+	g = (unsigned char) scRGB2sRGB_channel(Y2v, v.b, 255);
+	b = (unsigned char) scRGB2sRGB_channel(Y2v, v.c, 255);
 }
 
 // Fill the steps and table pointers of a RouteArgs (tables are built and uploaded on first use);

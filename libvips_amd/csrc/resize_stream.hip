@@ -435,7 +435,7 @@ int resize_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh, int hs,
 	for (int k = 0; k < rh->n_point; k++)
 		a.ch[k] = chs[k];
 	const size_t lds = (size_t) RS_NP * RS_SPAN + (size_t) RS_NP * a.s_pitch;
-	const int dw = getenv("VIPS_HIP_STREAM_DW") ? atoi(getenv("VIPS_HIP_STREAM_DW")) : 2;
+	const int dw = getenv("VIPS_HIP_STREAM_DW") ? atoi(getenv("VIPS_HIP_STREAM_DW")) : 1;
 
 	Gate gate("resize_stream_u8");
 	for (int base = 0; base < n; base += RS_MAXB) {

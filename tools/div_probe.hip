@@ -21,7 +21,7 @@ __global__ void probe_lab2xyz(unsigned long long *bad)
 	ref.a = (float) __ddiv_rn((double) L, 32767.0 / 100.0);
 	ref.b = (float) __ddiv_rn((double) A, 32768.0 / 128.0);
 	ref.c = ref.b;
-	fast.a = (float) DIV_CONST((double) L, 32767.0 / 100.0);
+	fast.a = (float) DIV_CONST_F((double) L, 32767.0 / 100.0);
 	fast.b = __fmul_rn((float) A, 0.00390625f);
 	fast.c = fast.b;
 	const Px x = step_Lab2XYZ(ref), y = step_Lab2XYZ_c(fast);
@@ -35,8 +35,8 @@ template <int WHICH>
 static __device__ bool cbrt_bucket_same(float v)
 {
 	const double num = (double) __fmul_rn(100000.0f, v);
-	const float fast = (float) (WHICH == 0 ? DIV_CONST(num, 95.0470) : WHICH == 1 ? DIV_CONST(num, 100.0)
-																			  : DIV_CONST(num, 108.8827));
+	const float fast = (float) (WHICH == 0 ? DIV_CONST_F(num, 95.0470) : WHICH == 1 ? DIV_CONST_F(num, 100.0)
+																				: DIV_CONST_F(num, 108.8827));
 	const float ref = (float) (WHICH == 0 ? __ddiv_rn(num, 95.0470) : WHICH == 1 ? __ddiv_rn(num, 100.0)
 																			 : __ddiv_rn(num, 108.8827));
 	return __float_as_uint(fast) == __float_as_uint(ref);
