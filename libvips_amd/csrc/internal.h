@@ -41,6 +41,16 @@ hipStream_t stream();
 // Synchronise and destroy the calling thread's own stream (threads the library starts itself).
 void release_thread_stream();
 
+// The calling thread launches on `s` while this lives (nullptr: no change).  For work the
+// library spreads over a second stream itself; whoever does so orders the streams with events
+// and keeps pool blocks both streams touch alive until both are synchronised.
+struct ScopedStream {
+	explicit ScopedStream(hipStream_t s);
+	~ScopedStream();
+	hipStream_t saved;
+	bool saved_external, active;
+};
+
 // Kernel gates: VIPS_GATE_START/STOP analogue around a launch.
 struct Gate {
 	explicit Gate(const char *name);

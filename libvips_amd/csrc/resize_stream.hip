@@ -51,6 +51,8 @@ struct StreamArgs {
 	int tw, seg;                 // output columns per strip, output rows per segment
 	int s_pitch;                 // bytes per row of the shrinkh slab
 	int debug;                   // $VIPS_HIP_STREAM_DEBUG: 1 skip the horizontal pass (timing only)
+	int nstrips, nsegs, n_images; // the launch: strips x segments x images
+	int grouped;                  // the strips of a (segment, image) on one XCD
 	unsigned int cv[RS_NP];      // vertical taps (2q, 2q + 1) as i16 pairs
 	short ch[16];                // horizontal taps
 };
@@ -130,13 +132,36 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 	typedef const unsigned int __attribute__((address_space(1))) *GlobalIn1;
 	typedef unsigned int rs_uint2 __attribute__((ext_vector_type(2)));
 	typedef const rs_uint2 __attribute__((address_space(1))) *GlobalIn2;
-	const GlobalIn in = (GlobalIn) kp[blockIdx.z];
-	const GlobalOut out = (GlobalOut) kp[RS_MAXB + blockIdx.z];
+	// block -> (strip, segment, image).  Workgroup w runs on XCD w % 8: the strips of one
+	// (segment, image) go to ONE XCD, next to each other in launch order, so the input lines two
+	// neighbouring strips share (the 11-column halo, and the 128-byte line their border falls
+	// in) come from HBM once and from that XCD's L2 the second time (dealt strip by strip round
+	// the XCDs the kernel fetched 1.16 x the image: rocprofv3 FETCH_SIZE, profiles/r02b_c4_pmc.txt)
+	// (a launch of few units -- one image -- deals its blocks round the XCDs one by one instead:
+	// with two blocks per CU the even spread matters more than the shared lines, 0.048 against
+	// 0.058 ms for one 8192 x 8192 x 3 image)
+	const int wg = blockIdx.x;
+	int strip, unit;
+	if (a.grouped) {
+		const int grp = (wg >> 3) / a.nstrips;
+		strip = (wg >> 3) - grp * a.nstrips;
+		unit = grp * 8 + (wg & 7);
+	}
+	else {
+		unit = wg / a.nstrips;
+		strip = wg - unit * a.nstrips;
+	}
+	if (unit >= a.nsegs * a.n_images)
+		return;
+	const int img = unit / a.nsegs;
+	const int seg_i = unit - img * a.nsegs;
+	const GlobalIn in = (GlobalIn) kp[img];
+	const GlobalOut out = (GlobalOut) kp[RS_MAXB + img];
 
 	const int t = threadIdx.x;
 	const int B = a.bands;
-	const int x0 = blockIdx.x * a.tw, nx = min(a.tw, a.out_width - x0);
-	const int y0 = blockIdx.y * a.seg, ny = min(a.seg, a.out_height - y0);
+	const int x0 = strip * a.tw, nx = min(a.tw, a.out_width - x0);
+	const int y0 = seg_i * a.seg, ny = min(a.seg, a.out_height - y0);
 	// columns of the shrinkh image the strip's taps touch, and the input bytes under them
 	const int c_lo = min(max(2 * x0 + a.fh, 0), a.w3 - 1);
 	const int c_hi = min(max(2 * (x0 + nx - 1) + a.fh + a.n_h - 1, 0), a.w3 - 1);
@@ -446,7 +471,17 @@ int resize_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh, int hs,
 			p.in[i] = (const unsigned char *) in[base + i]->data;
 			p.out[i] = (unsigned char *) out[base + i]->data;
 		}
-		const dim3 grid(nstrips, nsegs, count);
+		a.nstrips = nstrips;
+		a.nsegs = nsegs;
+		a.n_images = count;
+		const long long units = (long long) nsegs * count;
+		a.grouped = units >= 64;
+		const long long blocks = (a.grouped ? (units + 7) / 8 * 8 : units) * nstrips;
+		if (blocks > 0x7fffffffLL) {
+			error("resize", "image too large");
+			return -1;
+		}
+		const dim3 grid((unsigned int) blocks, 1, 1);
 		switch (vs) {
 		case 1:
 			stream_launch<1>(a, p, grid, lds, dw);

@@ -88,6 +88,23 @@ void release_thread_stream()
 	tls_stream_external = false;
 }
 
+ScopedStream::ScopedStream(hipStream_t s)
+	: saved(tls_stream), saved_external(tls_stream_external), active(s != nullptr)
+{
+	if (active) {
+		tls_stream = s;
+		tls_stream_external = true;
+	}
+}
+
+ScopedStream::~ScopedStream()
+{
+	if (active) {
+		tls_stream = saved;
+		tls_stream_external = saved_external;
+	}
+}
+
 _VipsHipImage *image_share(const _VipsHipImage *in)
 {
 	if (!in || !in->owns || !in->hold)

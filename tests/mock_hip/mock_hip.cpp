@@ -119,6 +119,7 @@ hipError_t hipEventDestroy(hipEvent_t e)
 }
 
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t)

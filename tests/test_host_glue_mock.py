@@ -212,6 +212,41 @@ assert mock.mock_hip_launches() > 0
 ''', tmp_path)
 
 
+def test_uniform_batch_takes_the_batch_launches(tmp_path):
+    """vips_hip_resize_sharpen_batch on a uniform batch of more than one launch's worth of images:
+    one resize launch and one sharpen launch per 64 images (with $VIPS_HIP_BATCH_OVERLAP the
+    sharpen on a second stream that is given back), thumbnails of the right geometry; a mixed batch goes image by image."""
+    run_child(r'''
+import ctypes, os
+import numpy as np
+import libvips_amd
+from libvips_amd import Image
+
+mock = ctypes.CDLL(os.environ["LD_PRELOAD"])
+mock.mock_hip_launches.restype = ctypes.c_long
+libvips_amd.init(0)
+ims = [Image.new_from_array(np.zeros((64, 688, 3), np.uint8), interpretation="srgb") for _ in range(70)]
+ims[0].resize(0.125)
+before = mock.mock_hip_live_streams()
+for overlap in ("", "1"):
+    os.environ["VIPS_HIP_BATCH_OVERLAP"] = overlap
+    if not overlap:
+        del os.environ["VIPS_HIP_BATCH_OVERLAP"]
+    n0 = mock.mock_hip_launches()
+    outs = libvips_amd.resize_sharpen_batch(ims, 0.125, threads=4)
+    assert mock.mock_hip_launches() - n0 == 4, mock.mock_hip_launches() - n0   # 2 chunks x (resize + sharpen)
+    assert mock.mock_hip_live_streams() == before
+    assert all((o.width, o.height, o.bands) == (86, 8, 3) for o in outs)
+os.environ.pop("VIPS_HIP_BATCH_OVERLAP", None)
+n0 = mock.mock_hip_launches()
+outs = libvips_amd.resize_sharpen_batch(ims, 0.125, sharpen=False, threads=4)
+assert mock.mock_hip_launches() - n0 == 2
+mixed = ims[:3] + [Image.new_from_array(np.zeros((64, 700, 3), np.uint8), interpretation="srgb")]
+outs = libvips_amd.resize_sharpen_batch(mixed, 0.125, threads=2)
+assert [(o.width, o.height) for o in outs] == [(86, 8)] * 3 + [(88, 8)]
+''', tmp_path)
+
+
 @pytest.mark.skipif(not helpers.have_module(), reason="oracle/_ref or host/_build missing")
 def test_module_plumbing_through_libvips(tmp_path):
     """The *_hip operations driven through the reference's own operation API: build(), the

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (device vs oracle/port) beyond the fixed test cases: random sizes,
 bands, formats and parameters for reduce / resize (down and up) / gaussblur / conv / shrink.
-usage: python tools/fuzz_gpu.py [seconds] [seed].  Prints every mismatch; exit code 1 if any."""
+usage: python tools/fuzz_gpu.py [seconds] [seed] [kind].  Prints every mismatch; exit code 1 if any."""
 import os
 import random
 import sys
@@ -39,7 +39,9 @@ def main():
     n = bad = 0
     while time.time() - t0 < budget:
         kind = rng.choice(["reduce8", "reduce", "resize", "upsize", "gaussblur", "conv", "shrink", "thumb",
-                           "approx"])
+                           "approx", "resize2k"])
+        if len(sys.argv) > 3:
+            kind = sys.argv[3]
         seed = rng.randrange(1 << 30)
         try:
             if kind == "reduce8":
@@ -61,6 +63,24 @@ def main():
                 got = Image.new_from_array(src).reduce(hs, vs, kernel=k).numpy()
                 want = Port.reduce(src, hs, vs, k)
                 desc = (kind, w, h, b, dt.__name__, hs, vs, k)
+            elif kind == "resize2k":
+                # uchar by 1 / (2 k) on rows of >= 2 KB: the one-kernel chain (resize_stream.hip), and
+                # the one-kernel sharpen behind it on sRGB
+                b = rng.choice([1, 2, 3, 3, 4])
+                w, h = rng.randrange(2048 // b + 1, 4300), rng.randrange(8, 1500)
+                k1, k2 = rng.choice([1, 2, 3, 4, 5, 6, 8]), rng.choice([1, 2, 3, 4, 5, 6, 8])
+                if rng.random() < 0.6:
+                    k2 = k1
+                src = helpers.lcg_image(w, h, b, np.uint8, seed)
+                sharpen = b == 3 and rng.random() < 0.5
+                im = Image.new_from_array(src, interpretation="srgb" if sharpen else "multiband")
+                out = im.resize(0.5 / k1, vscale=0.5 / k2)
+                want = Port.resize(src, 0.5 / k1, 0.5 / k2)
+                if sharpen:
+                    out = out.sharpen()
+                    want = PortCC.sharpen(want, "srgb")
+                got = out.numpy()
+                desc = (kind, w, h, b, k1, k2, sharpen)
             elif kind in ("resize", "upsize"):
                 w, h, b = rng.randrange(2, 300), rng.randrange(2, 300), rng.randrange(1, 5)
                 dt = rng.choice(ALL_TYPES)
