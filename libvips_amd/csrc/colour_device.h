@@ -46,8 +46,10 @@ static __device__ __forceinline__ double div_const(double a, double y, double r)
 	const double q0 = __dmul_rn(a, r);
 	const double e = __fma_rn(-y, q0, a);
 	const double q1 = __fma_rn(e, r, q0);
-	// an infinite quotient has no finite residual: keep it (the reference gets inf too)
-	return isinf(q0) ? q0 : q1;
+	// an infinite (or NaN) dividend has no finite residual: v_div_fixup_f64 puts IEEE division's
+	// special cases (and its sign of zero) back in one instruction, and passes every other
+	// quotient through
+	return __builtin_amdgcn_div_fixup(q1, y, a);
 }
 #define DIV_CONST(A, Y) div_const((A), (Y), 1.0 / (Y))
 
@@ -76,11 +78,11 @@ static __device__ __forceinline__ float cbrt_lerp(const float *__restrict__ tabl
 																   : DIV_CONST(num, 108.8827));
 	// VIPS_CLIP(0, (int) nX, QUANT_ELEMENTS - 2); (int) of NaN / overflow is the x86
 	// "integer indefinite" INT_MIN, which the clip turns into 0
-	int i;
-	if (!FINITE && !(n > -2147483904.0f && n < 2147483648.0f))
-		i = INT_MIN;
-	else
-		i = (int) n;
+	// (v_cvt_i32_f32 saturates and turns NaN into 0: after the clip only n >= 2^31 -- INT_MAX
+	// here, INT_MIN there -- needs telling apart)
+	int i = __float2int_rz(n);
+	if (!FINITE)
+		i = n >= 2147483648.0f ? 0 : i;
 	i = min(max(i, 0), 100000 - 2);
 	const float f = __fsub_rn(n, (float) i);
 	// table[i] and table[i + 1] in one 8-byte access (dword aligned is enough for global memory)
@@ -218,10 +220,12 @@ static __device__ __forceinline__ int load_as_uchar_like(T v, int maxv)
 template <>
 __device__ __forceinline__ int load_as_uchar_like<float>(float v, int maxv)
 {
-	// CAST_FLOAT_INT: clip as double, then C truncation
-	double d = (double) v;
-	d = (double) maxv < d ? (double) maxv : d;
-	d = 0.0 > d ? 0.0 : d;
+	// CAST_FLOAT_INT: clip as double, then C truncation.  float -> double is exact and monotonic
+	// and both limits are floats, so the same compares and selects on the float give the same
+	// value (NaN falls through both, as it does in double)
+	float d = v;
+	d = (float) maxv < d ? (float) maxv : d;
+	d = 0.0f > d ? 0.0f : d;
 	return (int) d;
 }
 template <>

@@ -90,7 +90,8 @@ static __device__ __forceinline__ double ss_div_scale(double s, const StreamArgs
 	const double q0 = __dmul_rn(s, a.rscale);
 	const double e = __fma_rn(-a.scale, q0, s);
 	const double q1 = __fma_rn(e, a.rscale, q0);
-	return isinf(q0) ? q0 : q1;
+	// IEEE division's special cases (infinite or NaN sums) in one instruction
+	return __builtin_amdgcn_div_fixup(q1, a.scale, s);
 }
 
 // what a pass stores
@@ -159,6 +160,9 @@ static __device__ __forceinline__ void ss_hpass(const StreamArgs &a, const doubl
 #pragma unroll
 		for (int ii = 0; ii < 4; ii++) {
 			if (g + 1 < NG || ii < a.rem) { // whole groups unconditional, the last one tap by tap
+				// (a real branch: if-converted, the absent taps cost 8 multiply-adds and 16 selects each)
+				if (g + 1 == NG)
+					asm volatile("");
 				const double c = cg[ii];
 #pragma unroll
 				for (int k = 0; k < SS_T; k++)
@@ -224,8 +228,10 @@ static __device__ __forceinline__ void ss_vpass(const StreamArgs &a, const doubl
 		for (int k = 0; k < 4; k++) {
 			const int d = 4 * (NG - 1) + k;
 			const int slot = (ROT - d) & (SS_SLOTS - 1);
-			if (k < a.rem)
+			if (k < a.rem) {
+				asm volatile(""); // a real branch (see ss_hpass)
 				acc[slot] = ss_mac<MODE>(d == 0 ? seed : acc[slot], kr[d], dv);
+			}
 		}
 		__builtin_amdgcn_sched_barrier(0);
 	}
@@ -238,6 +244,7 @@ convsep_stream(StreamArgs a, RouteArgs route)
 	extern __shared__ __attribute__((aligned(16))) float ss_lds[];
 	__shared__ int s_item;
 	__shared__ __attribute__((aligned(16))) double s_coef[SS_SLOTS];
+	__shared__ float s_v2y[EPI == 2 ? 256 : 1]; // the sRGB -> scRGB table of the spelled-out epilogue
 	const int in_row = a.bands * a.spw;   // floats per staged row (planar per band)
 	const int in_buf = SS_T * in_row;
 	const int x_buf = SS_T * a.w;
@@ -248,6 +255,8 @@ convsep_stream(StreamArgs a, RouteArgs route)
 	const int t = threadIdx.x;
 	if (t < SS_SLOTS)
 		s_coef[t] = a.coef[t];
+	if (EPI == 2 && t < 256)
+		s_v2y[t] = route.tables.v2Y_8[t];
 	const double *kc = s_coef; // (the first barrier of the work loop publishes it)
 	const int E = a.width * a.bands;
 	const int items = a.strips * a.segs;
@@ -302,18 +311,27 @@ convsep_stream(StreamArgs a, RouteArgs route)
 		const bool second_lane = SS_NT + t < staged;
 		const unsigned int lds_in = (unsigned int) (size_t) s_in; // LDS byte address
 		auto dma_rows = [&](int q, int slot) __attribute__((always_inline)) {
+			// (opaque copies: hoisted out of the phase loop, the eight row offsets and the eight
+			// first rows sit in scalar registers that spill, and every use is a v_readlane --
+			// re-made here they are a scalar multiply and add each)
+			int in_row_o = in_row, y_first_o = y_first;
+			asm volatile("" : "+s"(in_row_o), "+s"(y_first_o));
 			const unsigned int buf = lds_in + (unsigned int) (slot * in_buf + wv * 64) * 4u;
+			// (the lane predicate once around the eight rows, not around each)
+			if (first && first_lane) {
 #pragma unroll
-			for (int i = 0; i < SS_T; i++) {
-				const int row = min(max(y_first + q * SS_T + i, 0), a.height - 1);
-				const char *src = reinterpret_cast<const char *>(a.in) + (long long) row * a.in_stride;
-				if (first) {
-					if (first_lane)
-						ss_dma_dword(src, goff[0], buf + (unsigned int) (i * in_row) * 4u);
+				for (int i = 0; i < SS_T; i++) {
+					const int row = min(max(y_first_o + q * SS_T + i, 0), a.height - 1);
+					const char *src = reinterpret_cast<const char *>(a.in) + (long long) row * a.in_stride;
+					ss_dma_dword(src, goff[0], buf + (unsigned int) (i * in_row_o) * 4u);
 				}
-				if (second) {
-					if (second_lane)
-						ss_dma_dword(src, goff[1], buf + (unsigned int) (i * in_row + SS_NT) * 4u);
+			}
+			if (second && second_lane) {
+#pragma unroll
+				for (int i = 0; i < SS_T; i++) {
+					const int row = min(max(y_first_o + q * SS_T + i, 0), a.height - 1);
+					const char *src = reinterpret_cast<const char *>(a.in) + (long long) row * a.in_stride;
+					ss_dma_dword(src, goff[1], buf + (unsigned int) (i * in_row_o + SS_NT) * 4u);
 				}
 			}
 		};
@@ -398,9 +416,9 @@ convsep_stream(StreamArgs a, RouteArgs route)
 							// sRGB -> scRGB -> XYZ -> Lab spelled out (what route_pixel does for these
 							// steps, without its step loop and the scalars that loop keeps live)
 							Px v;
-							v.a = route.tables.v2Y_8[load_as_uchar_like<float>(src[0], 255)];
-							v.b = route.tables.v2Y_8[load_as_uchar_like<float>(src[1], 255)];
-							v.c = route.tables.v2Y_8[load_as_uchar_like<float>(src[2], 255)];
+							v.a = s_v2y[load_as_uchar_like<float>(src[0], 255)];
+							v.b = s_v2y[load_as_uchar_like<float>(src[1], 255)];
+							v.c = s_v2y[load_as_uchar_like<float>(src[2], 255)];
 							v = step_XYZ2Lab(step_scRGB2XYZ(v), route.tables.cbrt);
 							o0 = v.a;
 							o1 = v.b;
@@ -408,7 +426,11 @@ convsep_stream(StreamArgs a, RouteArgs route)
 						}
 						else
 							route_pixel<float, float>(route, src[0], src[1], src[2], o0, o1, o2);
-						float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(a.out) + (long long) (y0 + j) * a.out_stride) + 3LL * px;
+						// one 12-byte store at a scalar base (the step's first row) + a 32-bit lane offset
+						// (the host checked 8 rows of the output fit 32 bits)
+						char *row0 = reinterpret_cast<char *>(a.out) + (long long) (y0 + q * SS_T - SS_SLOTS) * a.out_stride;
+						const unsigned int off = (unsigned int) r * (unsigned int) a.out_stride + 12u * (unsigned int) px;
+						float *dst = reinterpret_cast<float *>(row0 + off);
 						dst[0] = o0;
 						dst[1] = o1;
 						dst[2] = o2;
@@ -496,6 +518,9 @@ int convsep_stream_fused(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 		return 1;
 	const bool epi = n_route > 0;
 	if (epi && in->bands != 3)
+		return 1;
+	// the epilogue addresses the rows of a step with 32-bit offsets
+	if (epi && (unsigned long long) out->stride * (SS_T + 1) > 0xffffffffULL)
 		return 1;
 	const int n = c->mask_width;
 
