@@ -397,7 +397,8 @@ convsep_stream(StreamArgs a, RouteArgs route)
 			// ---- colour epilogue of step p - 2: blurred rows (LDS) -> the route -> the final image.
 			// One pixel per item, items dealt round the block (a 4-pixels-per-thread form with
 			// wide loads and stores measured slower: a third of the threads idle while the rest
-			// run four conversions back to back).
+			// run four conversions back to back; so did thread -> (row, every 96th pixel), which
+			// needs no wrap-around arithmetic but makes every wave run three turns: +4 %).
 			if (EPI && p >= 2 && p - 2 < steps) {
 				const int q = p - 2;
 				const float *os = s_o + (q & 1) * x_buf;
