@@ -241,7 +241,7 @@ int reduce_axis(VipsHipImage *in, VipsHipImage **out, double shrink, int kernel,
 int resize_down_u8_stream(VipsHipImage *const *in, int n, VipsHipImage **out, const AxisPlan &pv, const AxisPlan &ph,
 	int shrunk_width, int kernel)
 {
-	if (pv.residual != 2.0 || ph.residual != 2.0 || kernel != VIPS_HIP_KERNEL_LANCZOS3 || n < 1)
+	if (pv.residual != 2.0 || ph.residual != 2.0 || kernel == VIPS_HIP_KERNEL_NEAREST || n < 1)
 		return 1;
 	const int shrunk_height =
 		pv.int_shrink > 1 ? vips_hip_shrink_out_size(in[0]->height, pv.int_shrink, 1) : in[0]->height;

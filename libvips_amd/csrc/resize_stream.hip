@@ -37,7 +37,7 @@ namespace vh {
 constexpr int RS_SPAN = 2048; // bytes of a row a strip covers
 constexpr int RS_NT = 256;    // a strip's outputs are at most this many band elements wide
 constexpr int RS_MAXB = 64;        // images per launch
-constexpr int RS_NP = 7;           // coefficient pairs of the 13-tap vertical reduce = rows per slab
+constexpr int RS_NP = 7;           // most coefficient pairs of a vertical reduce (13 taps) = most rows per slab
 
 struct StreamArgs {
 	long long in_stride, out_stride;
@@ -108,15 +108,17 @@ static __device__ __forceinline__ unsigned int rs_box2(unsigned int sums, unsign
 
 // DW = dwords of a row per lane (2: 256 threads with 7 x 8 sums each; 1: 512 threads, half the
 // registers, twice the waves)
-template <int VS, int DW>
+// NP = coefficient pairs of the vertical reduce = output rows in flight per column = rows per
+// slab: 7 (13 taps: lanczos3), 5 (9 taps: lanczos2, cubic, mitchell), 3 (5 taps: linear)
+template <int VS, int DW, int NP>
 __global__ void __launch_bounds__(RS_SPAN / (4 * DW))
 resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 {
 	constexpr int NT = RS_SPAN / (4 * DW);
 	constexpr int NB = 4 * DW; // byte columns per lane
 	extern __shared__ __attribute__((aligned(16))) unsigned int rs_lds[];
-	unsigned char *T = reinterpret_cast<unsigned char *>(rs_lds); // RS_NP rows of RS_SPAN bytes
-	unsigned char *S = T + RS_NP * RS_SPAN;                        // RS_NP rows of s_pitch bytes
+	unsigned char *T = reinterpret_cast<unsigned char *>(rs_lds); // NP rows of RS_SPAN bytes
+	unsigned char *S = T + NP * RS_SPAN;                        // NP rows of s_pitch bytes
 	(void) ptrs_by_value;
 	// the image pointers where they lie in the kernarg segment (a by-value array indexed
 	// dynamically would be copied to scratch)
@@ -196,19 +198,19 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 		return v;
 	};
 
-	// 7 output rows in flight per byte column; a sum starts at the rounding term of its final
+	// NP output rows in flight per byte column; a sum starts at the rounding term of its final
 	// (sum + 2048) >> 12 (templates.h:152-157)
-	int acc[RS_NP][NB];
+	int acc[NP][NB];
 	int half = INTERPOLATE_SCALE >> 1;
 	asm volatile("" : "+v"(half)); // one register for all sums to start from
 #pragma unroll
-	for (int s = 0; s < RS_NP; s++)
+	for (int s = 0; s < NP; s++)
 #pragma unroll
 		for (int b = 0; b < NB; b++)
 			acc[s][b] = 0;
 
 	// pair j of the segment = shrunk rows r0 + 2j, r0 + 2j + 1; it is tap pair q of output row
-	// y0 + j - q.  Pair -1 is a dummy that lets a slab of 7 output rows end with a body.
+	// y0 + j - q.  Pair -1 is a dummy that lets a slab of NP output rows end with a body.
 	const int r0 = 2 * y0 + a.fv;
 	Row ring[2][VS];
 #pragma unroll
@@ -217,11 +219,11 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 		for (int k = 0; k < VS; k++)
 			ring[h][k] = load(r0 - 2 + h, k);
 
-	const int nbody = (ny + RS_NP - 1) / RS_NP + 1;
+	const int nbody = (ny + NP - 1) / NP + 1;
 	for (int n = 0; n < nbody; n++) {
 #pragma unroll
-		for (int p = 0; p < RS_NP; p++) {
-			const int j = RS_NP * n + p - 1;
+		for (int p = 0; p < NP; p++) {
+			const int j = NP * n + p - 1;
 			// the two shrunk rows: per dword column the even bytes (0, 2) and the odd bytes (1, 3)
 			// as 16-bit lanes: [h][2 d] even, [h][2 d + 1] odd
 			unsigned int sb[2][2 * DW];
@@ -253,15 +255,15 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 				const int w = (b >> 2) * 2 + (b & 1);
 				const unsigned int pk = __builtin_amdgcn_perm(sb[1][w], sb[0][w], (b & 2) ? 0x07060302u : 0x05040100u);
 #pragma unroll
-				for (int q = 0; q < RS_NP; q++) {
-					const int slot = (p - 1 - q + 2 * RS_NP) % RS_NP;
+				for (int q = 0; q < NP; q++) {
+					const int slot = (p - 1 - q + 2 * NP) % NP;
 					if (q == 0)
 						asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(acc[slot][b]) : "v"(pk), "s"(a.cv[0]), "v"(half));
 					else
 						acc[slot][b] = rs_dot2(pk, a.cv[q], acc[slot][b]);
 				}
 			}
-			// output row y0 + j - 6 is complete: slab row p
+			// output row y0 + j - (NP - 1) is complete: slab row p
 			unsigned int packed[DW];
 #pragma unroll
 			for (int d = 0; d < DW; d++)
@@ -278,9 +280,9 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 		if (n == 0 || (a.debug & 1))
 			continue;
 
-		// ---- the slab: output rows y0 + 7 (n - 1) ...
-		const int yb = RS_NP * (n - 1);
-		const int nr = min(RS_NP, ny - yb);
+		// ---- the slab: output rows y0 + NP (n - 1) ...
+		const int yb = NP * (n - 1);
+		const int nr = min(NP, ny - yb);
 		__syncthreads();
 		// (everything the horizontal pass derives from the thread index is made anew per slab:
 		// hoisted out of the row loop it would sit in ~30 registers through the vertical pass)
@@ -295,19 +297,19 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 				const int b = e - c * B;
 				const int px0 = (c_lo + c) * a.hs;
 				const unsigned char *src = T + b - start_al;
-				unsigned int sum[RS_NP];
+				unsigned int sum[NP];
 #pragma unroll
-				for (int r = 0; r < RS_NP; r++)
+				for (int r = 0; r < NP; r++)
 					sum[r] = (unsigned int) (a.hs / 2);
 #pragma unroll 4
 				for (int k = 0; k < a.hs; k++) {
 					const int off = min(px0 + k, a.width - 1) * B;
 #pragma unroll
-					for (int r = 0; r < RS_NP; r++)
+					for (int r = 0; r < NP; r++)
 						sum[r] += src[r * RS_SPAN + off];
 				}
 #pragma unroll
-				for (int r = 0; r < RS_NP; r++)
+				for (int r = 0; r < NP; r++)
 					S[r * a.s_pitch + e] = (unsigned char) ((sum[r] * a.mult_h) >> 24);
 			}
 		}
@@ -318,9 +320,9 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 			const int x = (int) ((th * magic) >> 16);
 			const int b = th - x * B;
 			const int f = 2 * (x0 + x) + a.fh;
-			int sum[RS_NP];
+			int sum[NP];
 #pragma unroll
-			for (int r = 0; r < RS_NP; r++)
+			for (int r = 0; r < NP; r++)
 				sum[r] = 0;
 #pragma unroll
 			for (int k = 0; k < 13; k++) {
@@ -328,13 +330,13 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 					const int off = (min(max(f + k, 0), a.w3 - 1) - c_lo) * B + b;
 					const int ck = a.ch[k];
 #pragma unroll
-					for (int r = 0; r < RS_NP; r++)
+					for (int r = 0; r < NP; r++)
 						sum[r] += ck * (int) S[r * a.s_pitch + off];
 				}
 			}
 			const GlobalOut dst = out + (long long) (y0 + yb) * a.out_stride + (long long) x0 * B + th;
 #pragma unroll
-			for (int r = 0; r < RS_NP; r++)
+			for (int r = 0; r < NP; r++)
 				if (r < nr)
 					dst[(long long) r * a.out_stride] = (unsigned char) rs_fin(sum[r]);
 		}
@@ -356,13 +358,24 @@ bool stream_regular(const std::vector<ReducePos> &pos, int *first0, int *phase)
 	return true;
 }
 
-template <int VS>
-void stream_launch(const StreamArgs &a, const StreamPtrs &p, dim3 grid, size_t lds, int dw)
+template <int VS, int NP>
+void stream_launch_np(const StreamArgs &a, const StreamPtrs &p, dim3 grid, size_t lds, int dw)
 {
-	if (dw == 1)
-		hipLaunchKernelGGL((resize_stream_u8<VS, 1>), grid, dim3(RS_SPAN / 4, 1, 1), lds, stream(), a, p);
+	if (dw == 2 && NP == RS_NP)
+		hipLaunchKernelGGL((resize_stream_u8<VS, NP == RS_NP ? 2 : 1, NP>), grid, dim3(RS_SPAN / 8, 1, 1), lds, stream(), a, p);
 	else
-		hipLaunchKernelGGL((resize_stream_u8<VS, 2>), grid, dim3(RS_SPAN / 8, 1, 1), lds, stream(), a, p);
+		hipLaunchKernelGGL((resize_stream_u8<VS, 1, NP>), grid, dim3(RS_SPAN / 4, 1, 1), lds, stream(), a, p);
+}
+
+template <int VS>
+void stream_launch(const StreamArgs &a, const StreamPtrs &p, dim3 grid, size_t lds, int dw, int np)
+{
+	if (np == 7)
+		stream_launch_np<VS, 7>(a, p, grid, lds, dw);
+	else if (np == 5)
+		stream_launch_np<VS, 5>(a, p, grid, lds, dw);
+	else
+		stream_launch_np<VS, 3>(a, p, grid, lds, dw);
 }
 
 } // namespace
@@ -402,8 +415,10 @@ int resize_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh, int hs,
 		return 0;
 	if (rv->in_size != h1 || rv->out_size != o0->height || rh->in_size != w3 || rh->out_size != o0->width)
 		return 0;
-	if (rv->n_point != 13 || rh->n_point > 13 || rh->n_point < 1)
+	// 13, 9 or 5 vertical taps (7, 5, 3 coefficient pairs); at most 13 horizontal ones
+	if ((rv->n_point != 13 && rv->n_point != 9 && rv->n_point != 5) || rh->n_point > 13 || rh->n_point < 1)
 		return 0;
+	const int np = (rv->n_point + 1) / 2;
 	std::vector<ReducePos> pv, ph;
 	reduce_positions(rv, 0, o0->height, tile, pv);
 	reduce_positions(rh, 0, o0->width, 0, ph);
@@ -446,12 +461,12 @@ int resize_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh, int hs,
 	const int seg_min = getenv("VIPS_HIP_STREAM_SEG") ? atoi(getenv("VIPS_HIP_STREAM_SEG")) : 28;
 	if (seg < seg_min)
 		seg = seg_min;
-	seg = (seg + RS_NP - 1) / RS_NP * RS_NP;
+	seg = (seg + np - 1) / np * np;
 	nsegs = (o0->height + seg - 1) / seg;
 	a.seg = seg;
 	a.debug = getenv("VIPS_HIP_STREAM_DEBUG") ? atoi(getenv("VIPS_HIP_STREAM_DEBUG")) : 0;
 	const short *cvs = &rv->matrixs[(size_t) phase_v * rv->n_point];
-	for (int q = 0; q < RS_NP; q++) {
+	for (int q = 0; q < np; q++) {
 		const unsigned int lo = (unsigned short) cvs[2 * q];
 		const unsigned int hi = 2 * q + 1 < rv->n_point ? (unsigned short) cvs[2 * q + 1] : 0u;
 		a.cv[q] = lo | (hi << 16);
@@ -459,7 +474,7 @@ int resize_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh, int hs,
 	const short *chs = &rh->matrixs[(size_t) phase_h * rh->n_point];
 	for (int k = 0; k < rh->n_point; k++)
 		a.ch[k] = chs[k];
-	const size_t lds = (size_t) RS_NP * RS_SPAN + (size_t) RS_NP * a.s_pitch;
+	const size_t lds = (size_t) np * RS_SPAN + (size_t) np * a.s_pitch;
 	const int dw = getenv("VIPS_HIP_STREAM_DW") ? atoi(getenv("VIPS_HIP_STREAM_DW")) : 1;
 
 	Gate gate("resize_stream_u8");
@@ -484,25 +499,25 @@ int resize_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh, int hs,
 		const dim3 grid((unsigned int) blocks, 1, 1);
 		switch (vs) {
 		case 1:
-			stream_launch<1>(a, p, grid, lds, dw);
+			stream_launch<1>(a, p, grid, lds, dw, np);
 			break;
 		case 2:
-			stream_launch<2>(a, p, grid, lds, dw);
+			stream_launch<2>(a, p, grid, lds, dw, np);
 			break;
 		case 3:
-			stream_launch<3>(a, p, grid, lds, dw);
+			stream_launch<3>(a, p, grid, lds, dw, np);
 			break;
 		case 4:
-			stream_launch<4>(a, p, grid, lds, dw);
+			stream_launch<4>(a, p, grid, lds, dw, np);
 			break;
 		case 5:
-			stream_launch<5>(a, p, grid, lds, dw);
+			stream_launch<5>(a, p, grid, lds, dw, np);
 			break;
 		case 6:
-			stream_launch<6>(a, p, grid, lds, dw);
+			stream_launch<6>(a, p, grid, lds, dw, np);
 			break;
 		default:
-			stream_launch<8>(a, p, grid, lds, dw);
+			stream_launch<8>(a, p, grid, lds, dw, np);
 			break;
 		}
 		if (hipGetLastError() != hipSuccess) {

@@ -437,6 +437,29 @@ def test_resize_stream_fused(bands, size, scale, vscale, monkeypatch):
     assert np.array_equal(got, im.resize(scale, **kw).numpy())
 
 
+@pytest.mark.parametrize("kernel", ["linear", "cubic", "mitchell", "lanczos2", "mks2013"])
+@pytest.mark.parametrize("bands,size,scale", [(3, (2048, 1203), 0.125), (1, (4104, 777), 0.25), (4, (2560, 1004), 0.1)])
+def test_resize_stream_other_kernels(kernel, bands, size, scale, monkeypatch):
+    """The one-kernel chain with 5 (linear), 9 (cubic, mitchell, lanczos2) and 13 (mks2013)
+    vertical taps: 3, 5 and 7 output rows in flight per column."""
+    w, h = size
+    src = helpers.lcg_image(w, h, bands, np.uint8, 79)
+    im = Image.new_from_array(src)
+    monkeypatch.setenv("VIPS_HIP_STREAM_BLOCKS", "4096")
+    libvips_amd.lib.vips_hip_gate_reset()
+    libvips_amd.lib.vips_hip_gate_enable(1)
+    try:
+        got = im.resize(scale, kernel=kernel).numpy()
+        report = libvips_amd.gate_report()
+    finally:
+        libvips_amd.lib.vips_hip_gate_enable(0)
+        libvips_amd.lib.vips_hip_gate_reset()
+    assert list(report) == ["resize_stream_u8"], report
+    assert_same(got, Port.resize(src, scale, kernel=kernel), str((kernel, bands, size, scale)))
+    monkeypatch.setenv("VIPS_HIP_NO_RESIZE_STREAM", "1")
+    assert np.array_equal(got, im.resize(scale, kernel=kernel).numpy())
+
+
 def test_resize_stream_batch_chunks():
     """More images than one launch of the streaming resize / the one-kernel sharpen holds (64):
     every image of the batch equals the pipeline run on it alone."""

@@ -74,13 +74,14 @@ def main():
                 src = helpers.lcg_image(w, h, b, np.uint8, seed)
                 sharpen = b == 3 and rng.random() < 0.5
                 im = Image.new_from_array(src, interpretation="srgb" if sharpen else "multiband")
-                out = im.resize(0.5 / k1, vscale=0.5 / k2)
-                want = Port.resize(src, 0.5 / k1, 0.5 / k2)
+                k = rng.choice(["lanczos3", "lanczos3", "linear", "cubic", "mitchell", "lanczos2", "mks2013", "mks2021"])
+                out = im.resize(0.5 / k1, vscale=0.5 / k2, kernel=k)
+                want = Port.resize(src, 0.5 / k1, 0.5 / k2, kernel=k)
                 if sharpen:
                     out = out.sharpen()
                     want = PortCC.sharpen(want, "srgb")
                 got = out.numpy()
-                desc = (kind, w, h, b, k1, k2, sharpen)
+                desc = (kind, w, h, b, k1, k2, k, sharpen)
             elif kind in ("resize", "upsize"):
                 w, h, b = rng.randrange(2, 300), rng.randrange(2, 300), rng.randrange(1, 5)
                 dt = rng.choice(ALL_TYPES)
