@@ -127,7 +127,7 @@ colour_route_kernel(RouteArgs a)
 			if (y < a.height) {
 				const TIN *p = (const TIN *) (a.in + (long long) y * a.in_stride) + (long long) x * a.in_bands;
 				TOUT *q = (TOUT *) (a.out + (long long) y * a.out_stride) + (long long) x * a.out_bands;
-				route_pixel<TIN, TOUT>(a, i0[r], i1[r], i2[r], q[0], q[1], q[2]);
+				route_pixel<TIN, TOUT>(a, a.tables.v2Y_8, a.tables.Y2v_8, i0[r], i1[r], i2[r], q[0], q[1], q[2]);
 				for (int e = 0; e < a.extra_bands; e++)
 					q[3 + e] = Carry<TIN, TOUT>::run(p[3 + e], a.alpha_scale);
 			}
@@ -146,10 +146,18 @@ struct __attribute__((aligned(4 * sizeof(T)))) Vec4 {
 	T v[4];
 };
 
-template <typename TIN, typename TOUT>
+template <typename TIN, typename TOUT, int ROUTE>
 __global__ void __launch_bounds__(256)
 colour_route_x4_kernel(RouteArgs a)
 {
+	// the two 8-bit tables in LDS: up to six of a pixel's table reads stay off the vector memory path
+	__shared__ float s_v2Y[256];
+	__shared__ int s_Y2v[260];
+	s_v2Y[threadIdx.x] = a.tables.v2Y_8[threadIdx.x];
+	s_Y2v[threadIdx.x] = a.tables.Y2v_8[threadIdx.x];
+	if (threadIdx.x == 0)
+		s_Y2v[256] = a.tables.Y2v_8[256];
+	__syncthreads();
 	const int x4 = blockIdx.x * blockDim.x + threadIdx.x;
 	if (x4 * 4 >= a.width)
 		return;
@@ -158,10 +166,10 @@ colour_route_x4_kernel(RouteArgs a)
 		Vec4<TOUT> *q = (Vec4<TOUT> *) (a.out + (long long) y * a.out_stride) + (long long) x4 * 3;
 		const Vec4<TIN> v0 = p[0], v1 = p[1], v2 = p[2];
 		Vec4<TOUT> r0, r1, r2;
-		route_pixel<TIN, TOUT>(a, v0.v[0], v0.v[1], v0.v[2], r0.v[0], r0.v[1], r0.v[2]);
-		route_pixel<TIN, TOUT>(a, v0.v[3], v1.v[0], v1.v[1], r0.v[3], r1.v[0], r1.v[1]);
-		route_pixel<TIN, TOUT>(a, v1.v[2], v1.v[3], v2.v[0], r1.v[2], r1.v[3], r2.v[0]);
-		route_pixel<TIN, TOUT>(a, v2.v[1], v2.v[2], v2.v[3], r2.v[1], r2.v[2], r2.v[3]);
+		route_pixel<TIN, TOUT, ROUTE>(a, s_v2Y, s_Y2v, v0.v[0], v0.v[1], v0.v[2], r0.v[0], r0.v[1], r0.v[2]);
+		route_pixel<TIN, TOUT, ROUTE>(a, s_v2Y, s_Y2v, v0.v[3], v1.v[0], v1.v[1], r0.v[3], r1.v[0], r1.v[1]);
+		route_pixel<TIN, TOUT, ROUTE>(a, s_v2Y, s_Y2v, v1.v[2], v1.v[3], v2.v[0], r1.v[2], r1.v[3], r2.v[0]);
+		route_pixel<TIN, TOUT, ROUTE>(a, s_v2Y, s_Y2v, v2.v[1], v2.v[2], v2.v[3], r2.v[1], r2.v[2], r2.v[3]);
 		q[0] = r0;
 		q[1] = r1;
 		q[2] = r2;
@@ -990,9 +998,30 @@ int colour_route(const int *steps, int n_steps, double alpha_scale, const VipsHi
 		!(a.in_stride % (4 * ies)) && !(a.out_stride % (4 * oes));
 	// (one row per block: the table-gathering route kernels measured faster with many short blocks)
 	const dim3 grid4((a.width / 4 + 255) / 256, a.height < 32768 ? a.height : 32768, 1);
+	// the routes with their steps compiled in (colour_device.h kStaticRoutes), for the formats they
+	// are met with: sRGB -> Lab / LabS from uchar and float, LabS / Lab -> sRGB uchar
+	int route_id = 0;
+	for (int r = 1; r < kStaticRouteCount && x4; r++)
+		if (n_steps == kStaticRoutes[r][0] && !memcmp(steps, &kStaticRoutes[r][1], sizeof(int) * n_steps))
+			route_id = r;
+	bool launched = false;
+#define STATIC_ROUTE(R, TIN, FIN, TOUT, FOUT) \
+	if (!launched && route_id == R && in->format == FIN && want_out == FOUT) { \
+		hipLaunchKernelGGL((colour_route_x4_kernel<TIN, TOUT, R>), grid4, block, 0, stream(), a); \
+		launched = true; \
+	}
+	STATIC_ROUTE(1, float, VIPS_HIP_FORMAT_FLOAT, float, VIPS_HIP_FORMAT_FLOAT)
+	STATIC_ROUTE(1, unsigned char, VIPS_HIP_FORMAT_UCHAR, float, VIPS_HIP_FORMAT_FLOAT)
+	STATIC_ROUTE(2, float, VIPS_HIP_FORMAT_FLOAT, short, VIPS_HIP_FORMAT_SHORT)
+	STATIC_ROUTE(2, unsigned char, VIPS_HIP_FORMAT_UCHAR, short, VIPS_HIP_FORMAT_SHORT)
+	STATIC_ROUTE(3, short, VIPS_HIP_FORMAT_SHORT, unsigned char, VIPS_HIP_FORMAT_UCHAR)
+	STATIC_ROUTE(4, float, VIPS_HIP_FORMAT_FLOAT, unsigned char, VIPS_HIP_FORMAT_UCHAR)
+#undef STATIC_ROUTE
 #define GO(TIN, TOUT) \
-	if (x4) \
-		hipLaunchKernelGGL((colour_route_x4_kernel<TIN, TOUT>), grid4, block, 0, stream(), a); \
+	if (launched) \
+		; \
+	else if (x4) \
+		hipLaunchKernelGGL((colour_route_x4_kernel<TIN, TOUT, 0>), grid4, block, 0, stream(), a); \
 	else \
 		hipLaunchKernelGGL((colour_route_kernel<TIN, TOUT>), grid, block, 0, stream(), a)
 #define GO_IN(TOUT) \

@@ -369,20 +369,33 @@ CARRY_INT(short, unsigned short)
 CARRY_INT(short, short)
 #undef CARRY_INT
 
-// The chain for one pixel: stored bands in, stored bands out.
-template <typename TIN, typename TOUT>
-static __device__ __forceinline__ void route_pixel(const RouteArgs &a, TIN i0, TIN i1, TIN i2,
-	TOUT &o0, TOUT &o1, TOUT &o2)
+// Routes compiled in: with ROUTE > 0 the steps are constants, the step loop unrolls and its
+// branches fold away (ROUTE 0 reads a.steps at run time: any chain).  Row = {n, steps...}.
+constexpr int kStaticRoutes[5][5] = {
+	{ 0, -1, -1, -1, -1 },
+	{ 3, VIPS_HIP_COLOUR_sRGB2scRGB, VIPS_HIP_COLOUR_scRGB2XYZ, VIPS_HIP_COLOUR_XYZ2Lab, -1 },
+	{ 4, VIPS_HIP_COLOUR_sRGB2scRGB, VIPS_HIP_COLOUR_scRGB2XYZ, VIPS_HIP_COLOUR_XYZ2Lab, VIPS_HIP_COLOUR_Lab2LabS },
+	{ 4, VIPS_HIP_COLOUR_LabS2Lab, VIPS_HIP_COLOUR_Lab2XYZ, VIPS_HIP_COLOUR_XYZ2scRGB, VIPS_HIP_COLOUR_scRGB2sRGB },
+	{ 3, VIPS_HIP_COLOUR_Lab2XYZ, VIPS_HIP_COLOUR_XYZ2scRGB, VIPS_HIP_COLOUR_scRGB2sRGB, -1 },
+};
+constexpr int kStaticRouteCount = 5;
+
+// The chain for one pixel: stored bands in, stored bands out.  v2Y8 / Y2v8: the two 8-bit
+// tables wherever the caller keeps them (a.tables' own, or copies in LDS).
+template <typename TIN, typename TOUT, int ROUTE = 0>
+static __device__ __forceinline__ void route_pixel(const RouteArgs &a, const float *v2Y8, const int *Y2v8, TIN i0,
+	TIN i1, TIN i2, TOUT &o0, TOUT &o1, TOUT &o2)
 {
 	Px v;
-	const int first = a.steps[0];
+	const int n_steps = ROUTE ? kStaticRoutes[ROUTE][0] : a.n_steps;
+	const int first = ROUTE ? kStaticRoutes[ROUTE][1] : a.steps[0];
 	int s = 0;
 	// ---- the first step fixes how the stored bands are interpreted
 	if (first == VIPS_HIP_COLOUR_sRGB2scRGB) {
 		// vips_colour_code_build casts to uchar (colour.c:428-434), sRGB2scRGB.c:72-90
-		v.a = a.tables.v2Y_8[load_as_uchar_like<TIN>(i0, 255)];
-		v.b = a.tables.v2Y_8[load_as_uchar_like<TIN>(i1, 255)];
-		v.c = a.tables.v2Y_8[load_as_uchar_like<TIN>(i2, 255)];
+		v.a = v2Y8[load_as_uchar_like<TIN>(i0, 255)];
+		v.b = v2Y8[load_as_uchar_like<TIN>(i1, 255)];
+		v.c = v2Y8[load_as_uchar_like<TIN>(i2, 255)];
 		s = 1;
 	}
 	else if (first == VIPS_HIP_COLOUR_sRGB2scRGB16) {
@@ -407,7 +420,25 @@ static __device__ __forceinline__ void route_pixel(const RouteArgs &a, TIN i0, T
 
 	// ---- float -> float steps
 	int last = -1;
-	for (; s < a.n_steps; s++) {
+#pragma unroll
+	for (int k = 0; k < 4; k++) { // (a ROUTE has at most 4 steps; the run-time loop takes what is left)
+		if (!ROUTE)
+			break;
+		if (k < s || k >= n_steps)
+			continue;
+		const int st = kStaticRoutes[ROUTE][1 + k];
+		if (st == VIPS_HIP_COLOUR_scRGB2XYZ)
+			v = step_scRGB2XYZ(v);
+		else if (st == VIPS_HIP_COLOUR_XYZ2Lab)
+			v = step_XYZ2Lab(v, a.tables.cbrt);
+		else if (st == VIPS_HIP_COLOUR_Lab2XYZ)
+			v = step_Lab2XYZ(v);
+		else if (st == VIPS_HIP_COLOUR_XYZ2scRGB)
+			v = step_XYZ2scRGB(v);
+		else
+			last = st;
+	}
+	for (; !ROUTE && s < n_steps; s++) {
 		const int st = a.steps[s];
 		if (st == VIPS_HIP_COLOUR_scRGB2XYZ)
 			v = step_scRGB2XYZ(v);
@@ -424,13 +455,19 @@ static __device__ __forceinline__ void route_pixel(const RouteArgs &a, TIN i0, T
 	// ---- the last step fixes the stored format
 	if (last == VIPS_HIP_COLOUR_scRGB2sRGB || last == VIPS_HIP_COLOUR_scRGB2sRGB16) {
 		const bool wide = last == VIPS_HIP_COLOUR_scRGB2sRGB16;
-		const int *lut = wide ? a.tables.Y2v_16 : a.tables.Y2v_8;
-		const int maxval = wide ? 65535 : 255;
 		int r = 0, g = 0, b = 0;
 		if (!(isnan(v.a) || isnan(v.b) || isnan(v.c))) {
-			r = scRGB2sRGB_channel(lut, v.a, maxval);
-			g = scRGB2sRGB_channel(lut, v.b, maxval);
-			b = scRGB2sRGB_channel(lut, v.c, maxval);
+			// (two arms: the tables may live in different address spaces)
+			if (wide) {
+				r = scRGB2sRGB_channel(a.tables.Y2v_16, v.a, 65535);
+				g = scRGB2sRGB_channel(a.tables.Y2v_16, v.b, 65535);
+				b = scRGB2sRGB_channel(a.tables.Y2v_16, v.c, 65535);
+			}
+			else {
+				r = scRGB2sRGB_channel(Y2v8, v.a, 255);
+				g = scRGB2sRGB_channel(Y2v8, v.b, 255);
+				b = scRGB2sRGB_channel(Y2v8, v.c, 255);
+			}
 		}
 		o0 = (TOUT) r;
 		o1 = (TOUT) g;

@@ -426,7 +426,7 @@ convsep_stream(StreamArgs a, RouteArgs route)
 							o2 = v.c;
 						}
 						else
-							route_pixel<float, float>(route, src[0], src[1], src[2], o0, o1, o2);
+							route_pixel<float, float>(route, route.tables.v2Y_8, route.tables.Y2v_8, src[0], src[1], src[2], o0, o1, o2);
 						// one 12-byte store at a scalar base (the step's first row) + a 32-bit lane offset
 						// (the host checked 8 rows of the output fit 32 bits)
 						char *row0 = reinterpret_cast<char *>(a.out) + (long long) (y0 + q * SS_T - SS_SLOTS) * a.out_stride;
