@@ -99,7 +99,11 @@ template <int MODE>
 static __device__ __forceinline__ float ss_fin(double s, const StreamArgs &a, int pass)
 {
 	if constexpr (MODE == 1) {
-		const double q = a.scale != 1.0 ? ss_div_scale(s, a) : s;
+		double q = s;
+		if (a.scale != 1.0) {
+			asm volatile(""); // a wave-uniform branch, not two selects per output
+			q = ss_div_scale(s, a);
+		}
 		return (float) __dadd_rn(q, pass == 1 ? a.offset1 : a.offset2);
 	}
 	else
