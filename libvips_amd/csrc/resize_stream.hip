@@ -170,10 +170,11 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 	const int ncol = c_hi - c_lo + 1;
 	const int row_bytes = a.width * B;
 	// the strip's span starts at the dword holding its first byte, or earlier when it would run
-	// over the end of the row (the host checked row_bytes >= RS_SPAN and row_bytes % 4 == 0)
-	const int start_al = min((c_lo * a.hs * B) & ~3, row_bytes - RS_SPAN);
+	// over the end of the row (row_bytes % 4 == 0: host); a row shorter than the span is one strip
+	// whose lanes beyond the row re-read its last dword (nothing reads what they make)
+	const int start_al = max(min((c_lo * a.hs * B) & ~3, row_bytes - RS_SPAN), 0);
 	const GlobalIn span = in + start_al; // uniform: rows load as scalar base + lane offset
-	const unsigned int lane_off = (unsigned int) (4 * DW * t);
+	const unsigned int lane_off = (unsigned int) min(4 * DW * t, row_bytes - 4 * DW - start_al);
 
 	struct Row {
 		unsigned int w[DW];
@@ -405,7 +406,7 @@ int resize_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh, int hs,
 	}
 	const int B = i0->bands;
 	const long long row_bytes = (long long) i0->width * B;
-	if ((row_bytes & 3) || row_bytes < RS_SPAN || row_bytes > 0x3fffffffLL)
+	if ((row_bytes & 3) || row_bytes < 8 || row_bytes > 0x3fffffffLL)
 		return 0;
 	if ((unsigned long long) i0->stride * (unsigned long long) i0->height > 0xffffffffULL)
 		return 0;
@@ -475,7 +476,9 @@ int resize_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh, int hs,
 	for (int k = 0; k < rh->n_point; k++)
 		a.ch[k] = chs[k];
 	const size_t lds = (size_t) np * RS_SPAN + (size_t) np * a.s_pitch;
-	const int dw = getenv("VIPS_HIP_STREAM_DW") ? atoi(getenv("VIPS_HIP_STREAM_DW")) : 1;
+	int dw = getenv("VIPS_HIP_STREAM_DW") ? atoi(getenv("VIPS_HIP_STREAM_DW")) : 1;
+	if (row_bytes < RS_SPAN)
+		dw = 1; // (a row shorter than the span: lanes beyond it clamp dword by dword)
 
 	Gate gate("resize_stream_u8");
 	for (int base = 0; base < n; base += RS_MAXB) {

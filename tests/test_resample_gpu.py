@@ -410,12 +410,14 @@ def test_resize_tail_fused(bands, size, scale, vscale, monkeypatch):
     ((2048, 1536), 0.125, None), ((4104, 1203), 0.125, None), ((2048, 1537), 0.25, None),
     ((2052, 1202), 1.0 / 6.0, None), ((2560, 1004), 0.1, None), ((3072, 1205), 1.0 / 12.0, None),
     ((4096, 1607), 1.0 / 16.0, None), ((2048, 1001), 0.5, None), ((4096, 900), 0.125, 0.25),
-    ((8192, 2563), 0.125, None), ((2048, 40), 0.25, None)])
+    ((8192, 2563), 0.125, None), ((2048, 40), 0.25, None), ((640, 481), 0.25, None), ((256, 64), 0.125, None),
+    ((100, 1000), 0.5, 0.1)])
 def test_resize_stream_fused(bands, size, scale, vscale, monkeypatch):
     """vips_resize by 1 / (2 k) on uchar in ONE kernel (resize_stream.hip: shrinkv -> reducev ->
     shrinkh -> reduceh streaming down column strips): ran alone, and bit-exact against the port
     and against the separate kernels; box shrinks 1..8 on either axis, heights the box does not
-    divide (ceil mode), several strips and segments, every band count."""
+    divide (ceil mode), several strips and segments, rows shorter than a strip's 2 KB span, every
+    band count."""
     w, h = size
     src = helpers.lcg_image(w, h, bands, np.uint8, 78)
     kw = {} if vscale is None else {"vscale": vscale}
