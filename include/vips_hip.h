@@ -568,10 +568,11 @@ VIPS_HIP_API int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out,
 	double sigma, double x1, double y2, double y3, double m1, double m2);
 /* BASELINE config 4: vips_resize(scale, kernel, gap) [then vips_sharpen(sigma, x1, y2, y3, m1,
  * m2)] on n independent images, as libvips would run n pipelines over its thread pool
- * (iofuncs/threadpool.c:625): n_threads host threads take images in turn, each on its own
- * stream, so one image's small kernels overlap another's streaming ones.  sigma < 0: no
- * sharpen.  Returns the number of images that failed (out[i] NULL); everything is complete
- * on return.
+ * (iofuncs/threadpool.c:625).  A batch of same-sized uchar images whose resize is by 1 / (2 k)
+ * runs as one launch of the whole resize chain and one of the sharpen per 64 images; any
+ * other batch on n_threads host threads that take images in turn, each on its own stream.
+ * sigma < 0: no sharpen.  Returns the number of images that failed (out[i] NULL), -1 when
+ * the batch failed as a whole (every out[i] NULL); everything is complete on return.
  */
 VIPS_HIP_API int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage **out,
 	double scale, int kernel, double gap,
