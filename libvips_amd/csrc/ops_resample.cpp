@@ -277,6 +277,65 @@ int resize_down_u8_stream(VipsHipImage *const *in, int n, VipsHipImage **out, co
 	return 0;
 }
 
+// n uchar images of one size through the vertical box shrink and the fused tail (reducev ->
+// shrinkh -> reduceh, resize_tail.hip), each one launch per 64 images: any scale the tail
+// kernel takes.  0 = done (out[] filled), 1 = not its case (nothing done), -1 = error
+int resize_down_u8_tail_batch(VipsHipImage *const *in, int n, VipsHipImage **out, const AxisPlan &pv,
+	const AxisPlan &ph, int shrunk_width, int kernel)
+{
+	if (pv.residual == 1.0 || ph.residual == 1.0 || n < 1)
+		return 1;
+	for (int i = 0; i < n; i++)
+		if (in[i]->width != in[0]->width || in[i]->height != in[0]->height || in[i]->bands != in[0]->bands ||
+			in[i]->format != VIPS_HIP_FORMAT_UCHAR)
+			return 1;
+	const int shrunk_height =
+		pv.int_shrink > 1 ? vips_hip_shrink_out_size(in[0]->height, pv.int_shrink, 1) : in[0]->height;
+	if (shrunk_height <= 0)
+		return 1;
+	ReducePtr rv = reduce_cached(kernel, pv.residual, shrunk_height, pv.size, pv.extra_pixels);
+	ReducePtr rh = rv ? reduce_cached(kernel, ph.residual, shrunk_width, ph.size, ph.extra_pixels) : ReducePtr();
+	if (!rv || !rh)
+		return -1;
+	std::vector<ImageRef> pre(n), o(n);
+	std::vector<VipsHipRegion> ri(n), rm(n), ro(n);
+	std::vector<const VipsHipRegion *> pi(n), pm(n), po(n);
+	for (int i = 0; i < n; i++) {
+		vips_hip_image_region(in[i], &ri[i]);
+		pi[i] = &ri[i];
+		if (pv.int_shrink > 1) {
+			pre[i].im = like(in[i], in[i]->width, shrunk_height);
+			if (!pre[i].im)
+				return -1;
+			vips_hip_image_region(pre[i].im, &rm[i]);
+		}
+		else
+			rm[i] = ri[i];
+		pm[i] = &rm[i];
+		o[i].im = like(in[i], ph.size, pv.size);
+		if (!o[i].im)
+			return -1;
+		vips_hip_image_region(o[i].im, &ro[i]);
+		po[i] = &ro[i];
+	}
+	if (pv.int_shrink > 1) {
+		const int done = shrinkv_u8_batch_try(pv.int_shrink, pi.data(), pm.data(), n);
+		if (done < 0)
+			return -1;
+		if (done == 0)
+			return 1;
+	}
+	const int done = resize_tail_u8_try(rv.get(), ph.int_shrink, shrunk_width, rh.get(), pm.data(), po.data(), n,
+		g_fatstrip_height);
+	if (done < 0)
+		return -1;
+	if (done == 0)
+		return 1; // (a shrinkv already queued wrote only to images dropped here)
+	for (int i = 0; i < n; i++)
+		out[i] = o[i].release();
+	return 0;
+}
+
 // vips_resize's downsizing of a uchar image on both axes (resize.c:207-228: reducev with its
 // box pre-shrink, then reduceh with its own): the vertical box shrink, then everything else in
 // one kernel (resize_tail.hip) when the geometry fits it.  1 = not this function's case.
@@ -314,7 +373,9 @@ int resize_down_u8(VipsHipImage *in, VipsHipImage **out, double vshrink, double 
 	VipsHipRegion ri, ro;
 	vips_hip_image_region(cur, &ri);
 	vips_hip_image_region(o.im, &ro);
-	const int done = resize_tail_u8_try(rv.get(), ph.int_shrink, shrunk_width, rh.get(), &ri, &ro, g_fatstrip_height);
+	const VipsHipRegion *pri = &ri, *pro = &ro;
+	const int done = resize_tail_u8_try(rv.get(), ph.int_shrink, shrunk_width, rh.get(), &pri, &pro, 1,
+		g_fatstrip_height);
 	if (done < 0)
 		return -1;
 	if (done > 0) {
@@ -333,7 +394,8 @@ int resize_down_u8(VipsHipImage *in, VipsHipImage **out, double vshrink, double 
 namespace vh {
 
 // vips_resize(scale) of n uchar images of one size in one launch, for the batch entry point:
-// 0 = done, 1 = not the streaming kernel's case (the caller resizes image by image), -1 = error
+// 0 = done, 1 = neither the streaming kernel's nor the fused tail's case (the caller resizes image
+// by image), -1 = error
 int resize_batch_u8(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel, double gap)
 {
 	if (n < 1 || !in[0] || in[0]->format != VIPS_HIP_FORMAT_UCHAR || kernel == VIPS_HIP_KERNEL_NEAREST)
@@ -355,7 +417,10 @@ int resize_batch_u8(VipsHipImage *const *in, int n, VipsHipImage **out, double s
 		ph.int_shrink > 1 ? vips_hip_shrink_out_size(in[0]->width, ph.int_shrink, 1) : in[0]->width;
 	if (shrunk_width <= 0)
 		return 1;
-	return resize_down_u8_stream(in, n, out, pv, ph, shrunk_width, kernel);
+	const int done = resize_down_u8_stream(in, n, out, pv, ph, shrunk_width, kernel);
+	if (done <= 0)
+		return done;
+	return resize_down_u8_tail_batch(in, n, out, pv, ph, shrunk_width, kernel);
 }
 
 } // namespace vh

@@ -14,14 +14,17 @@ namespace vh {
 int reducev_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out,
 	const ReducePos *pos, const short *table, int tile);
 int shrinkv_u8_try(int vshrink, const VipsHipRegion *in, const VipsHipRegion *out);
+// the same on n rects of one geometry, one launch per 64
+int shrinkv_u8_batch_try(int vshrink, const VipsHipRegion *const *in, const VipsHipRegion *const *out, int n);
 
 const ReducePos *reduce_device_positions(_VipsHipReduce *r, int start, int count, int tile);
 // device-resident coefficient table of a reduce (short or double), created on first use
 int reduce_tables(_VipsHipReduce *r, bool want_float, const void **table);
 
 // vips_resize's tail (reducev -> shrinkh -> reduceh) on a whole uchar image, resize_tail.hip
+// (n images of one geometry, one launch per 64)
 int resize_tail_u8_try(_VipsHipReduce *rv, int hshrink, int shrunk_width, _VipsHipReduce *rh,
-	const VipsHipRegion *in, const VipsHipRegion *out, int tile);
+	const VipsHipRegion *const *in, const VipsHipRegion *const *out, int n, int tile);
 
 // vips_resize's whole downsizing chain (shrinkv -> reducev -> shrinkh -> reduceh) on n uchar images
 // of one size in one streaming kernel, resize_stream.hip; 1 = handled, 0 = not its case

@@ -29,6 +29,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace vh {
 
@@ -1091,10 +1092,26 @@ reducev_u8_kernel(VerticalArgs a, int n_point, const ReducePos *__restrict__ pos
 
 // shrinkv.c:158-165,218-228 / shrinkv_hwy.cpp:90-203: column sums of vshrink rows, then
 // ((sum + vshrink/2) * (2^32 / (256 * vshrink))) >> 24 in unsigned 32-bit arithmetic.
+constexpr int SHRINKV_MAXB = 64; // images per launch (blockIdx.z)
+
+// the images of a launch, read where they lie in the kernarg segment
+struct ShrinkvPtrs {
+	const unsigned char *in[SHRINKV_MAXB]; // already offset to the first column of the rect
+	unsigned char *out[SHRINKV_MAXB];
+};
+
 template <int DW>
 __global__ void __launch_bounds__(256)
-shrinkv_u8_kernel(VerticalArgs a, int vshrink, unsigned int multiplier)
+shrinkv_u8_kernel(ShrinkvPtrs ptrs_by_value, VerticalArgs a, int vshrink, unsigned int multiplier)
 {
+	(void) ptrs_by_value;
+	typedef const unsigned long long __attribute__((address_space(4))) *KernargPtrs;
+	const KernargPtrs kp = (KernargPtrs) __builtin_amdgcn_kernarg_segment_ptr();
+	// (pointers made from integers are generic to the compiler: say they are global)
+	typedef const unsigned char __attribute__((address_space(1))) *GlobalIn;
+	typedef unsigned char __attribute__((address_space(1))) *GlobalOut;
+	const GlobalIn in = (GlobalIn) kp[blockIdx.z];
+	const GlobalOut out = (GlobalOut) kp[SHRINKV_MAXB + blockIdx.z];
 	const int t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t * DW >= a.ndw)
 		return;
@@ -1108,10 +1125,12 @@ shrinkv_u8_kernel(VerticalArgs a, int vshrink, unsigned int multiplier)
 			even[w] = odd[w] = 0;
 		for (int i = 0; i < vshrink; i++) {
 			const int row = min(y0 + i, a.im_height - 1) - a.in_top;
-			const unsigned int *p = (const unsigned int *) (a.in + row * a.in_stride) + t * DW;
+			typedef unsigned int sv_uint4 __attribute__((ext_vector_type(4)));
+			const unsigned int __attribute__((address_space(1))) *p =
+				(const unsigned int __attribute__((address_space(1))) *) (in + row * a.in_stride) + t * DW;
 			unsigned int v[DW];
 			if (DW == 4) {
-				const uint4 x = *reinterpret_cast<const uint4 *>(p);
+				const sv_uint4 x = *(const sv_uint4 __attribute__((address_space(1))) *) p;
 				v[0] = x.x, v[1 % DW] = x.y, v[2 % DW] = x.z, v[3 % DW] = x.w;
 			}
 			else {
@@ -1125,7 +1144,8 @@ shrinkv_u8_kernel(VerticalArgs a, int vshrink, unsigned int multiplier)
 				odd[w] += (v[w] >> 8) & 0x00ff00ffu;
 			}
 		}
-		unsigned int *dst = (unsigned int *) (a.out + (long long) y * a.out_stride) + t * DW;
+		unsigned int __attribute__((address_space(1))) *dst =
+			(unsigned int __attribute__((address_space(1))) *) (out + (long long) y * a.out_stride) + t * DW;
 		unsigned int o[DW];
 #pragma unroll
 		for (int w = 0; w < DW; w++) {
@@ -1135,8 +1155,11 @@ shrinkv_u8_kernel(VerticalArgs a, int vshrink, unsigned int multiplier)
 			const unsigned int b3 = (((odd[w] >> 16) + amend) * multiplier) >> 24;
 			o[w] = (b0 & 0xffu) | ((b1 & 0xffu) << 8) | ((b2 & 0xffu) << 16) | (b3 << 24);
 		}
-		if (DW == 4)
-			*reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1 % DW], o[2 % DW], o[3 % DW]);
+		if (DW == 4) {
+			typedef unsigned int sv_uint4 __attribute__((ext_vector_type(4)));
+			const sv_uint4 ov = { o[0], o[1 % DW], o[2 % DW], o[3 % DW] };
+			*(sv_uint4 __attribute__((address_space(1))) *) dst = ov;
+		}
 		else {
 #pragma unroll
 			for (int w = 0; w < DW; w++)
@@ -1289,26 +1312,54 @@ int reducev_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsH
 	return 1;
 }
 
-int shrinkv_u8_try(int vshrink, const VipsHipRegion *in, const VipsHipRegion *out)
+// vips_shrinkv on n uchar rects of one geometry: one launch per SHRINKV_MAXB of them
+int shrinkv_u8_batch_try(int vshrink, const VipsHipRegion *const *in, const VipsHipRegion *const *out, int n)
 {
+	if (n < 1 || vshrink > 256)
+		return 0;
 	VerticalArgs a;
 	int dw;
-	if (vshrink > 256 || !vertical_args(in, out, &a, &dw))
+	if (!vertical_args(in[0], out[0], &a, &dw))
 		return 0;
+	std::vector<VerticalArgs> each(n);
+	for (int i = 0; i < n; i++) {
+		int dwi;
+		if (!vertical_args(in[i], out[i], &each[i], &dwi))
+			return 0;
+		const VerticalArgs &b = each[i];
+		if (b.in_stride != a.in_stride || b.out_stride != a.out_stride || b.in_top != a.in_top ||
+			b.im_height != a.im_height || b.out_top != a.out_top || b.out_height != a.out_height || b.ndw != a.ndw)
+			return 0;
+		dw = dwi < dw ? dwi : dw;
+	}
 	const unsigned int multiplier = (unsigned int) ((1LL << 32) / ((1 << 8) * (long long) vshrink));
 	const int threads = (a.ndw + dw - 1) / dw;
 	dim3 block(256, 1, 1);
-	dim3 grid((threads + 255) / 256, out->height < 32768 ? out->height : 32768, 1);
 	Gate gate("shrinkv_u8");
-	if (dw == 4)
-		hipLaunchKernelGGL(shrinkv_u8_kernel<4>, grid, block, 0, stream(), a, vshrink, multiplier);
-	else
-		hipLaunchKernelGGL(shrinkv_u8_kernel<1>, grid, block, 0, stream(), a, vshrink, multiplier);
-	if (hipGetLastError() != hipSuccess) {
-		error("shrinkv", "kernel launch failed");
-		return -1;
+	for (int base = 0; base < n; base += SHRINKV_MAXB) {
+		const int count = n - base < SHRINKV_MAXB ? n - base : SHRINKV_MAXB;
+		ShrinkvPtrs p;
+		memset(&p, 0, sizeof(p));
+		for (int i = 0; i < count; i++) {
+			p.in[i] = each[base + i].in;
+			p.out[i] = each[base + i].out;
+		}
+		dim3 grid((threads + 255) / 256, a.out_height < 32768 ? a.out_height : 32768, count);
+		if (dw == 4)
+			hipLaunchKernelGGL(shrinkv_u8_kernel<4>, grid, block, 0, stream(), p, a, vshrink, multiplier);
+		else
+			hipLaunchKernelGGL(shrinkv_u8_kernel<1>, grid, block, 0, stream(), p, a, vshrink, multiplier);
+		if (hipGetLastError() != hipSuccess) {
+			error("shrinkv", "kernel launch failed");
+			return -1;
+		}
 	}
 	return 1;
+}
+
+int shrinkv_u8_try(int vshrink, const VipsHipRegion *in, const VipsHipRegion *out)
+{
+	return shrinkv_u8_batch_try(vshrink, &in, &out, 1);
 }
 
 

@@ -31,9 +31,15 @@
 
 namespace vh {
 
+constexpr int TAIL_MAXB = 64; // images per launch (blockIdx.y)
+
+// the images of a launch, read where they lie in the kernarg segment
+struct TailPtrs {
+	const unsigned char *in[TAIL_MAXB];
+	unsigned char *out[TAIL_MAXB];
+};
+
 struct TailArgs {
-	const unsigned char *in;
-	unsigned char *out;
 	long long in_stride, out_stride;
 	int width, height, bands;   // the input image (after shrinkv)
 	int hshrink, shrunk_width;  // shrinkh
@@ -152,10 +158,16 @@ static __device__ __forceinline__ void tail_vrows(const TailArgs &a, unsigned in
 
 template <int NV>
 __global__ void __launch_bounds__(TAIL_NT)
-resize_tail_u8(TailArgs a, const ReducePos *__restrict__ posv, const short *__restrict__ tabv,
+resize_tail_u8(TailPtrs ptrs_by_value, TailArgs a, const ReducePos *__restrict__ posv, const short *__restrict__ tabv,
 	const ReducePos *__restrict__ posh, const short *__restrict__ tabh)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned int tail_lds[];
+	(void) ptrs_by_value;
+	typedef const unsigned long long __attribute__((address_space(4))) *KernargPtrs;
+	const KernargPtrs kp = (KernargPtrs) __builtin_amdgcn_kernarg_segment_ptr();
+	const unsigned char *in = reinterpret_cast<const unsigned char *>(kp[blockIdx.y]);
+	// (a pointer made from an integer is generic to the compiler: the stores say they are global)
+	unsigned char __attribute__((address_space(1))) *out = (unsigned char __attribute__((address_space(1))) *) kp[TAIL_MAXB + blockIdx.y];
 	unsigned int *tile = tail_lds;
 	unsigned char *shrunk = reinterpret_cast<unsigned char *>(tail_lds + a.max_rows * a.pitch);
 	// the tile's coefficients and positions: vertical taps of output row y as (tap 2p, tap 2p + 1)
@@ -199,7 +211,7 @@ resize_tail_u8(TailArgs a, const ReducePos *__restrict__ posv, const short *__re
 			const unsigned int lds_tile = (unsigned int) (size_t) tile;
 			for (int r = wv; r < nrows; r += TAIL_NT / 64) {
 				const int row = min(max(r_lo + r, 0), a.height - 1);
-				const unsigned char *src = a.in + (long long) row * a.in_stride + start_al;
+				const unsigned char *src = in + (long long) row * a.in_stride + start_al;
 				for (int k = 0; k < ndw; k += 64) {
 					if (k + lane < ndw)
 						tail_dma_dword(src, (unsigned int) (k + lane) * 4u, lds_tile + (unsigned int) (r * a.pitch + k) * 4u);
@@ -213,7 +225,7 @@ resize_tail_u8(TailArgs a, const ReducePos *__restrict__ posv, const short *__re
 			const int nfull = nbytes >> 2;
 			for (int r = wv; r < nrows; r += TAIL_NT / 64) {
 				const int row = min(max(r_lo + r, 0), a.height - 1);
-				const unsigned char *src = a.in + (long long) row * a.in_stride + start_al;
+				const unsigned char *src = in + (long long) row * a.in_stride + start_al;
 				for (int k = lane; k < nfull; k += 64) {
 					unsigned int v;
 					__builtin_memcpy(&v, src + 4 * k, 4);
@@ -321,7 +333,7 @@ resize_tail_u8(TailArgs a, const ReducePos *__restrict__ posv, const short *__re
 				for (int j = 0; j < 4; j++) {
 					const int y = yb + j * groups;
 					if (y < ny)
-						a.out[(long long) (y0 + y) * a.out_stride + (long long) (x0 + x) * B + b] =
+						out[(long long) (y0 + y) * a.out_stride + (long long) (x0 + x) * B + b] =
 							(unsigned char) tail_fin(sum[j]);
 				}
 			}
@@ -426,11 +438,11 @@ TailPlan tail_plan(const _VipsHipReduce *rv, int hs, int W3, const _VipsHipReduc
 }
 
 template <int NV>
-void tail_launch(const TailArgs &a, unsigned int blocks, size_t lds, const ReducePos *posv, const short *tabv,
-	const ReducePos *posh, const short *tabh)
+void tail_launch(const TailPtrs &p, int count, const TailArgs &a, unsigned int blocks, size_t lds, const ReducePos *posv,
+	const short *tabv, const ReducePos *posh, const short *tabh)
 {
-	hipLaunchKernelGGL(resize_tail_u8<NV>, dim3(blocks, 1, 1), dim3(TAIL_NT, 1, 1), lds, stream(), a, posv, tabv, posh,
-		tabh);
+	hipLaunchKernelGGL(resize_tail_u8<NV>, dim3(blocks, count, 1), dim3(TAIL_NT, 1, 1), lds, stream(), p, a, posv, tabv,
+		posh, tabh);
 }
 
 } // namespace
@@ -438,11 +450,25 @@ void tail_launch(const TailArgs &a, unsigned int blocks, size_t lds, const Reduc
 // vips_reducev(rv) -> vips_shrinkh(hs, ceil) -> vips_reduceh(rh) of a whole uchar image in one
 // kernel.  `in` is the image after the vertical box shrink, `out` the resized image; W3 the
 // width after shrinkh.  1 = handled, 0 = not this kernel's case, -1 = error.
-int resize_tail_u8_try(_VipsHipReduce *rv, int hs, int W3, _VipsHipReduce *rh, const VipsHipRegion *in,
-	const VipsHipRegion *out, int tile)
+int resize_tail_u8_try(_VipsHipReduce *rv, int hs, int W3, _VipsHipReduce *rh, const VipsHipRegion *const *ins,
+	const VipsHipRegion *const *outs, int n_images, int tile)
 {
-	if (getenv("VIPS_HIP_NO_RESIZE_TAIL"))
+	if (getenv("VIPS_HIP_NO_RESIZE_TAIL") || n_images < 1)
 		return 0;
+	const VipsHipRegion *in = ins[0], *out = outs[0];
+	bool aligned = true;
+	for (int i = 0; i < n_images; i++) {
+		const VipsHipRegion *ri = ins[i], *ro = outs[i];
+		if (ri->format != in->format || ri->bands != in->bands || ri->left != in->left || ri->top != in->top ||
+			ri->width != in->width || ri->height != in->height || ri->im_width != in->im_width ||
+			ri->im_height != in->im_height || ri->stride != in->stride)
+			return 0;
+		if (ro->format != out->format || ro->bands != out->bands || ro->left != out->left || ro->top != out->top ||
+			ro->width != out->width || ro->height != out->height || ro->im_width != out->im_width ||
+			ro->im_height != out->im_height || ro->stride != out->stride)
+			return 0;
+		aligned = aligned && !(((uintptr_t) ri->data & 3) || (ri->stride & 3));
+	}
 	if (in->format != VIPS_HIP_FORMAT_UCHAR || out->format != VIPS_HIP_FORMAT_UCHAR || in->bands != out->bands ||
 		in->bands < 1 || in->bands > 4)
 		return 0;
@@ -486,8 +512,6 @@ int resize_tail_u8_try(_VipsHipReduce *rv, int hs, int W3, _VipsHipReduce *rh, c
 		return -1;
 
 	TailArgs a;
-	a.in = (const unsigned char *) in->data;
-	a.out = (unsigned char *) out->data;
 	a.in_stride = (long long) in->stride;
 	a.out_stride = (long long) out->stride;
 	a.width = in->width;
@@ -509,7 +533,7 @@ int resize_tail_u8_try(_VipsHipReduce *rv, int hs, int W3, _VipsHipReduce *rh, c
 	a.s_pitch = plan.s_pitch;
 	a.max_rows = plan.max_rows;
 	a.np4 = tail_np4(a.n_v);
-	a.aligned = !(((uintptr_t) in->data & 3) || (in->stride & 3));
+	a.aligned = aligned;
 	const long long blocks = (long long) a.nbx * a.band * 8;
 	if (blocks > 0x7fffffffLL)
 		return 0;
@@ -520,31 +544,40 @@ int resize_tail_u8_try(_VipsHipReduce *rv, int hs, int W3, _VipsHipReduce *rh, c
 	a.off_first = offsets[2];
 	a.debug = getenv("VIPS_HIP_TAIL_DEBUG") ? atoi(getenv("VIPS_HIP_TAIL_DEBUG")) : 0;
 	Gate gate("resize_tail_u8");
+	for (int base = 0; base < n_images; base += TAIL_MAXB) {
+		const int count = n_images - base < TAIL_MAXB ? n_images - base : TAIL_MAXB;
+		TailPtrs p;
+		memset(&p, 0, sizeof(p));
+		for (int i = 0; i < count; i++) {
+			p.in[i] = (const unsigned char *) ins[base + i]->data;
+			p.out[i] = (unsigned char *) outs[base + i]->data;
+		}
 #define TAIL_CASE(N) \
 	case N: \
-		tail_launch<N>(a, (unsigned int) blocks, lds, posv, (const short *) tabv, posh, (const short *) tabh); \
+		tail_launch<N>(p, count, a, (unsigned int) blocks, lds, posv, (const short *) tabv, posh, (const short *) tabh); \
 		break;
-	switch (a.n_v) {
-		TAIL_CASE(3)
-		TAIL_CASE(5)
-		TAIL_CASE(7)
-		TAIL_CASE(9)
-		TAIL_CASE(11)
-		TAIL_CASE(13)
-		TAIL_CASE(15)
-		TAIL_CASE(17)
-		TAIL_CASE(19)
-		TAIL_CASE(21)
-		TAIL_CASE(23)
-		TAIL_CASE(25)
-	default:
-		tail_launch<0>(a, (unsigned int) blocks, lds, posv, (const short *) tabv, posh, (const short *) tabh);
-		break;
-	}
+		switch (a.n_v) {
+			TAIL_CASE(3)
+			TAIL_CASE(5)
+			TAIL_CASE(7)
+			TAIL_CASE(9)
+			TAIL_CASE(11)
+			TAIL_CASE(13)
+			TAIL_CASE(15)
+			TAIL_CASE(17)
+			TAIL_CASE(19)
+			TAIL_CASE(21)
+			TAIL_CASE(23)
+			TAIL_CASE(25)
+		default:
+			tail_launch<0>(p, count, a, (unsigned int) blocks, lds, posv, (const short *) tabv, posh, (const short *) tabh);
+			break;
+		}
 #undef TAIL_CASE
-	if (hipGetLastError() != hipSuccess) {
-		error("resize", "kernel launch failed");
-		return -1;
+		if (hipGetLastError() != hipSuccess) {
+			error("resize", "kernel launch failed");
+			return -1;
+		}
 	}
 	return 1;
 }

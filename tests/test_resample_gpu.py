@@ -462,9 +462,13 @@ def test_resize_stream_other_kernels(kernel, bands, size, scale, monkeypatch):
     assert np.array_equal(got, im.resize(scale, kernel=kernel).numpy())
 
 
-def test_resize_stream_batch_chunks():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_resize_stream_batch_chunks(overlap, monkeypatch):
     """More images than one launch of the streaming resize / the one-kernel sharpen holds (64):
-    every image of the batch equals the pipeline run on it alone."""
+    every image of the batch equals the pipeline run on it alone; also with the sharpen of a
+    chunk on a second stream next to the next chunk's resize ($VIPS_HIP_BATCH_OVERLAP)."""
+    if overlap:
+        monkeypatch.setenv("VIPS_HIP_BATCH_OVERLAP", "1")
     srcs = [helpers.lcg_image(688, 96, 3, np.uint8, 900 + k) for k in range(70)]
     ims = [Image.new_from_array(s, interpretation="srgb") for s in srcs]
     libvips_amd.lib.vips_hip_gate_reset()
@@ -479,6 +483,30 @@ def test_resize_stream_batch_chunks():
     for k in (0, 1, 63, 64, 69):
         assert np.array_equal(outs[k].numpy(), ims[k].resize(0.125).sharpen().numpy()), k
         assert np.array_equal(outs[k].numpy(), helpers.PortCC.sharpen(Port.resize(srcs[k], 0.125)))
+
+
+@pytest.mark.parametrize("scale,want", [(0.07, ["resize_tail_u8", "sharpen_fused_u8", "shrinkv_u8"]),
+                                        (0.3, ["resize_tail_u8", "sharpen_fused_u8"])])
+def test_resize_batch_any_scale(scale, want):
+    """A uniform batch whose scale is not 1 / (2 k): the vertical box shrink and the fused tail
+    (reducev -> shrinkh -> reduceh) each as one launch per 64 images, then the batched sharpen;
+    every image equals the pipeline run on it alone and the port."""
+    srcs = [helpers.lcg_image(2052, 777, 3, np.uint8, 400 + k) for k in range(70)]
+    ims = [Image.new_from_array(s, interpretation="srgb") for s in srcs]
+    libvips_amd.lib.vips_hip_gate_reset()
+    libvips_amd.lib.vips_hip_gate_enable(1)
+    try:
+        outs = libvips_amd.resize_sharpen_batch(ims, scale, threads=4)
+        report = libvips_amd.gate_report()
+    finally:
+        libvips_amd.lib.vips_hip_gate_enable(0)
+        libvips_amd.lib.vips_hip_gate_reset()
+    assert sorted(report) == want, report
+    assert all(v[0] == 2 for v in report.values()), report  # two chunks: 64 + 6 images
+    for k in (0, 1, 63, 64, 69):
+        assert np.array_equal(outs[k].numpy(), ims[k].resize(scale).sharpen().numpy()), k
+    for k in (0, 69):
+        assert np.array_equal(outs[k].numpy(), helpers.PortCC.sharpen(Port.resize(srcs[k], scale)))
 
 
 def test_resize_sharpen_batch():

@@ -16,6 +16,7 @@ KNOBS = ("VIPS_HIP_NO_RESIZE_TAIL", "VIPS_HIP_NO_FUSED_SHARPEN", "VIPS_HIP_TAIL_
          "VIPS_HIP_NO_RESIZE_STREAM", "VIPS_HIP_NO_BATCH_LAUNCH", "VIPS_HIP_STREAM_BLOCKS", "VIPS_HIP_STREAM_SEG",
          "VIPS_HIP_STREAM_DEBUG", "VIPS_HIP_BATCH_OVERLAP", "VIPS_HIP_STREAM_DW")
 n, count = 8192, int(os.environ.get("C4_IMAGES", "64"))
+scale = float(os.environ.get("C4_SCALE", "0.125"))
 libvips_amd.init(0)
 dev = torch.device("cuda", 0)
 store = torch.empty((count, n, n, 3), dtype=torch.uint8, device=dev)
@@ -29,27 +30,27 @@ for spec in sys.argv[1:] or ["default:"]:
     for k in KNOBS:
         os.environ.pop(k, None)
     os.environ.update(dict(kv.split("=") for kv in rest.split(",") if kv))
-    one = ims[0].resize(0.125).sharpen().numpy()
+    one = ims[0].resize(scale).sharpen().numpy()
     if ref is None:
         ref = one
     same = bool((one == ref).all())
     lib.vips_hip_gate_reset()
     lib.vips_hip_gate_enable(1)
     for _ in range(4):
-        ims[0].resize(0.125)
+        ims[0].resize(scale)
     libvips_amd.synchronize()
     lib.vips_hip_gate_enable(0)
     rep = {k: round(v[1] / v[0], 4) for k, v in libvips_amd.gate_report().items()}
     lib.vips_hip_gate_reset()
-    libvips_amd.resize_sharpen_batch(ims, 0.125, threads=8)
+    libvips_amd.resize_sharpen_batch(ims, scale, threads=8)
     best = 1e9
     for _ in range(3):
         t0 = time.perf_counter()
-        libvips_amd.resize_sharpen_batch(ims, 0.125, threads=8)
+        libvips_amd.resize_sharpen_batch(ims, scale, threads=8)
         best = min(best, (time.perf_counter() - t0) / count * 1e3)
     lib.vips_hip_gate_reset()
     lib.vips_hip_gate_enable(1)
-    libvips_amd.resize_sharpen_batch(ims, 0.125, threads=8)
+    libvips_amd.resize_sharpen_batch(ims, scale, threads=8)
     lib.vips_hip_gate_enable(0)
     inb = {k: round(v[1] / count, 4) for k, v in libvips_amd.gate_report().items()}
     lib.vips_hip_gate_reset()
