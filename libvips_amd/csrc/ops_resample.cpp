@@ -241,7 +241,7 @@ int reduce_axis(VipsHipImage *in, VipsHipImage **out, double shrink, int kernel,
 int resize_down_u8_stream(VipsHipImage *const *in, int n, VipsHipImage **out, const AxisPlan &pv, const AxisPlan &ph,
 	int shrunk_width, int kernel)
 {
-	if (pv.residual != 2.0 || ph.residual != 2.0 || kernel == VIPS_HIP_KERNEL_NEAREST || n < 1)
+	if (pv.residual == 1.0 || ph.residual == 1.0 || kernel == VIPS_HIP_KERNEL_NEAREST || n < 1)
 		return 1;
 	const int shrunk_height =
 		pv.int_shrink > 1 ? vips_hip_shrink_out_size(in[0]->height, pv.int_shrink, 1) : in[0]->height;
@@ -266,8 +266,15 @@ int resize_down_u8_stream(VipsHipImage *const *in, int n, VipsHipImage **out, co
 		pi[i] = &ri[i];
 		po[i] = &ro[i];
 	}
-	const int done = resize_stream_u8_try(rv.get(), pv.int_shrink, rh.get(), ph.int_shrink, shrunk_height,
-		shrunk_width, pi.data(), po.data(), n, g_fatstrip_height);
+	// residual reduces of exactly 2 on both axes: the static-rotation kernel (resize_stream.hip);
+	// any other: the scheduled one (resize_streamg.hip)
+	int done = 0;
+	if (pv.residual == 2.0 && ph.residual == 2.0)
+		done = resize_stream_u8_try(rv.get(), pv.int_shrink, rh.get(), ph.int_shrink, shrunk_height, shrunk_width,
+			pi.data(), po.data(), n, g_fatstrip_height);
+	if (done == 0)
+		done = resize_streamg_u8_try(rv.get(), pv.int_shrink, rh.get(), ph.int_shrink, shrunk_height, shrunk_width,
+			pi.data(), po.data(), n, g_fatstrip_height);
 	if (done < 0)
 		return -1;
 	if (done == 0)
@@ -351,7 +358,7 @@ int resize_down_u8(VipsHipImage *in, VipsHipImage **out, double vshrink, double 
 	if (shrunk_width <= 0)
 		return 1;
 	{
-		// all four operations in one kernel when both residuals are exactly 2 (resize_stream.hip)
+		// all four operations in one kernel (resize_stream.hip, resize_streamg.hip)
 		const int done = resize_down_u8_stream(&in, 1, out, pv, ph, shrunk_width, kernel);
 		if (done <= 0)
 			return done;

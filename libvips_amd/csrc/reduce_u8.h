@@ -30,6 +30,9 @@ int resize_tail_u8_try(_VipsHipReduce *rv, int hshrink, int shrunk_width, _VipsH
 // of one size in one streaming kernel, resize_stream.hip; 1 = handled, 0 = not its case
 int resize_stream_u8_try(_VipsHipReduce *rv, int vshrink, _VipsHipReduce *rh, int hshrink, int shrunk_height,
 	int shrunk_width, const VipsHipRegion *const *in, const VipsHipRegion *const *out, int n, int tile);
+// the same for any residual reduce, from a host-made schedule of the vertical pass, resize_streamg.hip
+int resize_streamg_u8_try(_VipsHipReduce *rv, int vshrink, _VipsHipReduce *rh, int hshrink, int shrunk_height,
+	int shrunk_width, const VipsHipRegion *const *in, const VipsHipRegion *const *out, int n, int tile);
 // the same from images (ops_resample.cpp); 0 = done, 1 = not its case, -1 = error
 int resize_batch_u8(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel, double gap);
 

@@ -485,12 +485,49 @@ def test_resize_stream_batch_chunks(overlap, monkeypatch):
         assert np.array_equal(outs[k].numpy(), helpers.PortCC.sharpen(Port.resize(srcs[k], 0.125)))
 
 
-@pytest.mark.parametrize("scale,want", [(0.07, ["resize_tail_u8", "sharpen_fused_u8", "shrinkv_u8"]),
-                                        (0.3, ["resize_tail_u8", "sharpen_fused_u8"])])
-def test_resize_batch_any_scale(scale, want):
-    """A uniform batch whose scale is not 1 / (2 k): the vertical box shrink and the fused tail
-    (reducev -> shrinkh -> reduceh) each as one launch per 64 images, then the batched sharpen;
-    every image equals the pipeline run on it alone and the port."""
+@pytest.mark.parametrize("bands", [1, 2, 3, 4])
+@pytest.mark.parametrize("size,scale,vscale", [
+    ((2048, 1536), 0.11, None), ((1531, 1203), 0.3, None), ((4100, 1051), 0.07, 0.19),
+    ((640, 480), 0.45, 0.26), ((3000, 700), 0.021, 0.3), ((1024, 1024), 1.0 / 3.0, 0.125),
+    ((516, 2049), 0.26, 0.031), ((200, 100), 0.2, None), ((8192, 300), 0.025, 0.4), ((8192, 2563), 1.0 / 9.0, None)])
+def test_resize_stream_general(bands, size, scale, vscale, monkeypatch):
+    """vips_resize on uchar at ANY scale in one kernel (resize_streamg.hip: the vertical pass from a
+    host-made schedule of rows, slots and coefficient phases): ran alone when the rows are dword
+    multiples, bit-exact against the port and against the separate kernels; box shrinks 1..40,
+    residuals between 1 and 4 on either axis, all band counts, several strips and segments."""
+    w, h = size
+    src = helpers.lcg_image(w, h, bands, np.uint8, 81)
+    kw = {} if vscale is None else {"vscale": vscale}
+    im = Image.new_from_array(src)
+    monkeypatch.setenv("VIPS_HIP_STREAM_BLOCKS", "4096")
+    libvips_amd.lib.vips_hip_gate_reset()
+    libvips_amd.lib.vips_hip_gate_enable(1)
+    try:
+        got = im.resize(scale, **kw).numpy()
+        report = libvips_amd.gate_report()
+    finally:
+        libvips_amd.lib.vips_hip_gate_enable(0)
+        libvips_amd.lib.vips_hip_gate_reset()
+    if (w * bands) % 4 == 0:
+        assert list(report) == ["resize_streamg_u8"], report
+    assert_same(got, Port.resize(src, scale, **kw), str((bands, size, scale, vscale)))
+    monkeypatch.delenv("VIPS_HIP_STREAM_BLOCKS")
+    assert np.array_equal(got, im.resize(scale, **kw).numpy())
+    monkeypatch.setenv("VIPS_HIP_NO_RESIZE_STREAM", "1")
+    assert np.array_equal(got, im.resize(scale, **kw).numpy())
+
+
+@pytest.mark.parametrize("scale,env,want", [
+    (0.07, "", ["resize_streamg_u8", "sharpen_fused_u8"]),
+    (0.07, "VIPS_HIP_NO_RESIZE_STREAMG", ["resize_tail_u8", "sharpen_fused_u8", "shrinkv_u8"]),
+    (0.3, "VIPS_HIP_NO_RESIZE_STREAMG", ["resize_tail_u8", "sharpen_fused_u8"])])
+def test_resize_batch_any_scale(scale, env, want, monkeypatch):
+    """A uniform batch whose scale is not 1 / (2 k): the scheduled one-kernel chain
+    (resize_streamg.hip), or without it the vertical box shrink and the fused tail (reducev ->
+    shrinkh -> reduceh), each one launch per 64 images, then the batched sharpen; every image
+    equals the pipeline run on it alone and the port."""
+    if env:
+        monkeypatch.setenv(env, "1")
     srcs = [helpers.lcg_image(2052, 777, 3, np.uint8, 400 + k) for k in range(70)]
     ims = [Image.new_from_array(s, interpretation="srgb") for s in srcs]
     libvips_amd.lib.vips_hip_gate_reset()
