@@ -209,11 +209,18 @@ resize_streamg_u8(GenArgs a, GenPtrs ptrs_by_value)
 				for (int r = 0; r < RG_K; r++)
 					sum[r] += ck * (int) S[r * a.s_pitch + off];
 			}
+			// The stores are spelled out in assembly on purpose: gfx9 counts loads and stores in one
+			// counter and they may finish out of order, so with a store the compiler knows of still
+			// pending it drains EVERY outstanding load at the top of the row loop (vmcnt(0)) and the
+			// prefetch is lost.  Stores it does not see only make its counted waits stricter.
 			const GlobalOut dst = out + (long long) ybase * a.out_stride + (long long) x0 * B + th;
 #pragma unroll
 			for (int r = 0; r < RG_K; r++)
-				if (r < nr)
-					dst[(long long) r * a.out_stride] = (unsigned char) rg_fin(sum[r]);
+				if (r < nr) {
+					const unsigned int v = rg_fin(sum[r]);
+					const GlobalOut p = dst + (long long) r * a.out_stride;
+					asm volatile("global_store_byte %0, %1, off" : : "v"(p), "v"(v) : "memory");
+				}
 		}
 	};
 
@@ -318,32 +325,50 @@ resize_streamg_u8(GenArgs a, GenPtrs ptrs_by_value)
 			}
 		}
 	};
-	// One step = one group: the next group's loads go out first, into the OTHER buffer (two
-	// buffers swapped by unrolling: a register copy would wait for the loads it copies).
-	int k = k_first, g = 0;
-	auto step = [&](unsigned int (&cur)[4], unsigned int (&nxt)[4]) __attribute__((always_inline)) {
-		const bool last = g + 1 == groups;
-		const int kn = last ? k + 1 : k, gn = last ? 0 : g + 1;
-		issue(kn, gn, nxt); // (past the last row: a clamped row nobody sums)
+	// One step = one group.  Three buffers rotate (by unrolling: a register copy would wait for
+	// the loads it copies): the group two steps ahead is requested before the current one is
+	// summed, so a lane has 3 GS loads in flight (with two buffers the kernel ran at 3.7 TB/s,
+	// the latency of one group's loads still showing).
+	int k = k_first, g = 0; // the group being summed
+	auto after = [&](int &kk, int &gg) __attribute__((always_inline)) {
+		const bool last = gg + 1 == groups;
+		kk = last ? kk + 1 : kk;
+		gg = last ? 0 : gg + 1;
+	};
+	int k1 = k, g1 = g;
+	after(k1, g1);
+	int k2 = k1, g2 = g1; // the group the next step requests
+	after(k2, g2);
+	auto step = [&](unsigned int (&cur)[4], unsigned int (&fill)[4]) __attribute__((always_inline)) {
+		issue(k2, g2, fill); // (past the last row: a clamped row nobody sums)
 #pragma unroll
 		for (int j = 0; j < GS; j++) {
 			const unsigned int keep = GS * g + j < a.vs ? 0xffffffffu : 0u; // (scalar)
 			e += cur[j] & (0x00ff00ffu & keep);
 			o += __builtin_amdgcn_perm(0u, cur[j], 0x0c030c01u) & keep;
 		}
-		if (last) {
-			finish_row(k);
+		if (g + 1 == groups) {
+			if (k <= k_last)
+				finish_row(k);
 			e = o = 0;
 		}
-		k = kn;
-		g = gn;
+		k = k1;
+		g = g1;
+		k1 = k2;
+		g1 = g2;
+		after(k2, g2);
 	};
-	issue(k_first, 0, buf_a);
+	unsigned int buf_c[4] = { 0, 0, 0, 0 };
+	issue(k, g, buf_a);
+	issue(k1, g1, buf_b);
 	const int total = (k_last - k_first + 1) * groups;
-	for (int st = 0; st < total; st += 2) {
-		step(buf_a, buf_b);
-		if (st + 1 < total)
-			step(buf_b, buf_a);
+	// (whole turns of three steps: a step under a branch makes its buffer a merge of loaded and
+	// not loaded, and the merge waits for every load; the one or two steps past the end sum
+	// clamped rows into nothing)
+	for (int st = 0; st < total; st += 3) {
+		step(buf_a, buf_c);
+		step(buf_b, buf_a);
+		step(buf_c, buf_b);
 	}
 	if (trow > 0)
 		hphase(ybase, trow);
