@@ -104,6 +104,8 @@ static __device__ __forceinline__ float ss_fin(double s, const StreamArgs &a, in
 			asm volatile(""); // a wave-uniform branch, not two selects per output
 			q = ss_div_scale(s, a);
 		}
+		// (+ offset even when it is zero: a branch around the addition -- it is a no-op for a zero
+		// offset and a positive scale -- measured 3 % slower than the 16 additions per step)
 		return (float) __dadd_rn(q, pass == 1 ? a.offset1 : a.offset2);
 	}
 	else

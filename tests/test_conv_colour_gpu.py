@@ -335,6 +335,24 @@ def test_fused_convsep_float_offsets_and_nonfinite():
         assert np.array_equal(got, want, equal_nan=True), precision
 
 
+def test_fused_convsep_float_signed_zeros():
+    """The sign of zero through the streaming kernel: blocks of +0.0, -0.0 and tiny negative
+    pixels, masks with a positive and with a NEGATIVE scale, offsets 0.0, -0.0 and non-zero -- the
+    bits of every output (v_div_fixup_f64 restores IEEE division's sign of zero; `+ offset` is only
+    skipped where it cannot matter)."""
+    src = helpers.lcg_image(300, 120, 3, np.float32, 71)
+    src[:40] = 0.0
+    src[40:80, :150] = -0.0
+    src[40:80, 150:] = -1e-40
+    src[100:, 200:] = -0.0
+    mask = np.array([[1.0, 2.0, 5.0, 7.0, 5.0, 2.0, 1.0]])
+    for m, scale in ((mask, 23.0), (mask, -23.0), (-mask, 1.0), (mask, 1.0)):
+        for offset in (0.0, -0.0, 2.5):
+            got = Image.new_from_array(src).convsep(m, scale=scale, offset=offset, precision="integer").numpy()
+            want = PortCC.convsep(src, m, scale, offset, "integer")
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (scale, offset)
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.int16])
 @pytest.mark.parametrize("shape", [(700, 300, 3), (1500, 90, 1), (37, 411, 4), (2300, 140, 2), (5, 3, 3)])
 @pytest.mark.parametrize("sigma", [0.6, 2.0, 8.0])

@@ -117,3 +117,21 @@ def test_port_vs_ref_c5_conv31():
     want = Ref.run_mask("conv", src, mask, scale, 0.0, "precision=float")
     got = PortCC.conv(src, mask, scale, 0.0, "float")
     assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+
+
+@needs_ref
+def test_port_vs_ref_convsep_signed_zeros():
+    """The sign of zero through convsep on float (convi.c:721-741: the sum starts at +0.0, the
+    division by a negative scale makes -0.0, + offset): the port against the compiled reference,
+    bit for bit -- the input the GPU suite's test_fused_convsep_float_signed_zeros uses."""
+    src = helpers.lcg_image(300, 120, 3, np.float32, 71)
+    src[:40] = 0.0
+    src[40:80, :150] = -0.0
+    src[40:80, 150:] = -1e-40
+    src[100:, 200:] = -0.0
+    mask = np.array([[1.0, 2.0, 5.0, 7.0, 5.0, 2.0, 1.0]])
+    for m, scale in ((mask, 23.0), (mask, -23.0), (-mask, 1.0), (mask, 1.0)):
+        for offset in (0.0, -0.0, 2.5):
+            want = Ref.run_mask("convsep", src, m, scale, offset, "precision=integer")
+            got = PortCC.convsep(src, m, scale, offset, "integer")
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (scale, offset)
