@@ -384,6 +384,66 @@ def run_c2(ctx, args):
     }
 
 
+# ------------------------------------------------------------------------------------- C1
+
+def run_c1(ctx, steps, warmup, verify=True, cpu=True, size=4096):
+    """BASELINE configs[0], the device part: vips_thumbnail_image(width 512) of a size x size x 3
+    uchar sRGB image resident in HBM (what `vipsthumbnail --size 512x512` runs after the load:
+    vips_resize(1/8), here the one-kernel chain).  One step = one thumbnail."""
+    torch = ctx.torch
+    from libvips_amd import Image
+
+    n = size
+    with torch.cuda.stream(ctx.stream):
+        src = lcg_image_device(torch, n, n, 3, 12345, ctx.device)
+    torch.cuda.synchronize()
+    im = Image.new_from_tensor(src, interpretation="srgb")
+
+    def step():
+        return im.thumbnail_image(512)
+
+    elapsed, out = ctx.timed(step, steps, warmup)
+    ms = elapsed / steps * 1e3
+    report = ctx.gates(step, 4)
+    t = out.width
+    alg = n * n * 3 + t * out.height * 3
+    entry = {
+        "name": "c1",
+        "workload": "vips_thumbnail_image(512) of %dx%dx3 u8 sRGB -> %dx%dx3 (the device part of BASELINE configs[0])"
+                    % (n, n, t, out.height),
+        "ms": round(ms, 4),
+        "steps": steps,
+        "mpixels_per_s": round(float(n) * n / (ms * 1e-3) / 1e6, 1),
+        "algorithmic_bytes": alg,
+        "bound": "hbm",
+        "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "dtype": "u8",
+        "kernels": kernels_of(report),
+    }
+    helpers = ref_or_none()
+    if helpers is not None and (verify or cpu):
+        chain = "thumbnail_image:width=512"
+        interp = helpers.INTERP["srgb"]
+        host = src.cpu().numpy()
+        if verify:
+            want = helpers.Ref.run_chain(chain, host, interp)
+            got = out.numpy()
+            exact = got.shape == want.shape and bool(np.array_equal(got, want))
+            entry["parity"] = {"against": "oracle/_ref (compiled reference), whole thumbnail", "bit_exact": exact}
+            if not exact:
+                raise SystemExit("bench.py: C1 thumbnail differs from the reference")
+        if cpu:
+            secs = helpers.Ref.time_chain(chain, host, repeats=3, interpretation=interp,
+                                          concurrency=os.cpu_count() or 1)
+            entry["cpu_baseline"] = {
+                "value": round(float(n) * n / secs / 1e6, 1), "unit": "Mpixels/s",
+                "cores": helpers.Ref.concurrency(), "kind": "reference",
+                "sample": "the same %dx%dx3 image through vips_thumbnail_image, best of 3" % (n, n)}
+    del im, src, out
+    ctx.trim()
+    return entry
+
+
 # ------------------------------------------------------------------------------------- C3
 
 def run_c3(ctx, steps, warmup, verify=True, cpu=True, size=32768):
@@ -779,6 +839,7 @@ def main():
         if ctx.rank == 0 and ctx.world == 1 and not args.no_configs and args.size == 16384:
             k = max(2, min(args.steps, 5))
             line["configs"] = [
+                run_c1(ctx, 20, 3, verify, cpu),
                 run_c3(ctx, k, 2, verify, cpu),
                 run_c4(ctx, max(1, min(args.steps, 3)), 2, args.images or 256, verify, cpu),
                 run_c5slab(ctx, max(2, min(args.steps, 4)), 2, verify, cpu),
