@@ -69,6 +69,8 @@ struct StreamArgs {
 	int step_rows, step_px; // block size / pxw and % pxw: the epilogue walks its items without dividing
 	int ring;         // staged-row buffers in LDS (2..4): the LDS-DMA runs ring - 1 steps ahead
 	int strips, segs, seg_rows;
+	int has_scale;    // scale != 1 (an integer for the kernel to test: a scalar compare and branch;
+	                  // the f64 compare makes a lane mask that is kept -- spilled -- for every use)
 	double scale, rscale;
 	double offset1, offset2;
 	int *counter;
@@ -100,7 +102,9 @@ static __device__ __forceinline__ float ss_fin(double s, const StreamArgs &a, in
 {
 	if constexpr (MODE == 1) {
 		double q = s;
-		if (a.scale != 1.0) {
+		int has_scale = a.has_scale;
+		asm volatile("" : "+s"(has_scale)); // (tested here, as a scalar: hoisted, the test is a lane mask that spills)
+		if (has_scale) {
 			asm volatile(""); // a wave-uniform branch, not two selects per output
 			q = ss_div_scale(s, a);
 		}
@@ -163,9 +167,12 @@ static __device__ __forceinline__ void ss_hpass(const StreamArgs &a, const doubl
 #pragma unroll
 		for (int ii = 0; ii < 4; ii++)
 			cg[ii] = kc[4 * g + ii];
+		int rem = a.rem;
+		if (g + 1 == NG)
+			asm volatile("" : "+s"(rem)); // (compared here as a scalar: hoisted, each test is a lane mask that spills)
 #pragma unroll
 		for (int ii = 0; ii < 4; ii++) {
-			if (g + 1 < NG || ii < a.rem) { // whole groups unconditional, the last one tap by tap
+			if (g + 1 < NG || ii < rem) { // whole groups unconditional, the last one tap by tap
 				// (a real branch: if-converted, the absent taps cost 8 multiply-adds and 16 selects each)
 				if (g + 1 == NG)
 					asm volatile("");
@@ -230,11 +237,13 @@ static __device__ __forceinline__ void ss_vpass(const StreamArgs &a, const doubl
 			const int slot = (ROT - d) & (SS_SLOTS - 1);
 			acc[slot] = ss_mac<MODE>(d == 0 ? seed : acc[slot], kr[d], dv);
 		}
+		int rem = a.rem;
+		asm volatile("" : "+s"(rem)); // (see ss_hpass)
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
 			const int d = 4 * (NG - 1) + k;
 			const int slot = (ROT - d) & (SS_SLOTS - 1);
-			if (k < a.rem) {
+			if (k < rem) {
 				asm volatile(""); // a real branch (see ss_hpass)
 				acc[slot] = ss_mac<MODE>(d == 0 ? seed : acc[slot], kr[d], dv);
 			}
@@ -559,6 +568,7 @@ int convsep_stream_fused(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 	if (integer && c->scale_i == 0)
 		return 1;
 	a.rscale = 1.0 / a.scale;
+	a.has_scale = a.scale != 1.0;
 	a.offset1 = integer ? (double) c->offset_i : c->offset;
 	a.offset2 = integer ? (double) (int) rint(offset2) : offset2;
 
