@@ -25,10 +25,15 @@ def _build_mock():
     if not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
         return False
     os.makedirs(os.path.dirname(MOCK_SO), exist_ok=True)
+    # (several pytest-xdist workers may get here at once: build aside, then rename into place)
+    tmp = "%s.%d.tmp" % (MOCK_SO, os.getpid())
     proc = subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
-                           "-I/opt/rocm/include", "-o", MOCK_SO, MOCK_SRC],
+                           "-I/opt/rocm/include", "-o", tmp, MOCK_SRC],
                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    return proc.returncode == 0
+    if proc.returncode != 0:
+        return False
+    os.replace(tmp, MOCK_SO)
+    return True
 
 
 def _gpu_present():
