@@ -519,6 +519,12 @@ int resize_streamg_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh, int hs
 		return 0;
 	if (rv->n_point < 1 || rv->n_point > 64 || rh->n_point < 1 || rh->n_point > RG_MAXH)
 		return 0;
+	// Without a vertical box shrink every INPUT row costs a schedule step (NS x 4 multiply-adds per
+	// dword), and with few taps the fused tail's dot2 walk is cheaper: measured on 64 images of
+	// 8192^2 x 3 at scale 0.45 (15 taps) 0.34 against 0.27 ms per image, at 0.3 (21 taps) 0.22
+	// against 0.26 (profiles/r02_probes.txt).  $VIPS_HIP_STREAMG_ALWAYS=1 takes this kernel anyway.
+	if (vs == 1 && rv->n_point < 19 && !getenv("VIPS_HIP_STREAMG_ALWAYS"))
+		return 0;
 
 	GenPlan plan;
 	{

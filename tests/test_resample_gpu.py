@@ -500,6 +500,7 @@ def test_resize_stream_general(bands, size, scale, vscale, monkeypatch):
     kw = {} if vscale is None else {"vscale": vscale}
     im = Image.new_from_array(src)
     monkeypatch.setenv("VIPS_HIP_STREAM_BLOCKS", "4096")
+    monkeypatch.setenv("VIPS_HIP_STREAMG_ALWAYS", "1")  # also where the dispatcher prefers the fused tail
     libvips_amd.lib.vips_hip_gate_reset()
     libvips_amd.lib.vips_hip_gate_enable(1)
     try:
