@@ -104,6 +104,23 @@ def file_sha(path):
         return None
 
 
+def span_sha(path, span=None):
+    """Hash of a kernel's own source: the text between `// [span NAME]` and `// [/span NAME]` in
+    `path` (the whole file without a span), so that edits to other kernels of the same file do not
+    make the committed counters look stale."""
+    try:
+        text = open(path, "rb").read()
+    except IOError:
+        return None
+    if span:
+        a = text.find(("// [span %s]" % span).encode())
+        b = text.find(("// [/span %s]" % span).encode())
+        if a < 0 or b < a:
+            return None
+        text = text[a:b]
+    return hashlib.sha256(text).hexdigest()[:16]
+
+
 def traffic_for(kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
     (profiles/traffic.json; PMC passes cannot run inside the timed bench).  An entry is only
@@ -117,7 +134,7 @@ def traffic_for(kernel_name):
         return None
     entry = table[max(keys, key=len)]
     src = entry.get("source")
-    if not src or entry.get("source_sha") != file_sha(os.path.join(ROOT, src)):
+    if not src or entry.get("source_sha") != span_sha(os.path.join(ROOT, src), entry.get("span")):
         return None  # stale: the kernel changed since the counters were collected
     return entry.get("traffic_bytes")
 
@@ -166,6 +183,31 @@ class Ctx(object):
         if self.dist is not None:
             self.dist.barrier()
             self.torch.cuda.synchronize()
+
+    def settle(self, step, chunk=20, max_launches=1500, tol=0.01):
+        """Run `step` until the GPU's clocks have settled: chunks of `chunk` launches, each between
+        a pair of events, until two consecutive chunks agree within `tol` (or max_launches).
+        On these boxes the first ~100-300 launches of a heavy kernel after a quiet spell run
+        5-25 % slower (tools/c2_steps.py, profiles/r03_c2_ramp.txt: fast for ~8 launches, then a
+        dip, then a slow recovery -- the power controller hunting), which is longer than the
+        5-step warm-up the driver asks for.  Returns what it saw; the bench line carries it."""
+        torch = self.torch
+        means = []
+        with torch.cuda.stream(self.stream):
+            while len(means) * chunk < max_launches:
+                e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+                e0.record(self.stream)
+                for _ in range(chunk):
+                    step()
+                e1.record(self.stream)
+                e1.synchronize()
+                means.append(e0.elapsed_time(e1) / chunk)
+                if len(means) >= 3 and abs(means[-1] - means[-2]) <= tol * means[-1] and \
+                        abs(means[-2] - means[-3]) <= tol * means[-2]:
+                    break
+        return {"launches": len(means) * chunk, "first_chunk_ms": round(means[0], 4),
+                "slowest_chunk_ms": round(max(means), 4), "last_chunk_ms": round(means[-1], 4),
+                "chunk": chunk}
 
     def timed(self, step, steps, warmup):
         """warmup untimed steps, then exactly `steps` between fences; MAX over ranks (s)."""
@@ -251,6 +293,18 @@ def run_c2(ctx, args):
     def step():
         return im.reduce(shrink, shrink, kernel="lanczos3")
 
+    # The driver's command first, as it is: W warm-up steps, K timed steps, from a GPU that has only
+    # run the image generator -- `cold` below.  Then the same region again once the clocks have
+    # settled (Ctx.settle): that is the line's ms_per_step / value, the rate a pipeline of images
+    # sees; the cold region and the ramp are reported beside it, nothing is dropped.
+    cold = None
+    if not args.no_settle:
+        cold_elapsed, _ = ctx.timed(step, args.steps, args.warmup)
+        cold = {"ms_per_step": round(cold_elapsed / args.steps * 1e3, 4),
+                "kernel_ms": round(ctx.event_ms / args.steps, 4),
+                "what": "the first %d + %d launches of the process (W warm-up + K timed), before the "
+                        "clocks settled" % (args.warmup, args.steps)}
+        cold["settle"] = ctx.settle(step)
     elapsed, out = ctx.timed(step, args.steps, args.warmup)
     region_ms = ctx.event_ms / args.steps  # one launch per step: the kernel's average launch duration
     in_pixels = float(n) * n
@@ -310,6 +364,10 @@ def run_c2(ctx, args):
                 roofline["frac_of_measured_copy"] = round(achieved / roofline["measured_copy_GBps"], 4)
             except Exception:  # the reference rates are a courtesy, never a reason to fail the bench
                 pass
+
+    if roofline and cold:
+        # the same fraction over the driver's first W + K launches (clocks not settled)
+        roofline["frac_cold"] = round(roofline["algorithmic_bytes"] / (cold["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
 
     # ---- parity of the timed steps' output + CPU baseline: the reference itself on this box's
     # host cores (rank 0, N = 1 only)
@@ -379,6 +437,7 @@ def run_c2(ctx, args):
             "partition": "one independent image per GPU, no data-path collective",
         },
         "roofline": roofline,
+        "clock_ramp": cold,
         "parity": parity,
         "cpu_baseline": cpu_baseline,
     }
@@ -825,6 +884,8 @@ def main():
     ap.add_argument("--images", type=int, default=None, help="c4: images per GPU (default 256 at N=1, 128 at N>1: "
                                                              "1024 images on 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-settle", action="store_true",
+                    help="c2: time the first W + K launches of the process only (no clock-settling phase)")
     ap.add_argument("--no-configs", action="store_true", help="c2: leave the C3/C4/C5 entries out")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparisons with the reference")
     args = ap.parse_args()

@@ -350,6 +350,7 @@ reduce_fused_u8x4(FusedArgs a, FusedCoefs<S, D> k_by_value)
 // Output rows are staged in LDS for the whole tile and written in one burst at its end: on
 // this part a 1.5 % stream of writes trickling into a streaming read costs 13 % of the
 // read rate (tools/write_probe.hip: 0.175 -> 0.198 ms per GiB), a burst at the end 4 %.
+// [span reduce_fused_u8_mfma] (profiles/traffic.json is stamped with the hash of the text between these marks)
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
@@ -365,21 +366,29 @@ constexpr int MFMA_TABLE_ENTRIES = MFMA_SLOTS * 2 * 2 * 4; // half4v entries per
 constexpr int HSEG_OUT = 8;                                // outputs per horizontal segment
 // bytes per (row, channel) T plane: 512 samples + 4, so that the 32 planes a half-wave of the
 // horizontal pass reads (8 rows x 4 channels, one dword each) fall in 32 distinct banks
-constexpr int MFMA_PLANE = FUSED_SPAN + 4;
-constexpr int MFMA_PLANES_BYTES = MFMA_SLOTS * 4 * MFMA_PLANE;
-constexpr int MFMA_STAGE_PITCH = 60; // dwords per staged output row (owt <= 59)
-constexpr int MFMA_MAX_OHT = 88;     // 4 blocks per CU: (160 KB / 4) - planes - tables
+// Geometry of a block of NTH threads (256: four blocks per CU, 59-pixel tiles; 512: two blocks
+// per CU, 123-pixel tiles -- half the halo columns per input byte).  A lane owns two pixels.
+template <int NTH>
+struct MfmaGeo {
+	static constexpr int SPAN = 2 * NTH;            // input columns per tile
+	static constexpr int PLANE = SPAN + 4;          // odd number of dwords: see above
+	static constexpr int PLANES_BYTES = MFMA_SLOTS * 4 * PLANE;
+	static constexpr int STAGE_PITCH = SPAN / 8 - 4; // dwords per staged output row (owt <= SPAN/8 - 5)
+	static constexpr int BLOCKS_PER_CU = 1024 / NTH;
+	// (160 KB / blocks per CU) - planes - tables, in staged rows
+	static constexpr int MAX_OHT = NTH == 256 ? 88 : 92;
+	// stage_rows = rows the stage must hold: a burst leaves as soon as burst_rows are complete,
+	// and a horizontal pass completes at most 8 more
+	static constexpr size_t lds_bytes(int stage_rows)
+	{
+		return (size_t) PLANES_BYTES + 2 * MFMA_TABLE_ENTRIES * 8 + (size_t) stage_rows * STAGE_PITCH * 4;
+	}
+};
 
-// stage_rows = rows the stage must hold: a burst leaves as soon as burst_rows are complete, and a
-// horizontal pass completes at most 8 more
-static constexpr size_t mfma_lds_bytes(int stage_rows)
-{
-	return (size_t) MFMA_PLANES_BYTES + 2 * MFMA_TABLE_ENTRIES * 8 + (size_t) stage_rows * MFMA_STAGE_PITCH * 4;
-}
-
-template <int D, bool NT = false, int PROF = 0, bool PAIRS = false>
+template <int D, bool NT = false, int PROF = 0, bool PAIRS = false, int NTH = FUSED_THREADS>
 struct MfmaStep {
 	static constexpr int S = 8;
+	static constexpr int MFMA_PLANE = MfmaGeo<NTH>::PLANE;
 
 	// Rows first_row + dir * i, I0 <= i < I0 + N.  The launcher only picks this kernel for
 	// windows < 2 GB, so every address is the uniform base (an SGPR pair) plus one 32-bit lane
@@ -491,8 +500,11 @@ struct MfmaStep {
 						asm volatile("" : "+v"(px[i].x), "+v"(px[i].y));
 				}
 			}
-			else if (p == 1 && more)
+			else if (p == 1 && more) {
+				if (a.debug & 32) // profiling: never more than one quad of rows in flight per wave
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 				load_rows<4 * Q, 4>(a, px, next_row, dir, ca, cb, interior);
+			}
 #pragma unroll
 			for (int c = 0; c < 4; c++) {
 				acc[p * 4 + c][0] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, b[c], acc[p * 4 + c][0], 0, 0, 0);
@@ -582,12 +594,15 @@ struct MfmaStep {
 // them, so horizontal neighbours (which read their shared halo columns in lock-step) and
 // most vertical neighbours (which the serpentine walk makes meet at their shared halo rows)
 // share an L2.  Measured on C2: row-major 0.218 ms, column-major 0.221, no serpentine 0.225.
-template <int D, int NB, int OCC, bool NT, int PROF = 0, bool PAIRS = false>
-__global__ void __launch_bounds__(FUSED_THREADS, OCC)
+template <int D, int NB, int OCC, bool NT, int PROF = 0, bool PAIRS = false, int NTH = FUSED_THREADS>
+__global__ void __launch_bounds__(NTH, OCC)
 reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 {
 	constexpr int S = 8;
-	typedef MfmaStep<D, NT, PROF, PAIRS> Step;
+	typedef MfmaStep<D, NT, PROF, PAIRS, NTH> Step;
+	typedef MfmaGeo<NTH> Geo;
+	constexpr int MFMA_PLANE = Geo::PLANE, MFMA_PLANES_BYTES = Geo::PLANES_BYTES;
+	constexpr int MFMA_STAGE_PITCH = Geo::STAGE_PITCH, FUSED_SPAN = Geo::SPAN;
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	// T planes (the horizontal walker over-reads the end of a plane by up to 8 * (D - 1)
 	// samples: into the next plane / the tables -- any byte is a finite f16 denormal), the two
@@ -669,7 +684,7 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 		const int jhi = min(g0 + MFMA_SLOTS - 1 - (D - 1), oh - 1); // inclusive
 		if (jhi < jlo)
 			continue;
-		__syncthreads();
+		if (!(a.debug & 64)) __syncthreads(); // (bit 64: timing probe without the batch barriers -- wrong pixels)
 		const int nrows = jhi - jlo + 1;
 		const int r_lo = jlo - (g0 - (D - 1));
 		if (!(a.debug & 1)) {
@@ -692,7 +707,7 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 				*reinterpret_cast<uint2 *>(srow) = make_uint2(pix[0], pix[1]);
 			}
 		}
-		__syncthreads();
+		if (!(a.debug & 64)) __syncthreads();
 
 		// ---- output: staged rows leave in bursts of burst_rows (and at the tile's end), a wave
 		// per row, a lane per pixel; the next write into the stage is behind the next barrier
@@ -700,8 +715,9 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 		if ((done - flushed >= a.burst_rows || done == oh) && !(a.debug & 2)) {
 			// 16 lanes per row, 4 pixels (one dwordx4 store, dword aligned) per lane: the burst is
 			// the kernel's tail, so it wants few, wide store instructions
-			const int part = t & 15;
-			for (int r = t >> 4; r < done - flushed; r += FUSED_THREADS / 16) {
+			constexpr int LPR = NTH / 16; // lanes per row: 4 pixels each
+			const int part = t & (LPR - 1);
+			for (int r = t / LPR; r < done - flushed; r += 16) {
 				const int jj = flushed + r;
 				unsigned int *dst = reinterpret_cast<unsigned int *>(
 					a.out + (long long) (y0 + (flip ? oh - 1 - jj : jj)) * a.out_stride + (long long) x0 * 4);
@@ -722,6 +738,8 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 			flushed = done;
 	}
 }
+
+// [/span reduce_fused_u8_mfma]
 
 // ------------------------------------------------ vertical-only pass on the matrix cores
 //
@@ -954,27 +972,36 @@ static void mfma_build_tables(const std::vector<int> &taps, const std::vector<in
 					}
 }
 
-template <int D>
+template <int D, int NTH>
 static int launch_fused_mfma(const FusedArgs &args, int tiles, const MfmaTables *d_tables)
 {
 	Gate gate("reduce_fused_u8_mfma");
+	typedef MfmaGeo<NTH> Geo;
 	const int grid = (tiles + 7) / 8 * 8; // XCD remap wants a multiple of 8
 	const int stage_rows = args.burst_rows + 7 < args.oht ? args.burst_rows + 7 : args.oht;
-	const size_t lds = mfma_lds_bytes(stage_rows);
-	if ((args.debug & 24) == 8) // profiling builds: arithmetic only / loads only
+	const size_t lds = Geo::lds_bytes(stage_rows);
+	static bool attr_set = false; // per instantiation: above 64 KB of dynamic LDS needs the opt-in
+	if (!attr_set && lds > 64 * 1024) {
+		VH_CHECK(hipFuncSetAttribute((const void *) reduce_fused_u8x4_mfma<D, 1, 4, false, 0, true, NTH>,
+			hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+		VH_CHECK(hipFuncSetAttribute((const void *) reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true, NTH>,
+			hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+		attr_set = true;
+	}
+	if (NTH == FUSED_THREADS && (args.debug & 24) == 8) // profiling builds: arithmetic only / loads only
 		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 8, true>), dim3(grid), dim3(FUSED_THREADS), lds,
 			stream(), args, d_tables);
-	else if ((args.debug & 24) == 16)
+	else if (NTH == FUSED_THREADS && (args.debug & 24) == 16)
 		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 16, true>), dim3(grid), dim3(FUSED_THREADS), lds,
 			stream(), args, d_tables);
 	else if (args.debug & 4) // profiling: nt (streaming) loads
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true>), dim3(grid), dim3(FUSED_THREADS), lds,
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true, NTH>), dim3(grid), dim3(NTH), lds,
 			stream(), args, d_tables);
 	else
 		// plain loads: nt loads run within noise of them (+-1.5 % either way between boxes) but
 		// fetch 9 % more from the fabric (rocprofv3 FETCH_SIZE 1 221 MB against 1 120 MB per
 		// launch: the halo lines a neighbouring tile just read are not kept in L2)
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, false, 0, true>), dim3(grid), dim3(FUSED_THREADS), lds,
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, false, 0, true, NTH>), dim3(grid), dim3(NTH), lds,
 			stream(), args, d_tables);
 	VH_CHECK(hipGetLastError());
 	return 0;
@@ -1463,6 +1490,10 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 	args.burst_rows = 1 << 20;
 	args.owt = FUSED_SPAN / S - D + 1;
 	args.tiles_x = (out->width + args.owt - 1) / args.owt;
+	// MFMA kernel: threads per block (VIPS_HIP_FUSED_NTH=256|512; tiles of 59 / 123 pixels)
+	const int nth = getenv("VIPS_HIP_FUSED_NTH") && atoi(getenv("VIPS_HIP_FUSED_NTH")) == 512 ? 512 : 256;
+	const int mfma_span = 2 * nth;
+	const int mfma_max_oht = nth == 512 ? MfmaGeo<512>::MAX_OHT : MfmaGeo<256>::MAX_OHT;
 
 	_VipsHipReduce *rv = const_cast<_VipsHipReduce *>(reducev);
 	// S = 8: both passes on the matrix cores when the exactness bounds hold
@@ -1504,7 +1535,7 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 				if (align && !(in->stride & 127)) {
 					const long long addr = (long long) (uintptr_t) in->data + 4LL * ((long long) fx0 - in->left);
 					const int off = (int) (((addr % 128) + 128) % 128); // bytes past a line start
-					const int owt = ((FUSED_SPAN - off / 4) / S - D + 1) & ~3;
+					const int owt = ((mfma_span - off / 4) / S - D + 1) & ~3;
 					if (!(off & 15) && owt >= 32) {
 						args.xshift = off / 4;
 						args.owt = owt;
@@ -1520,7 +1551,7 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 				int oht = out->height;
 				for (int k = 1; k <= 4096; k++) {
 					oht = (out->height + base * k - 1) / (base * k);
-					if (oht <= MFMA_MAX_OHT)
+					if (oht <= mfma_max_oht)
 						break;
 				}
 				args.oht = oht < 1 ? 1 : oht;
@@ -1530,7 +1561,7 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 				args.stagger = e ? atoi(e) & 7 : 0;
 				e = getenv("VIPS_HIP_FUSED_BURST");
 				const int burst = e ? atoi(e) : 0;
-				args.burst_rows = burst > 0 ? (burst + 7) & ~7 : MFMA_MAX_OHT + 8;
+				args.burst_rows = burst > 0 ? (burst + 7) & ~7 : mfma_max_oht + 8;
 			}
 			const int tiles_y = (out->height + args.oht - 1) / args.oht;
 			const int tiles = args.tiles_x * tiles_y;
@@ -1553,9 +1584,11 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 					d_tables = (const MfmaTables *) it->second;
 			}
 			if (D == 6)
-				return launch_fused_mfma<6>(args, tiles, d_tables);
+				return nth == 512 ? launch_fused_mfma<6, 512>(args, tiles, d_tables)
+								  : launch_fused_mfma<6, 256>(args, tiles, d_tables);
 			if (D == 7)
-				return launch_fused_mfma<7>(args, tiles, d_tables);
+				return nth == 512 ? launch_fused_mfma<7, 512>(args, tiles, d_tables)
+								  : launch_fused_mfma<7, 256>(args, tiles, d_tables);
 		}
 	}
 

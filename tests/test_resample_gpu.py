@@ -217,7 +217,8 @@ def test_fused_reduce_rgba(shrink, size):
 @pytest.mark.parametrize("kernel", ["lanczos3"])
 @pytest.mark.parametrize("size", [(4099, 3001), (2048, 1024), (1000, 8), (96, 2600), (9000, 700), (8192, 8197)])
 @pytest.mark.parametrize("align", [0, 1])
-def test_fused_reduce_mfma_variants(align, size, kernel):
+@pytest.mark.parametrize("nth", [256, 512])
+def test_fused_reduce_mfma_variants(nth, align, size, kernel):
     """Both tile layouts of the matrix-core kernel on the same inputs: line-aligned tiles (lanes
     start on the 128-byte line holding the first tap; the default when base and stride allow)
     and tiles that start at the first tap (VIPS_HIP_FUSED_ALIGN=0: what windows with an odd
@@ -230,6 +231,7 @@ def test_fused_reduce_mfma_variants(align, size, kernel):
     w, h = size
     src = helpers.lcg_image(w, h, 4, np.uint8, 47)
     os.environ["VIPS_HIP_FUSED_ALIGN"] = str(align)
+    os.environ["VIPS_HIP_FUSED_NTH"] = str(nth)  # 59-pixel tiles (256 threads) / 123-pixel tiles (512)
     lib.vips_hip_gate_reset()
     lib.vips_hip_gate_enable(1)
     try:
@@ -237,6 +239,7 @@ def test_fused_reduce_mfma_variants(align, size, kernel):
         report = libvips_amd.gate_report()
     finally:
         del os.environ["VIPS_HIP_FUSED_ALIGN"]
+        del os.environ["VIPS_HIP_FUSED_NTH"]
         lib.vips_hip_gate_enable(0)
         lib.vips_hip_gate_reset()
     assert list(report) == ["reduce_fused_u8_mfma"], report
@@ -244,7 +247,8 @@ def test_fused_reduce_mfma_variants(align, size, kernel):
 
 
 @pytest.mark.parametrize("align", [0, 1])
-def test_fused_reduce_region_windows(align):
+@pytest.mark.parametrize("nth", [256, 512])
+def test_fused_reduce_region_windows(nth, align):
     """vips_hip_reduce_gen the way a strip owner (one GPU of several, libvips_amd/sharding.py)
     calls it: an output sub-rect and an input window that only just covers the rows and
     columns vips_hip_reduce{v,h}_need report, at image edges and in the middle; must equal
@@ -257,6 +261,7 @@ def test_fused_reduce_region_windows(align):
     rv = _ffi.check_handle(lib.vips_hip_reduce_new(5, 8.0, h, oh, math.nan))
     rh = _ffi.check_handle(lib.vips_hip_reduce_new(5, 8.0, w, ow, math.nan))
     os.environ["VIPS_HIP_FUSED_ALIGN"] = str(align)
+    os.environ["VIPS_HIP_FUSED_NTH"] = str(nth)
     try:
         for (left, top, width, height) in ((0, 0, ow, 37), (0, 37, ow, oh - 37), (10, 50, 200, 100),
                                            (ow - 61, oh - 40, 61, 40), (0, 100, 59, 1)):
@@ -275,6 +280,7 @@ def test_fused_reduce_region_windows(align):
             assert np.array_equal(dout.numpy(), full[top:top + height, left:left + width]), (left, top, width, height)
     finally:
         del os.environ["VIPS_HIP_FUSED_ALIGN"]
+        del os.environ["VIPS_HIP_FUSED_NTH"]
         lib.vips_hip_reduce_free(rv)
         lib.vips_hip_reduce_free(rh)
 

@@ -149,8 +149,8 @@ static __device__ __forceinline__ bool tile_of_block(const TileGeo &g, int *bx, 
 	return true;
 }
 
-template <int VB, bool NT, int DEPTH>
-__global__ void __launch_bounds__(256) tile_plain(const unsigned char *__restrict__ in, TileGeo g, unsigned *sink)
+template <int VB, bool NT, int DEPTH, int THREADS = 256>
+__global__ void __launch_bounds__(THREADS) tile_plain(const unsigned char *__restrict__ in, TileGeo g, unsigned *sink)
 {
 	typedef unsigned int vec __attribute__((ext_vector_type(VB / 4)));
 	extern __shared__ unsigned char pad[];
@@ -173,6 +173,55 @@ __global__ void __launch_bounds__(256) tile_plain(const unsigned char *__restric
 #pragma unroll
 			for (int k = 0; k < VB / 4; k++)
 				acc ^= v[i][k];
+	}
+	if (acc == 0x12345678) {
+		*sink = acc;
+		pad[threadIdx.x] = 1;
+	}
+}
+
+// two buffers of DEPTH rows, refilled as soon as consumed (the fused kernel's pattern: DEPTH..2*DEPTH
+// loads in flight per wave); WAITALL = wait for everything outstanding before each refill
+template <int VB, bool NT, int DEPTH, bool WAITALL>
+__global__ void __launch_bounds__(256) tile_pipe(const unsigned char *__restrict__ in, TileGeo g, unsigned *sink)
+{
+	typedef unsigned int vec __attribute__((ext_vector_type(VB / 4)));
+	extern __shared__ unsigned char pad[];
+	int bx, by;
+	if (!tile_of_block(g, &bx, &by))
+		return;
+	const int dir = (by & 1) ? -1 : 1;
+	const int r0 = (by & 1) ? by * g.row_pitch + g.rows - 1 : by * g.row_pitch;
+	const unsigned char *p = in + (size_t) bx * g.col_pitch + threadIdx.x * VB;
+	unsigned acc = 0;
+	vec v[2][DEPTH];
+	auto load = [&](int b, int r) __attribute__((always_inline)) {
+#pragma unroll
+		for (int i = 0; i < DEPTH; i++) {
+			const vec *q = reinterpret_cast<const vec *>(p + (size_t) (r0 + dir * (r + i)) * PITCH);
+			v[b][i] = NT ? __builtin_nontemporal_load(q) : *q;
+		}
+	};
+	auto eat = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+		for (int i = 0; i < DEPTH; i++)
+#pragma unroll
+			for (int k = 0; k < VB / 4; k++)
+				acc ^= v[b][i][k];
+	};
+	load(0, 0);
+	load(1, DEPTH);
+	for (int r = 0; r < g.rows; r += 2 * DEPTH) {
+		eat(0);
+		if (WAITALL)
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		if (r + 2 * DEPTH < g.rows)
+			load(0, r + 2 * DEPTH);
+		eat(1);
+		if (WAITALL)
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		if (r + 3 * DEPTH < g.rows)
+			load(1, r + 3 * DEPTH);
 	}
 	if (acc == 0x12345678) {
 		*sink = acc;
@@ -294,12 +343,23 @@ static void run_dma(const char *name, int rows, int pitch)
 }
 
 
-template <int VB, bool NT, int DEPTH>
+template <int VB, bool NT, int DEPTH, int THREADS = 256>
 static void run_tile_plain(const char *name, TileGeo g, int lds_pad)
 {
 	const int tiles = g.tiles_x * g.tiles_y, grid = (tiles + 7) / 8 * 8;
-	CHECK(hipFuncSetAttribute((const void *) tile_plain<VB, NT, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	double ms = time_ms([&] { tile_plain<VB, NT, DEPTH><<<grid, 256, lds_pad>>>((const unsigned char *) g_in, g, g_sink); }, 20);
+	CHECK(hipFuncSetAttribute((const void *) tile_plain<VB, NT, DEPTH, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	double ms = time_ms([&] { tile_plain<VB, NT, DEPTH, THREADS><<<grid, THREADS, lds_pad>>>((const unsigned char *) g_in, g, g_sink); }, 20);
+	const double bytes = (double) tiles * g.rows * THREADS * VB;
+	printf("%-30s %2dx%2d tiles rows %4d pitch %4d B lds %3d KB: %.4f ms  %.0f GB/s requested (%.3fx of 1 GiB)\n", name,
+		g.tiles_x, g.tiles_y, g.rows, g.col_pitch, lds_pad / 1024, ms, bytes / ms / 1e6, bytes / BYTES);
+}
+
+template <int VB, bool NT, int DEPTH, bool WAITALL>
+static void run_tile_pipe(const char *name, TileGeo g, int lds_pad)
+{
+	const int tiles = g.tiles_x * g.tiles_y, grid = (tiles + 7) / 8 * 8;
+	CHECK(hipFuncSetAttribute((const void *) tile_pipe<VB, NT, DEPTH, WAITALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	double ms = time_ms([&] { tile_pipe<VB, NT, DEPTH, WAITALL><<<grid, 256, lds_pad>>>((const unsigned char *) g_in, g, g_sink); }, 20);
 	const double bytes = (double) tiles * g.rows * 256 * VB;
 	printf("%-30s %2dx%2d tiles rows %4d pitch %4d B lds %3d KB: %.4f ms  %.0f GB/s requested (%.3fx of 1 GiB)\n", name,
 		g.tiles_x, g.tiles_y, g.rows, g.col_pitch, lds_pad / 1024, ms, bytes / ms / 1e6, bytes / BYTES);
@@ -350,11 +410,80 @@ static void tile_section()
 	run_tile_dma<16, 4096, 4, 8, true>("tile dma w16 4K r4 g8 nt big", big, 0);
 }
 
+// round 3: 1024-pixel tiles (512 threads x 8 B or 256 threads x 16 B), two blocks per CU
+static void wide_section()
+{
+	const TileGeo u59 = { 35, 29, 608, 568, 1888 };
+	const TileGeo w123 = { 17, 30, 592, 552, 3936 };  // oht 69
+	const TileGeo w120 = { 18, 28, 632, 592, 3840 };  // line-aligned pitch, oht 74
+	const TileGeo w123t = { 17, 15, 1136, 1096, 3936 }; // one block per CU
+	const TileGeo u59t = { 35, 15, 1136, 1096, 1888 };  // 256 threads, two blocks per CU, tall
+	const int K80 = 80 * 1024, K40 = 40 * 1024;
+	run_tile_plain<8, false, 8>("u59 256x8 d8", u59, K40);
+	run_tile_plain<8, false, 4>("u59 256x8 d4", u59, K40);
+	run_tile_plain<8, true, 4>("u59 256x8 nt d4", u59, K40);
+	run_tile_plain<8, false, 8, 512>("w123 512x8 d8", w123, K80);
+	run_tile_plain<8, true, 8, 512>("w123 512x8 nt d8", w123, K80);
+	run_tile_plain<8, false, 4, 512>("w123 512x8 d4", w123, K80);
+	run_tile_plain<8, true, 4, 512>("w123 512x8 nt d4", w123, K80);
+	run_tile_plain<8, true, 2, 512>("w123 512x8 nt d2", w123, K80);
+	run_tile_plain<8, false, 4, 512>("w120 512x8 d4 aligned", w120, K80);
+	run_tile_plain<8, true, 4, 512>("w120 512x8 nt d4 aligned", w120, K80);
+	run_tile_plain<8, true, 8, 512>("w120 512x8 nt d8 aligned", w120, K80);
+	run_tile_plain<16, false, 8>("w123 256x16 d8", w123, K80);
+	run_tile_plain<16, true, 8>("w123 256x16 nt d8", w123, K80);
+	run_tile_plain<16, false, 4>("w123 256x16 d4", w123, K80);
+	run_tile_plain<16, true, 4>("w123 256x16 nt d4", w123, K80);
+	run_tile_plain<16, true, 4>("w120 256x16 nt d4 aligned", w120, K80);
+	run_tile_plain<16, true, 8>("w120 256x16 nt d8 aligned", w120, K80);
+	run_tile_plain<16, true, 4>("w123 256x16 nt d4 4blk/CU", w123, K40);
+	run_tile_plain<8, true, 4, 512>("w123t 512x8 nt d4 1blk/CU", w123t, 0);
+	run_tile_plain<8, true, 8, 512>("w123t 512x8 nt d8 1blk/CU", w123t, 0);
+	run_tile_plain<8, true, 4>("u59t 256x8 nt d4 2blk/CU", u59t, K80);
+	run_tile_plain<8, true, 8>("u59t 256x8 nt d8 2blk/CU", u59t, K80);
+	run_tile_plain<8, false, 8>("u59t 256x8 d8 2blk/CU", u59t, K80);
+}
+
+// round 3: how many rows in flight per wave does the shipped geometry want?
+static void depth_section()
+{
+	const TileGeo u59 = { 35, 29, 608, 568, 1888 };
+	const int K40 = 40 * 1024;
+	run_tile_plain<8, false, 2>("u59 d2", u59, K40);
+	run_tile_plain<8, false, 3>("u59 d3", u59, K40);
+	run_tile_plain<8, false, 4>("u59 d4", u59, K40);
+	run_tile_plain<8, false, 5>("u59 d5", u59, K40);
+	run_tile_plain<8, false, 6>("u59 d6", u59, K40);
+	run_tile_plain<8, false, 8>("u59 d8", u59, K40);
+	run_tile_plain<8, true, 4>("u59 nt d4", u59, K40);
+	run_tile_pipe<8, false, 4, false>("u59 pipe 2x4", u59, K40);
+	run_tile_pipe<8, false, 4, true>("u59 pipe 2x4 waitall", u59, K40);
+	run_tile_pipe<8, true, 4, true>("u59 pipe 2x4 waitall nt", u59, K40);
+	run_tile_pipe<8, false, 2, false>("u59 pipe 2x2", u59, K40);
+	run_tile_pipe<8, false, 2, true>("u59 pipe 2x2 waitall", u59, K40);
+	run_tile_pipe<8, false, 3, false>("u59 pipe 2x3", u59, K40);
+	run_tile_pipe<8, false, 8, false>("u59 pipe 2x8", u59, K40);
+}
+
 int main()
 {
 	CHECK(hipMalloc(&g_in, BYTES + (64 << 20)));
 	CHECK(hipMalloc(&g_sink, 4));
 	CHECK(hipMemset(g_in, 1, BYTES));
+	if (getenv("PROBE_DEPTH")) {
+		for (int rep = 0; rep < 2; rep++) {
+			printf("---- depth, pass %d\n", rep);
+			depth_section();
+		}
+		return 0;
+	}
+	if (getenv("PROBE_WIDE")) {
+		for (int rep = 0; rep < 2; rep++) {
+			printf("---- wide tiles, pass %d\n", rep);
+			wide_section();
+		}
+		return 0;
+	}
 	if (getenv("PROBE_TILES")) {
 		for (int rep = 0; rep < 2; rep++) {
 			printf("---- tiles, pass %d\n", rep);

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Stamp profiles/traffic.json with HBM bytes per launch of the C2 kernel from a rocprofv3 PMC
+summary (profiles/rocprof_summary.py output) and the hash of the kernel's own source span.
+
+usage: python tools/update_traffic.py profiles/r03_c2_pmc.txt
+Reads the FETCH_SIZE / WRITE_SIZE (KB) rows of the reduce_fused_u8x4_mfma kernel; traffic =
+FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE.
+"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import span_sha  # noqa: E402
+
+
+def main():
+    path = sys.argv[1]
+    fetch = write = None
+    for line in open(path):
+        if "reduce_fused_u8x4_mfma" not in line:
+            continue
+        m = re.search(r"\b(FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([0-9.]+)", line)
+        if m:
+            kb = float(m.group(3))
+            if m.group(1) == "FETCH_SIZE":
+                fetch = kb
+            else:
+                write = kb
+    if fetch is None or write is None:
+        raise SystemExit("no FETCH_SIZE / WRITE_SIZE rows for reduce_fused_u8x4_mfma in %s" % path)
+    src = "libvips_amd/csrc/reduce_u8.hip"
+    span = "reduce_fused_u8_mfma"
+    fetch_b = int(round(fetch * 2 * 1024))
+    write_b = int(round(write * 1024))
+    table = {
+        "_comment": "HBM bytes per launch from rocprofv3 PMC passes: FETCH_SIZE x 2 (gfx950 correction, "
+                    "MI355X_MICROARCH.md section HBM) + WRITE_SIZE.  bench.py reports an entry only while "
+                    "source_sha equals the hash of the kernel's own source span (bench.span_sha).",
+        "reduce_fused_u8_mfma": {
+            "traffic_bytes": fetch_b + write_b,
+            "fetch_bytes_x2": fetch_b,
+            "write_bytes": write_b,
+            "algorithmic_bytes": 16384 * 16384 * 4 + 2048 * 2048 * 4,
+            "source": src,
+            "span": span,
+            "source_sha": span_sha(os.path.join(ROOT, src), span),
+            "profile": os.path.relpath(os.path.abspath(path), ROOT),
+        },
+    }
+    with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
+        json.dump(table, f, indent=1)
+        f.write("\n")
+    print(json.dumps(table["reduce_fused_u8_mfma"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
