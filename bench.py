@@ -265,6 +265,26 @@ def ref_or_none():
     return helpers if helpers.have_ref() else None
 
 
+def cpu_baselines(helpers, chain, host, pixels, interp=0, repeats=5, single_rows=None, what=""):
+    """The compiled reference on this box's host cores: best of `repeats` with every core
+    (VIPS_CONCURRENCY = cores) and with ONE thread; the one-thread run may take a
+    bounded sample of the rows (`single_rows`) so that the bench stays within minutes."""
+    cores = os.cpu_count() or 1
+    secs = helpers.Ref.time_chain(chain, host, repeats=repeats, interpretation=interp, concurrency=cores)
+    used = helpers.Ref.concurrency()
+    sample1 = host if single_rows is None or single_rows >= host.shape[0] else np.ascontiguousarray(host[:single_rows])
+    frac = float(sample1.shape[0]) / host.shape[0]
+    secs1 = helpers.Ref.time_chain(chain, sample1, repeats=repeats, interpretation=interp, concurrency=1)
+    helpers.Ref.lib().ref_init(cores)
+    return {
+        "value": round(pixels / secs / 1e6, 1), "unit": "Mpixels/s", "cores": used, "kind": "reference",
+        "sample": "%s, best of %d; libvips 8.19.0 scalar C path (no Highway/ORC)" % (what, repeats),
+        "single_core": {"value": round(pixels * frac / secs1 / 1e6, 1), "unit": "Mpixels/s", "cores": 1,
+                        "sample": "%s, best of %d, VIPS_CONCURRENCY=1" %
+                                  (what if frac == 1.0 else "the top %d rows of it" % sample1.shape[0], repeats)},
+    }
+
+
 def same_float(a, b):
     """Bit-exact, else the largest difference in units in the last place."""
     if a.shape != b.shape:
@@ -382,19 +402,12 @@ def run_c2(ctx, args):
         cores = os.cpu_count() or 1
         chain = "reduce:hshrink=8,vshrink=8,kernel=lanczos3"
         if helpers is not None:
-            secs = th.Ref.time_chain(chain, host, repeats=3, concurrency=cores)
             want = th.Ref.run_chain(chain, host)
             parity = {"against": "oracle/_ref (compiled reference), whole output",
                       "bit_exact": bool(got.shape == want.shape and np.array_equal(got, want)),
                       "checksum": th.checksum(got)}
-            cpu_baseline = {
-                "value": round(in_pixels / secs / 1e6, 1),
-                "unit": "Mpixels/s",
-                "cores": th.Ref.concurrency(),
-                "kind": "reference",
-                "sample": "full %dx%dx4 u8 image, vips_reduce(8,8,lanczos3) -> write_to_memory, "
-                          "best of 3; libvips 8.19.0 scalar C path (no Highway/ORC)" % (n, n),
-            }
+            cpu_baseline = cpu_baselines(th, chain, host, in_pixels, single_rows=n // 4,
+                                         what="full %dx%dx4 u8 image, vips_reduce(8,8,lanczos3) -> write_to_memory" % (n, n))
         else:
             rows = 2048
             t1 = time.perf_counter()
@@ -474,8 +487,11 @@ def run_c1(ctx, steps, warmup, verify=True, cpu=True, size=4096):
         "steps": steps,
         "mpixels_per_s": round(float(n) * n / (ms * 1e-3) / 1e6, 1),
         "algorithmic_bytes": alg,
-        "bound": "hbm",
+        # one 50 MB image read again every step sits in the 256 MiB Infinity Cache and its kernel
+        # is 133 short blocks: the step is bound by launch and memory LATENCY, not by HBM rate
+        "bound": "latency",
         "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "frac_of": "8 TB/s HBM, for scale only (input is Infinity-Cache resident)",
         "dtype": "u8",
         "kernels": kernels_of(report),
     }
@@ -492,12 +508,8 @@ def run_c1(ctx, steps, warmup, verify=True, cpu=True, size=4096):
             if not exact:
                 raise SystemExit("bench.py: C1 thumbnail differs from the reference")
         if cpu:
-            secs = helpers.Ref.time_chain(chain, host, repeats=3, interpretation=interp,
-                                          concurrency=os.cpu_count() or 1)
-            entry["cpu_baseline"] = {
-                "value": round(float(n) * n / secs / 1e6, 1), "unit": "Mpixels/s",
-                "cores": helpers.Ref.concurrency(), "kind": "reference",
-                "sample": "the same %dx%dx3 image through vips_thumbnail_image, best of 3" % (n, n)}
+            entry["cpu_baseline"] = cpu_baselines(helpers, chain, host, float(n) * n, interp,
+                                                  what="the same %dx%dx3 image through vips_thumbnail_image" % (n, n))
     del im, src, out
     ctx.trim()
     return entry
@@ -529,6 +541,8 @@ def run_c3(ctx, steps, warmup, verify=True, cpu=True, size=32768):
     ms = elapsed / steps * 1e3
     report = ctx.gates(step, 2)
     alg = 2 * n * n * 12
+    # the reference sums both passes in double (convi.c:721-741): 2 x 29 taps per band element
+    flops = 2.0 * 58 * n * n * 3
     entry = {
         "name": "c3",
         "workload": "vips_gaussblur(sigma=8) + vips_colourspace(sRGB->Lab) %dx%dx3 f32, BASELINE configs[2]" % (n, n),
@@ -536,8 +550,14 @@ def run_c3(ctx, steps, warmup, verify=True, cpu=True, size=32768):
         "steps": steps,
         "mpixels_per_s": round(float(n) * n / (ms * 1e-3) / 1e6, 1),
         "algorithmic_bytes": alg,
-        "bound": "hbm",
-        "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        # bound by FP64 instruction issue, not by HBM: both fractions
+        "bound": "fp64",
+        "tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+        "frac": round(flops / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
+        "frac_fp64": round(flops / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
+        "frac_hbm": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "float_mode": "exact (bit for bit)" if ctx.lib.vips_hip_get_exact_float() else
+                      "default (fused multiply-adds, coefficients / scale: <= 1 ULP)",
         "dtype": "f32 (f64 sums)",
         "kernels": kernels_of(report),
     }
@@ -640,7 +660,8 @@ def run_c4(ctx, steps, warmup, images, verify=True, cpu=True, size=8192):
         if verify:
             checked = []
             exact = True
-            for k in sorted(set((0, len(ims) - 1))):
+            # first, a pair either side of a 64-image launch boundary, middle, last
+            for k in sorted(set(k for k in (0, 63, 64, len(ims) // 2, len(ims) - 1) if 0 <= k < len(ims))):
                 host = store[k].cpu().numpy()
                 want = helpers.Ref.run_chain(chain, host, interp)
                 got = outs[k].numpy()
@@ -652,13 +673,8 @@ def run_c4(ctx, steps, warmup, images, verify=True, cpu=True, size=8192):
                 raise SystemExit("bench.py: C4 thumbnails differ from the reference")
         if cpu and ctx.rank == 0:
             host = store[0].cpu().numpy()
-            secs = helpers.Ref.time_chain(chain, host, repeats=2, interpretation=interp,
-                                          concurrency=os.cpu_count() or 1)
-            entry["cpu_baseline"] = {
-                "value": round(float(n) * n / secs / 1e6, 1), "unit": "Mpixels/s",
-                "images_per_s": round(1.0 / secs, 2),
-                "cores": helpers.Ref.concurrency(), "kind": "reference",
-                "sample": "one %dx%dx3 image through the same pipeline, best of 2" % (n, n)}
+            entry["cpu_baseline"] = cpu_baselines(helpers, chain, host, float(n) * n, interp, single_rows=n // 4,
+                                                  what="one %dx%dx3 image through the same pipeline" % (n, n))
     del ims, outs, store
     ctx.trim()
     return entry
@@ -773,17 +789,19 @@ def run_c5(ctx, steps, warmup, verify=True, width=65536, im_height=65536):
     mask, scale = c5_mask(vh)
     plan = sharding.StripPlan(im_height, im_height, ctx.world, sharding.conv_need(31, im_height))
     s0, s1 = plan.in_bounds[ctx.rank]  # conv: output rows = input rows
+    # the rank's strip lives in its persistent window (sharding.StripWindow): the exchange
+    # receives the 15-row halos straight into the window's margins, nothing else moves
+    sw = sharding.StripWindow(plan, ctx.rank, (width, 1), torch.uint16, ctx.device)
     with torch.cuda.stream(ctx.stream):
-        strip = c5_rows_device(torch, width, s0, s1 - s0, ctx.device)
+        sw.own.copy_(c5_rows_device(torch, width, s0, s1 - s0, ctx.device))
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
+    strip = sw.own
 
     def step():
         if ctx.dist is not None:
-            window, w0 = sharding.exchange_halos(strip, plan, ctx.rank, ctx.dist)
-        else:
-            window, w0 = strip, s0
-        return sharding.conv_strip(window, w0, plan, ctx.rank, mask, scale=scale, precision="float")
+            sw.exchange(ctx.dist)
+        return sharding.conv_strip(sw.window, sw.top, plan, ctx.rank, mask, scale=scale, precision="float")
 
     elapsed, out = ctx.timed(step, steps, warmup)
     ms = elapsed / steps * 1e3
@@ -840,6 +858,26 @@ def run_c5(ctx, steps, warmup, verify=True, width=65536, im_height=65536):
     return line
 
 
+def c5_entry(line):
+    """The whole-image C5 line (world 1: the 65536 x 65536 image as ONE strip on this GPU) as a
+    configs[] entry next to the slab."""
+    roof = line["roofline"]
+    return {
+        "name": "c5",
+        "workload": line["config"]["workload"] + " -- the WHOLE image on one GPU (25.8 GB in + out)",
+        "ms": line["ms_per_step"],
+        "steps": line["steps"],
+        "mpixels_per_s": line["value"],
+        "algorithmic_bytes": roof["algorithmic_bytes"],
+        "bound": "fp64",
+        "tflops": roof["achieved"],
+        "frac": roof["frac"],
+        "frac_hbm": round(roof["algorithmic_bytes"] / (line["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "dtype": "f64 sums -> f32",
+        "parity": line["parity"],
+    }
+
+
 def entry_as_line(entry, ctx, steps, warmup, metric, scaling="weak"):
     """A configs[] entry promoted to the bench line (--config c3 / c4 / c5slab)."""
     bound = entry.get("bound", "hbm")
@@ -881,8 +919,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5slab", "c5"])
     ap.add_argument("--size", type=int, default=None, help="image edge (default: the BASELINE size of the config)")
-    ap.add_argument("--images", type=int, default=None, help="c4: images per GPU (default 256 at N=1, 128 at N>1: "
-                                                             "1024 images on 8 GPUs)")
+    ap.add_argument("--images", type=int, default=None, help="c4: images per GPU (default 1024 at N=1 -- the whole "
+                                                             "BASELINE batch, 206 GB, on one GPU -- and 1024 / N at N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-settle", action="store_true",
                     help="c2: time the first W + K launches of the process only (no clock-settling phase)")
@@ -902,15 +940,16 @@ def main():
             line["configs"] = [
                 run_c1(ctx, 20, 3, verify, cpu),
                 run_c3(ctx, k, 2, verify, cpu),
-                run_c4(ctx, max(1, min(args.steps, 3)), 2, args.images or 256, verify, cpu),
+                run_c4(ctx, max(1, min(args.steps, 3)), 1, args.images or 1024, verify, cpu),
                 run_c5slab(ctx, max(2, min(args.steps, 4)), 2, verify, cpu),
+                c5_entry(run_c5(ctx, 2, 1, verify)),
             ]
     elif args.config == "c3":
         e = run_c3(ctx, args.steps, args.warmup, verify, cpu, args.size or 32768)
         line = entry_as_line(e, ctx, args.steps, args.warmup,
                              "Mpixels/s, vips_gaussblur(sigma 8) + sRGB->Lab on 32768x32768x3 float")
     elif args.config == "c4":
-        images = args.images or (256 if ctx.world == 1 else 128)
+        images = args.images or max(1, 1024 // ctx.world)
         e = run_c4(ctx, args.steps, args.warmup, images, verify, cpu, args.size or 8192)
         line = entry_as_line(e, ctx, args.steps, args.warmup,
                              "Mpixels/s (input), batched thumbnail pipeline resize(1/8)+sharpen over 8192x8192x3 uchar images")

@@ -91,11 +91,12 @@ static __device__ __forceinline__ float cbrt_lerp(const float *__restrict__ tabl
 	return __fadd_rn(pair.x, __fmul_rn(f, __fsub_rn(pair.y, pair.x)));
 }
 
+template <bool FINITE = false>
 static __device__ __forceinline__ Px step_XYZ2Lab(Px p, const float *__restrict__ table)
 {
-	const float cbx = cbrt_lerp<0>(table, p.a);
-	const float cby = cbrt_lerp<1>(table, p.b);
-	const float cbz = cbrt_lerp<2>(table, p.c);
+	const float cbx = cbrt_lerp<0, FINITE>(table, p.a);
+	const float cby = cbrt_lerp<1, FINITE>(table, p.b);
+	const float cbz = cbrt_lerp<2, FINITE>(table, p.c);
 	Px q;
 	q.a = __fsub_rn(__fmul_rn(116.0F, cby), 16.0F);
 	q.b = __fmul_rn(500.0F, __fsub_rn(cbx, cby));

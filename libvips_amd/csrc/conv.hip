@@ -518,7 +518,9 @@ convf_rows_lds(ConvArgs a)
 	const int gy = a.out_top + y0 - a.half_h;   // image row of step q = 0
 	const int groups = (a.mask_width + 7) / 8;
 	const int win = CONVF_LDS_SPAN + 8 * groups + 8; // staged elements a row needs (incl. group over-read)
-	const int steps = a.mask_height + R - 1;
+	// input rows the block's output rows need: a last block of fewer than R rows stops early, so
+	// that in region mode nothing below the window's last needed row is read
+	const int steps = a.mask_height + min(R, a.out_height - y0) - 1;
 
 	double acc[R][T];
 #pragma unroll

@@ -40,6 +40,14 @@
 //           Markstein's correctly rounded 3-operation form.
 //   MODE 2  convf (convf.c:163-181): sum seeded with the offset, coefficient = mask / scale
 //           (double), separate multiply and add.
+//   MODE 3  the library's default float mode (vips_hip_set_exact_float(0)) for either precision:
+//           the sum is seeded with the offset, the coefficients are mask / scale in double and
+//           every tap is one fused multiply-add -- no division, no separate offset addition, no
+//           second rounding per tap.  The double sum differs from the reference's by a few
+//           units of 2^-53 relative to its terms, so the float it rounds to is the reference's
+//           except where the reference's sum lies that close to a rounding boundary, and then it
+//           is the neighbouring float: within 1 ULP for sums that do not cancel (every
+//           gaussian), the tolerance BASELINE.json's north_star grants float paths.
 // Each output sums its taps in mask order in both passes (rows arrive in tap order).
 #include "colour_device.h"
 #include "conv.h"
@@ -80,7 +88,7 @@ struct StreamArgs {
 template <int MODE>
 static __device__ __forceinline__ double ss_mac(double s, double c, double v)
 {
-	if constexpr (MODE == 1)
+	if constexpr (MODE == 1 || MODE == 3)
 		return __fma_rn(c, v, s);
 	else
 		return __dadd_rn(s, __dmul_rn(c, v));
@@ -151,7 +159,7 @@ static __device__ __forceinline__ void ss_hpass(const StreamArgs &a, const doubl
 			win[8 + m] = (double) r2[m];
 		}
 	}
-	const double seed = MODE == 2 ? a.offset1 : 0.0;
+	const double seed = MODE >= 2 ? a.offset1 : 0.0;
 #pragma unroll
 	for (int k = 0; k < SS_T; k++)
 		hacc[k] = seed;
@@ -216,7 +224,7 @@ static __device__ __forceinline__ void ss_vpass(const StreamArgs &a, const doubl
 #pragma unroll
 	for (int d = 0; d < 4 * NG; d++)
 		kr[d] = kc[d];
-	const double seed = MODE == 2 ? a.offset2 : 0.0;
+	const double seed = MODE >= 2 ? a.offset2 : 0.0;
 #pragma unroll
 	for (int r = 0; r < SS_T; r++) {
 		const int ROT = (Q4 * SS_T + r) & (SS_SLOTS - 1); // constant after unrolling
@@ -435,7 +443,9 @@ convsep_stream(StreamArgs a, RouteArgs route)
 							v.a = s_v2y[load_as_uchar_like<float>(src[0], 255)];
 							v.b = s_v2y[load_as_uchar_like<float>(src[1], 255)];
 							v.c = s_v2y[load_as_uchar_like<float>(src[2], 255)];
-							v = step_XYZ2Lab(step_scRGB2XYZ(v), route.tables.cbrt);
+							// (table values: small finite numbers, so the quotients of XYZ2Lab need no
+							// inf / NaN care)
+							v = step_XYZ2Lab<true>(step_scRGB2XYZ(v), route.tables.cbrt);
 							o0 = v.a;
 							o1 = v.b;
 							o2 = v.c;
@@ -501,18 +511,24 @@ static int ss_launch_ng(int ng, const StreamArgs &a, const RouteArgs &route, siz
 }
 
 template <int NT>
-static int ss_launch_mode(bool integer, int epi, int ng, const StreamArgs &a, const RouteArgs &route, size_t lds, int grid)
+static int ss_launch_mode(bool integer, bool fast, int epi, int ng, const StreamArgs &a, const RouteArgs &route, size_t lds,
+	int grid)
 {
+	const char *plain = integer ? "convsep_stream_convi" : "convsep_stream_convf";
+	const char *colour = integer ? "convsep_stream_convi_colour" : "convsep_stream_convf_colour";
+	if (fast) {
+		if (epi == 2)
+			return ss_launch_ng<3, 2, NT>(ng, a, route, lds, grid, colour);
+		return epi ? ss_launch_ng<3, 1, NT>(ng, a, route, lds, grid, colour) : ss_launch_ng<3, 0, NT>(ng, a, route, lds, grid, plain);
+	}
 	if (integer) {
 		if (epi == 2)
-			return ss_launch_ng<1, 2, NT>(ng, a, route, lds, grid, "convsep_stream_convi_colour");
-		return epi ? ss_launch_ng<1, 1, NT>(ng, a, route, lds, grid, "convsep_stream_convi_colour")
-				   : ss_launch_ng<1, 0, NT>(ng, a, route, lds, grid, "convsep_stream_convi");
+			return ss_launch_ng<1, 2, NT>(ng, a, route, lds, grid, colour);
+		return epi ? ss_launch_ng<1, 1, NT>(ng, a, route, lds, grid, colour) : ss_launch_ng<1, 0, NT>(ng, a, route, lds, grid, plain);
 	}
 	if (epi == 2)
-		return ss_launch_ng<2, 2, NT>(ng, a, route, lds, grid, "convsep_stream_convf_colour");
-	return epi ? ss_launch_ng<2, 1, NT>(ng, a, route, lds, grid, "convsep_stream_convf_colour")
-			   : ss_launch_ng<2, 0, NT>(ng, a, route, lds, grid, "convsep_stream_convf");
+		return ss_launch_ng<2, 2, NT>(ng, a, route, lds, grid, colour);
+	return epi ? ss_launch_ng<2, 1, NT>(ng, a, route, lds, grid, colour) : ss_launch_ng<2, 0, NT>(ng, a, route, lds, grid, plain);
 }
 
 // Both passes of a separable convolution on a float image (and, with route_steps, the colour
@@ -554,19 +570,28 @@ int convsep_stream_fused(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 	a.rem = n - 4 * (ng - 1);
 	for (int k = 0; k < SS_SLOTS; k++)
 		a.coef[k] = 0.0;
+	if (integer && c->scale_i == 0)
+		return 1;
+	// MODE 3 (see the head of the file) unless the caller asked for the reference's bits; masks
+	// whose taps differ in sign can cancel, and a cancelling sum has no 1 ULP bound: exact arithmetic
+	bool fast = !vips_hip_get_exact_float();
+	for (int k = 0; k < n && fast; k++) {
+		const double ck = integer ? (double) c->coeffi[k] : c->coefff[k];
+		const double c0 = integer ? (double) c->coeffi[0] : c->coefff[0];
+		if ((ck < 0.0) != (c0 < 0.0))
+			fast = false;
+	}
 	for (int k = 0; k < n; k++) {
 		if (integer) {
 			// the product must be exact for the fused multiply-add to round like mul + add
 			if (c->coeffi[k] >= (1 << 29) || c->coeffi[k] <= -(1 << 29))
 				return 1;
-			a.coef[k] = (double) c->coeffi[k];
+			a.coef[k] = fast ? (double) c->coeffi[k] / (double) c->scale_i : (double) c->coeffi[k];
 		}
 		else
 			a.coef[k] = c->coefff[k];
 	}
 	a.scale = integer ? (double) c->scale_i : 1.0;
-	if (integer && c->scale_i == 0)
-		return 1;
 	a.rscale = 1.0 / a.scale;
 	a.has_scale = a.scale != 1.0;
 	a.offset1 = integer ? (double) c->offset_i : c->offset;
@@ -635,7 +660,7 @@ int convsep_stream_fused(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 			  route_steps[2] == VIPS_HIP_COLOUR_XYZ2Lab)
 		? 2
 		: 1;
-	const int r = ss_launch_mode<768>(integer, epi_kind, ng, a, route, lds, grid);
+	const int r = ss_launch_mode<768>(integer, fast, epi_kind, ng, a, route, lds, grid);
 	vips_hip_free(counter);
 	return r;
 }

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstring>
 #include <list>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -768,6 +769,44 @@ int vips_hip_gaussblur_colourspace(VipsHipImage *in, VipsHipImage **out, double 
 
 static int sharpen_fused_images(VipsHipImage *const *in, int n_images, VipsHipImage **out, double sigma, double x1,
 	double y2, double y3, double m1, double m2);
+
+// The two CU partitions of the batched pipeline (see vips_hip_resize_sharpen_batch): streams
+// restricted to 3/4 and 1/4 of the CUs.  Bit i of a CU mask is CU i / xcds of XCD i % xcds on this
+// part, so a run of consecutive bits takes the same share of every XCD.  Made once per device and
+// kept (a masked stream is a hardware queue with a fixed mask).
+struct BatchStreams {
+	hipStream_t resize = nullptr, sharpen = nullptr;
+};
+static BatchStreams *batch_streams()
+{
+	static std::mutex mutex;
+	static std::map<int, BatchStreams> by_device;
+	int device = 0;
+	if (hipGetDevice(&device) != hipSuccess)
+		return nullptr;
+	std::lock_guard<std::mutex> lock(mutex);
+	auto it = by_device.find(device);
+	if (it != by_device.end())
+		return it->second.resize ? &it->second : nullptr;
+	BatchStreams &bs = by_device[device];
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+		return nullptr;
+	const int cus = prop.multiProcessorCount;
+	const int share = getenv("VIPS_HIP_BATCH_SHARPEN_CUS") ? atoi(getenv("VIPS_HIP_BATCH_SHARPEN_CUS")) : cus / 4;
+	if (cus < 16 || cus > 1024 || share < 8 || share > cus - 8)
+		return nullptr;
+	std::vector<uint32_t> lo((cus + 31) / 32, 0u), hi((cus + 31) / 32, 0u);
+	for (int i = 0; i < cus; i++)
+		(i < cus - share ? lo : hi)[i / 32] |= 1u << (i % 32);
+	if (hipExtStreamCreateWithCUMask(&bs.resize, (uint32_t) lo.size(), lo.data()) != hipSuccess ||
+		hipExtStreamCreateWithCUMask(&bs.sharpen, (uint32_t) hi.size(), hi.data()) != hipSuccess) {
+		bs.resize = bs.sharpen = nullptr; // (the plain one-stream order then)
+		(void) hipGetLastError();
+		return nullptr;
+	}
+	return &bs;
+}
 // BASELINE config 4, the batched thumbnail pipeline: vips_resize(scale) [then vips_sharpen()] on
 // n independent images.  libvips runs such a batch as n pipelines over its thread pool
 // (iofuncs/threadpool.c:625); here n_threads host threads each take the next image, every thread
@@ -789,32 +828,60 @@ int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage *
 		n_threads = 1;
 	if (n_threads > n)
 		n_threads = n;
+	for (int i = 0; i < n; i++)
+		out[i] = nullptr;
 	// A batch of uchar images of one size whose resize is the streaming kernel's case: one launch
 	// per 64 images for the whole resize chain (resize_stream.hip) and one for the sharpen.
-	// $VIPS_HIP_BATCH_OVERLAP=1 runs the sharpen of a chunk on a second stream behind an event,
-	// next to the resize of the following chunk (one is bound by HBM, the other by the FP64
-	// pipe) -- measured SLOWER on the MI355X, 0.048 against 0.046 ms per image: side by side
-	// the two kernels take 0.044 + 0.016 ms instead of 0.036 + 0.009.  Off by default.
+	//
+	// The resize chain is bound by HBM, the sharpen by the FP64 pipe.  Queued one behind the other
+	// on one stream they cost the sum of their times (0.040 + 0.010 ms per 8192 x 8192 image);
+	// left to share every CU (two plain streams) each gets in the other's way and the sum stays
+	// (round 2: 0.044 + 0.016 side by side).  So the CUs are PARTITIONED: the resize of chunk k + 1
+	// runs on a stream masked to 3/4 of the CUs of every XCD (hipExtStreamCreateWithCUMask) next to
+	// the sharpen of chunk k on the other quarter -- measured on the MI355X (tools/c4_cumask.py):
+	// resize 0.0405 ms per image on 256 CUs, 0.0440 on 192; sharpen x 4 on 64 CUs = about the same
+	// time, so a pair of chunks takes what the resize alone takes on 192 CUs.  The last chunk's
+	// sharpen has nothing to hide behind and runs on every CU.  $VIPS_HIP_BATCH_OVERLAP=0: one
+	// stream, one stage after the other.
 	if (n > 0 && !getenv("VIPS_HIP_NO_BATCH_LAUNCH")) {
 		const int chunk = 64;
-		std::vector<ImageRef> small(n); // held to the end: two streams read and write them
+		std::vector<ImageRef> small(n); // held to the end: several streams read and write them
 		std::vector<VipsHipImage *> ps(n, nullptr);
 		const int first = n < chunk ? n : chunk;
-		const int r = vh::resize_batch_u8(in, first, ps.data(), scale, kernel, gap);
-		if (r < 0)
+		const char *ov = getenv("VIPS_HIP_BATCH_OVERLAP");
+		BatchStreams *bs = sigma >= 0.0 && n > chunk && !(ov && atoi(ov) == 0) ? batch_streams() : nullptr;
+		hipStream_t main_stream = stream();
+		std::vector<hipEvent_t> events;
+		auto event_on = [&](hipStream_t s) -> hipEvent_t {
+			hipEvent_t ev = nullptr;
+			if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+				return nullptr;
+			events.push_back(ev);
+			return hipEventRecord(ev, s) == hipSuccess ? ev : nullptr;
+		};
+		int bad = 0;
+		if (bs) {
+			// both partitions start behind whatever the caller queued on its stream
+			hipEvent_t ev = event_on(main_stream);
+			if (!ev || hipStreamWaitEvent(bs->resize, ev, 0) != hipSuccess || hipStreamWaitEvent(bs->sharpen, ev, 0) != hipSuccess)
+				bad = 1;
+		}
+		int r = 0;
+		if (!bad) {
+			ScopedStream on(bs ? bs->resize : nullptr); // (a null stream leaves the thread's own)
+			r = vh::resize_batch_u8(in, first, ps.data(), scale, kernel, gap);
+		}
+		if (r < 0 || bad) {
+			for (hipEvent_t ev : events)
+				(void) hipEventDestroy(ev);
 			return -1;
+		}
 		if (r == 0) {
-			hipStream_t side = nullptr;
-			std::vector<hipEvent_t> events;
-			const bool overlap = sigma >= 0.0 && n > chunk && getenv("VIPS_HIP_BATCH_OVERLAP");
-			if (overlap && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess)
-				side = nullptr;
-			int bad = 0;
-			for (int i = 0; i < n; i++)
-				out[i] = nullptr;
 			for (int base = 0; base < n && !bad; base += chunk) {
 				const int cnt = n - base < chunk ? n - base : chunk;
+				const bool last = base + cnt >= n;
 				if (base > 0) {
+					ScopedStream on(bs ? bs->resize : nullptr);
 					const int rr = vh::resize_batch_u8(in + base, cnt, ps.data() + base, scale, kernel, gap);
 					if (rr < 0)
 						bad = 1;
@@ -832,17 +899,19 @@ int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage *
 						out[i] = small[i].release();
 					continue;
 				}
-				hipEvent_t ev = nullptr;
-				if (side && (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess ||
-								hipEventRecord(ev, stream()) != hipSuccess ||
-								hipStreamWaitEvent(side, ev, 0) != hipSuccess))
-					bad = 1;
-				if (ev)
-					events.push_back(ev);
+				// the sharpen of this chunk: behind its resize, on the sharpen partition -- the
+				// last chunk's on the caller's stream (every CU), which then also waits for the rest
+				hipStream_t sharpen_on = nullptr;
+				if (bs) {
+					sharpen_on = last ? main_stream : bs->sharpen;
+					hipEvent_t ev = event_on(bs->resize);
+					if (!ev || hipStreamWaitEvent(sharpen_on, ev, 0) != hipSuccess)
+						bad = 1;
+				}
 				if (bad)
 					break;
 				{
-					ScopedStream on(side); // (a null stream leaves the thread's own)
+					ScopedStream on(sharpen_on);
 					int done = sharpen_fused_images(ps.data() + base, cnt, out + base, sigma, x1, y2, y3, m1, m2);
 					if (done > 0) {
 						done = 0;
@@ -853,13 +922,19 @@ int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage *
 						bad = 1;
 				}
 			}
+			if (bs) {
+				// the caller's stream ends behind both partitions, so that everything the batch
+				// queued is ordered on it
+				for (hipStream_t s : { bs->resize, bs->sharpen }) {
+					hipEvent_t ev = event_on(s);
+					if (!ev || hipStreamWaitEvent(main_stream, ev, 0) != hipSuccess)
+						bad = 1;
+				}
+			}
 			if (vips_hip_synchronize())
 				bad = 1;
-			if (side) {
-				if (hipStreamSynchronize(side) != hipSuccess)
-					bad = 1;
-				(void) hipStreamDestroy(side);
-			}
+			if (bs && (hipStreamSynchronize(bs->resize) != hipSuccess || hipStreamSynchronize(bs->sharpen) != hipSuccess))
+				bad = 1;
 			for (hipEvent_t ev : events)
 				(void) hipEventDestroy(ev);
 			if (bad) {
@@ -871,6 +946,8 @@ int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage *
 			}
 			return 0;
 		}
+		for (hipEvent_t ev : events)
+			(void) hipEventDestroy(ev);
 	}
 	std::atomic<int> next(0), failed(0);
 	std::mutex err_mutex;

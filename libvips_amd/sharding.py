@@ -95,36 +95,53 @@ class StripPlan(object):
         return out
 
 
+class StripWindow(object):
+    """A rank's PERSISTENT window: its own rows with room for the halo rows of its neighbours
+    above and below, allocated once.  The rank keeps its strip IN the window (``own`` is a view of
+    it: generate or load the strip there), and every exchange receives the neighbours' rows
+    straight into the halo margins and sends straight from ``own`` -- no window is built per
+    step and nothing is copied twice (the per-step window cost a copy of the
+    whole strip, 1 GiB for BASELINE config 5 at 8 ranks)."""
+
+    def __init__(self, plan, rank, row_shape, dtype, device):
+        import torch
+
+        self.plan, self.rank = plan, rank
+        self.i0, self.i1 = plan.in_bounds[rank]
+        self.top, self.bottom = plan.windows[rank]
+        self.window = torch.empty((self.bottom - self.top,) + tuple(row_shape), dtype=dtype, device=device)
+        self.own = self.window[self.i0 - self.top:self.i1 - self.top]
+        self._transfers = [t for t in plan.transfers() if rank in (t[0], t[1])]
+
+    def exchange(self, dist=None, group=None):
+        """One batch of point-to-point sends / receives (RCCL ncclSend / ncclRecv pairs on GPUs):
+        rows of ``own`` out of the window, halo rows into it.  Slices of whole rows are
+        contiguous, so the transports read and write the window itself."""
+        if dist is None:
+            import torch.distributed as dist
+        ops = []
+        for src, dst, lo, hi in self._transfers:
+            if src == self.rank:
+                ops.append(dist.P2POp(dist.isend, self.window[lo - self.top:hi - self.top], dst, group))
+            else:
+                ops.append(dist.P2POp(dist.irecv, self.window[lo - self.top:hi - self.top], src, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return self.window, self.top
+
+
 def exchange_halos(strip, plan, rank, dist=None, group=None):
-    """Return this rank's window (its strip plus the halo rows the plan says it needs).
+    """Return this rank's window (its strip plus the halo rows the plan says it needs) for a
+    strip held OUTSIDE a window: builds a StripWindow, copies the strip in and exchanges.  A
+    program that steps repeatedly keeps a StripWindow instead (bench.py --config c5).
 
-    ``strip``: tensor [rows, width, bands] holding rows plan.in_bounds[rank].  Uses one
-    batch of point-to-point sends/receives (RCCL ncclSend/ncclRecv pairs on GPUs).
-    """
-    import torch
-
-    if dist is None:
-        import torch.distributed as dist
+    ``strip``: tensor [rows, width, bands] holding rows plan.in_bounds[rank]."""
     i0, i1 = plan.in_bounds[rank]
-    w0, w1 = plan.windows[rank]
     assert strip.shape[0] == i1 - i0
-    window = torch.empty((w1 - w0,) + tuple(strip.shape[1:]), dtype=strip.dtype, device=strip.device)
-    window[i0 - w0:i1 - w0] = strip
-    ops = []
-    recv_slots = []
-    for src, dst, lo, hi in plan.transfers():
-        if src == rank:
-            ops.append(dist.P2POp(dist.isend, strip[lo - i0:hi - i0].contiguous(), dst, group))
-        elif dst == rank:
-            buf = torch.empty((hi - lo,) + tuple(strip.shape[1:]), dtype=strip.dtype, device=strip.device)
-            recv_slots.append((buf, lo, hi))
-            ops.append(dist.P2POp(dist.irecv, buf, src, group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    for buf, lo, hi in recv_slots:
-        window[lo - w0:hi - w0] = buf
-    return window, w0
+    sw = StripWindow(plan, rank, tuple(strip.shape[1:]), strip.dtype, strip.device)
+    sw.own.copy_(strip)
+    return sw.exchange(dist, group)
 
 
 def _order_after_torch(tensor):

@@ -13,13 +13,62 @@
 
 extern "C" {
 
+// $MOCK_HIP_DEVICES fake devices (default 1); the current device is per thread, as in HIP
+static int mock_devices()
+{
+	const char *e = getenv("MOCK_HIP_DEVICES");
+	const int n = e ? atoi(e) : 1;
+	return n < 1 ? 1 : n;
+}
+static thread_local int g_current_device = 0;
+static long g_set_device_calls[16];
+
 hipError_t hipGetDeviceCount(int *count)
 {
-	*count = 1;
+	*count = mock_devices();
 	return hipSuccess;
 }
 
-hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipSetDevice(int d)
+{
+	if (d < 0 || d >= mock_devices())
+		return hipErrorInvalidDevice;
+	g_current_device = d;
+	if (d < 16)
+		__sync_fetch_and_add(&g_set_device_calls[d], 1);
+	return hipSuccess;
+}
+
+hipError_t hipGetDevice(int *d)
+{
+	*d = g_current_device;
+	return hipSuccess;
+}
+
+// how often a thread bound itself to device d: lets the tests see work spread over devices
+long mock_hip_set_device_calls(int d) { return d >= 0 && d < 16 ? g_set_device_calls[d] : 0; }
+
+hipError_t hipDeviceCanAccessPeer(int *can, int, int)
+{
+	*can = 1;
+	return hipSuccess;
+}
+
+hipError_t hipDeviceEnablePeerAccess(int, unsigned int) { return hipSuccess; }
+
+static long g_peer_copies = 0, g_peer_bytes = 0;
+
+hipError_t hipMemcpyPeerAsync(void *dst, int, const void *src, int, size_t size, hipStream_t)
+{
+	if (size)
+		memmove(dst, src, size);
+	__sync_fetch_and_add(&g_peer_copies, 1);
+	__sync_fetch_and_add(&g_peer_bytes, (long) size);
+	return hipSuccess;
+}
+
+long mock_hip_peer_copies(void) { return g_peer_copies; }
+long mock_hip_peer_bytes(void) { return g_peer_bytes; }
 
 hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_tR0600 *prop, int)
 {
@@ -82,6 +131,13 @@ hipError_t hipMemsetAsync(void *dst, int value, size_t size, hipStream_t)
 static int g_streams = 0;
 
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned int)
+{
+	*s = (hipStream_t) malloc(8);
+	__sync_fetch_and_add(&g_streams, 1);
+	return hipSuccess;
+}
+
+hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, uint32_t, const uint32_t *)
 {
 	*s = (hipStream_t) malloc(8);
 	__sync_fetch_and_add(&g_streams, 1);

@@ -291,6 +291,35 @@ def test_c5_conv31_default_mode(bands):
 
 
 @pytest.mark.parametrize("precision", ["integer", "float"])
+@pytest.mark.parametrize("shape", [(700, 300), (2300, 140), (37, 411), (1030, 77)])
+@pytest.mark.parametrize("sigma,space", [(8.0, "lab"), (2.0, None), (3.1, "xyz"), (0.6, None)])
+def test_gaussblur_default_mode(shape, sigma, space, precision):
+    """The library's DEFAULT float mode on the streaming separable convolution (convsep_stream.hip
+    MODE 3: coefficients mask / scale, one fused multiply-add per tap, no division): within 1 ULP of
+    the exact mode -- which the tests above hold to the reference bit for bit -- with and without the
+    colour epilogue.  Tolerance: 1 ULP (BASELINE.json north_star, float paths)."""
+    w, h = shape
+    src = helpers.lcg_image(w, h, 3, np.float32, 69)
+    lib = _ffi.lib
+
+    def run():
+        im = Image.new_from_array(src, interpretation="srgb")
+        if space is None:
+            return im.gaussblur(sigma, precision=precision).numpy()
+        return im.gaussblur_colourspace(sigma, space, precision=precision).numpy()
+
+    assert lib.vips_hip_get_exact_float() == 1
+    exact = run()
+    lib.vips_hip_set_exact_float(0)
+    try:
+        fast = run()
+    finally:
+        lib.vips_hip_set_exact_float(1)
+    assert fast.dtype == np.float32 and fast.shape == exact.shape
+    assert ulp_distance(fast, exact) <= 1
+
+
+@pytest.mark.parametrize("precision", ["integer", "float"])
 @pytest.mark.parametrize("shape", [(700, 300, 3), (1500, 90, 1), (37, 411, 4), (2300, 140, 2), (5, 3, 3)])
 @pytest.mark.parametrize("sigma", [0.6, 2.0, 8.0])
 def test_fused_convsep_float(shape, sigma, precision):

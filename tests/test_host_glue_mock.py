@@ -219,8 +219,9 @@ assert mock.mock_hip_launches() > 0
 
 def test_uniform_batch_takes_the_batch_launches(tmp_path):
     """vips_hip_resize_sharpen_batch on a uniform batch of more than one launch's worth of images:
-    one resize launch and one sharpen launch per 64 images (with $VIPS_HIP_BATCH_OVERLAP the
-    sharpen on a second stream that is given back), thumbnails of the right geometry; a mixed batch goes image by image."""
+    one resize launch and one sharpen launch per 64 images (resize and sharpen on the two CU-masked
+    streams the library keeps per device, or with $VIPS_HIP_BATCH_OVERLAP=0 on the caller's),
+    thumbnails of the right geometry; a mixed batch goes image by image."""
     run_child(r'''
 import ctypes, os
 import numpy as np
@@ -232,8 +233,11 @@ mock.mock_hip_launches.restype = ctypes.c_long
 libvips_amd.init(0)
 ims = [Image.new_from_array(np.zeros((64, 688, 3), np.uint8), interpretation="srgb") for _ in range(70)]
 ims[0].resize(0.125)
+s0 = mock.mock_hip_live_streams()
+libvips_amd.resize_sharpen_batch(ims, 0.125, threads=4)
 before = mock.mock_hip_live_streams()
-for overlap in ("", "1"):
+assert before == s0 + 2, (s0, before)  # the two CU partitions, made once and kept
+for overlap in ("", "0"):
     os.environ["VIPS_HIP_BATCH_OVERLAP"] = overlap
     if not overlap:
         del os.environ["VIPS_HIP_BATCH_OVERLAP"]

@@ -114,18 +114,20 @@ def test_halo_exchange_gloo(world, tmp_path):
 
 
 @pytest.mark.gpu
-def test_conv_strips_on_gpu_match_whole_image():
+@pytest.mark.parametrize("height,width,world", [(600, 400, 4), (602, 640, 3), (1031, 2100, 5)])
+def test_conv_strips_on_gpu_match_whole_image(height, width, world):
     """Single GPU, world emulated sequentially: every rank's window -> vips_hip_conv_gen
-    reproduces the rows of the whole-image conv (what the 8-GPU C5 run does per device)."""
+    reproduces the rows of the whole-image conv (what the 8-GPU C5 run does per device).
+    Widths >= 512 take the LDS row-streaming kernel (C5's own); strips whose height is not a
+    multiple of its 4-row blocks sit in windows that end exactly at their last needed row
+    (the last block must not read below the window)."""
     import libvips_amd
     from libvips_amd import Image
 
     libvips_amd.init(0)
-    height, width = 600, 400
     full = helpers.lcg_image(width, height, 1, np.uint16, 92)
     mask, scale = libvips_amd.gaussmat(5, 0.01, False, "float")
     whole = Image.new_from_array(full).conv(mask, scale=scale, precision="float").numpy()
-    world = 4
     plan = sharding.StripPlan(height, height, world, sharding.conv_need(mask.shape[0], height))
     for rank in range(world):
         w0, w1 = plan.windows[rank]
@@ -180,7 +182,18 @@ def _bench_c5_worker(rank, world, port, size, out_dir):
         plan = sharding.StripPlan(size, size, world, sharding.conv_need(31, size))
         s0, s1 = plan.in_bounds[rank]
         strip = bench.c5_rows_device(torch, size, s0, s1 - s0, torch.device("cpu"))
-        window, w0 = sharding.exchange_halos(strip.view(torch.int16), plan, rank, dist)
+        # as bench.run_c5: the strip lives in the rank's persistent window, every step's exchange
+        # receives into the window's margins (two steps here: nothing is reallocated or rebuilt)
+        sw = sharding.StripWindow(plan, rank, (size, 1), torch.int16, torch.device("cpu"))
+        sw.own.copy_(strip.view(torch.int16))
+        where = sw.window.data_ptr()
+        for step in range(2):
+            if step:
+                for t in plan.transfers():  # scribble over the halos: the next exchange must refill them
+                    if t[1] == rank:
+                        sw.window[t[2] - sw.top:t[3] - sw.top] = -1
+            window, w0 = sw.exchange(dist)
+            assert window.data_ptr() == where and w0 == sw.top
         np.save(os.path.join(out_dir, "w%d.npy" % rank), window.numpy().view(np.uint16))
         np.save(os.path.join(out_dir, "t%d.npy" % rank), np.array([w0]))
         dist.barrier()

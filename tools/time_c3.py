@@ -38,6 +38,13 @@ def run(name, env, fn):
 
 scale = (32768.0 / n) ** 2
 print("image %d^2 (x%.0f for 32768^2)" % (n, scale))
+for exact in (1, 0):
+    lib.vips_hip_set_exact_float(exact)
+    tag = "exact" if exact else "default"
+    run("blur stream 768 [%s]" % tag, {}, lambda: im.gaussblur(8.0))
+    run("blur+lab stream 768 [%s]" % tag, {}, lambda: im.gaussblur_colourspace(8.0, "lab"))
+    run("blur float precision [%s]" % tag, {}, lambda: im.gaussblur(8.0, precision="float"))
+lib.vips_hip_set_exact_float(1)
 run("blur old kernel", {"VIPS_HIP_NO_STREAM_CONVSEP": "1"}, lambda: im.gaussblur(8.0))
 run("blur stream 768", {}, lambda: im.gaussblur(8.0))
 run("blur+lab stream 768", {}, lambda: im.gaussblur_colourspace(8.0, "lab"))
