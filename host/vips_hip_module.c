@@ -368,6 +368,7 @@ hip_eval_fused(VipsHipOp *op)
 	const char *nick = VIPS_OBJECT_GET_CLASS(op)->nickname;
 	gboolean done = FALSE;
 	VipsHipOp *up;
+	gboolean retried = FALSE;
 
 	if (!hclass->fuse || !op->upstream || op->upstream_device != vips_hip_op_device_fn())
 		return FALSE;
@@ -389,12 +390,17 @@ hip_eval_fused(VipsHipOp *op)
 					op->result = NULL;
 				}
 				hip_fail(nick);
+				retried = TRUE;
 			}
 			vips_hip_image_unref(fresh);
 		}
 	}
 	g_mutex_unlock(&up->lock);
-	vips_error_clear(); /* a failed attempt falls back to the two operations, which report for themselves */
+	/* a FAILED attempt falls back to the two operations, which report for themselves: only then
+	 * is the message it just logged dropped (libvips' error buffer is process-wide: clearing it
+	 * on every evaluation would wipe what other pipelines logged) */
+	if (retried)
+		vips_error_clear();
 
 	return done;
 }

@@ -93,17 +93,35 @@ typedef enum {
 
 /* ------------------------------------------------------------------ runtime */
 
-/* Select the device this PROCESS works on (one process per GPU) and create the
- * library's streams/pools on it.  Safe to call repeatedly and from every thread
- * with the same device; a different device than the first call's fails (-1).
- * Threads that never call it (libvips workers inside the module, the batch
- * thread pool) use the process's device, or $VIPS_HIP_DEVICE, or 0.  Fails (-1)
- * when no gfx950 device is visible: there is NO CPU fallback anywhere in this
- * library.
+/* Bind the CALLING THREAD to a device (hipSetDevice is per thread) and create the library's
+ * per-device state on it: the HBM pool, the plan caches and the thread's stream are per device,
+ * so one process can drive every GPU of a node from its threads -- the shape of libvips' own
+ * parallelism, a worker pool inside one process (iofuncs/threadpool.c:625) -- as well as the
+ * one-process-per-GPU shape of the multi-rank programs.  Safe to call repeatedly; calling it
+ * with another device re-binds the thread (its external stream, if any, is dropped).
+ *
+ * A thread that never calls it is bound on first use: to the next entry of $VIPS_HIP_DEVICES (a
+ * comma list, e.g. "0,1,2,3,4,5,6,7", dealt round-robin over such threads -- how the libvips
+ * module spreads a worker pool over the GPUs), else to $VIPS_HIP_DEVICE, else to the device of
+ * the process's first vips_hip_init(), else to device 0.
+ *
+ * Library-made images remember their device and every image-level operation runs on the device
+ * its input lives on (the calling thread is re-bound if need be); plan handles
+ * (vips_hip_reduce_new() ...) belong to the device of the thread that made them and fail loudly
+ * on another.  Fails (-1) when no gfx950 device is visible: there is NO CPU fallback anywhere in
+ * this library.
  */
 VIPS_HIP_API int vips_hip_init(int device);
+/* Finish and drop the calling thread's streams and cached blocks; the thread may bind again. */
 VIPS_HIP_API void vips_hip_shutdown(void);
 VIPS_HIP_API int vips_hip_device_count(void);
+/* The device the calling thread is bound to, -1 when it has not been bound yet. */
+VIPS_HIP_API int vips_hip_current_device(void);
+/* The devices work is spread over: $VIPS_HIP_DEVICES in order (entries may repeat), else the
+ * calling thread's device alone.  Fills devices[0 .. max) and returns how many there are,
+ * -1 on a malformed list.
+ */
+VIPS_HIP_API int vips_hip_devices(int *devices, int max);
 
 /* Thread-local error log, same shape as vips_error_buffer()/vips_error_clear()
  * (iofuncs/error.c): messages are "domain: text\n".
@@ -441,6 +459,8 @@ VIPS_HIP_API VipsHipImage *vips_hip_image_new_from_device(void *device_data,
 VIPS_HIP_API void vips_hip_image_unref(VipsHipImage *image);
 VIPS_HIP_API int vips_hip_image_write_to_memory(const VipsHipImage *image, void *host_data);
 VIPS_HIP_API void *vips_hip_image_get_data(const VipsHipImage *image);
+/* the device the pixels live on (-1 for a NULL image) */
+VIPS_HIP_API int vips_hip_image_get_device(const VipsHipImage *image);
 VIPS_HIP_API int vips_hip_image_get_width(const VipsHipImage *image);
 VIPS_HIP_API int vips_hip_image_get_height(const VipsHipImage *image);
 VIPS_HIP_API int vips_hip_image_get_bands(const VipsHipImage *image);
@@ -566,6 +586,33 @@ VIPS_HIP_API int vips_hip_gaussblur(VipsHipImage *in, VipsHipImage **out,
 	double sigma, double min_ampl, int precision);
 VIPS_HIP_API int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out,
 	double sigma, double x1, double y2, double y3, double m1, double m2);
+/* ------------------------------------------------- row strips over the devices of one process
+ *
+ * BASELINE config 5 (vips_conv 31 x 31 on 65536 x 65536 ushort tiled across 8 GPUs) the way
+ * libvips itself is parallel: threads of ONE process (iofuncs/threadpool.c:301-373, 625), here a
+ * thread per device.  An image is held as n row strips, strip k in a persistent window on
+ * devices[k] with room for `halo` rows of its neighbours above and below;
+ * vips_hip_strips_exchange() moves every halo row device to device (hipMemcpyPeerAsync, xGMI)
+ * straight into the window that needs it; vips_hip_conv_strips() = that exchange + the region
+ * operation vips_hip_conv_gen() on every window at once.  Pixels are the single-device result's
+ * bit for bit.  (The one-process-per-GPU form of the same partition, halos over RCCL, is
+ * libvips_amd/sharding.py.)
+ */
+typedef struct _VipsHipStrips VipsHipStrips;
+VIPS_HIP_API VipsHipStrips *vips_hip_strips_new(int im_width, int im_height, int bands, int format,
+	int n, const int *devices, int halo);
+VIPS_HIP_API void vips_hip_strips_free(VipsHipStrips *strips);
+VIPS_HIP_API int vips_hip_strips_count(const VipsHipStrips *strips);
+/* strip k: its device, the region of its own rows and the region of its whole window (own rows +
+ * halos), both in image coordinates, pointing into the window (fill `own`, read `window`) */
+VIPS_HIP_API int vips_hip_strips_region(const VipsHipStrips *strips, int k, int *device,
+	VipsHipRegion *own, VipsHipRegion *window);
+/* the own rows must be complete (synchronised) on entry; the halos are complete on return */
+VIPS_HIP_API int vips_hip_strips_exchange(VipsHipStrips *strips);
+/* out[0 .. n): strip k of vips_conv(image), an image on devices[k] */
+VIPS_HIP_API int vips_hip_conv_strips(VipsHipStrips *strips, VipsHipImage **out, const double *mask,
+	int mask_width, int mask_height, double scale, double offset, int precision);
+
 /* BASELINE config 4: vips_resize(scale, kernel, gap) [then vips_sharpen(sigma, x1, y2, y3, m1,
  * m2)] on n independent images, as libvips would run n pipelines over its thread pool
  * (iofuncs/threadpool.c:625).  A batch of same-sized uchar images whose resize is by 1 / (2 k)

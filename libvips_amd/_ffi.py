@@ -102,6 +102,8 @@ _SIGNATURES = {
     "vips_hip_init": (c_int, [c_int]),
     "vips_hip_shutdown": (None, []),
     "vips_hip_device_count": (c_int, []),
+    "vips_hip_current_device": (c_int, []),
+    "vips_hip_devices": (c_int, [P(c_int), c_int]),
     "vips_hip_error_buffer": (c_char_p, []),
     "vips_hip_error_clear": (None, []),
     "vips_hip_set_stream": (c_int, [c_void_p]),
@@ -182,6 +184,7 @@ _SIGNATURES = {
     "vips_hip_image_unref": (None, [c_void_p]),
     "vips_hip_image_write_to_memory": (c_int, [c_void_p, c_void_p]),
     "vips_hip_image_get_data": (c_void_p, [c_void_p]),
+    "vips_hip_image_get_device": (c_int, [c_void_p]),
     "vips_hip_image_get_width": (c_int, [c_void_p]),
     "vips_hip_image_get_height": (c_int, [c_void_p]),
     "vips_hip_image_get_bands": (c_int, [c_void_p]),
@@ -218,6 +221,12 @@ _SIGNATURES = {
     "vips_hip_gaussblur": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_int]),
     "vips_hip_sharpen": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_double, c_double, c_double, c_double]),
     "vips_hip_colourspace": (c_int, [c_void_p, P(c_void_p), c_int]),
+    "vips_hip_strips_new": (c_void_p, [c_int, c_int, c_int, c_int, c_int, P(c_int), c_int]),
+    "vips_hip_strips_free": (None, [c_void_p]),
+    "vips_hip_strips_count": (c_int, [c_void_p]),
+    "vips_hip_strips_region": (c_int, [c_void_p, c_int, P(c_int), P(Region), P(Region)]),
+    "vips_hip_strips_exchange": (c_int, [c_void_p]),
+    "vips_hip_conv_strips": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_int, c_double, c_double, c_int]),
     "vips_hip_resize_sharpen_batch": (c_int, [P(c_void_p), c_int, P(c_void_p), c_double, c_int, c_double,
                                              c_double, c_double, c_double, c_double, c_double, c_double, c_int]),
     "vips_hip_gaussblur_colourspace": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_int, c_int]),

@@ -419,6 +419,7 @@ struct _VipsHipConva {
 	long long w_abs_sum; // sum |W|
 	bool w_negative;     // some line / column has a negative factor
 	std::mutex mutex;
+	mutable std::atomic<int> device{ -1 }; // where the device tables live (vh::plan_device)
 };
 
 namespace vh {
@@ -1019,6 +1020,8 @@ int vips_hip_conva_gen(const VipsHipConva *plan, const VipsHipRegion *in, const 
 		error("conva", "not a conva plan");
 		return -1;
 	}
+	if (plan_device("conva", &plan->device))
+		return -1;
 	_VipsHipConva *c = const_cast<_VipsHipConva *>(plan);
 	if (check_pair("conva", in, out, c->mask_width, c->mask_height))
 		return -1;
@@ -1072,6 +1075,8 @@ int vips_hip_convasep_gen(const VipsHipConva *plan, const VipsHipRegion *in, con
 		error("convasep", "not a convasep plan");
 		return -1;
 	}
+	if (plan_device("convasep", &plan->device))
+		return -1;
 	_VipsHipConva *c = const_cast<_VipsHipConva *>(plan);
 	vertical = vertical ? 1 : 0;
 	if (check_pair("convasep", in, out, vertical ? 1 : c->lines.width, vertical ? c->lines.width : 1))

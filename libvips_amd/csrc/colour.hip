@@ -42,7 +42,9 @@ static inline int rows_grid(int gx, int height)
 
 
 static std::mutex &g_tables_mutex = *new std::mutex;
-static ColourTables g_tables = { nullptr, nullptr, nullptr, nullptr, nullptr };
+// one set per device (the tables are device memory)
+static ColourTables g_tables_by_device[64];
+#define g_tables (g_tables_by_device[current_device() < 0 ? 0 : current_device() & 63])
 
 // calcul_tables(), LabQ2sRGB.c:130-160
 static void calcul_tables(int range, std::vector<int> &Y2v, std::vector<float> &v2Y)

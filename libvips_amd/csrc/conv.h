@@ -15,6 +15,7 @@ struct _VipsHipConv {
 	std::vector<int> pos; // index into the mask, row-major
 	int scale_i, rounding, offset_i;
 	double scale, offset;
+	mutable std::atomic<int> device{ -1 }; // where the device tables live (vh::plan_device)
 	// device tables
 	void *d_coeff; // int[nnz] or double[nnz]
 	short *d_dx, *d_dy;

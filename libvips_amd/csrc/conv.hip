@@ -940,6 +940,8 @@ int vips_hip_conv_gen(const VipsHipConv *conv, const VipsHipRegion *in, const Vi
 		return -1;
 	}
 	_VipsHipConv *c = const_cast<_VipsHipConv *>(conv);
+	if (plan_device(domain, &conv->device))
+		return -1;
 	if (check_region(domain, in) || check_region(domain, out))
 		return -1;
 	if (in->bands != out->bands || out->format != vips_hip_conv_out_format(c, in->format)) {

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstddef>
 #include <cstdint>
@@ -36,6 +37,9 @@ int hip_failed(hipError_t err, const char *what);
 // Make sure a device has been selected for this thread (vips_hip_init(0) on
 // first use) -- returns -1 with an error when no GPU is present.
 int ensure_init();
+
+// The device the calling thread is bound to (-1: none yet).
+int current_device();
 
 hipStream_t stream();
 // Synchronise and destroy the calling thread's own stream (threads the library starts itself).
@@ -113,6 +117,10 @@ static inline int region_elems_per_pel(const VipsHipRegion *r)
 // Common checks on a pair of regions handed to a gen.
 int check_region(const char *domain, const VipsHipRegion *r);
 
+// A plan handle's device tables live on ONE device: the device of the thread that first runs
+// it (*device < 0: taken now).  Running it from a thread bound to another device fails loudly.
+int plan_device(const char *domain, std::atomic<int> *device);
+
 // Small device-resident table upload with caching handled by the callers.
 void *upload(const void *host, size_t size);
 
@@ -121,6 +129,7 @@ void *upload(const void *host, size_t size);
 // The image object (layer 3).
 struct _VipsHipImage {
 	void *data;
+	int device = -1; // the device the pixels live on
 	int width, height, bands, format, interpretation;
 	size_t stride;
 	bool owns; // data came from the pool
@@ -130,6 +139,9 @@ struct _VipsHipImage {
 };
 
 namespace vh {
+// Run where the data lives: make sure a device is selected and bind the calling thread to the
+// device `image` is on (every image-level operation starts with this).
+int bind_to(const _VipsHipImage *image);
 // A second image object on the same pixels (library-owned images only; nullptr otherwise).
 _VipsHipImage *image_share(const _VipsHipImage *in);
 } // namespace vh

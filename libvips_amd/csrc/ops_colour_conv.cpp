@@ -43,12 +43,13 @@ struct ImageRef {
 typedef std::shared_ptr<VipsHipConv> ConvPtr;
 
 struct ConvKey {
+	int device; // a mask's device tables live on one device
 	std::vector<double> mask;
 	int mw, mh, precision;
 	double scale, offset;
 	bool operator==(const ConvKey &o) const
 	{
-		return mw == o.mw && mh == o.mh && precision == o.precision &&
+		return device == o.device && mw == o.mw && mh == o.mh && precision == o.precision &&
 			memcmp(&scale, &o.scale, sizeof(double)) == 0 &&
 			memcmp(&offset, &o.offset, sizeof(double)) == 0 && mask.size() == o.mask.size() &&
 			memcmp(mask.data(), o.mask.data(), mask.size() * sizeof(double)) == 0;
@@ -63,7 +64,9 @@ ConvPtr conv_cached(const double *mask, int mw, int mh, double scale, double off
 {
 	if (!mask || mw <= 0 || mh <= 0 || (long long) mw * mh > 65536)
 		return ConvPtr(vips_hip_conv_new(mask, mw, mh, scale, offset, precision), vips_hip_conv_free);
-	ConvKey key = { std::vector<double>(mask, mask + (size_t) mw * mh), mw, mh, precision, scale, offset };
+	if (ensure_init())
+		return ConvPtr();
+	ConvKey key = { current_device(), std::vector<double>(mask, mask + (size_t) mw * mh), mw, mh, precision, scale, offset };
 	{
 		std::lock_guard<std::mutex> lock(g_conv_mutex);
 		for (auto it = g_conv_cache.begin(); it != g_conv_cache.end(); ++it)
@@ -104,7 +107,9 @@ ConvaPtr conva_cached(const double *mask, int mw, int mh, double scale, double o
 	};
 	if (!mask || mw <= 0 || mh <= 0 || (long long) mw * mh > 65536)
 		return ConvaPtr(make(), vips_hip_conva_free);
-	ConvaKey key = { { std::vector<double>(mask, mask + (size_t) mw * mh), mw, mh, separable ? 1 : 0, scale, offset },
+	if (ensure_init())
+		return ConvaPtr();
+	ConvaKey key = { { current_device(), std::vector<double>(mask, mask + (size_t) mw * mh), mw, mh, separable ? 1 : 0, scale, offset },
 		layers, cluster };
 	{
 		std::lock_guard<std::mutex> lock(g_conv_mutex);
@@ -127,15 +132,18 @@ ConvaPtr conva_cached(const double *mask, int mw, int mh, double scale, double o
 
 // the sharpen LUT (sharpen.c:230-257), cached by its parameters
 struct LutKey {
+	int device;
 	double p[5];
-	bool operator==(const LutKey &o) const { return memcmp(p, o.p, sizeof(p)) == 0; }
+	bool operator==(const LutKey &o) const { return device == o.device && memcmp(p, o.p, sizeof(p)) == 0; }
 };
 typedef std::shared_ptr<int> LutPtr;
 std::list<std::pair<LutKey, LutPtr>> &g_lut_cache = *new std::list<std::pair<LutKey, LutPtr>>;
 
 LutPtr sharpen_lut_cached(double x1, double y2, double y3, double m1, double m2)
 {
-	LutKey key = { { x1, y2, y3, m1, m2 } };
+	if (ensure_init())
+		return LutPtr();
+	LutKey key = { current_device(), { x1, y2, y3, m1, m2 } };
 	{
 		std::lock_guard<std::mutex> lock(g_conv_mutex);
 		for (auto it = g_lut_cache.begin(); it != g_lut_cache.end(); ++it)
@@ -431,6 +439,8 @@ extern "C" {
 int vips_hip_conv(VipsHipImage *in, VipsHipImage **out, const double *mask, int mask_width,
 	int mask_height, double scale, double offset, int precision)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	if (!in || !out || !mask) {
 		error("conv", "null argument");
 		return -1;
@@ -445,6 +455,8 @@ int vips_hip_conv(VipsHipImage *in, VipsHipImage **out, const double *mask, int 
 int vips_hip_conva(VipsHipImage *in, VipsHipImage **out, const double *mask, int mask_width,
 	int mask_height, double scale, double offset, int layers, int cluster)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	if (!in || !out) {
 		error("conva", "null argument");
 		return -1;
@@ -468,6 +480,8 @@ int vips_hip_conva(VipsHipImage *in, VipsHipImage **out, const double *mask, int
 int vips_hip_convasep(VipsHipImage *in, VipsHipImage **out, const double *mask, int mask_n,
 	double scale, double offset, int layers)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	if (!in || !out) {
 		error("convasep", "null argument");
 		return -1;
@@ -507,6 +521,8 @@ int vips_hip_convasep(VipsHipImage *in, VipsHipImage **out, const double *mask, 
 int vips_hip_convsep(VipsHipImage *in, VipsHipImage **out, const double *mask, int mask_n,
 	double scale, double offset, int precision)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	if (!in || !out || !mask) {
 		error("convsep", "null argument");
 		return -1;
@@ -555,6 +571,8 @@ int vips_hip_convsep(VipsHipImage *in, VipsHipImage **out, const double *mask, i
 int vips_hip_gaussblur(VipsHipImage *in, VipsHipImage **out, double sigma, double min_ampl,
 	int precision)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	if (!in || !out) {
 		error("gaussblur", "null argument");
 		return -1;
@@ -579,6 +597,8 @@ int vips_hip_gaussblur(VipsHipImage *in, VipsHipImage **out, double sigma, doubl
 
 int vips_hip_cast(VipsHipImage *in, VipsHipImage **out, int format)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	if (!in || !out) {
 		error("cast", "null argument");
 		return -1;
@@ -616,17 +636,23 @@ static int premultiply_image(VipsHipImage *in, VipsHipImage **out, int uchar, in
 
 int vips_hip_premultiply(VipsHipImage *in, VipsHipImage **out, int uchar)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	return premultiply_image(in, out, uchar, 0);
 }
 
 int vips_hip_unpremultiply(VipsHipImage *in, VipsHipImage **out, int uchar)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	return premultiply_image(in, out, uchar, 1);
 }
 
 // vips_colourspace_build, colour/colourspace.c:551-612
 int vips_hip_colourspace(VipsHipImage *in, VipsHipImage **out, int space)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	if (!in || !out) {
 		error("colourspace", "null argument");
 		return -1;
@@ -724,6 +750,8 @@ int vips_hip_colourspace(VipsHipImage *in, VipsHipImage **out, int space)
 int vips_hip_gaussblur_colourspace(VipsHipImage *in, VipsHipImage **out, double sigma, double min_ampl,
 	int precision, int space)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	if (!in || !out) {
 		error("gaussblur", "null argument");
 		return -1;
@@ -815,15 +843,10 @@ static BatchStreams *batch_streams()
 // sigma < 0 skips the sharpen.  Returns the number of images that failed (their outs[] are
 // NULL; the first error message is left in the caller's error buffer); all work is complete
 // on return.
-int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel,
+// ... on the device the calling thread drives (every image of `in` lives there)
+static int resize_sharpen_batch_here(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel,
 	double gap, double sigma, double x1, double y2, double y3, double m1, double m2, int n_threads)
 {
-	if (!in || !out || n < 0) {
-		error("resize_sharpen_batch", "null argument");
-		return -1;
-	}
-	if (ensure_init())
-		return -1;
 	if (n_threads < 1)
 		n_threads = 1;
 	if (n_threads > n)
@@ -998,9 +1021,67 @@ int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage *
 	return failed.load();
 }
 
+// The batch SCATTER of BASELINE config 4 inside one process: the images of a batch may live on
+// several devices (whoever loaded them dealt them out: vips_hip_devices()); each device's share
+// runs on a host thread bound to that device -- its own pool, plan caches and streams -- with no
+// data moving between devices.  One device: the calling thread does the work itself.
+int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel,
+	double gap, double sigma, double x1, double y2, double y3, double m1, double m2, int n_threads)
+{
+	if (!in || !out || n < 0) {
+		error("resize_sharpen_batch", "null argument");
+		return -1;
+	}
+	if (ensure_init())
+		return -1;
+	std::map<int, std::vector<int>> by_device;
+	for (int i = 0; i < n; i++)
+		by_device[in[i] ? in[i]->device : current_device()].push_back(i);
+	if (by_device.size() <= 1) {
+		if (n > 0 && vh::bind_to(in[by_device.begin()->second[0]]))
+			return -1;
+		return resize_sharpen_batch_here(in, n, out, scale, kernel, gap, sigma, x1, y2, y3, m1, m2, n_threads);
+	}
+	for (int i = 0; i < n; i++)
+		out[i] = nullptr;
+	std::mutex err_mutex;
+	std::string first_error;
+	std::atomic<int> failed(0);
+	std::vector<std::thread> workers;
+	for (auto &group : by_device) {
+		const int device = group.first;
+		const std::vector<int> &idx = group.second;
+		workers.emplace_back([&, device]() {
+			std::vector<VipsHipImage *> sub_in(idx.size()), sub_out(idx.size(), nullptr);
+			for (size_t k = 0; k < idx.size(); k++)
+				sub_in[k] = in[idx[k]];
+			int r = vips_hip_init(device);
+			if (!r)
+				r = resize_sharpen_batch_here(sub_in.data(), (int) idx.size(), sub_out.data(), scale, kernel, gap, sigma,
+					x1, y2, y3, m1, m2, n_threads);
+			for (size_t k = 0; k < idx.size(); k++)
+				out[idx[k]] = sub_out[k];
+			if (r) {
+				failed.fetch_add(r < 0 ? (int) idx.size() : r);
+				std::lock_guard<std::mutex> lock(err_mutex);
+				if (first_error.empty())
+					first_error = vips_hip_error_buffer();
+			}
+			release_thread_stream(); // results cross to the caller's thread
+		});
+	}
+	for (std::thread &t : workers)
+		t.join();
+	if (!first_error.empty())
+		error("resize_sharpen_batch", "%s", first_error.c_str());
+	return failed.load() == n ? -1 : failed.load();
+}
+
 // vips_extract_area (conversion/extract.c:137-187): a rectangle of the image, as a new image
 int vips_hip_extract_area(VipsHipImage *in, VipsHipImage **out, int left, int top, int width, int height)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	if (!in || !out) {
 		error("extract_area", "null argument");
 		return -1;
@@ -1029,6 +1110,8 @@ int vips_hip_extract_area(VipsHipImage *in, VipsHipImage **out, int left, int to
 int vips_hip_thumbnail_image(VipsHipImage *in, VipsHipImage **out, int width, int height, int size,
 	int linear)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	return vips_hip_thumbnail_image_crop(in, out, width, height, size, linear, 0);
 }
 
@@ -1038,6 +1121,8 @@ int vips_hip_thumbnail_image(VipsHipImage *in, VipsHipImage **out, int width, in
 int vips_hip_thumbnail_image_crop(VipsHipImage *in, VipsHipImage **out, int width, int height, int size,
 	int linear, int crop)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	const char *domain = "thumbnail";
 	if (!in || !out) {
 		error(domain, "null argument");
@@ -1226,6 +1311,8 @@ static int sharpen_fused_images(VipsHipImage *const *in, int n_images, VipsHipIm
 int vips_hip_sharpen(VipsHipImage *in, VipsHipImage **out, double sigma, double x1, double y2,
 	double y3, double m1, double m2)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	if (!in || !out) {
 		error("sharpen", "null argument");
 		return -1;

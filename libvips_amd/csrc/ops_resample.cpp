@@ -30,11 +30,12 @@ namespace {
 // VipsOperations.  Entries are handed out as shared_ptr so an eviction cannot
 // pull tables out from under a running call.
 struct ReduceKey {
+	int device; // the tables of a built reduce live on one device
 	int kernel, in_size, out_size;
 	double shrink, extra;
 	bool operator==(const ReduceKey &o) const
 	{
-		return kernel == o.kernel && in_size == o.in_size && out_size == o.out_size &&
+		return device == o.device && kernel == o.kernel && in_size == o.in_size && out_size == o.out_size &&
 			memcmp(&shrink, &o.shrink, sizeof(double)) == 0 &&
 			memcmp(&extra, &o.extra, sizeof(double)) == 0;
 	}
@@ -52,7 +53,9 @@ ReducePtr reduce_cached(int kernel, double shrink, int in_size, int out_size, do
 {
 	if (std::isnan(extra))
 		extra = out_size * shrink - in_size;
-	ReduceKey key = { kernel, in_size, out_size, shrink, extra };
+	if (ensure_init())
+		return ReducePtr();
+	ReduceKey key = { current_device(), kernel, in_size, out_size, shrink, extra };
 	{
 		std::lock_guard<std::mutex> lock(g_cache_mutex);
 		for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
@@ -436,21 +439,29 @@ extern "C" {
 
 int vips_hip_shrinkh(VipsHipImage *in, VipsHipImage **out, int hshrink, int ceil_mode)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	return shrink_axis(in, out, hshrink, ceil_mode, false);
 }
 
 int vips_hip_shrinkv(VipsHipImage *in, VipsHipImage **out, int vshrink, int ceil_mode)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	return shrink_axis(in, out, vshrink, ceil_mode, true);
 }
 
 int vips_hip_reduceh(VipsHipImage *in, VipsHipImage **out, double hshrink, int kernel, double gap)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	return reduce_axis(in, out, hshrink, kernel, gap, false);
 }
 
 int vips_hip_reducev(VipsHipImage *in, VipsHipImage **out, double vshrink, int kernel, double gap)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	return reduce_axis(in, out, vshrink, kernel, gap, true);
 }
 
@@ -458,6 +469,8 @@ int vips_hip_reducev(VipsHipImage *in, VipsHipImage **out, double vshrink, int k
 int vips_hip_reduce(VipsHipImage *in, VipsHipImage **out, double hshrink, double vshrink,
 	int kernel, double gap)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	if (!in || !out) {
 		error("reduce", "null argument");
 		return -1;
@@ -503,6 +516,8 @@ int vips_hip_reduce(VipsHipImage *in, VipsHipImage **out, double hshrink, double
 int vips_hip_shrink(VipsHipImage *in, VipsHipImage **out, double hshrink, double vshrink,
 	int ceil_mode)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	if (!in || !out) {
 		error("shrink", "null argument");
 		return -1;
@@ -524,6 +539,8 @@ int vips_hip_shrink(VipsHipImage *in, VipsHipImage **out, double hshrink, double
 int vips_hip_resize(VipsHipImage *in, VipsHipImage **out, double scale, double vscale_arg,
 	int kernel, double gap)
 {
+	if (in && vh::bind_to(in)) // run where the pixels live
+		return -1;
 	if (!in || !out) {
 		error("resize", "null argument");
 		return -1;

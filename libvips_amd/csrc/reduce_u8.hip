@@ -1406,6 +1406,8 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 		error(domain, "null reduce");
 		return -1;
 	}
+	if (plan_device(domain, &reducev->device) || plan_device(domain, &reduceh->device))
+		return -1;
 	if (check_region(domain, in) || check_region(domain, out))
 		return -1;
 	if (in->format != VIPS_HIP_FORMAT_UCHAR || out->format != VIPS_HIP_FORMAT_UCHAR ||

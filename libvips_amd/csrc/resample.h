@@ -3,6 +3,7 @@
 
 #include "internal.h"
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -40,6 +41,7 @@ struct _VipsHipReduce {
 	// device copies of position arrays keyed by (start, count, tile)
 	std::map<std::tuple<int, int, int>, vh::ReducePos *> pos_cache;
 	std::mutex mutex;
+	mutable std::atomic<int> device{ -1 }; // where the device tables live (vh::plan_device)
 };
 
 namespace vh {

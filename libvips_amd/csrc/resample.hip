@@ -480,6 +480,8 @@ static int reduce_gen(const char *domain, const VipsHipReduce *reduce, const Vip
 	_VipsHipReduce *r = const_cast<_VipsHipReduce *>(reduce);
 	if (reduce_check(domain, r, in, out, vertical))
 		return -1;
+	if (plan_device(domain, &r->device))
+		return -1;
 
 	const int fmt = format_real(out->format);
 	const bool want_float = fmt == VIPS_HIP_FORMAT_FLOAT;

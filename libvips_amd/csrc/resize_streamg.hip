@@ -383,7 +383,8 @@ struct GenPlan {
 	GenRow *d_sched;
 };
 
-typedef std::tuple<int, double, int, int, double, int, double, int, int, double, int, int, int, int> GenKey;
+// (the last field is the device the schedule lives on)
+typedef std::tuple<int, double, int, int, double, int, double, int, int, double, int, int, int, int, int> GenKey;
 
 std::mutex g_gen_mutex;
 std::map<GenKey, GenPlan> g_gen_plans;
@@ -529,7 +530,7 @@ int resize_streamg_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh, int hs
 	GenPlan plan;
 	{
 		const GenKey key(rv->kernel, rv->shrink, rv->in_size, rv->out_size, rv->offset, hs, rh->shrink, rh->in_size,
-			rh->out_size, rh->offset, i0->width, B, tile, rh->kernel);
+			rh->out_size, rh->offset, i0->width, B, tile, rh->kernel, current_device());
 		std::lock_guard<std::mutex> lock(g_gen_mutex);
 		auto it = g_gen_plans.find(key);
 		if (it == g_gen_plans.end()) {

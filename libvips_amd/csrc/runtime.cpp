@@ -21,17 +21,50 @@
 namespace vh {
 
 static thread_local std::string tls_error;
-static thread_local hipStream_t tls_stream = nullptr;
-static thread_local bool tls_stream_external = false;
 static thread_local int tls_device = -1;
+// the calling thread's own stream per device it has been bound to, and the external stream
+// (vips_hip_set_stream) of its current binding
+constexpr int MAX_DEVICES = 64;
+static thread_local hipStream_t tls_own_stream[MAX_DEVICES];
+static thread_local hipStream_t tls_external = nullptr;
+static thread_local bool tls_stream_external = false;
 
 static std::mutex g_mutex;
-static bool g_inited = false;
-// One process drives one device (one process per GPU): the first
-// vips_hip_init() -- or $VIPS_HIP_DEVICE for threads that never call it, e.g. libvips
-// workers inside the module -- fixes it, and the pool, the plan caches and every thread
-// the library starts itself (vips_hip_thumbnail_batch) then live on that device.
+static bool g_checked[MAX_DEVICES]; // gfx950 confirmed
+// A THREAD drives one device at a time (hipSetDevice is per thread): vips_hip_init(d) binds the
+// calling thread; a thread that never calls it is bound on first use -- to the next entry of
+// $VIPS_HIP_DEVICES (a comma list, dealt round-robin over such threads: how one libvips process
+// spreads its worker pool over the GPUs of a node, iofuncs/threadpool.c:625), else to
+// $VIPS_HIP_DEVICE, else to the device of the process's first vips_hip_init(), else to 0.
+// Pools, plan caches and library-made images are per device; an image operation runs on the
+// device its input lives on (bind_to).
 static std::atomic<int> g_device{ -1 };
+static std::atomic<unsigned int> g_next_slot{ 0 };
+
+// $VIPS_HIP_DEVICES, validated; empty when unset or malformed (an error is left for the caller)
+static int devices_from_env(std::vector<int> &out)
+{
+	out.clear();
+	const char *env = getenv("VIPS_HIP_DEVICES");
+	if (!env || !*env)
+		return 0;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+		return 0;
+	const char *p = env;
+	while (*p) {
+		char *end = nullptr;
+		const long d = strtol(p, &end, 10);
+		if (end == p || d < 0 || d >= n || d >= MAX_DEVICES || (*end && *end != ',')) {
+			error("vips_hip_init", "VIPS_HIP_DEVICES=\"%s\": not a comma list of devices 0..%d", env, n - 1);
+			out.clear();
+			return -1;
+		}
+		out.push_back((int) d);
+		p = *end ? end + 1 : end;
+	}
+	return 0;
+}
 
 void error(const char *domain, const char *fmt, ...)
 {
@@ -56,23 +89,70 @@ int ensure_init()
 {
 	if (tls_device >= 0)
 		return 0;
-	int device = g_device.load();
-	if (device < 0) {
-		const char *env = getenv("VIPS_HIP_DEVICE");
-		device = env && *env ? atoi(env) : 0;
+	std::vector<int> list;
+	if (devices_from_env(list))
+		return -1;
+	int device;
+	if (!list.empty())
+		device = list[g_next_slot.fetch_add(1) % list.size()];
+	else {
+		device = g_device.load();
+		if (device < 0) {
+			const char *env = getenv("VIPS_HIP_DEVICE");
+			device = 0;
+			if (env && *env) {
+				char *end = nullptr;
+				const long d = strtol(env, &end, 10);
+				if (end == env || *end || d < 0 || d >= MAX_DEVICES) {
+					error("vips_hip_init", "VIPS_HIP_DEVICE=\"%s\" is not a device number", env);
+					return -1;
+				}
+				device = (int) d;
+			}
+		}
 	}
 	return vips_hip_init(device);
+}
+
+int current_device()
+{
+	return tls_device;
+}
+
+// Run where the data lives: bind the calling thread to the device `image` is on.
+int bind_to(const _VipsHipImage *image)
+{
+	if (ensure_init())
+		return -1;
+	if (!image || image->device < 0 || image->device == tls_device)
+		return 0;
+	return vips_hip_init(image->device);
+}
+
+int plan_device(const char *domain, std::atomic<int> *device)
+{
+	if (ensure_init())
+		return -1;
+	int none = -1;
+	if (device->compare_exchange_strong(none, tls_device) || none == tls_device)
+		return 0;
+	error(domain, "this plan's tables are on device %d, the calling thread drives device %d "
+		"(a plan handle belongs to one device: make one per device)", none, tls_device);
+	return -1;
 }
 
 hipStream_t stream()
 {
 	if (tls_stream_external)
-		return tls_stream;
-	if (!tls_stream) {
-		if (hipStreamCreateWithFlags(&tls_stream, hipStreamNonBlocking) != hipSuccess)
-			tls_stream = nullptr;
+		return tls_external;
+	if (tls_device < 0)
+		return nullptr;
+	hipStream_t &own = tls_own_stream[tls_device];
+	if (!own) {
+		if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess)
+			own = nullptr;
 	}
-	return tls_stream;
+	return own;
 }
 
 // For threads the library itself starts (vips_hip_thumbnail_batch): finish and destroy the
@@ -80,19 +160,26 @@ hipStream_t stream()
 // for the life of the thread and never destroyed (no HIP calls from thread-exit destructors).
 void release_thread_stream()
 {
-	if (tls_stream && !tls_stream_external) {
-		(void) hipStreamSynchronize(tls_stream);
-		(void) hipStreamDestroy(tls_stream);
-	}
-	tls_stream = nullptr;
+	const int bound = tls_device;
+	for (int d = 0; d < MAX_DEVICES; d++)
+		if (tls_own_stream[d]) {
+			if (d != bound)
+				(void) hipSetDevice(d);
+			(void) hipStreamSynchronize(tls_own_stream[d]);
+			(void) hipStreamDestroy(tls_own_stream[d]);
+			tls_own_stream[d] = nullptr;
+		}
+	if (bound >= 0)
+		(void) hipSetDevice(bound);
+	tls_external = nullptr;
 	tls_stream_external = false;
 }
 
 ScopedStream::ScopedStream(hipStream_t s)
-	: saved(tls_stream), saved_external(tls_stream_external), active(s != nullptr)
+	: saved(tls_external), saved_external(tls_stream_external), active(s != nullptr)
 {
 	if (active) {
-		tls_stream = s;
+		tls_external = s;
 		tls_stream_external = true;
 	}
 }
@@ -100,7 +187,7 @@ ScopedStream::ScopedStream(hipStream_t s)
 ScopedStream::~ScopedStream()
 {
 	if (active) {
-		tls_stream = saved;
+		tls_external = saved;
 		tls_stream_external = saved_external;
 	}
 }
@@ -139,6 +226,7 @@ int check_region(const char *domain, const VipsHipRegion *r)
 // lists of threads that exit and everything at vips_hip_pool_trim(); results cross threads
 // only after a synchronize (image download, the module's build()).
 struct Pool {
+	int device = 0;
 	std::mutex mutex;
 	std::map<size_t, std::vector<void *>> free_lists; // global: orphaned blocks
 	std::unordered_map<void *, size_t> live;
@@ -159,10 +247,10 @@ struct Pool {
 					pool->free_lists[kv.first].push_back(p);
 		}
 	};
-	static Local &local()
+	Local &local()
 	{
-		static thread_local Local l;
-		return l;
+		static thread_local Local l[MAX_DEVICES]; // the calling thread's lists, one per device
+		return l[device];
 	}
 
 	static size_t bucket(size_t size)
@@ -235,9 +323,23 @@ struct Pool {
 			live_bytes -= b;
 			cached_bytes += b;
 		}
+		if (current_device() != device) {
+			// freed by a thread bound to another device: that thread queues nothing on this
+			// device, so the block waits in the global list (blocks cross devices and threads
+			// only after a synchronize, see above)
+			std::lock_guard<std::mutex> lock(mutex);
+			free_lists[b].push_back(p);
+			return;
+		}
 		Local &l = local();
 		l.pool = this;
 		l.lists[b].push_back(p);
+	}
+
+	bool owns(void *p)
+	{
+		std::lock_guard<std::mutex> lock(mutex);
+		return live.find(p) != live.end();
 	}
 
 	// frees the calling thread's cache and the global list (other threads keep theirs)
@@ -260,13 +362,55 @@ struct Pool {
 	}
 };
 
-// Leaked on purpose: other translation units release blocks from their own static
-// destructors, and static destruction order across units is unspecified.
-static Pool &g_pool = *new Pool;
+// One pool per device.  Leaked on purpose: other translation units release blocks from their own
+// static destructors, and static destruction order across units is unspecified.
+static Pool *g_pools[MAX_DEVICES];
+static std::mutex &g_pools_mutex = *new std::mutex;
+
+static Pool &pool_of(int device)
+{
+	if (device < 0 || device >= MAX_DEVICES)
+		device = 0;
+	std::lock_guard<std::mutex> lock(g_pools_mutex);
+	if (!g_pools[device]) {
+		g_pools[device] = new Pool;
+		g_pools[device]->device = device;
+	}
+	return *g_pools[device];
+}
+
+// the pool of the calling thread's device
+static Pool &pool()
+{
+	return pool_of(current_device());
+}
+
+// a block goes back to the pool it came from, whichever device the freeing thread drives
+static void pool_release(void *p)
+{
+	if (!p)
+		return;
+	Pool &mine = pool();
+	if (mine.owns(p)) {
+		mine.release(p);
+		return;
+	}
+	for (int d = 0; d < MAX_DEVICES; d++) {
+		Pool *other;
+		{
+			std::lock_guard<std::mutex> lock(g_pools_mutex);
+			other = g_pools[d];
+		}
+		if (other && other != &mine && other->owns(p)) {
+			other->release(p);
+			return;
+		}
+	}
+}
 
 void *upload(const void *host, size_t size)
 {
-	void *d = g_pool.alloc(size);
+	void *d = pool().alloc(size);
 	if (!d)
 		return nullptr;
 	// Stream-ordered: the block may have been released to the pool by a plan
@@ -277,7 +421,7 @@ void *upload(const void *host, size_t size)
 	if (hipMemcpyAsync(d, host, size, hipMemcpyHostToDevice, s) != hipSuccess ||
 		hipStreamSynchronize(s) != hipSuccess) {
 		error("vips_hip", "table upload failed");
-		g_pool.release(d);
+		pool_release(d);
 		return nullptr;
 	}
 	return d;
@@ -336,47 +480,61 @@ int vips_hip_init(int device)
 		error("vips_hip_init", "no HIP device visible (this library has no CPU path)");
 		return -1;
 	}
-	if (device < 0 || device >= n) {
+	if (device < 0 || device >= n || device >= MAX_DEVICES) {
 		error("vips_hip_init", "device %d out of range (have %d)", device, n);
 		return -1;
-	}
-	{
-		std::lock_guard<std::mutex> lock(g_mutex);
-		const int bound = g_device.load();
-		if (bound >= 0 && bound != device) {
-			error("vips_hip_init", "this process is bound to device %d (asked for %d): the device "
-				"pool and plan caches are per process -- run one process per GPU", bound, device);
-			return -1;
-		}
 	}
 	VH_CHECK(hipSetDevice(device));
 	{
 		std::lock_guard<std::mutex> lock(g_mutex);
-		if (!g_inited) {
+		if (!g_checked[device]) {
 			hipDeviceProp_t prop;
 			VH_CHECK(hipGetDeviceProperties(&prop, device));
 			if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-				error("vips_hip_init", "device is %s, this library is built for gfx950 only",
+				error("vips_hip_init", "device %d is %s, this library is built for gfx950 only", device,
 					prop.gcnArchName);
 				return -1;
 			}
-			g_inited = true;
+			g_checked[device] = true;
 		}
-		g_device.store(device);
+		int none = -1;
+		g_device.compare_exchange_strong(none, device); // the default of threads that never ask
+	}
+	if (tls_device != device) {
+		// an external stream belongs to the device it was made on
+		tls_external = nullptr;
+		tls_stream_external = false;
 	}
 	tls_device = device;
 	return 0;
 }
 
+int vips_hip_current_device(void)
+{
+	return tls_device;
+}
+
+int vips_hip_devices(int *devices, int max)
+{
+	std::vector<int> list;
+	if (devices_from_env(list))
+		return -1;
+	if (list.empty()) {
+		if (ensure_init())
+			return -1;
+		list.push_back(tls_device);
+	}
+	for (int i = 0; i < (int) list.size() && i < max; i++)
+		if (devices)
+			devices[i] = list[i];
+	return (int) list.size();
+}
+
 void vips_hip_shutdown(void)
 {
-	if (tls_stream && !tls_stream_external) {
-		(void) hipStreamSynchronize(tls_stream);
-		(void) hipStreamDestroy(tls_stream);
-	}
-	tls_stream = nullptr;
-	tls_stream_external = false;
-	g_pool.trim();
+	release_thread_stream();
+	vips_hip_pool_trim();
+	tls_device = -1; // the thread may bind again, to any device
 }
 
 const char *vips_hip_error_buffer(void)
@@ -393,19 +551,14 @@ int vips_hip_set_stream(void *s)
 {
 	if (ensure_init())
 		return -1;
-	if (tls_stream && !tls_stream_external) {
-		(void) hipStreamSynchronize(tls_stream);
-		(void) hipStreamDestroy(tls_stream);
-		tls_stream = nullptr;
+	hipStream_t &own = tls_own_stream[tls_device];
+	if (own) {
+		(void) hipStreamSynchronize(own);
+		(void) hipStreamDestroy(own);
+		own = nullptr;
 	}
-	if (s) {
-		tls_stream = (hipStream_t) s;
-		tls_stream_external = true;
-	}
-	else {
-		tls_stream = nullptr;
-		tls_stream_external = false;
-	}
+	tls_external = (hipStream_t) s;
+	tls_stream_external = s != nullptr;
 	return 0;
 }
 
@@ -462,12 +615,12 @@ void *vips_hip_malloc(size_t size)
 {
 	if (ensure_init())
 		return nullptr;
-	return g_pool.alloc(size ? size : 1);
+	return pool().alloc(size ? size : 1);
 }
 
 void vips_hip_free(void *ptr)
 {
-	g_pool.release(ptr);
+	pool_release(ptr);
 }
 
 void *vips_hip_malloc_host(size_t size)
@@ -535,13 +688,33 @@ int vips_hip_memcpy2d_d2h(void *dst, size_t dpitch, const void *src, size_t spit
 
 size_t vips_hip_pool_bytes(void)
 {
-	std::lock_guard<std::mutex> lock(g_pool.mutex);
-	return g_pool.cached_bytes + g_pool.live_bytes;
+	size_t total = 0;
+	for (int d = 0; d < MAX_DEVICES; d++) {
+		Pool *p;
+		{
+			std::lock_guard<std::mutex> lock(g_pools_mutex);
+			p = g_pools[d];
+		}
+		if (p) {
+			std::lock_guard<std::mutex> lock(p->mutex);
+			total += p->cached_bytes + p->live_bytes;
+		}
+	}
+	return total;
 }
 
+// the calling thread's caches and the orphaned blocks of every device
 void vips_hip_pool_trim(void)
 {
-	g_pool.trim();
+	for (int d = 0; d < MAX_DEVICES; d++) {
+		Pool *p;
+		{
+			std::lock_guard<std::mutex> lock(g_pools_mutex);
+			p = g_pools[d];
+		}
+		if (p)
+			p->trim();
+	}
 }
 
 void *vips_hip_event_new(void)
@@ -677,12 +850,13 @@ VipsHipImage *vips_hip_image_new(int width, int height, int bands, int format,
 	im->interpretation = interpretation;
 	im->stride = (size_t) width * bands * es;
 	im->owns = true;
-	im->data = g_pool.alloc(im->stride * height);
+	im->device = current_device();
+	im->data = pool().alloc(im->stride * height);
 	if (!im->data) {
 		delete im;
 		return nullptr;
 	}
-	im->hold = std::shared_ptr<void>(im->data, [](void *p) { g_pool.release(p); });
+	im->hold = std::shared_ptr<void>(im->data, [](void *p) { pool_release(p); });
 	return im;
 }
 
@@ -722,6 +896,8 @@ VipsHipImage *vips_hip_image_new_from_device(void *device_data, int width, int h
 	im->stride = (size_t) width * bands * es;
 	im->owns = false;
 	im->data = device_data;
+	// the caller's memory: taken to be on the device the calling thread drives
+	im->device = current_device();
 	return im;
 }
 
@@ -738,11 +914,14 @@ int vips_hip_image_write_to_memory(const VipsHipImage *image, void *host_data)
 		error("vips_hip_image_write_to_memory", "null argument");
 		return -1;
 	}
+	if (bind_to(image))
+		return -1;
 	return vips_hip_memcpy_d2h(host_data, image->data, image->stride * image->height);
 }
 
 // the getters of a NULL image answer 0 / NULL instead of crashing
 void *vips_hip_image_get_data(const VipsHipImage *image) { return image ? image->data : nullptr; }
+int vips_hip_image_get_device(const VipsHipImage *image) { return image ? image->device : -1; }
 int vips_hip_image_get_width(const VipsHipImage *image) { return image ? image->width : 0; }
 int vips_hip_image_get_height(const VipsHipImage *image) { return image ? image->height : 0; }
 int vips_hip_image_get_bands(const VipsHipImage *image) { return image ? image->bands : 0; }

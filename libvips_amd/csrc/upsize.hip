@@ -268,11 +268,12 @@ static void coefficients_catmull(double c[4], const double x)
 }
 
 static std::mutex &g_up_mutex = *new std::mutex;
-static const BicubicTables *g_bicubic = nullptr;
+static const BicubicTables *g_bicubic_by_device[64]; // device memory: one per device
 
 static const BicubicTables *bicubic_tables()
 {
 	std::lock_guard<std::mutex> lock(g_up_mutex);
+	const BicubicTables *&g_bicubic = g_bicubic_by_device[current_device() < 0 ? 0 : current_device() & 63];
 	if (!g_bicubic) {
 		BicubicTables t;
 		// bicubic.cpp:624-633
@@ -288,11 +289,12 @@ static const BicubicTables *bicubic_tables()
 
 // the per-column x coordinates, cached (a table upload synchronises the stream)
 struct TabKey {
+	int device;
 	int out_left, out_width, window_offset, tile_width;
 	double ia, tidx;
 	bool operator==(const TabKey &o) const
 	{
-		return out_left == o.out_left && out_width == o.out_width && window_offset == o.window_offset &&
+		return device == o.device && out_left == o.out_left && out_width == o.out_width && window_offset == o.window_offset &&
 			tile_width == o.tile_width && memcmp(&ia, &o.ia, sizeof(double)) == 0 &&
 			memcmp(&tidx, &o.tidx, sizeof(double)) == 0;
 	}
@@ -485,7 +487,7 @@ int vips_hip_upsize_gen(const VipsHipRegion *in, const VipsHipRegion *out, doubl
 	a.id = tmp * hscale;
 	a.tidy = idy - 1; // affine.c:538-539
 	a.window_offset = window_offset;
-	TabKey key = { out->left, out->width, window_offset, tile_width, ia, idx - 1 };
+	TabKey key = { current_device(), out->left, out->width, window_offset, tile_width, ia, idx - 1 };
 	TabPtr tab = column_table(key, out->im_width);
 	if (!tab)
 		return -1;

@@ -254,6 +254,8 @@ VipsHipImage *vips_hip_image_new_from_vfile(const char *path)
 
 int vips_hip_image_write_to_vfile(const VipsHipImage *image, const char *path)
 {
+	if (image && vh::bind_to(image)) // run where the pixels live
+		return -1;
 	if (!image || !path) {
 		error("VipsImage", "null argument");
 		return -1;

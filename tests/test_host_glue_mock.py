@@ -46,7 +46,7 @@ pytestmark = pytest.mark.skipif(_gpu_present() or not _build_mock(),
                                 reason="a real GPU is present, or the mock runtime cannot be built")
 
 
-def run_child(body, tmp_path):
+def run_child(body, tmp_path, extra_env=None):
     script = os.path.join(str(tmp_path), "child.py")
     with open(script, "w") as f:
         f.write("import sys\nsys.path.insert(0, %r)\n" % helpers.ROOT)
@@ -54,6 +54,7 @@ def run_child(body, tmp_path):
         f.write(body)
         f.write("\nprint('CHILD-OK', flush=True)\n")
     env = dict(os.environ, LD_PRELOAD=MOCK_SO)
+    env.update(extra_env or {})
     proc = subprocess.run([sys.executable, script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                           env=env, timeout=600)
     assert proc.returncode == 0 and "CHILD-OK" in proc.stdout, proc.stdout[-3000:]
@@ -254,6 +255,118 @@ mixed = ims[:3] + [Image.new_from_array(np.zeros((64, 700, 3), np.uint8), interp
 outs = libvips_amd.resize_sharpen_batch(mixed, 0.125, threads=2)
 assert [(o.width, o.height) for o in outs] == [(86, 8)] * 3 + [(88, 8)]
 ''', tmp_path)
+
+
+def test_two_devices_in_one_process(tmp_path):
+    """The multi-device host logic against TWO fake devices (MOCK_HIP_DEVICES=2): threads that
+    never call vips_hip_init() are dealt round-robin over $VIPS_HIP_DEVICES; a thread re-binds with
+    vips_hip_init(); images remember their device and an operation runs where its input lives; a
+    plan handle belongs to one device and fails loudly on the other; a batch whose images live on
+    both devices is scattered to one worker per device; row strips over the devices exchange their
+    halos with peer copies straight into persistent windows (pixel-exact: copies are real here) and
+    vips_hip_conv_strips() returns one output strip per device."""
+    run_child(r'''
+import ctypes, math, os, threading
+import numpy as np
+import libvips_amd
+from libvips_amd import Image, _ffi
+from libvips_amd._ffi import Region, lib
+from tests import helpers
+
+mock = ctypes.CDLL(os.environ["LD_PRELOAD"])
+for f in ("mock_hip_set_device_calls", "mock_hip_peer_copies", "mock_hip_peer_bytes"):
+    getattr(mock, f).restype = ctypes.c_long
+assert lib.vips_hip_device_count() == 2
+
+# threads that never bind themselves: dealt round-robin over $VIPS_HIP_DEVICES
+seen = []
+def worker():
+    im = Image.new_from_array(np.zeros((8, 8, 3), np.uint8))
+    seen.append((lib.vips_hip_current_device(), lib.vips_hip_image_get_device(im._h)))
+ts = [threading.Thread(target=worker) for _ in range(6)]
+for t in ts:
+    t.start()
+    t.join()
+assert sorted(d for d, _ in seen) == [0, 0, 0, 1, 1, 1], seen
+assert all(d == i for d, i in seen)
+devs = (ctypes.c_int * 8)()
+assert lib.vips_hip_devices(devs, 8) == 2 and list(devs[:2]) == [0, 1]
+
+# explicit binding, images remember their device, ops run where the pixels live
+libvips_amd.init(1)
+assert lib.vips_hip_current_device() == 1
+on1 = Image.new_from_array(helpers.lcg_image(640, 64, 3, np.uint8, 7), interpretation="srgb")
+assert lib.vips_hip_image_get_device(on1._h) == 1
+libvips_amd.init(0)
+on0 = Image.new_from_array(helpers.lcg_image(640, 64, 3, np.uint8, 8), interpretation="srgb")
+out = on1.resize(0.5)                      # input on device 1: the thread is re-bound
+assert lib.vips_hip_current_device() == 1 and lib.vips_hip_image_get_device(out._h) == 1
+out = on0.gaussblur(2.0)
+assert lib.vips_hip_current_device() == 0 and lib.vips_hip_image_get_device(out._h) == 0
+
+# a plan handle belongs to the device it first ran on
+rv = _ffi.check_handle(lib.vips_hip_reduce_new(5, 2.0, 64, 32, math.nan))
+src, dst = on0.region(), Image.new_from_array(np.zeros((32, 640, 3), np.uint8)).region()
+assert lib.vips_hip_reducev_gen(rv, ctypes.byref(src), ctypes.byref(dst)) == 0
+libvips_amd.init(1)
+assert lib.vips_hip_reducev_gen(rv, ctypes.byref(src), ctypes.byref(dst)) == -1
+assert "device 0" in _ffi.error_buffer() and "device 1" in _ffi.error_buffer(), _ffi.error_buffer()
+lib.vips_hip_error_clear()
+lib.vips_hip_reduce_free(rv)
+
+# a batch over both devices: one worker per device, outputs stay where their inputs are
+ims = []
+for k in range(10):
+    libvips_amd.init(k % 2)
+    ims.append(Image.new_from_array(np.zeros((64, 688, 3), np.uint8), interpretation="srgb"))
+libvips_amd.init(0)
+before = [mock.mock_hip_set_device_calls(d) for d in (0, 1)]
+outs = libvips_amd.resize_sharpen_batch(ims, 0.125, threads=2)
+assert [lib.vips_hip_image_get_device(o._h) for o in outs] == [k % 2 for k in range(10)]
+assert all((o.width, o.height, o.bands) == (86, 8, 3) for o in outs)
+assert all(mock.mock_hip_set_device_calls(d) > before[d] for d in (0, 1))
+assert lib.vips_hip_current_device() == 0
+
+# row strips over the devices: persistent windows, halos by peer copies
+H, W, halo = 101, 37, 15
+full = helpers.lcg_image(W, H, 1, np.uint16, 91)
+devices = (ctypes.c_int * 3)(0, 1, 0)
+strips = _ffi.check_handle(lib.vips_hip_strips_new(W, H, 1, 2, 3, devices, halo))
+assert lib.vips_hip_strips_count(strips) == 3
+wins = []
+for k in range(3):
+    dev, own, win = ctypes.c_int(), Region(), Region()
+    assert lib.vips_hip_strips_region(strips, k, ctypes.byref(dev), ctypes.byref(own), ctypes.byref(win)) == 0
+    assert dev.value == devices[k] and own.top >= win.top and own.top + own.height <= win.top + win.height
+    rows = np.ascontiguousarray(full[own.top:own.top + own.height])
+    ctypes.memmove(own.data, rows.ctypes.data, rows.nbytes)   # "device" memory is host memory here
+    wins.append((win.top, win.height, win.data))
+assert [w[0] for w in wins] == [0, 34 - halo, 68 - halo] and wins[2][0] + wins[2][1] == H
+n0, b0 = mock.mock_hip_peer_copies(), mock.mock_hip_peer_bytes()
+for step in range(2):                                          # persistent: nothing is rebuilt
+    assert lib.vips_hip_strips_exchange(strips) == 0
+    for top, height, data in wins:
+        got = np.frombuffer((ctypes.c_char * (height * W * 2)).from_address(data), dtype=np.uint16).reshape(height, W, 1)
+        assert np.array_equal(got, full[top:top + height]), (step, top)
+assert mock.mock_hip_peer_copies() - n0 == 2 * 4                # 2 boundaries x 2 directions, twice
+assert mock.mock_hip_peer_bytes() - b0 == 2 * 4 * halo * W * 2
+mask, scale = libvips_amd.gaussmat(5, 0.01, False, "float")
+m = np.ascontiguousarray(mask, dtype=np.float64)
+outs = (ctypes.c_void_p * 3)()
+assert lib.vips_hip_conv_strips(strips, outs, m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), m.shape[1], m.shape[0],
+                                scale, 0.0, 1) == 0, _ffi.error_buffer()
+for k in range(3):
+    assert lib.vips_hip_image_get_device(outs[k]) == devices[k]
+    assert lib.vips_hip_image_get_width(outs[k]) == W and lib.vips_hip_image_get_format(outs[k]) == 6
+    lib.vips_hip_image_unref(outs[k])
+short = _ffi.check_handle(lib.vips_hip_strips_new(W, H, 1, 2, 2, devices, 3))
+assert lib.vips_hip_conv_strips(short, outs, m.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), m.shape[1], m.shape[0],
+                                scale, 0.0, 1) == -1 and "halo" in _ffi.error_buffer()
+lib.vips_hip_error_clear()
+lib.vips_hip_strips_free(short)
+lib.vips_hip_strips_free(strips)
+assert lib.vips_hip_current_device() == 0
+''', tmp_path, {"MOCK_HIP_DEVICES": "2", "VIPS_HIP_DEVICES": "0,1"})
 
 
 @pytest.mark.skipif(not helpers.have_module(), reason="oracle/_ref or host/_build missing")
