@@ -456,6 +456,88 @@ def run_c2(ctx, args):
     }
 
 
+# ------------------------------------------------------------------------------- module e2e
+
+def run_module_e2e(ctx, kernel_ms=None):
+    """SURVEY.md 8(d) "exclude H2D / D2H (report separately)": the C2 operation end to end the way a
+    libvips user meets it -- `reduce_hip` from the loadable module on a HOST-resident 16384 x 16384
+    RGBA image, evaluated through vips_image_write_to_memory() -- beside the built-in `reduce` on
+    the same cores, with the two PCIe legs timed on their own.  Two module runs: the whole image in
+    one piece (pageable upload) and, with a 512 MiB budget, the overlapped strip loop (pull into
+    pinned memory / upload / kernels / download on two streams)."""
+    import ctypes
+
+    helpers = ref_or_none()
+    if helpers is None or not helpers.have_module():
+        return None
+    torch, lib = ctx.torch, ctx.lib
+    helpers.Ref.load_module()
+    n = 16384
+    with torch.cuda.stream(ctx.stream):
+        src = lcg_image_device(torch, n, n, 4, 12345, ctx.device)
+    torch.cuda.synchronize()
+    host = src.cpu().numpy()
+    nbytes = host.nbytes
+    cores = os.cpu_count() or 1
+    args = "hshrink=8,vshrink=8,kernel=lanczos3"
+    want = helpers.Ref.run_chain("reduce:" + args, host)
+    got = helpers.Ref.run_chain("reduce_hip:" + args, host)
+    exact = bool(got.shape == want.shape and np.array_equal(got, want))
+    t_whole = helpers.Ref.time_chain("reduce_hip:" + args, host, repeats=3, concurrency=cores)
+    os.environ["VIPS_HIP_BUDGET"] = "512m"
+    try:
+        got_strips = helpers.Ref.run_chain("reduce_hip:" + args, host)
+        t_strips = helpers.Ref.time_chain("reduce_hip:" + args, host, repeats=3, concurrency=cores)
+    finally:
+        del os.environ["VIPS_HIP_BUDGET"]
+    exact = exact and bool(np.array_equal(got_strips, want))
+    t_ref = helpers.Ref.time_chain("reduce:" + args, host, repeats=3, concurrency=cores)
+
+    # the PCIe legs alone: the 1 GiB image up (pageable as libvips hands it over, and pinned), the
+    # 16 MiB result down
+    def best(fn, reps=3):
+        t = 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            t = min(t, time.perf_counter() - t0)
+        return t
+
+    dev = lib.vips_hip_malloc(nbytes)
+    pinned = lib.vips_hip_malloc_host(nbytes)
+    ctypes.memmove(pinned, host.ctypes.data, nbytes)
+    out_bytes = want.nbytes
+    h2d_pageable = best(lambda: lib.vips_hip_memcpy_h2d(dev, host.ctypes.data, nbytes))
+    h2d_pinned = best(lambda: lib.vips_hip_memcpy_h2d(dev, pinned, nbytes))
+    d2h_pinned = best(lambda: lib.vips_hip_memcpy_d2h(pinned, dev, out_bytes))
+    lib.vips_hip_free(dev)
+    lib.vips_hip_free_host(pinned)
+    del src
+    ctx.trim()
+    if not exact:
+        raise SystemExit("bench.py: reduce_hip through the module differs from the built-in reduce")
+    return {
+        "name": "module_e2e",
+        "workload": "reduce_hip (loadable module) vs reduce (built-in) on a host-resident %dx%dx4 u8 image, "
+                    "vips_image_write_to_memory, %d host cores" % (n, n, cores),
+        "ms_module_whole_image": round(t_whole * 1e3, 2),
+        "ms_module_strips_512m": round(t_strips * 1e3, 2),
+        "ms_builtin_reduce": round(t_ref * 1e3, 2),
+        "speedup_vs_builtin": round(t_ref / min(t_whole, t_strips), 2),
+        "h2d_ms_pageable": round(h2d_pageable * 1e3, 2),
+        "h2d_GBps_pageable": round(nbytes / h2d_pageable / 1e9, 1),
+        "h2d_ms_pinned": round(h2d_pinned * 1e3, 2),
+        "h2d_GBps_pinned": round(nbytes / h2d_pinned / 1e9, 1),
+        "d2h_ms_result": round(d2h_pinned * 1e3, 3),
+        "kernel_ms": kernel_ms,
+        "mpixels_per_s_e2e": round(float(n) * n / min(t_whole, t_strips) / 1e6, 1),
+        "parity": {"against": "the built-in reduce in the same process, whole output, both module paths",
+                   "bit_exact": exact},
+        "note": "the device kernel is %s of the end-to-end time: a host-resident image is bound by PCIe"
+                % ("%.1f %%" % (100.0 * kernel_ms / (min(t_whole, t_strips) * 1e3)) if kernel_ms else "a small part"),
+    }
+
+
 # ------------------------------------------------------------------------------------- C1
 
 def run_c1(ctx, steps, warmup, verify=True, cpu=True, size=4096):
@@ -556,8 +638,7 @@ def run_c3(ctx, steps, warmup, verify=True, cpu=True, size=32768):
         "frac": round(flops / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
         "frac_fp64": round(flops / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
         "frac_hbm": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-        "float_mode": "exact (bit for bit)" if ctx.lib.vips_hip_get_exact_float() else
-                      "default (fused multiply-adds, coefficients / scale: <= 1 ULP)",
+        "float_mode": "the reference's own arithmetic (the fused blur + colour kernel has no other mode)",
         "dtype": "f32 (f64 sums)",
         "kernels": kernels_of(report),
     }
@@ -944,6 +1025,10 @@ def main():
                 run_c5slab(ctx, max(2, min(args.steps, 4)), 2, verify, cpu),
                 c5_entry(run_c5(ctx, 2, 1, verify)),
             ]
+            if verify and cpu:
+                e2e = run_module_e2e(ctx, line["roofline"]["kernel_ms"] if line.get("roofline") else None)
+                if e2e:
+                    line["configs"].append(e2e)
     elif args.config == "c3":
         e = run_c3(ctx, args.steps, args.warmup, verify, cpu, args.size or 32768)
         line = entry_as_line(e, ctx, args.steps, args.warmup,

@@ -154,6 +154,7 @@ typedef struct _VipsHipOp {
 	char *eval_error;       /* non-NULL: evaluation failed, with this message */
 	VipsHipImage *result;   /* the result on the device (NULL after a strip-mined run) */
 	VipsPel *host;          /* the result on the host, for generate */
+	gboolean host_pinned;   /* ... in pinned memory (vips_hip_malloc_host) */
 } VipsHipOp;
 
 typedef struct _VipsHipOpClass {
@@ -171,6 +172,14 @@ typedef struct _VipsHipOpClass {
 	void (*strip_need)(struct _VipsHipOp *op, void *plan, int out_top, int out_rows, int *in_top, int *in_rows);
 	int (*strip_run)(struct _VipsHipOp *op, void *plan, const VipsHipRegion *in, const VipsHipRegion *out);
 	void (*strip_close)(struct _VipsHipOp *op, void *plan);
+
+	/* Optional, instead of the four hooks above: operations whose output row y reads input rows
+	 * y - above .. y + below only (pointwise: 0, 0).  Their region form is the image-level
+	 * operation itself run on a window -- the rows of the strip plus that halo -- of which the
+	 * strip's rows are kept: at the image's own top and bottom the window ends where the image
+	 * ends, so the edge handling is the whole-image operation's.  Returns 1 when this instance
+	 * cannot be strip-mined. */
+	int (*halo)(struct _VipsHipOp *op, VipsImage *in, int *above, int *below);
 
 	/* Optional: this operation and the not-yet-evaluated *_hip operation that makes its input
 	 * as ONE device call (colourspace_hip after gaussblur_hip: BASELINE config 3 in one kernel).
@@ -232,10 +241,98 @@ hip_check_header(VipsHipOp *op, int width, int height, int bands, int format)
 	return 0;
 }
 
-/* The image in row strips: pull the input rows a strip needs from upstream (a threaded
- * vips_sink_memory() of a vips_crop()), upload, run the region form, download into the host
- * result.  Returns 1 when this operation cannot be strip-mined.
+/* ---- the strip loop: images over the HBM budget
+ *
+ * The reference evaluates any pipeline with bounded memory: a sink asks for tiles, threads
+ * compute them (iofuncs/sink.c:469, thread.c:301-325) and sinkdisc.c:177-220 writes one buffer
+ * behind the one being filled.  Here the unit is a row strip of gigabytes and the stages are
+ * pull (libvips' own threaded evaluation of the upstream pipeline, straight into PINNED
+ * memory), upload, kernels, download: strip k + 1 is pulled while strip k's upload, kernels
+ * and download run on the device, strips alternate between two streams and two pinned input
+ * buffers, and the result lands in one pinned host image that generate serves rows from.
  */
+
+/* pull target: rows [top, top + rows) of an image into a buffer */
+typedef struct _HipPull {
+	VipsPel *buf;
+	size_t ls;
+	int top;
+} HipPull;
+
+static int
+hip_pull_gen(VipsRegion *region, void *seq, void *a, void *b, gboolean *stop)
+{
+	HipPull *pull = (HipPull *) b;
+	VipsRect *r = &region->valid;
+	const size_t ps = VIPS_IMAGE_SIZEOF_PEL(region->im);
+
+	for (int y = 0; y < r->height; y++)
+		memcpy(pull->buf + (size_t) (r->top + y - pull->top) * pull->ls + (size_t) r->left * ps,
+			VIPS_REGION_ADDR(region, r->left, r->top + y), (size_t) r->width * ps);
+
+	return 0;
+}
+
+/* rows [top, top + rows) of @in into @buf, evaluated by libvips' thread pool */
+static int
+hip_pull_rows(VipsImage *in, int top, int rows, VipsPel *buf)
+{
+	VipsImage *crop = NULL;
+	HipPull pull = { buf, VIPS_IMAGE_SIZEOF_LINE(in), 0 };
+	int result;
+
+	if (vips_crop(in, &crop, 0, top, in->Xsize, rows, NULL))
+		return -1;
+	result = vips_sink(crop, vips_start_one, hip_pull_gen, vips_stop_one, crop, &pull);
+	g_object_unref(crop);
+
+	return result;
+}
+
+/* The generic region form of operations with a halo hook: the image-level operation on the
+ * window, the strip's rows copied out. */
+typedef struct _HaloStrip {
+	int above, below;
+} HaloStrip;
+
+static int
+hip_halo_run(VipsHipOp *op, HaloStrip *plan, const VipsHipRegion *in, const VipsHipRegion *out)
+{
+	VipsHipOpClass *hclass = VIPS_HIP_OP_GET_CLASS(op);
+	VipsHipImage *window, *made = NULL;
+	int result = -1;
+
+	if (!(window = vips_hip_image_new_from_device(in->data, in->width, in->height, in->bands, in->format,
+			  op->ready->Type)))
+		return -1;
+	if (!hclass->compute(op, window, &made)) {
+		const int skip = out->top - in->top;
+
+		if (vips_hip_image_get_width(made) != out->width || vips_hip_image_get_height(made) != in->height ||
+			vips_hip_image_get_bands(made) != out->bands || vips_hip_image_get_format(made) != out->format ||
+			skip < 0 || skip + out->height > in->height)
+			vips_error(VIPS_OBJECT_GET_CLASS(op)->nickname, "%s", "window result does not match the strip");
+		else
+			result = vips_hip_memcpy_d2d(out->data,
+				(char *) vips_hip_image_get_data(made) + (size_t) skip * vips_hip_image_get_stride(made),
+				(size_t) out->height * out->stride);
+	}
+	/* (the pool orders reuse of these blocks behind the copy: same thread, same stream) */
+	vips_hip_image_unref(made);
+	vips_hip_image_unref(window);
+
+	return result;
+}
+
+/* how many strips the loop below has run in this process (the tests ask: was it strip-mined?) */
+static volatile gint hip_strips_done = 0;
+
+G_MODULE_EXPORT int
+vips_hip_module_strips_done(void)
+{
+	return g_atomic_int_get(&hip_strips_done);
+}
+
 static int
 hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
 {
@@ -244,86 +341,168 @@ hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
 	VipsImage *out = op->out;
 	const size_t ls = VIPS_IMAGE_SIZEOF_LINE(out);
 	const size_t in_ls = VIPS_IMAGE_SIZEOF_LINE(in);
+	const gboolean generic = hclass->halo != NULL && !hclass->strip_open;
+	HaloStrip halo = { 0, 0 };
 	void *plan = NULL;
-	VipsPel *host;
-	int rows;
+	VipsPel *host = NULL;
+	gboolean pinned = TRUE;
+	VipsPel *stage[2] = { NULL, NULL };
+	void *stream[2] = { NULL, NULL };
+	void *computed[2] = { NULL, NULL }, *finished[2] = { NULL, NULL };
+	VipsHipImage *dev_in[2] = { NULL, NULL }, *dev_out[2] = { NULL, NULL };
+	int rows, max_in_rows = 0;
 	int result;
 
-	if (!hclass->strip_open || !hclass->strip_need || !hclass->strip_run)
-		return 1;
-	if ((result = hclass->strip_open(op, in, &plan)))
-		return result;
+	if (generic) {
+		if ((result = hclass->halo(op, in, &halo.above, &halo.below)))
+			return result;
+	}
+	else {
+		if (!hclass->strip_open || !hclass->strip_need || !hclass->strip_run)
+			return 1;
+		if ((result = hclass->strip_open(op, in, &plan)))
+			return result;
+	}
+
+#define STRIP_NEED(TOP, N, IN_TOP, IN_ROWS) \
+	do { \
+		if (generic) { \
+			*(IN_TOP) = (TOP) - halo.above; \
+			*(IN_ROWS) = (N) + halo.above + halo.below; \
+		} \
+		else \
+			hclass->strip_need(op, plan, (TOP), (N), (IN_TOP), (IN_ROWS)); \
+		if (*(IN_TOP) < 0) { \
+			*(IN_ROWS) += *(IN_TOP); \
+			*(IN_TOP) = 0; \
+		} \
+		*(IN_ROWS) = VIPS_MIN(*(IN_ROWS), in->Ysize - *(IN_TOP)); \
+	} while (0)
 
 	/* the tallest strip (a multiple of 16 lines: the reference's fat-strip height, which the
-	 * vertical reduce re-seeds its position on) whose input rows + output rows fit */
+	 * vertical reduce re-seeds its position on) of which TWO -- one being pulled and uploaded,
+	 * one being computed and downloaded -- fit with their input rows */
 	for (rows = VIPS_ROUND_UP(out->Ysize, 16); rows > 16; rows = VIPS_ROUND_UP(rows / 2, 16)) {
 		int in_top, in_rows;
 
-		hclass->strip_need(op, plan, 0, VIPS_MIN(rows, out->Ysize), &in_top, &in_rows);
-		if ((guint64) in_rows * in_ls + (guint64) rows * ls <= budget)
+		STRIP_NEED(0, VIPS_MIN(rows, out->Ysize), &in_top, &in_rows);
+		if (2 * ((guint64) in_rows * in_ls + (guint64) rows * ls) <= budget)
 			break;
 	}
+	for (int top = 0; top < out->Ysize; top += rows) {
+		int in_top, in_rows;
 
-	if (!(host = (VipsPel *) g_try_malloc(ls * out->Ysize))) {
-		vips_error(nick, "%s", "out of memory for the result");
-		if (hclass->strip_close)
-			hclass->strip_close(op, plan);
-		return -1;
+		STRIP_NEED(top, VIPS_MIN(rows, out->Ysize - top), &in_top, &in_rows);
+		max_in_rows = VIPS_MAX(max_in_rows, in_rows);
 	}
 
-	result = 0;
-	for (int top = 0; top < out->Ysize && !result; top += rows) {
+	/* the host result and the two staging buffers, pinned (a result too large to pin is
+	 * ordinary memory: its downloads then simply do not overlap); two input windows and two
+	 * output strips on the device, kept for the whole loop */
+	if (!(host = (VipsPel *) vips_hip_malloc_host(ls * out->Ysize))) {
+		vips_hip_error_clear();
+		pinned = FALSE;
+		host = (VipsPel *) g_try_malloc(ls * out->Ysize);
+	}
+	result = host ? 0 : -1;
+	if (!host)
+		vips_error(nick, "%s", "out of memory for the result");
+	for (int i = 0; i < 2 && !result; i++)
+		if (!(stage[i] = (VipsPel *) vips_hip_malloc_host((size_t) max_in_rows * in_ls)) ||
+			!(stream[i] = vips_hip_stream_new()) ||
+			!(computed[i] = vips_hip_event_new()) || !(finished[i] = vips_hip_event_new()) ||
+			!(dev_in[i] = vips_hip_image_new(in->Xsize, max_in_rows, in->Bands, in->BandFmt, in->Type)) ||
+			!(dev_out[i] = vips_hip_image_new(out->Xsize, VIPS_MIN(rows, out->Ysize), out->Bands, out->BandFmt, out->Type)))
+			result = hip_fail(nick);
+
+	if (!result) {
+		int in_top, in_rows;
+
+		STRIP_NEED(0, VIPS_MIN(rows, out->Ysize), &in_top, &in_rows);
+		result = hip_pull_rows(in, in_top, in_rows, stage[0]);
+	}
+	for (int top = 0, k = 0; top < out->Ysize && !result; top += rows, k++) {
+		const int b = k & 1;
 		const int n = VIPS_MIN(rows, out->Ysize - top);
-		VipsImage *crop = NULL, *mem = NULL;
-		VipsHipImage *dev_in = NULL, *dev_out = NULL;
 		VipsHipRegion ri, ro;
 		int in_top, in_rows;
 
-		hclass->strip_need(op, plan, top, n, &in_top, &in_rows);
-		if (in_top < 0) {
-			in_rows += in_top;
-			in_top = 0;
-		}
-		in_rows = VIPS_MIN(in_rows, in->Ysize - in_top);
-
+		STRIP_NEED(top, n, &in_top, &in_rows);
 		if (vips_image_iskilled(out)) {
 			vips_error(nick, "%s", "killed");
 			result = -1;
+			break;
 		}
-		else if (vips_crop(in, &crop, 0, in_top, in->Xsize, in_rows, NULL) ||
-			!(mem = vips_image_copy_memory(crop)))
-			result = -1;
-		else if (!(dev_in = vips_hip_image_new_from_memory(VIPS_IMAGE_ADDR(mem, 0, 0),
-					   mem->Xsize, mem->Ysize, mem->Bands, mem->BandFmt, mem->Type)) ||
-			!(dev_out = vips_hip_image_new(out->Xsize, n, out->Bands, out->BandFmt, out->Type)))
+		/* strip k on stream b: its upload may run beside strip k - 1's kernels and download (the
+		 * other stream); its KERNELS wait for strip k - 1's -- the operation's temporaries come
+		 * from a pool that orders reuse within one stream, and kernels of two strips have nothing
+		 * to gain from running side by side */
+		if (vips_hip_set_stream(stream[b]) ||
+			vips_hip_memcpy_h2d_async(vips_hip_image_get_data(dev_in[b]), stage[b], (size_t) in_rows * in_ls) ||
+			(k > 0 && vips_hip_stream_wait_event(computed[1 - b]))) {
 			result = hip_fail(nick);
-		else {
-			vips_hip_image_region(dev_in, &ri);
-			ri.top = in_top;
-			ri.im_width = in->Xsize;
-			ri.im_height = in->Ysize;
-			vips_hip_image_region(dev_out, &ro);
-			ro.top = top;
-			ro.im_width = out->Xsize;
-			ro.im_height = out->Ysize;
-			if (hclass->strip_run(op, plan, &ri, &ro) ||
-				vips_hip_image_write_to_memory(dev_out, host + (size_t) top * ls))
+			break;
+		}
+		vips_hip_image_region(dev_in[b], &ri);
+		ri.top = in_top;
+		ri.height = in_rows;
+		ri.im_width = in->Xsize;
+		ri.im_height = in->Ysize;
+		vips_hip_image_region(dev_out[b], &ro);
+		ro.top = top;
+		ro.height = n;
+		ro.im_width = out->Xsize;
+		ro.im_height = out->Ysize;
+		if ((generic ? hip_halo_run(op, &halo, &ri, &ro) : hclass->strip_run(op, plan, &ri, &ro)) ||
+			vips_hip_event_record(computed[b]) ||
+			(pinned ? vips_hip_memcpy_d2h_async(host + (size_t) top * ls, vips_hip_image_get_data(dev_out[b]), (size_t) n * ls)
+					: vips_hip_memcpy_d2h(host + (size_t) top * ls, vips_hip_image_get_data(dev_out[b]), (size_t) n * ls)) ||
+			vips_hip_event_record(finished[b])) {
+			result = hip_fail(nick);
+			break;
+		}
+		g_atomic_int_inc(&hip_strips_done);
+		/* meanwhile, on the host: strip k + 1 is pulled into the buffer strip k - 1 was uploaded
+		 * from (that strip is complete: its stream comes next) */
+		if (top + rows < out->Ysize) {
+			if (k > 0 && vips_hip_event_synchronize(finished[1 - b])) {
+				result = hip_fail(nick);
+				break;
+			}
+			STRIP_NEED(top + rows, VIPS_MIN(rows, out->Ysize - top - rows), &in_top, &in_rows);
+			result = hip_pull_rows(in, in_top, in_rows, stage[1 - b]);
+		}
+	}
+#undef STRIP_NEED
+
+	/* everything queued must finish before its memory goes back (also on the failure paths) */
+	for (int i = 0; i < 2; i++) {
+		if (stream[i]) {
+			(void) vips_hip_set_stream(stream[i]);
+			if (vips_hip_synchronize() && !result)
 				result = hip_fail(nick);
 		}
-
-		vips_hip_image_unref(dev_out);
-		vips_hip_image_unref(dev_in);
-		VIPS_UNREF(mem);
-		VIPS_UNREF(crop);
+		vips_hip_image_unref(dev_in[i]);
+		vips_hip_image_unref(dev_out[i]);
 	}
-
-	if (hclass->strip_close)
+	(void) vips_hip_set_stream(NULL);
+	for (int i = 0; i < 2; i++) {
+		vips_hip_stream_free(stream[i]);
+		vips_hip_event_free(computed[i]);
+		vips_hip_event_free(finished[i]);
+		vips_hip_free_host(stage[i]);
+	}
+	if (!generic && hclass->strip_close)
 		hclass->strip_close(op, plan);
 	if (result) {
-		g_free(host);
+		if (pinned)
+			vips_hip_free_host(host);
+		else
+			g_free(host);
 		return -1;
 	}
 	op->host = host;
+	op->host_pinned = pinned;
 
 	return 0;
 }
@@ -680,7 +859,11 @@ vips_hip_op_dispose(GObject *gobject)
 {
 	VipsHipOp *op = VIPS_HIP_OP(gobject);
 
-	VIPS_FREE(op->host);
+	if (op->host_pinned)
+		vips_hip_free_host(op->host);
+	else
+		g_free(op->host);
+	op->host = NULL;
 	VIPS_FREE(op->eval_error);
 	if (op->result) {
 		vips_hip_image_unref(op->result);
@@ -746,6 +929,181 @@ vips_hip_op_init(VipsHipOp *op)
 	class->strip_run = type_name##_strip_run; \
 	class->strip_close = type_name##_strip_close;
 
+#define HIP_HALO(type_name) class->halo = type_name##_halo;
+
+/* ---- the region form of the whole resample family
+ *
+ * vips_reduce / vips_resize / vips_shrink are, per axis, an optional integer box shrink (the
+ * `gap` pre-shrink, reduceh.cpp:430-455 / reducev.cpp:894-917, or vips_shrink's own) and an
+ * optional residual reduce, vertical axis first (reduce.c:98-121, resize.c:207-228, shrink.c:77-119):
+ *     shrinkv(int_v) -> reducev(rv) -> shrinkh(int_h) -> reduceh(rh)
+ * Each stage has a generate replacement in the C ABI that works in whole-image coordinates, so a
+ * strip of output rows is made by walking its row range back through the vertical stages
+ * (vips_hip_reducev_need, x int_v) and the four gens forward, the rows between them on the device.
+ */
+typedef struct _ResampleStrip {
+	int int_v, int_h;
+	VipsHipReduce *rv, *rh;
+	int w0, h0; /* input */
+	int h1;     /* rows after shrinkv */
+	int h2;     /* ... after reducev = output rows */
+	int w1;     /* columns after shrinkh */
+	int w2;     /* ... after reduceh = output columns */
+} ResampleStrip;
+
+/* one axis of vips_reduceh_build / vips_reducev_build: the output size, the integer pre-shrink
+ * `gap` buys and the residual factor (reduceh.cpp:396-481, reducev.cpp:859-941) */
+static int
+resample_axis(const char *nick, int in_size, double shrink, VipsKernel kernel, double gap,
+	int *int_shrink, int *shrunk_size, VipsHipReduce **reduce, int *out_size)
+{
+	int size = (int) ((double) in_size / shrink + 0.5);
+	double extra = size * shrink - in_size;
+	double residual = shrink;
+
+	*int_shrink = 1;
+	*shrunk_size = in_size;
+	*reduce = NULL;
+	if (size <= 0) {
+		vips_error(nick, "%s", "image has shrunk to nothing");
+		return -1;
+	}
+	if (gap > 0.0 && kernel != VIPS_KERNEL_NEAREST) {
+		const int k = (int) floor((double) in_size / size / gap);
+
+		if (k > 1) {
+			*int_shrink = k;
+			residual /= k;
+			extra /= k;
+			*shrunk_size = vips_hip_shrink_out_size(in_size, k, 1); /* "ceil", TRUE */
+		}
+	}
+	*out_size = residual == 1.0 ? *shrunk_size : size;
+	if (residual != 1.0 &&
+		!(*reduce = vips_hip_reduce_new(kernel, residual, *shrunk_size, size, extra)))
+		return hip_fail(nick);
+
+	return 0;
+}
+
+static void
+resample_strip_close(VipsHipOp *op, void *plan)
+{
+	ResampleStrip *p = (ResampleStrip *) plan;
+
+	if (p) {
+		vips_hip_reduce_free(p->rv);
+		vips_hip_reduce_free(p->rh);
+		g_free(p);
+	}
+}
+
+/* vshrink / hshrink >= 1: the factors of the two axes (1 = untouched); int_only: box shrinks of
+ * exactly these (integer) factors, rounding up when ceil is set, no reduce */
+static int
+resample_strip_open(VipsHipOp *op, VipsImage *in, double vshrink, double hshrink, VipsKernel kernel, double gap,
+	gboolean int_only, gboolean ceil, void **plan)
+{
+	const char *nick = VIPS_OBJECT_GET_CLASS(op)->nickname;
+	ResampleStrip *p = g_new0(ResampleStrip, 1);
+
+	p->w0 = in->Xsize;
+	p->h0 = in->Ysize;
+	p->int_v = p->int_h = 1;
+	p->h1 = p->h2 = p->h0;
+	p->w1 = p->w2 = p->w0;
+	if (int_only) {
+		p->int_v = (int) vshrink;
+		p->int_h = (int) hshrink;
+		p->h1 = p->h2 = p->int_v > 1 ? vips_hip_shrink_out_size(p->h0, p->int_v, ceil) : p->h0;
+		p->w1 = p->w2 = p->int_h > 1 ? vips_hip_shrink_out_size(p->w0, p->int_h, ceil) : p->w0;
+	}
+	else if ((vshrink != 1.0 && resample_axis(nick, p->h0, vshrink, kernel, gap, &p->int_v, &p->h1, &p->rv, &p->h2)) ||
+		(hshrink != 1.0 && resample_axis(nick, p->w0, hshrink, kernel, gap, &p->int_h, &p->w1, &p->rh, &p->w2))) {
+		resample_strip_close(op, p);
+		return -1;
+	}
+	if (p->h2 != op->out->Ysize || p->w2 != op->out->Xsize || p->h1 <= 0 || p->w1 <= 0) {
+		/* not the decomposition the original operation's header came from: whole image only */
+		resample_strip_close(op, p);
+		return 1;
+	}
+	*plan = p;
+
+	return 0;
+}
+
+static void
+resample_strip_need(VipsHipOp *op, void *plan, int out_top, int out_rows, int *in_top, int *in_rows)
+{
+	ResampleStrip *p = (ResampleStrip *) plan;
+	int top = out_top, rows = out_rows;
+
+	if (p->rv)
+		vips_hip_reducev_need(p->rv, out_top, out_rows, &top, &rows);
+	*in_top = top * p->int_v;
+	*in_rows = rows * p->int_v;
+}
+
+static int
+resample_strip_run(VipsHipOp *op, void *plan, const VipsHipRegion *in, const VipsHipRegion *out)
+{
+	ResampleStrip *p = (ResampleStrip *) plan;
+	VipsHipImage *tmp[3] = { NULL, NULL, NULL };
+	VipsHipRegion cur = *in, next;
+	int n = 0, result = 0;
+	int top1 = out->top, rows1 = out->height;
+
+	if (p->rv)
+		vips_hip_reducev_need(p->rv, out->top, out->height, &top1, &rows1);
+
+	/* a stage writes into a device image of its own unless it is the last one, which writes `out` */
+#define STAGE(LAST, WIDTH, TOP, ROWS, IM_W, IM_H, CALL) \
+	do { \
+		if (LAST) \
+			next = *out; \
+		else { \
+			if (!(tmp[n] = vips_hip_image_new((WIDTH), (ROWS), in->bands, in->format, 0))) { \
+				result = -1; \
+				break; \
+			} \
+			vips_hip_image_region(tmp[n], &next); \
+			next.top = (TOP); \
+			next.im_width = (IM_W); \
+			next.im_height = (IM_H); \
+			n++; \
+		} \
+		if (CALL) \
+			result = -1; \
+		cur = next; \
+	} while (0)
+
+	if (!result && p->int_v > 1)
+		STAGE(!p->rv && p->int_h == 1 && !p->rh, p->w0, top1, rows1, p->w0, p->h1,
+			vips_hip_shrinkv_gen(p->int_v, &cur, &next));
+	/* 16: the fat-strip height the reference's sink evaluates reducev in (thread.c:301-325), what
+	 * the whole-image path uses (strips are multiples of 16 lines) */
+	if (!result && p->rv)
+		STAGE(p->int_h == 1 && !p->rh, p->w0, out->top, out->height, p->w0, p->h2,
+			vips_hip_reducev_gen_tiled(p->rv, &cur, &next, 16));
+	if (!result && p->int_h > 1)
+		STAGE(!p->rh, p->w1, out->top, out->height, p->w1, p->h2, vips_hip_shrinkh_gen(p->int_h, &cur, &next));
+	if (!result && p->rh)
+		STAGE(TRUE, p->w2, out->top, out->height, p->w2, p->h2, vips_hip_reduceh_gen(p->rh, &cur, &next));
+#undef STAGE
+	/* (the pool orders reuse of these blocks behind the kernels: same thread, same stream) */
+	for (int i = 0; i < 3; i++)
+		vips_hip_image_unref(tmp[i]);
+
+	return result ? hip_fail(VIPS_OBJECT_GET_CLASS(op)->nickname) : 0;
+}
+
+#define HIP_RESAMPLE_STRIPS(type_name) \
+	class->strip_open = type_name##_strip_open; \
+	class->strip_need = resample_strip_need; \
+	class->strip_run = resample_strip_run; \
+	class->strip_close = resample_strip_close;
+
 /* reduce_hip: resample/reduce.c:98-200 */
 typedef struct _VipsReduceHip {
 	VipsHipOp parent_instance;
@@ -761,83 +1119,42 @@ vips_reduce_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
 	return vips_hip_reduce(in, out, reduce->hshrink, reduce->vshrink, reduce->kernel, reduce->gap);
 }
 
-/* The region form of reduce_hip: the plans the whole-image operation would make
- * (ops_resample.cpp vips_hip_reduce), run per strip through the generate replacements. */
-typedef struct _ReduceStrip {
-	VipsHipReduce *rv, *rh;
-	int in_width, out_height;
-} ReduceStrip;
-
-static void
-vips_reduce_hip_strip_close(VipsHipOp *op, void *plan)
-{
-	ReduceStrip *p = (ReduceStrip *) plan;
-
-	if (p) {
-		vips_hip_reduce_free(p->rv);
-		vips_hip_reduce_free(p->rh);
-		g_free(p);
-	}
-}
-
+/* The region form (images over the HBM budget): RGBA uchar with an even integer factor and no
+ * pre-shrink takes the fused kernel per strip, everything else the chain of generate
+ * replacements. */
 static int
 vips_reduce_hip_strip_open(VipsHipOp *op, VipsImage *in, void **plan)
 {
 	VipsReduceHip *reduce = (VipsReduceHip *) op;
-	ReduceStrip *p;
 
-	/* a reducing gap puts integer pre-shrinks in front; factor 1 is a copy: whole image only */
-	if (reduce->gap > 0.0 || reduce->hshrink == 1.0 || reduce->vshrink == 1.0 ||
-		reduce->kernel == VIPS_KERNEL_NEAREST)
+	if (reduce->kernel == VIPS_KERNEL_NEAREST)
 		return 1;
-	p = g_new0(ReduceStrip, 1);
-	p->in_width = in->Xsize;
-	p->out_height = op->out->Ysize;
-	p->rv = vips_hip_reduce_new(reduce->kernel, reduce->vshrink, in->Ysize, op->out->Ysize, NAN);
-	p->rh = vips_hip_reduce_new(reduce->kernel, reduce->hshrink, in->Xsize, op->out->Xsize, NAN);
-	if (!p->rv || !p->rh) {
-		vips_reduce_hip_strip_close(op, p);
-		return hip_fail("reduce_hip");
-	}
-	*plan = p;
-
-	return 0;
-}
-
-static void
-vips_reduce_hip_strip_need(VipsHipOp *op, void *plan, int out_top, int out_rows, int *in_top, int *in_rows)
-{
-	vips_hip_reducev_need(((ReduceStrip *) plan)->rv, out_top, out_rows, in_top, in_rows);
+	return resample_strip_open(op, in, reduce->vshrink, reduce->hshrink, reduce->kernel, reduce->gap, FALSE, FALSE,
+		plan);
 }
 
 static int
 vips_reduce_hip_strip_run(VipsHipOp *op, void *plan, const VipsHipRegion *in, const VipsHipRegion *out)
 {
-	ReduceStrip *p = (ReduceStrip *) plan;
-	VipsHipImage *mid;
-	VipsHipRegion rmid;
-	int r;
+	ResampleStrip *p = (ResampleStrip *) plan;
 
-	/* 16: the fat-strip height the reference's sink evaluates reducev in (thread.c:301-325),
-	 * what the whole-image path uses */
-	if ((r = vips_hip_reduce_gen_tiled(p->rv, p->rh, in, out, 16)) <= 0)
-		return r;
-	/* not the fused uchar RGBA case: the two passes, the rows between them on the device */
-	if (!(mid = vips_hip_image_new(p->in_width, out->height, in->bands, in->format, 0)))
-		return -1;
-	vips_hip_image_region(mid, &rmid);
-	rmid.top = out->top;
-	rmid.im_width = p->in_width;
-	rmid.im_height = p->out_height;
-	r = vips_hip_reducev_gen_tiled(p->rv, in, &rmid, 16) || vips_hip_reduceh_gen(p->rh, &rmid, out);
-	/* the pool orders reuse of mid's block behind these kernels (same thread, same stream) */
-	vips_hip_image_unref(mid);
+	if (p->int_v == 1 && p->int_h == 1 && p->rv && p->rh) {
+		const int r = vips_hip_reduce_gen_tiled(p->rv, p->rh, in, out, 16);
 
-	return r ? -1 : 0;
+		if (r <= 0)
+			return r;
+	}
+	return resample_strip_run(op, plan, in, out);
 }
 
+#define VIPS_REDUCE_HIP_STRIPS \
+	class->strip_open = vips_reduce_hip_strip_open; \
+	class->strip_need = resample_strip_need; \
+	class->strip_run = vips_reduce_hip_strip_run; \
+	class->strip_close = resample_strip_close;
+
 HIP_SUBCLASS_FULL(VipsReduceHip, vips_reduce_hip, "reduce_hip", "reduce an image (MI355X)",
-	HIP_STRIPS(vips_reduce_hip))
+	VIPS_REDUCE_HIP_STRIPS)
 
 static void
 vips_reduce_hip_args(VipsReduceHipClass *class)
@@ -886,8 +1203,30 @@ vips_reducev_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
 	return vips_hip_reducev(in, out, r->shrink, r->kernel, r->gap);
 }
 
-HIP_SUBCLASS(VipsReducehHip, vips_reduceh_hip, "reduceh_hip", "shrink an image horizontally (MI355X)")
-HIP_SUBCLASS(VipsReducevHip, vips_reducev_hip, "reducev_hip", "shrink an image vertically (MI355X)")
+static int
+vips_reduceh_hip_strip_open(VipsHipOp *op, VipsImage *in, void **plan)
+{
+	VipsReduce1Hip *r = (VipsReduce1Hip *) op;
+
+	if (r->kernel == VIPS_KERNEL_NEAREST)
+		return 1;
+	return resample_strip_open(op, in, 1.0, r->shrink, r->kernel, r->gap, FALSE, FALSE, plan);
+}
+
+static int
+vips_reducev_hip_strip_open(VipsHipOp *op, VipsImage *in, void **plan)
+{
+	VipsReduce1Hip *r = (VipsReduce1Hip *) op;
+
+	if (r->kernel == VIPS_KERNEL_NEAREST)
+		return 1;
+	return resample_strip_open(op, in, r->shrink, 1.0, r->kernel, r->gap, FALSE, FALSE, plan);
+}
+
+HIP_SUBCLASS_FULL(VipsReducehHip, vips_reduceh_hip, "reduceh_hip", "shrink an image horizontally (MI355X)",
+	HIP_RESAMPLE_STRIPS(vips_reduceh_hip))
+HIP_SUBCLASS_FULL(VipsReducevHip, vips_reducev_hip, "reducev_hip", "shrink an image vertically (MI355X)",
+	HIP_RESAMPLE_STRIPS(vips_reducev_hip))
 
 #define REDUCE1_ARGS(class, NAME, LONG) \
 	VIPS_ARG_DOUBLE(class, NAME, 3, LONG, LONG " shrink factor", \
@@ -939,7 +1278,22 @@ vips_shrink_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
 	return vips_hip_shrink(in, out, shrink->hshrink, shrink->vshrink, shrink->ceil);
 }
 
-HIP_SUBCLASS(VipsShrinkHip, vips_shrink_hip, "shrink_hip", "shrink an image (MI355X)")
+/* shrink.c:77-119: integer factors are the two box shrinks; anything else is vips_reducev /
+ * vips_reduceh with "gap", 1.0 */
+static int
+vips_shrink_hip_strip_open(VipsHipOp *op, VipsImage *in, void **plan)
+{
+	VipsShrinkHip *shrink = (VipsShrinkHip *) op;
+
+	if ((int) shrink->hshrink == shrink->hshrink && (int) shrink->vshrink == shrink->vshrink)
+		return resample_strip_open(op, in, shrink->vshrink, shrink->hshrink, VIPS_KERNEL_LANCZOS3, 0.0, TRUE,
+			shrink->ceil, plan);
+	return resample_strip_open(op, in, shrink->vshrink, shrink->hshrink, VIPS_KERNEL_LANCZOS3, 1.0, FALSE, FALSE,
+		plan);
+}
+
+HIP_SUBCLASS_FULL(VipsShrinkHip, vips_shrink_hip, "shrink_hip", "shrink an image (MI355X)",
+	HIP_RESAMPLE_STRIPS(vips_shrink_hip))
 
 static void
 vips_shrink_hip_args(VipsShrinkHipClass *class)
@@ -983,8 +1337,26 @@ vips_shrinkv_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
 	return vips_hip_shrinkv(in, out, s->shrink, s->ceil);
 }
 
-HIP_SUBCLASS(VipsShrinkhHip, vips_shrinkh_hip, "shrinkh_hip", "shrink an image horizontally (MI355X)")
-HIP_SUBCLASS(VipsShrinkvHip, vips_shrinkv_hip, "shrinkv_hip", "shrink an image vertically (MI355X)")
+static int
+vips_shrinkh_hip_strip_open(VipsHipOp *op, VipsImage *in, void **plan)
+{
+	VipsShrink1Hip *s = (VipsShrink1Hip *) op;
+
+	return s->shrink == 1 ? 1 : resample_strip_open(op, in, 1.0, s->shrink, VIPS_KERNEL_LANCZOS3, 0.0, TRUE, s->ceil, plan);
+}
+
+static int
+vips_shrinkv_hip_strip_open(VipsHipOp *op, VipsImage *in, void **plan)
+{
+	VipsShrink1Hip *s = (VipsShrink1Hip *) op;
+
+	return s->shrink == 1 ? 1 : resample_strip_open(op, in, s->shrink, 1.0, VIPS_KERNEL_LANCZOS3, 0.0, TRUE, s->ceil, plan);
+}
+
+HIP_SUBCLASS_FULL(VipsShrinkhHip, vips_shrinkh_hip, "shrinkh_hip", "shrink an image horizontally (MI355X)",
+	HIP_RESAMPLE_STRIPS(vips_shrinkh_hip))
+HIP_SUBCLASS_FULL(VipsShrinkvHip, vips_shrinkv_hip, "shrinkv_hip", "shrink an image vertically (MI355X)",
+	HIP_RESAMPLE_STRIPS(vips_shrinkv_hip))
 
 #define SHRINK1_ARGS(class, NAME, LONG) \
 	VIPS_ARG_INT(class, NAME, 8, LONG, LONG " shrink factor", \
@@ -1032,7 +1404,26 @@ vips_resize_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
 	return vips_hip_resize(in, out, resize->scale, vscale, resize->kernel, resize->gap);
 }
 
-HIP_SUBCLASS(VipsResizeHip, vips_resize_hip, "resize_hip", "resize an image (MI355X)")
+/* The downsizing half of vips_resize (resize.c:207-228: vips_reducev then vips_reduceh, each
+ * with its `gap` pre-shrink) has a region form; upsizing and the nearest kernel (vips_subsample,
+ * vips_affine: resize.c:165-203, 230-300) go through whole. */
+static int
+vips_resize_hip_strip_open(VipsHipOp *op, VipsImage *in, void **plan)
+{
+	VipsResizeHip *resize = (VipsResizeHip *) op;
+	double hscale = resize->scale;
+	double vscale = vips_object_argument_isset(VIPS_OBJECT(op), "vscale") ? resize->vscale : resize->scale;
+
+	if (resize->kernel == VIPS_KERNEL_NEAREST || hscale <= 0.0 || vscale <= 0.0 || hscale > 1.0 || vscale > 1.0)
+		return 1;
+	/* "Don't let either axis drop below 1 px." (resize.c:197-200) */
+	hscale = VIPS_MAX(hscale, 1.0 / in->Xsize);
+	vscale = VIPS_MAX(vscale, 1.0 / in->Ysize);
+	return resample_strip_open(op, in, 1.0 / vscale, 1.0 / hscale, resize->kernel, resize->gap, FALSE, FALSE, plan);
+}
+
+HIP_SUBCLASS_FULL(VipsResizeHip, vips_resize_hip, "resize_hip", "resize an image (MI355X)",
+	HIP_RESAMPLE_STRIPS(vips_resize_hip))
 
 static void
 vips_resize_hip_args(VipsResizeHipClass *class)
@@ -1074,8 +1465,40 @@ vips_thumbnail_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
 		thumbnail->linear, thumbnail->crop);
 }
 
-HIP_SUBCLASS(VipsThumbnailHip, vips_thumbnail_hip, "thumbnail_image_hip",
-	"generate thumbnail from image (MI355X)")
+/* The plain case -- a 3-band uchar sRGB image, not linear, no crop: a resize by the factor
+ * vips_thumbnail_calculate_shrink picks (thumbnail.c:413-467) -- has the resize's region form;
+ * alpha (premultiply), linear light and crops go through whole. */
+static int
+vips_thumbnail_hip_strip_open(VipsHipOp *op, VipsImage *in, void **plan)
+{
+	VipsThumbnailHip *thumbnail = (VipsThumbnailHip *) op;
+	const int width = thumbnail->width;
+	const int height = vips_object_argument_isset(VIPS_OBJECT(op), "height") ? thumbnail->height : width;
+	double hshrink, vshrink;
+
+	if (thumbnail->linear || thumbnail->crop != VIPS_INTERESTING_NONE || in->Bands != 3 ||
+		in->BandFmt != VIPS_FORMAT_UCHAR || in->Type != VIPS_INTERPRETATION_sRGB)
+		return 1;
+	hshrink = (double) in->Xsize / width;
+	vshrink = (double) in->Ysize / height;
+	if (thumbnail->size != VIPS_SIZE_FORCE) {
+		if (!(hshrink < vshrink))
+			vshrink = hshrink;
+		else
+			hshrink = vshrink;
+	}
+	if (thumbnail->size == VIPS_SIZE_UP || hshrink <= 1.0 || vshrink <= 1.0)
+		return 1;
+	hshrink = VIPS_MIN(hshrink, in->Xsize);
+	vshrink = VIPS_MIN(vshrink, in->Ysize);
+	/* (through 1 / scale, as vips_hip_thumbnail_image -> vips_hip_resize computes it) */
+	hshrink = 1.0 / (1.0 / hshrink);
+	vshrink = 1.0 / (1.0 / vshrink);
+	return resample_strip_open(op, in, vshrink, hshrink, VIPS_KERNEL_LANCZOS3, 2.0, FALSE, FALSE, plan);
+}
+
+HIP_SUBCLASS_FULL(VipsThumbnailHip, vips_thumbnail_hip, "thumbnail_image_hip",
+	"generate thumbnail from image (MI355X)", HIP_RESAMPLE_STRIPS(vips_thumbnail_hip))
 
 static void
 vips_thumbnail_hip_args(VipsThumbnailHipClass *class)
@@ -1251,6 +1674,15 @@ vips_thumbnail_file_hip_init(VipsThumbnailFileHip *thumbnail)
 	g_mutex_init(&thumbnail->lock);
 }
 
+/* a per-pixel operation: a strip reads exactly its own rows */
+static int
+hip_pointwise_halo(VipsHipOp *op, VipsImage *in, int *above, int *below)
+{
+	*above = *below = 0;
+
+	return 0;
+}
+
 /* conv_hip / convsep_hip: convolution/conv.c:120-175, convsep.c:120-170 */
 typedef struct _VipsConvHip {
 	VipsHipOp parent_instance;
@@ -1371,7 +1803,27 @@ vips_conv_hip_strip_run(VipsHipOp *op, void *plan, const VipsHipRegion *in, cons
 
 HIP_SUBCLASS_FULL(VipsConvHip, vips_conv_hip, "conv_hip", "convolution operation (MI355X)",
 	HIP_STRIPS(vips_conv_hip))
-HIP_SUBCLASS(VipsConvsepHip, vips_convsep_hip, "convsep_hip", "separable convolution operation (MI355X)")
+/* convsep.c:61-118: the mask runs along both axes; n taps read n / 2 rows above and the rest
+ * below (the same window whatever the precision: the approximate form's box sums included) */
+static int
+vips_convsep_hip_halo(VipsHipOp *op, VipsImage *in, int *above, int *below)
+{
+	VipsConvHip *conv = (VipsConvHip *) op;
+	VipsImage *M;
+	int n;
+
+	if (vips_check_matrix("convsep_hip", conv->mask, &M))
+		return -1;
+	n = M->Xsize * M->Ysize;
+	g_object_unref(M);
+	*above = n / 2;
+	*below = n - 1 - n / 2;
+
+	return 0;
+}
+
+HIP_SUBCLASS_FULL(VipsConvsepHip, vips_convsep_hip, "convsep_hip", "separable convolution operation (MI355X)",
+	HIP_HALO(vips_convsep_hip))
 
 #define CONV_ARGS(class) \
 	VIPS_ARG_IMAGE(class, "mask", 20, "Mask", "Input matrix image", \
@@ -1427,7 +1879,28 @@ vips_gaussblur_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
 	return vips_hip_gaussblur(in, out, g->sigma, g->min_ampl, g->precision);
 }
 
-HIP_SUBCLASS(VipsGaussblurHip, vips_gaussblur_hip, "gaussblur_hip", "gaussian blur (MI355X)")
+/* gaussblur.c:71-116: vips_gaussmat(sigma, min_ampl, separable, precision) then vips_convsep:
+ * the mask's width decides the rows a strip reads */
+static int
+vips_gaussblur_hip_halo(VipsHipOp *op, VipsImage *in, int *above, int *below)
+{
+	VipsGaussblurHip *g = (VipsGaussblurHip *) op;
+	int n;
+
+	if (g->sigma < 0.2) { /* gaussblur.c:88-92: a copy */
+		*above = *below = 0;
+		return 0;
+	}
+	if ((n = vips_hip_gaussmat(g->sigma, g->min_ampl, 1, g->precision, NULL, 0, NULL)) < 0)
+		return hip_fail("gaussblur_hip");
+	*above = n / 2;
+	*below = n - 1 - n / 2;
+
+	return 0;
+}
+
+HIP_SUBCLASS_FULL(VipsGaussblurHip, vips_gaussblur_hip, "gaussblur_hip", "gaussian blur (MI355X)",
+	HIP_HALO(vips_gaussblur_hip))
 
 static void
 vips_gaussblur_hip_args(VipsGaussblurHipClass *class)
@@ -1463,7 +1936,24 @@ vips_sharpen_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
 	return vips_hip_sharpen(in, out, s->sigma, s->x1, s->y2, s->y3, s->m1, s->m2);
 }
 
-HIP_SUBCLASS(VipsSharpenHip, vips_sharpen_hip, "sharpen_hip", "unsharp masking for print (MI355X)")
+/* sharpen.c:176-228: everything is per pixel except the blur of L with
+ * vips_gaussmat(sigma, 0.1, separable, integer) */
+static int
+vips_sharpen_hip_halo(VipsHipOp *op, VipsImage *in, int *above, int *below)
+{
+	VipsSharpenHip *s = (VipsSharpenHip *) op;
+	int n;
+
+	if ((n = vips_hip_gaussmat(s->sigma, 0.1, 1, VIPS_PRECISION_INTEGER, NULL, 0, NULL)) < 0)
+		return hip_fail("sharpen_hip");
+	*above = n / 2;
+	*below = n - 1 - n / 2;
+
+	return 0;
+}
+
+HIP_SUBCLASS_FULL(VipsSharpenHip, vips_sharpen_hip, "sharpen_hip", "unsharp masking for print (MI355X)",
+	HIP_HALO(vips_sharpen_hip))
 
 static void
 vips_sharpen_hip_args(VipsSharpenHipClass *class)
@@ -1524,7 +2014,7 @@ vips_colourspace_hip_fuse(VipsHipOp *op, VipsHipOp *up, VipsHipImage *up_in, Vip
 }
 
 HIP_SUBCLASS_FULL(VipsColourspaceHip, vips_colourspace_hip, "colourspace_hip",
-	"convert to a new colorspace (MI355X)", class->fuse = vips_colourspace_hip_fuse;)
+	"convert to a new colorspace (MI355X)", class->fuse = vips_colourspace_hip_fuse; class->halo = hip_pointwise_halo;)
 
 static void
 vips_colourspace_hip_args(VipsColourspaceHipClass *class)
@@ -1554,7 +2044,7 @@ vips_cast_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
 	return vips_hip_cast(in, out, c->format);
 }
 
-HIP_SUBCLASS(VipsCastHip, vips_cast_hip, "cast_hip", "cast an image (MI355X)")
+HIP_SUBCLASS_FULL(VipsCastHip, vips_cast_hip, "cast_hip", "cast an image (MI355X)", class->halo = hip_pointwise_halo;)
 
 static void
 vips_cast_hip_args(VipsCastHipClass *class)
@@ -1590,9 +2080,10 @@ vips_unpremultiply_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **o
 	return vips_hip_unpremultiply(in, out, ((VipsPremultiplyHip *) op)->uchar);
 }
 
-HIP_SUBCLASS(VipsPremultiplyHip, vips_premultiply_hip, "premultiply_hip", "premultiply image alpha (MI355X)")
-HIP_SUBCLASS(VipsUnpremultiplyHip, vips_unpremultiply_hip, "unpremultiply_hip",
-	"unpremultiply image alpha (MI355X)")
+HIP_SUBCLASS_FULL(VipsPremultiplyHip, vips_premultiply_hip, "premultiply_hip", "premultiply image alpha (MI355X)",
+	class->halo = hip_pointwise_halo;)
+HIP_SUBCLASS_FULL(VipsUnpremultiplyHip, vips_unpremultiply_hip, "unpremultiply_hip",
+	"unpremultiply image alpha (MI355X)", class->halo = hip_pointwise_halo;)
 
 #define PREMUL_ARGS(class) \
 	VIPS_ARG_BOOL(class, "uchar", 116, "Uchar", "Use the uchar fast path", \

@@ -168,6 +168,17 @@ VIPS_HIP_API void vips_hip_free_host(void *ptr);
 VIPS_HIP_API int vips_hip_memcpy_h2d(void *dst, const void *src, size_t size);
 VIPS_HIP_API int vips_hip_memcpy_d2h(void *dst, const void *src, size_t size);
 VIPS_HIP_API int vips_hip_memcpy_d2d(void *dst, const void *src, size_t size);
+/* The same copies QUEUED on the calling thread's current stream (pinned host memory --
+ * vips_hip_malloc_host() -- for them to overlap anything): how the module's strip loop keeps
+ * the upload of strip k + 1, the kernels of strip k and the download of strip k - 1 in flight
+ * together, the way sinkdisc.c:177-220 writes one buffer behind the one being filled.
+ */
+VIPS_HIP_API int vips_hip_memcpy_h2d_async(void *dst, const void *src, size_t size);
+VIPS_HIP_API int vips_hip_memcpy_d2h_async(void *dst, const void *src, size_t size);
+/* A stream of the calling thread's device, for vips_hip_set_stream(); freed after a
+ * synchronize. */
+VIPS_HIP_API void *vips_hip_stream_new(void);
+VIPS_HIP_API void vips_hip_stream_free(void *stream);
 VIPS_HIP_API int vips_hip_memcpy2d_h2d(void *dst, size_t dpitch,
 	const void *src, size_t spitch, size_t width_bytes, size_t height);
 VIPS_HIP_API int vips_hip_memcpy2d_d2h(void *dst, size_t dpitch,
@@ -180,6 +191,8 @@ VIPS_HIP_API void *vips_hip_event_new(void);
 VIPS_HIP_API void vips_hip_event_free(void *event);
 VIPS_HIP_API int vips_hip_event_record(void *event);
 VIPS_HIP_API double vips_hip_event_elapsed_ms(void *start, void *stop); /* syncs on stop */
+VIPS_HIP_API int vips_hip_event_synchronize(void *event); /* wait on the host for a recorded event */
+VIPS_HIP_API int vips_hip_stream_wait_event(void *event); /* the current stream waits for it */
 
 /* Per-kernel timing (the VIPS_GATE_START/STOP analogue, include/vips/gate.h):
  * when enabled every kernel launch is bracketed by events on its stream.

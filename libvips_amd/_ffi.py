@@ -115,6 +115,12 @@ _SIGNATURES = {
     "vips_hip_free_host": (None, [c_void_p]),
     "vips_hip_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),
     "vips_hip_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "vips_hip_memcpy_h2d_async": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "vips_hip_memcpy_d2h_async": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "vips_hip_stream_new": (c_void_p, []),
+    "vips_hip_stream_free": (None, [c_void_p]),
+    "vips_hip_event_synchronize": (c_int, [c_void_p]),
+    "vips_hip_stream_wait_event": (c_int, [c_void_p]),
     "vips_hip_memcpy_d2d": (c_int, [c_void_p, c_void_p, c_size_t]),
     "vips_hip_memcpy2d_h2d": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t]),
     "vips_hip_memcpy2d_d2h": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t]),

@@ -47,7 +47,17 @@
 //           units of 2^-53 relative to its terms, so the float it rounds to is the reference's
 //           except where the reference's sum lies that close to a rounding boundary, and then it
 //           is the neighbouring float: within 1 ULP for sums that do not cancel (every
-//           gaussian), the tolerance BASELINE.json's north_star grants float paths.
+//           gaussian), the tolerance BASELINE.json's north_star grants float paths.  "That close"
+//           is not rare: integer taps on pixels that are themselves short binary fractions (a
+//           cast uchar image, or the first pass's float output) put the quotient sum / scale
+//           EXACTLY on a float midpoint for about one element in a thousand, which the reference
+//           (exact sum, correctly rounded division) breaks to even and any other arithmetic
+//           breaks by its error's sign: 0.06 % of the elements of BASELINE config 3's blur differ
+//           by 1 ULP (tools/c3_fast_diff.py).  Behind a colour route that truncates to a table
+//           index (sRGB -> scRGB) such a pixel can land in the next table entry -- 21 of 268 M
+//           pixels at 16384^2, a whole table step in Lab -- so MODE 3 is never used with the
+//           colour epilogue: the fused blur + colourspace kernel always reproduces the
+//           reference's bits.
 // Each output sums its taps in mask order in both passes (rows arrive in tap order).
 #include "colour_device.h"
 #include "conv.h"
@@ -516,11 +526,8 @@ static int ss_launch_mode(bool integer, bool fast, int epi, int ng, const Stream
 {
 	const char *plain = integer ? "convsep_stream_convi" : "convsep_stream_convf";
 	const char *colour = integer ? "convsep_stream_convi_colour" : "convsep_stream_convf_colour";
-	if (fast) {
-		if (epi == 2)
-			return ss_launch_ng<3, 2, NT>(ng, a, route, lds, grid, colour);
-		return epi ? ss_launch_ng<3, 1, NT>(ng, a, route, lds, grid, colour) : ss_launch_ng<3, 0, NT>(ng, a, route, lds, grid, plain);
-	}
+	if (fast && !epi)
+		return ss_launch_ng<3, 0, NT>(ng, a, route, lds, grid, plain);
 	if (integer) {
 		if (epi == 2)
 			return ss_launch_ng<1, 2, NT>(ng, a, route, lds, grid, colour);
@@ -574,7 +581,7 @@ int convsep_stream_fused(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 		return 1;
 	// MODE 3 (see the head of the file) unless the caller asked for the reference's bits; masks
 	// whose taps differ in sign can cancel, and a cancelling sum has no 1 ULP bound: exact arithmetic
-	bool fast = !vips_hip_get_exact_float();
+	bool fast = !vips_hip_get_exact_float() && n_route == 0;
 	for (int k = 0; k < n && fast; k++) {
 		const double ck = integer ? (double) c->coeffi[k] : c->coefff[k];
 		const double c0 = integer ? (double) c->coeffi[0] : c->coefff[0];

@@ -656,6 +656,43 @@ int vips_hip_memcpy_d2h(void *dst, const void *src, size_t size)
 	return 0;
 }
 
+int vips_hip_memcpy_h2d_async(void *dst, const void *src, size_t size)
+{
+	if (ensure_init())
+		return -1;
+	VH_CHECK(hipMemcpyAsync(dst, src, size, hipMemcpyHostToDevice, stream()));
+	return 0;
+}
+
+int vips_hip_memcpy_d2h_async(void *dst, const void *src, size_t size)
+{
+	if (ensure_init())
+		return -1;
+	VH_CHECK(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToHost, stream()));
+	return 0;
+}
+
+void *vips_hip_stream_new(void)
+{
+	if (ensure_init())
+		return nullptr;
+	hipStream_t s = nullptr;
+	VH_CHECK_NULL(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+	return (void *) s;
+}
+
+void vips_hip_stream_free(void *s)
+{
+	if (!s)
+		return;
+	if (tls_stream_external && tls_external == (hipStream_t) s) {
+		tls_external = nullptr;
+		tls_stream_external = false;
+	}
+	(void) hipStreamSynchronize((hipStream_t) s);
+	(void) hipStreamDestroy((hipStream_t) s);
+}
+
 int vips_hip_memcpy_d2d(void *dst, const void *src, size_t size)
 {
 	if (ensure_init())
@@ -737,6 +774,28 @@ int vips_hip_event_record(void *event)
 	if (ensure_init())
 		return -1;
 	VH_CHECK(hipEventRecord((hipEvent_t) event, stream()));
+	return 0;
+}
+
+int vips_hip_event_synchronize(void *event)
+{
+	if (!event) {
+		error("vips_hip_event_synchronize", "null event");
+		return -1;
+	}
+	VH_CHECK(hipEventSynchronize((hipEvent_t) event));
+	return 0;
+}
+
+int vips_hip_stream_wait_event(void *event)
+{
+	if (ensure_init())
+		return -1;
+	if (!event) {
+		error("vips_hip_stream_wait_event", "null event");
+		return -1;
+	}
+	VH_CHECK(hipStreamWaitEvent(stream(), (hipEvent_t) event, 0));
 	return 0;
 }
 

@@ -195,8 +195,8 @@ class TestModuleOnGpu(object):
             strips = [Ref.run("reduce_hip", rgba, "hshrink=8,vshrink=8"), Ref.run("reduce_hip", rgb, "hshrink=2.5,vshrink=3.3"),
                       Ref.run("reduce_hip", flt, "hshrink=2,vshrink=4.1,kernel=cubic"),
                       Ref.run_mask("conv_hip", rgb, mask, scale, offset, "precision=integer")]
-            # an operation without a region form still works (whole image) under a tiny budget
-            assert np.array_equal(Ref.run("shrink_hip", rgb, "hshrink=3,vshrink=4"), Ref.run("shrink", rgb, "hshrink=3,vshrink=4"))
+            # an instance without a region form still works (whole image) under a tiny budget
+            assert np.array_equal(Ref.run("resize_hip", rgb, "scale=2.5,kernel=cubic"), Ref.run("resize", rgb, "scale=2.5,kernel=cubic"))
             # and a strip-mined result (host only) feeds a following *_hip op like any image
             chained = Ref.run_chain("reduce_hip:hshrink=8,vshrink=8;gaussblur_hip:sigma=1.5", rgba)
         finally:
@@ -209,6 +209,73 @@ class TestModuleOnGpu(object):
             assert np.array_equal(w.view(np.uint8), s.view(np.uint8))
             assert np.array_equal(s.view(np.uint8), b.view(np.uint8))
         assert np.array_equal(chained, Ref.run_chain("reduce:hshrink=8,vshrink=8;gaussblur:sigma=1.5", rgba))
+
+    @pytest.mark.parametrize("hip_op,ref_op,which,args", [
+        ("resize_hip", "resize", "rgb", "scale=0.125"),
+        ("resize_hip", "resize", "rgb", "scale=0.37"),
+        ("resize_hip", "resize", "rgba", "scale=0.3,vscale=0.21,kernel=cubic"),
+        ("resize_hip", "resize", "flt", "scale=0.45,gap=0"),
+        ("thumbnail_image_hip", "thumbnail_image", "rgb", "width=100"),
+        ("thumbnail_image_hip", "thumbnail_image", "rgb", "width=64,height=200,size=force"),
+        ("reduce_hip", "reduce", "rgb", "hshrink=5,vshrink=7,gap=2"),
+        ("reduceh_hip", "reduceh", "rgb", "hshrink=3.1"),
+        ("reducev_hip", "reducev", "rgb", "vshrink=3.1,gap=2"),
+        ("shrink_hip", "shrink", "rgb", "hshrink=3,vshrink=4"),
+        ("shrink_hip", "shrink", "rgb", "hshrink=2,vshrink=5,ceil=true"),
+        ("shrink_hip", "shrink", "rgb", "hshrink=2.5,vshrink=3.5"),
+        ("shrinkh_hip", "shrinkh", "rgba", "hshrink=3"),
+        ("shrinkv_hip", "shrinkv", "rgba", "vshrink=5,ceil=true"),
+        ("gaussblur_hip", "gaussblur", "rgb", "sigma=3"),
+        ("gaussblur_hip", "gaussblur", "flt", "sigma=2,precision=float"),
+        ("gaussblur_hip", "gaussblur", "rgb", "sigma=2,precision=approximate"),
+        ("sharpen_hip", "sharpen", "rgb", ""),
+        ("colourspace_hip", "colourspace", "rgb", "space=lab"),
+        ("cast_hip", "cast", "rgb", "format=float"),
+        ("premultiply_hip", "premultiply", "rgba", ""),
+        ("unpremultiply_hip", "unpremultiply", "rgba", ""),
+    ])
+    def test_every_strip_capable_op_over_budget(self, hip_op, ref_op, which, args):
+        """with the image over the HBM budget every operation of the module
+        that has a region form -- the whole resample family through the chain of generate
+        replacements, the neighbourhood and per-pixel operations through their halo window -- runs
+        the overlapped strip loop (several strips: the module counts them) and gives the built-in
+        operation's pixels bit for bit."""
+        import ctypes
+        import os
+
+        src = {"rgb": helpers.lcg_image(700, 900, 3, np.uint8, 82), "rgba": helpers.lcg_image(520, 603, 4, np.uint8, 81),
+               "flt": helpers.lcg_image(300, 500, 2, np.float32, 83)}[which]
+        interp = cases.INTERP["srgb"] if which != "flt" else 0
+        module = ctypes.CDLL(helpers.MODULE_LIB)
+        want = Ref.run(ref_op, src, args, interp)
+        whole = Ref.run(hip_op, src, args, interp)
+        os.environ["VIPS_HIP_BUDGET"] = "300k"
+        before = module.vips_hip_module_strips_done()
+        try:
+            got = Ref.run(hip_op, src, args, interp)
+        finally:
+            del os.environ["VIPS_HIP_BUDGET"]
+        assert module.vips_hip_module_strips_done() - before >= 2, "not strip-mined"
+        assert got.shape == want.shape and got.dtype == want.dtype
+        assert np.array_equal(got.view(np.uint8), whole.view(np.uint8))
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+
+    def test_convsep_over_budget(self):
+        import ctypes
+        import os
+
+        rgb = helpers.lcg_image(700, 900, 3, np.uint8, 82)
+        mask = np.array([[1.0, 4.0, 6.0, 9.0, 6.0, 4.0, 1.0]])
+        module = ctypes.CDLL(helpers.MODULE_LIB)
+        want = Ref.run_mask("convsep", rgb, mask, 31.0, 0.0, "precision=integer")
+        os.environ["VIPS_HIP_BUDGET"] = "300k"
+        before = module.vips_hip_module_strips_done()
+        try:
+            got = Ref.run_mask("convsep_hip", rgb, mask, 31.0, 0.0, "precision=integer")
+        finally:
+            del os.environ["VIPS_HIP_BUDGET"]
+        assert module.vips_hip_module_strips_done() - before >= 2
+        assert np.array_equal(got, want)
 
     def test_evaluation_is_lazy_and_happens_once(self):
         """Built but never read: no device work (the pool stays empty).  Read twice: evaluated
