@@ -324,6 +324,8 @@ hip_halo_run(VipsHipOp *op, HaloStrip *plan, const VipsHipRegion *in, const Vips
 	return result;
 }
 
+static const VipsPel *hip_host_pixels(VipsHipOp *op, VipsImage **mem);
+
 /* how many strips the loop below has run in this process (the tests ask: was it strip-mined?) */
 static volatile gint hip_strips_done = 0;
 
@@ -342,6 +344,8 @@ hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
 	const size_t ls = VIPS_IMAGE_SIZEOF_LINE(out);
 	const size_t in_ls = VIPS_IMAGE_SIZEOF_LINE(in);
 	const gboolean generic = hclass->halo != NULL && !hclass->strip_open;
+	VipsImage *resident_mem = NULL;
+	const VipsPel *resident = NULL;
 	HaloStrip halo = { 0, 0 };
 	void *plan = NULL;
 	VipsPel *host = NULL;
@@ -362,6 +366,16 @@ hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
 			return 1;
 		if ((result = hclass->strip_open(op, in, &plan)))
 			return result;
+	}
+
+	/* an input that already is host memory is uploaded from where it lies: nothing to pull */
+	if (op->in->dtype == VIPS_IMAGE_SETBUF || op->in->dtype == VIPS_IMAGE_SETBUF_FOREIGN ||
+		op->in->dtype == VIPS_IMAGE_MMAPIN || op->in->dtype == VIPS_IMAGE_MMAPINRW) {
+		resident = hip_host_pixels(op, &resident_mem);
+		if (resident_mem) { /* (it was not usable as it lies after all: pull like any other image) */
+			VIPS_UNREF(resident_mem);
+			resident = NULL;
+		}
 	}
 
 #define STRIP_NEED(TOP, N, IN_TOP, IN_ROWS) \
@@ -408,14 +422,14 @@ hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
 	if (!host)
 		vips_error(nick, "%s", "out of memory for the result");
 	for (int i = 0; i < 2 && !result; i++)
-		if (!(stage[i] = (VipsPel *) vips_hip_malloc_host((size_t) max_in_rows * in_ls)) ||
+		if ((!resident && !(stage[i] = (VipsPel *) vips_hip_malloc_host((size_t) max_in_rows * in_ls))) ||
 			!(stream[i] = vips_hip_stream_new()) ||
 			!(computed[i] = vips_hip_event_new()) || !(finished[i] = vips_hip_event_new()) ||
 			!(dev_in[i] = vips_hip_image_new(in->Xsize, max_in_rows, in->Bands, in->BandFmt, in->Type)) ||
 			!(dev_out[i] = vips_hip_image_new(out->Xsize, VIPS_MIN(rows, out->Ysize), out->Bands, out->BandFmt, out->Type)))
 			result = hip_fail(nick);
 
-	if (!result) {
+	if (!result && !resident) {
 		int in_top, in_rows;
 
 		STRIP_NEED(0, VIPS_MIN(rows, out->Ysize), &in_top, &in_rows);
@@ -438,7 +452,8 @@ hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
 		 * from a pool that orders reuse within one stream, and kernels of two strips have nothing
 		 * to gain from running side by side */
 		if (vips_hip_set_stream(stream[b]) ||
-			vips_hip_memcpy_h2d_async(vips_hip_image_get_data(dev_in[b]), stage[b], (size_t) in_rows * in_ls) ||
+			vips_hip_memcpy_h2d_async(vips_hip_image_get_data(dev_in[b]),
+				resident ? resident + (size_t) in_top * in_ls : stage[b], (size_t) in_rows * in_ls) ||
 			(k > 0 && vips_hip_stream_wait_event(computed[1 - b]))) {
 			result = hip_fail(nick);
 			break;
@@ -464,7 +479,7 @@ hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
 		g_atomic_int_inc(&hip_strips_done);
 		/* meanwhile, on the host: strip k + 1 is pulled into the buffer strip k - 1 was uploaded
 		 * from (that strip is complete: its stream comes next) */
-		if (top + rows < out->Ysize) {
+		if (!resident && top + rows < out->Ysize) {
 			if (k > 0 && vips_hip_event_synchronize(finished[1 - b])) {
 				result = hip_fail(nick);
 				break;
@@ -494,6 +509,7 @@ hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
 	}
 	if (!generic && hclass->strip_close)
 		hclass->strip_close(op, plan);
+	VIPS_UNREF(resident_mem);
 	if (result) {
 		if (pinned)
 			vips_hip_free_host(host);
@@ -507,6 +523,30 @@ hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
 	return 0;
 }
 
+/* The input's pixels on the host.  An image that already IS memory (vips_image_new_from_memory(),
+ * a loaded-to-memory file, a mapped .v) is used where it lies: vips_image_decode() of an uncoded
+ * image is a header-only vips_copy(), and pulling that "partial" image through
+ * vips_image_copy_memory() would allocate and fill a second copy of the whole image on the host
+ * (measured on the 1 GiB image of BASELINE config 2: ~300 ms, fifteen times the upload).  Anything
+ * else is evaluated into memory by libvips' threaded sink.  *mem is what the caller unrefs. */
+static const VipsPel *
+hip_host_pixels(VipsHipOp *op, VipsImage **mem)
+{
+	VipsImage *raw = op->in;
+
+	*mem = NULL;
+	if (raw->Coding == VIPS_CODING_NONE && raw->Xsize == op->ready->Xsize && raw->Ysize == op->ready->Ysize &&
+		raw->Bands == op->ready->Bands && raw->BandFmt == op->ready->BandFmt &&
+		(raw->dtype == VIPS_IMAGE_SETBUF || raw->dtype == VIPS_IMAGE_SETBUF_FOREIGN ||
+			raw->dtype == VIPS_IMAGE_MMAPIN || raw->dtype == VIPS_IMAGE_MMAPINRW) &&
+		!vips_image_wio_input(raw) && raw->data)
+		return (const VipsPel *) raw->data;
+	if (!(*mem = vips_image_copy_memory(op->ready)))
+		return NULL;
+
+	return VIPS_IMAGE_ADDR(*mem, 0, 0);
+}
+
 /* The operation's whole input on the device: the upstream *_hip operation's result (evaluated
  * now if it has not been), else the image pulled from upstream (a threaded vips_sink_memory())
  * and uploaded -- then *fresh is what the caller unrefs when it is done.  NULL on failure.
@@ -516,6 +556,7 @@ hip_input(VipsHipOp *op, VipsHipImage **fresh)
 {
 	VipsImage *in = op->ready;
 	VipsHipImage *dev = NULL;
+	const VipsPel *pixels;
 	VipsImage *mem;
 
 	*fresh = NULL;
@@ -523,10 +564,9 @@ hip_input(VipsHipOp *op, VipsHipImage **fresh)
 		dev = op->upstream_device(op->upstream);
 	if (dev)
 		return dev;
-	if (!(mem = vips_image_copy_memory(in)))
+	if (!(pixels = hip_host_pixels(op, &mem)))
 		return NULL;
-	*fresh = vips_hip_image_new_from_memory(VIPS_IMAGE_ADDR(mem, 0, 0),
-		mem->Xsize, mem->Ysize, mem->Bands, mem->BandFmt, mem->Type);
+	*fresh = vips_hip_image_new_from_memory(pixels, in->Xsize, in->Ysize, in->Bands, in->BandFmt, in->Type);
 	VIPS_UNREF(mem);
 	if (!*fresh)
 		hip_fail(VIPS_OBJECT_GET_CLASS(op)->nickname);
@@ -635,15 +675,15 @@ hip_eval(VipsHipOp *op)
 				return;
 			/* r == 1: no region form -- try the whole image (fails loudly if HBM runs out) */
 		}
-		if (!(mem = vips_image_copy_memory(in))) {
-			hip_eval_fail(op, class->nickname);
-			return;
-		}
-		if (!(fresh = vips_hip_image_new_from_memory(VIPS_IMAGE_ADDR(mem, 0, 0),
-				  mem->Xsize, mem->Ysize, mem->Bands, mem->BandFmt, mem->Type))) {
-			VIPS_UNREF(mem);
-			hip_eval_fail(op, class->nickname);
-			return;
+		{
+			const VipsPel *pixels = hip_host_pixels(op, &mem);
+
+			if (!pixels ||
+				!(fresh = vips_hip_image_new_from_memory(pixels, in->Xsize, in->Ysize, in->Bands, in->BandFmt, in->Type))) {
+				VIPS_UNREF(mem);
+				hip_eval_fail(op, class->nickname);
+				return;
+			}
 		}
 		VIPS_UNREF(mem);
 		dev = fresh;

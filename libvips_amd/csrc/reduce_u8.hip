@@ -500,11 +500,8 @@ struct MfmaStep {
 						asm volatile("" : "+v"(px[i].x), "+v"(px[i].y));
 				}
 			}
-			else if (p == 1 && more) {
-				if (a.debug & 32) // profiling: never more than one quad of rows in flight per wave
-					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			else if (p == 1 && more)
 				load_rows<4 * Q, 4>(a, px, next_row, dir, ca, cb, interior);
-			}
 #pragma unroll
 			for (int c = 0; c < 4; c++) {
 				acc[p * 4 + c][0] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, b[c], acc[p * 4 + c][0], 0, 0, 0);
@@ -684,7 +681,7 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 		const int jhi = min(g0 + MFMA_SLOTS - 1 - (D - 1), oh - 1); // inclusive
 		if (jhi < jlo)
 			continue;
-		if (!(a.debug & 64)) __syncthreads(); // (bit 64: timing probe without the batch barriers -- wrong pixels)
+		__syncthreads();
 		const int nrows = jhi - jlo + 1;
 		const int r_lo = jlo - (g0 - (D - 1));
 		if (!(a.debug & 1)) {
@@ -707,7 +704,7 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 				*reinterpret_cast<uint2 *>(srow) = make_uint2(pix[0], pix[1]);
 			}
 		}
-		if (!(a.debug & 64)) __syncthreads();
+		__syncthreads();
 
 		// ---- output: staged rows leave in bursts of burst_rows (and at the tile's end), a wave
 		// per row, a lane per pixel; the next write into the stage is behind the next barrier

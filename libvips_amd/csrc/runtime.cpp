@@ -623,19 +623,73 @@ void vips_hip_free(void *ptr)
 	pool_release(ptr);
 }
 
+// Pinned host memory is expensive to make (the pages are locked and mapped: ~0.1 s per GiB), and
+// the strip loop of the libvips module wants the same few staging buffers for every evaluation:
+// freed blocks are kept -- a handful, by exact size -- and handed out again.
+static std::mutex &g_pinned_mutex = *new std::mutex;
+static std::unordered_map<void *, size_t> &g_pinned_live = *new std::unordered_map<void *, size_t>;
+static std::vector<std::pair<size_t, void *>> &g_pinned_free = *new std::vector<std::pair<size_t, void *>>;
+constexpr size_t PINNED_CACHE_BLOCKS = 8;
+constexpr size_t PINNED_CACHE_BYTES = (size_t) 16 << 30;
+
 void *vips_hip_malloc_host(size_t size)
 {
 	if (ensure_init())
 		return nullptr;
+	size = size ? size : 1;
+	{
+		std::lock_guard<std::mutex> lock(g_pinned_mutex);
+		for (size_t i = 0; i < g_pinned_free.size(); i++)
+			if (g_pinned_free[i].first == size) {
+				void *p = g_pinned_free[i].second;
+				g_pinned_free.erase(g_pinned_free.begin() + i);
+				g_pinned_live[p] = size;
+				return p;
+			}
+	}
 	void *p = nullptr;
-	VH_CHECK_NULL(hipHostMalloc(&p, size ? size : 1, hipHostMallocDefault));
+	VH_CHECK_NULL(hipHostMalloc(&p, size, hipHostMallocDefault));
+	std::lock_guard<std::mutex> lock(g_pinned_mutex);
+	g_pinned_live[p] = size;
 	return p;
 }
 
 void vips_hip_free_host(void *ptr)
 {
-	if (ptr)
-		(void) hipHostFree(ptr);
+	if (!ptr)
+		return;
+	std::vector<void *> drop;
+	{
+		std::lock_guard<std::mutex> lock(g_pinned_mutex);
+		auto it = g_pinned_live.find(ptr);
+		if (it == g_pinned_live.end())
+			drop.push_back(ptr); // not ours to cache
+		else {
+			g_pinned_free.emplace_back(it->second, ptr);
+			g_pinned_live.erase(it);
+			size_t total = 0;
+			for (auto &b : g_pinned_free)
+				total += b.first;
+			while (g_pinned_free.size() > PINNED_CACHE_BLOCKS || total > PINNED_CACHE_BYTES) {
+				total -= g_pinned_free.front().first;
+				drop.push_back(g_pinned_free.front().second);
+				g_pinned_free.erase(g_pinned_free.begin());
+			}
+		}
+	}
+	for (void *p : drop)
+		(void) hipHostFree(p);
+}
+
+static void pinned_trim()
+{
+	std::vector<std::pair<size_t, void *>> drop;
+	{
+		std::lock_guard<std::mutex> lock(g_pinned_mutex);
+		drop.swap(g_pinned_free);
+	}
+	for (auto &b : drop)
+		(void) hipHostFree(b.second);
 }
 
 int vips_hip_memcpy_h2d(void *dst, const void *src, size_t size)
@@ -740,9 +794,10 @@ size_t vips_hip_pool_bytes(void)
 	return total;
 }
 
-// the calling thread's caches and the orphaned blocks of every device
+// the calling thread's caches and the orphaned blocks of every device, and the pinned cache
 void vips_hip_pool_trim(void)
 {
+	pinned_trim();
 	for (int d = 0; d < MAX_DEVICES; d++) {
 		Pool *p;
 		{
