@@ -385,7 +385,7 @@ struct MfmaGeo {
 	}
 };
 
-template <int D, bool NT = false, int PROF = 0, bool PAIRS = false, int NTH = FUSED_THREADS>
+template <int D, bool NT = false, int PROF = 0, bool PAIRS = false, int NTH = FUSED_THREADS, bool LATE = false>
 struct MfmaStep {
 	static constexpr int S = 8;
 	static constexpr int MFMA_PLANE = MfmaGeo<NTH>::PLANE;
@@ -418,7 +418,11 @@ struct MfmaStep {
 				const u32x2 v = NT ? __builtin_nontemporal_load(src) : *src;
 				px[i] = make_uint2(v.x, v.y);
 			}
-			if (PAIRS) { // branch-free: interior lanes carry cb = 0 (the compares live in SGPR masks)
+			// LATE (the default): the fix-up is applied where the rows are CONSUMED (quad()), not here.
+			// Here it made every wave wait for the loads it had just issued -- s_waitcnt vmcnt(3..0)
+			// right behind the four global_loads -- so a wave's own matrix work never ran under
+			// its own loads (round 3, read off the ISA: 0.1998 -> 0.1928 ms on one box).
+			if (PAIRS && !LATE) { // branch-free: interior lanes carry cb = 0 (the compares live in SGPR masks)
 #pragma unroll
 				for (int i = I0; i < I0 + N; i++) {
 					const unsigned int x = px[i].x, y = px[i].y;
@@ -482,12 +486,22 @@ struct MfmaStep {
 		}
 		const half4v a0 = lane_a[((ROT * 2 + Q) * 2 + 0) * 4];
 		const half4v a1 = lane_a[((ROT * 2 + Q) * 2 + 1) * 4];
+		uint2 row[4];
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			row[i] = px[4 * Q + i];
+			if (PAIRS && LATE) { // the edge fix-up of load_rows, at the point of use
+				const unsigned int x = row[i].x, y = row[i].y;
+				row[i].y = cb == 1 ? x : y;
+				row[i].x = cb == 2 ? y : x;
+			}
+		}
 #pragma unroll
 		for (int p = 0; p < 2; p++) {
-			const unsigned int r0 = p ? px[4 * Q + 0].y : px[4 * Q + 0].x;
-			const unsigned int r1 = p ? px[4 * Q + 1].y : px[4 * Q + 1].x;
-			const unsigned int r2 = p ? px[4 * Q + 2].y : px[4 * Q + 2].x;
-			const unsigned int r3 = p ? px[4 * Q + 3].y : px[4 * Q + 3].x;
+			const unsigned int r0 = p ? row[0].y : row[0].x;
+			const unsigned int r1 = p ? row[1].y : row[1].x;
+			const unsigned int r2 = p ? row[2].y : row[2].x;
+			const unsigned int r3 = p ? row[3].y : row[3].x;
 			half4v b[4];
 			b[0] = make_b<0>(r0, r1, r2, r3);
 			b[1] = make_b<1>(r0, r1, r2, r3);
@@ -591,12 +605,12 @@ struct MfmaStep {
 // them, so horizontal neighbours (which read their shared halo columns in lock-step) and
 // most vertical neighbours (which the serpentine walk makes meet at their shared halo rows)
 // share an L2.  Measured on C2: row-major 0.218 ms, column-major 0.221, no serpentine 0.225.
-template <int D, int NB, int OCC, bool NT, int PROF = 0, bool PAIRS = false, int NTH = FUSED_THREADS>
+template <int D, int NB, int OCC, bool NT, int PROF = 0, bool PAIRS = false, int NTH = FUSED_THREADS, bool LATE = false>
 __global__ void __launch_bounds__(NTH, OCC)
 reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 {
 	constexpr int S = 8;
-	typedef MfmaStep<D, NT, PROF, PAIRS, NTH> Step;
+	typedef MfmaStep<D, NT, PROF, PAIRS, NTH, LATE> Step;
 	typedef MfmaGeo<NTH> Geo;
 	constexpr int MFMA_PLANE = Geo::PLANE, MFMA_PLANES_BYTES = Geo::PLANES_BYTES;
 	constexpr int MFMA_STAGE_PITCH = Geo::STAGE_PITCH, FUSED_SPAN = Geo::SPAN;
@@ -985,21 +999,30 @@ static int launch_fused_mfma(const FusedArgs &args, int tiles, const MfmaTables 
 			hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
 		attr_set = true;
 	}
+	// the shipped form: edge fix-up at the point of use (LATE) and streaming (nt) loads;
+	// VIPS_HIP_FUSED_LATE=0 / VIPS_HIP_FUSED_NT=0 select the round-2 forms for A/B runs
+	const bool late = !(getenv("VIPS_HIP_FUSED_LATE") && atoi(getenv("VIPS_HIP_FUSED_LATE")) == 0);
+	const bool nt = (args.debug & 4) || !(getenv("VIPS_HIP_FUSED_NT") && atoi(getenv("VIPS_HIP_FUSED_NT")) == 0);
 	if (NTH == FUSED_THREADS && (args.debug & 24) == 8) // profiling builds: arithmetic only / loads only
 		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 8, true>), dim3(grid), dim3(FUSED_THREADS), lds,
 			stream(), args, d_tables);
 	else if (NTH == FUSED_THREADS && (args.debug & 24) == 16)
 		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 16, true>), dim3(grid), dim3(FUSED_THREADS), lds,
 			stream(), args, d_tables);
-	else if (args.debug & 4) // profiling: nt (streaming) loads
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true, NTH>), dim3(grid), dim3(NTH), lds,
-			stream(), args, d_tables);
+	else if (NTH != FUSED_THREADS || !late) {
+		if (nt)
+			hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true, NTH>), dim3(grid), dim3(NTH), lds,
+				stream(), args, d_tables);
+		else
+			hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, false, 0, true, NTH>), dim3(grid), dim3(NTH), lds,
+				stream(), args, d_tables);
+	}
+	else if (nt)
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true, FUSED_THREADS, true>), dim3(grid),
+			dim3(FUSED_THREADS), lds, stream(), args, d_tables);
 	else
-		// plain loads: nt loads run within noise of them (+-1.5 % either way between boxes) but
-		// fetch 9 % more from the fabric (rocprofv3 FETCH_SIZE 1 221 MB against 1 120 MB per
-		// launch: the halo lines a neighbouring tile just read are not kept in L2)
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, false, 0, true, NTH>), dim3(grid), dim3(NTH), lds,
-			stream(), args, d_tables);
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, false, 0, true, FUSED_THREADS, true>), dim3(grid),
+			dim3(FUSED_THREADS), lds, stream(), args, d_tables);
 	VH_CHECK(hipGetLastError());
 	return 0;
 }
@@ -1530,7 +1553,10 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 				// Measured on C2 with whole-pair edge loads: 0.1936 ms aligned (999 tiles of 56
 				// columns: more halo), 0.1902 ms with tiles that start at their first tap (1015
 				// tiles of 59) -- so alignment is opt-in (VIPS_HIP_FUSED_ALIGN=1).
-				const bool align = getenv("VIPS_HIP_FUSED_ALIGN") && atoi(getenv("VIPS_HIP_FUSED_ALIGN")) == 1;
+				// (round 3: with the fix-up at the point of use and nt loads the aligned layout is the
+				// faster one on every box measured -- 0.1934 against 0.1979, 0.1920 against 0.1928 --
+				// so it is the default where base and stride allow; VIPS_HIP_FUSED_ALIGN=0 for the other)
+				const bool align = !(getenv("VIPS_HIP_FUSED_ALIGN") && atoi(getenv("VIPS_HIP_FUSED_ALIGN")) == 0);
 				if (align && !(in->stride & 127)) {
 					const long long addr = (long long) (uintptr_t) in->data + 4LL * ((long long) fx0 - in->left);
 					const int off = (int) (((addr % 128) + 128) % 128); // bytes past a line start

@@ -217,8 +217,8 @@ def test_fused_reduce_rgba(shrink, size):
 @pytest.mark.parametrize("kernel", ["lanczos3"])
 @pytest.mark.parametrize("size", [(4099, 3001), (2048, 1024), (1000, 8), (96, 2600), (9000, 700), (8192, 8197)])
 @pytest.mark.parametrize("align", [0, 1])
-@pytest.mark.parametrize("nth", [256, 512])
-def test_fused_reduce_mfma_variants(nth, align, size, kernel):
+@pytest.mark.parametrize("nth,late", [(256, 1), (256, 0), (512, 1)])
+def test_fused_reduce_mfma_variants(nth, late, align, size, kernel):
     """Both tile layouts of the matrix-core kernel on the same inputs: line-aligned tiles (lanes
     start on the 128-byte line holding the first tap; the default when base and stride allow)
     and tiles that start at the first tap (VIPS_HIP_FUSED_ALIGN=0: what windows with an odd
@@ -232,6 +232,8 @@ def test_fused_reduce_mfma_variants(nth, align, size, kernel):
     src = helpers.lcg_image(w, h, 4, np.uint8, 47)
     os.environ["VIPS_HIP_FUSED_ALIGN"] = str(align)
     os.environ["VIPS_HIP_FUSED_NTH"] = str(nth)  # 59-pixel tiles (256 threads) / 123-pixel tiles (512)
+    # the edge fix-up at the point of use + nt loads (the shipped form) / at the loads + plain loads (round 2)
+    os.environ["VIPS_HIP_FUSED_LATE"] = os.environ["VIPS_HIP_FUSED_NT"] = str(late)
     lib.vips_hip_gate_reset()
     lib.vips_hip_gate_enable(1)
     try:
@@ -240,6 +242,8 @@ def test_fused_reduce_mfma_variants(nth, align, size, kernel):
     finally:
         del os.environ["VIPS_HIP_FUSED_ALIGN"]
         del os.environ["VIPS_HIP_FUSED_NTH"]
+        del os.environ["VIPS_HIP_FUSED_LATE"]
+        del os.environ["VIPS_HIP_FUSED_NT"]
         lib.vips_hip_gate_enable(0)
         lib.vips_hip_gate_reset()
     assert list(report) == ["reduce_fused_u8_mfma"], report
