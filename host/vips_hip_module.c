@@ -155,6 +155,10 @@ typedef struct _VipsHipOp {
 	VipsHipImage *result;   /* the result on the device (NULL after a strip-mined run) */
 	VipsPel *host;          /* the result on the host, for generate */
 	gboolean host_pinned;   /* ... in pinned memory (vips_hip_malloc_host) */
+	/* A device result comes down in bands of rows, each on its first touch: a consumer that asks
+	 * for one tile of a 17 GB result pays for one band, not for the image. */
+	int band_rows;          /* rows per band (0: `host` is complete) */
+	guint8 *band_done;      /* per band: already downloaded */
 } VipsHipOp;
 
 typedef struct _VipsHipOpClass {
@@ -325,6 +329,16 @@ hip_halo_run(VipsHipOp *op, HaloStrip *plan, const VipsHipRegion *in, const Vips
 }
 
 static const VipsPel *hip_host_pixels(VipsHipOp *op, VipsImage **mem);
+
+/* how many bands of device results have been downloaded in this process (the tests ask: did a
+ * small request pay for the whole image?) */
+static volatile gint hip_bands_done = 0;
+
+G_MODULE_EXPORT int
+vips_hip_module_bands_done(void)
+{
+	return g_atomic_int_get(&hip_bands_done);
+}
 
 /* how many strips the loop below has run in this process (the tests ask: was it strip-mined?) */
 static volatile gint hip_strips_done = 0;
@@ -766,14 +780,38 @@ vips_hip_op_gen(VipsRegion *out_region, void *seq, void *a, void *b, gboolean *s
 		return -1;
 	}
 	if (!op->host) {
-		VipsPel *host = VIPS_ARRAY(NULL, ls * out->Ysize, VipsPel);
+		/* the host copy of a device result: address space now, pixels band by band as they are
+		 * first asked for (~32 MB bands: large enough for the link, small enough to skip) */
+		const int band_rows = VIPS_CLIP(16, (int) (((size_t) 32 << 20) / ls), out->Ysize);
+		const int n_bands = (out->Ysize + band_rows - 1) / band_rows;
 
-		if (!host || vips_hip_image_write_to_memory(op->result, host)) {
+		op->band_done = g_new0(guint8, n_bands);
+		if (!(op->host = (VipsPel *) g_try_malloc(ls * out->Ysize))) {
 			g_mutex_unlock(&op->lock);
-			VIPS_FREE(host);
-			return hip_fail(VIPS_OBJECT_GET_CLASS(op)->nickname);
+			vips_error(VIPS_OBJECT_GET_CLASS(op)->nickname, "%s", "out of memory for the result");
+			return -1;
 		}
-		op->host = host;
+		op->band_rows = band_rows;
+	}
+	if (op->band_rows) {
+		const int first = r->top / op->band_rows, last = (r->top + r->height - 1) / op->band_rows;
+
+		for (int band = first; band <= last; band++)
+			if (!op->band_done[band]) {
+				const int top = band * op->band_rows;
+				const int rows = VIPS_MIN(op->band_rows, out->Ysize - top);
+
+				/* (vips_hip_memcpy_d2h binds nothing: run where the result lives) */
+				if (vips_hip_init(vips_hip_image_get_device(op->result)) ||
+					vips_hip_memcpy_d2h(op->host + (size_t) top * ls,
+						(const char *) vips_hip_image_get_data(op->result) + (size_t) top * vips_hip_image_get_stride(op->result),
+						(size_t) rows * ls)) {
+					g_mutex_unlock(&op->lock);
+					return hip_fail(VIPS_OBJECT_GET_CLASS(op)->nickname);
+				}
+				op->band_done[band] = 1;
+				g_atomic_int_inc(&hip_bands_done);
+			}
 	}
 	g_mutex_unlock(&op->lock);
 
@@ -904,6 +942,7 @@ vips_hip_op_dispose(GObject *gobject)
 	else
 		g_free(op->host);
 	op->host = NULL;
+	VIPS_FREE(op->band_done);
 	VIPS_FREE(op->eval_error);
 	if (op->result) {
 		vips_hip_image_unref(op->result);

@@ -239,7 +239,9 @@ ref_chain_build(VipsImage *x, const char *chain, VipsImage **result)
 			*colon = '\0';
 			args = colon + 1;
 		}
-		if (ref_build(stage, "in", cur, NULL, NULL, args, "out", &next)) {
+		/* (vips_extract_area / vips_crop name their image argument "input") */
+		if (ref_build(stage, !strcmp(stage, "extract_area") || !strcmp(stage, "crop") ? "input" : "in", cur, NULL, NULL,
+				args, "out", &next)) {
 			g_object_unref(cur);
 			g_free(copy);
 			return -1;

@@ -277,6 +277,24 @@ class TestModuleOnGpu(object):
         assert module.vips_hip_module_strips_done() - before >= 2
         assert np.array_equal(got, want)
 
+    def test_device_results_come_down_band_by_band(self):
+        """A consumer that reads a few rows of a large device result pays for the ~32 MB band(s)
+        they lie in, not for the image ("a chain ending in a CPU op pays a full
+        D2H even if one tile is wanted"); reading everything downloads every band once."""
+        import ctypes
+
+        src = helpers.lcg_image(4096, 3000, 3, np.uint8, 85)          # cast to float: 147 MB, 5 bands
+        module = ctypes.CDLL(helpers.MODULE_LIB)
+        want = Ref.run_chain("cast:format=float;extract_area:left=7,top=1500,width=50,height=10", src)
+        before = module.vips_hip_module_bands_done()
+        got = Ref.run_chain("cast_hip:format=float;extract_area:left=7,top=1500,width=50,height=10", src)
+        assert module.vips_hip_module_bands_done() - before == 1
+        assert np.array_equal(got, want)
+        before = module.vips_hip_module_bands_done()
+        whole = Ref.run("cast_hip", src, "format=float")
+        assert module.vips_hip_module_bands_done() - before == 5
+        assert np.array_equal(whole, Ref.run("cast", src, "format=float"))
+
     def test_evaluation_is_lazy_and_happens_once(self):
         """Built but never read: no device work (the pool stays empty).  Read twice: evaluated
         once (the second read is served from the host copy)."""
