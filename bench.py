@@ -878,11 +878,14 @@ def run_c5(ctx, steps, warmup, verify=True, width=65536, im_height=65536):
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     strip = sw.own
+    # ... and so does its output strip (17 GB at world 1: not something to allocate per step)
+    result = torch.empty((s1 - s0, width, 1), dtype=torch.float32, device=ctx.device)
 
     def step():
         if ctx.dist is not None:
             sw.exchange(ctx.dist)
-        return sharding.conv_strip(sw.window, sw.top, plan, ctx.rank, mask, scale=scale, precision="float")
+        return sharding.conv_strip(sw.window, sw.top, plan, ctx.rank, mask, scale=scale, precision="float",
+                                   out=result)
 
     elapsed, out = ctx.timed(step, steps, warmup)
     ms = elapsed / steps * 1e3
@@ -934,7 +937,7 @@ def run_c5(ctx, steps, warmup, verify=True, width=65536, im_height=65536):
         "parity": parity,
         "cpu_baseline": None,
     }
-    del strip, out
+    del strip, out, result, sw
     ctx.trim()
     return line
 

@@ -162,9 +162,11 @@ def _order_after_torch(tensor):
         cur.synchronize()
 
 
-def conv_strip(window, window_top, plan, rank, mask, scale=1.0, offset=0.0, precision="float"):
+def conv_strip(window, window_top, plan, rank, mask, scale=1.0, offset=0.0, precision="float", out=None):
     """Run vips_hip_conv_gen on this rank's window: returns its strip of output rows
-    (a torch CUDA tensor).  ``window`` is what exchange_halos returned."""
+    (a torch CUDA tensor; ``out`` if one of the right shape and type is passed: a program that
+    steps repeatedly keeps its output strip like it keeps its window).  ``window`` is what
+    exchange_halos / StripWindow.exchange returned."""
     import torch
 
     from . import PRECISIONS
@@ -182,8 +184,10 @@ def conv_strip(window, window_top, plan, rank, mask, scale=1.0, offset=0.0, prec
         in_fmt = DTYPE_FORMATS[np.dtype(str(window.dtype).replace("torch.", ""))]
         out_fmt = lib.vips_hip_conv_out_format(conv, in_fmt)
         o0, o1 = plan.out_bounds[rank]
-        out = torch.empty((o1 - o0, width, bands), device=window.device,
-                          dtype=getattr(torch, np.dtype(FORMAT_DTYPES[out_fmt]).name))
+        out_dtype = getattr(torch, np.dtype(FORMAT_DTYPES[out_fmt]).name)
+        if out is None:
+            out = torch.empty((o1 - o0, width, bands), device=window.device, dtype=out_dtype)
+        assert tuple(out.shape) == (o1 - o0, width, bands) and out.dtype == out_dtype and out.is_contiguous()
         rin = Region(window.data_ptr(), 0, window_top, width, rows, width, plan.in_height, bands, in_fmt,
                      width * bands * window.element_size())
         rout = Region(out.data_ptr(), 0, o0, width, o1 - o0, width, plan.out_height, bands, out_fmt,
