@@ -385,7 +385,7 @@ struct MfmaGeo {
 	}
 };
 
-template <int D, bool NT = false, int PROF = 0, bool PAIRS = false, int NTH = FUSED_THREADS, bool LATE = false>
+template <int D, bool NT = false, int PROF = 0, bool PAIRS = false, int NTH = FUSED_THREADS, int LATE = 0>
 struct MfmaStep {
 	static constexpr int S = 8;
 	static constexpr int MFMA_PLANE = MfmaGeo<NTH>::PLANE;
@@ -422,7 +422,7 @@ struct MfmaStep {
 			// Here it made every wave wait for the loads it had just issued -- s_waitcnt vmcnt(3..0)
 			// right behind the four global_loads -- so a wave's own matrix work never ran under
 			// its own loads (round 3, read off the ISA: 0.1998 -> 0.1928 ms on one box).
-			if (PAIRS && !LATE) { // branch-free: interior lanes carry cb = 0 (the compares live in SGPR masks)
+			if (PAIRS && LATE == 0) { // branch-free: interior lanes carry cb = 0 (the compares live in SGPR masks)
 #pragma unroll
 				for (int i = I0; i < I0 + N; i++) {
 					const unsigned int x = px[i].x, y = px[i].y;
@@ -490,7 +490,7 @@ struct MfmaStep {
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
 			row[i] = px[4 * Q + i];
-			if (PAIRS && LATE) { // the edge fix-up of load_rows, at the point of use
+			if (PAIRS && LATE != 0) { // the edge fix-up of load_rows, at the point of use
 				const unsigned int x = row[i].x, y = row[i].y;
 				row[i].y = cb == 1 ? x : y;
 				row[i].x = cb == 2 ? y : x;
@@ -589,6 +589,11 @@ struct MfmaStep {
 		if constexpr (ROT < MFMA_SLOTS) {
 			const int g = g0 + ROT;
 			if (g >= 0 && g < ngroups) {
+				// (the branches around a group and around its refill stay: without them -- every
+				// group refilling, the last one with its own rows again -- the compiler's waits
+				// become exact, eight rows stay in flight per wave, and the kernel is SLOWER: 0.1977
+				// against 0.1932 ms; branch-free over whole batches with padded tiles: 0.234.  Fewer
+				// requests in flight is what this part's memory system wants, §3.1 of DESIGN.md)
 				const bool more = g + NB < ngroups;
 				const int next_row = row0 + dir * S * (g + NB);
 				quad<ROT, 0>(a, px[ROT % NB], acc, lane_a, more, next_row, dir, ca, cb, interior);
@@ -605,7 +610,7 @@ struct MfmaStep {
 // them, so horizontal neighbours (which read their shared halo columns in lock-step) and
 // most vertical neighbours (which the serpentine walk makes meet at their shared halo rows)
 // share an L2.  Measured on C2: row-major 0.218 ms, column-major 0.221, no serpentine 0.225.
-template <int D, int NB, int OCC, bool NT, int PROF = 0, bool PAIRS = false, int NTH = FUSED_THREADS, bool LATE = false>
+template <int D, int NB, int OCC, bool NT, int PROF = 0, bool PAIRS = false, int NTH = FUSED_THREADS, int LATE = 0>
 __global__ void __launch_bounds__(NTH, OCC)
 reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 {
@@ -1018,10 +1023,10 @@ static int launch_fused_mfma(const FusedArgs &args, int tiles, const MfmaTables 
 				stream(), args, d_tables);
 	}
 	else if (nt)
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true, FUSED_THREADS, true>), dim3(grid),
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true, FUSED_THREADS, 1>), dim3(grid),
 			dim3(FUSED_THREADS), lds, stream(), args, d_tables);
 	else
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, false, 0, true, FUSED_THREADS, true>), dim3(grid),
+		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, false, 0, true, FUSED_THREADS, 1>), dim3(grid),
 			dim3(FUSED_THREADS), lds, stream(), args, d_tables);
 	VH_CHECK(hipGetLastError());
 	return 0;
