@@ -1021,6 +1021,12 @@ vips_hip_op_init(VipsHipOp *op)
  * (vips_hip_reducev_need, x int_v) and the four gens forward, the rows between them on the device.
  */
 typedef struct _ResampleStrip {
+	/* upsizing (both scales >= 1): vips_resize's scale-only affine (resize.c:230-300), one
+	 * generate replacement that works in whole-image coordinates */
+	gboolean upsize;
+	double hscale, vscale, idx, idy;
+	int interpolate;
+
 	int int_v, int_h;
 	VipsHipReduce *rv, *rh;
 	int w0, h0; /* input */
@@ -1118,6 +1124,13 @@ resample_strip_need(VipsHipOp *op, void *plan, int out_top, int out_rows, int *i
 	ResampleStrip *p = (ResampleStrip *) plan;
 	int top = out_top, rows = out_rows;
 
+	if (p->upsize) {
+		/* output row y reads input rows around y / vscale: the bicubic stencil (4 rows) and the
+		 * centre-sampling displacement lie well inside a margin of 4 rows either side */
+		*in_top = (int) floor(out_top / p->vscale) - 4;
+		*in_rows = (int) ceil((out_top + out_rows) / p->vscale) + 4 - *in_top;
+		return;
+	}
 	if (p->rv)
 		vips_hip_reducev_need(p->rv, out_top, out_rows, &top, &rows);
 	*in_top = top * p->int_v;
@@ -1133,6 +1146,10 @@ resample_strip_run(VipsHipOp *op, void *plan, const VipsHipRegion *in, const Vip
 	int n = 0, result = 0;
 	int top1 = out->top, rows1 = out->height;
 
+	if (p->upsize)
+		return vips_hip_upsize_gen(in, out, p->hscale, p->vscale, p->idx, p->idy, p->interpolate, 0)
+			? hip_fail(VIPS_OBJECT_GET_CLASS(op)->nickname)
+			: 0;
 	if (p->rv)
 		vips_hip_reducev_need(p->rv, out->top, out->height, &top1, &rows1);
 
@@ -1483,9 +1500,10 @@ vips_resize_hip_compute(VipsHipOp *op, VipsHipImage *in, VipsHipImage **out)
 	return vips_hip_resize(in, out, resize->scale, vscale, resize->kernel, resize->gap);
 }
 
-/* The downsizing half of vips_resize (resize.c:207-228: vips_reducev then vips_reduceh, each
- * with its `gap` pre-shrink) has a region form; upsizing and the nearest kernel (vips_subsample,
- * vips_affine: resize.c:165-203, 230-300) go through whole. */
+/* Both halves of vips_resize have a region form: downsizing (resize.c:207-228: vips_reducev then
+ * vips_reduceh, each with its `gap` pre-shrink) and upsizing (the scale-only vips_affine,
+ * resize.c:230-300); the nearest kernel (vips_subsample, vips_zoom: resize.c:165-203, 257-266) and
+ * one axis up with the other down go through whole. */
 static int
 vips_resize_hip_strip_open(VipsHipOp *op, VipsImage *in, void **plan)
 {
@@ -1493,8 +1511,32 @@ vips_resize_hip_strip_open(VipsHipOp *op, VipsImage *in, void **plan)
 	double hscale = resize->scale;
 	double vscale = vips_object_argument_isset(VIPS_OBJECT(op), "vscale") ? resize->vscale : resize->scale;
 
-	if (resize->kernel == VIPS_KERNEL_NEAREST || hscale <= 0.0 || vscale <= 0.0 || hscale > 1.0 || vscale > 1.0)
+	if (resize->kernel == VIPS_KERNEL_NEAREST || hscale <= 0.0 || vscale <= 0.0)
 		return 1;
+	if (hscale >= 1.0 && vscale >= 1.0) {
+		/* pure upsizing: vips_affine with the matrix (hscale, 0, 0, vscale), centre sampling and
+		 * the interpolator the kernel maps to (resize.c:118-133, 268-300) */
+		ResampleStrip *p;
+
+		if (hscale == 1.0 && vscale == 1.0)
+			return 1;
+		p = g_new0(ResampleStrip, 1);
+		p->upsize = TRUE;
+		p->hscale = hscale;
+		p->vscale = vscale;
+		p->idx = 0.5 * (1.0 - 1.0 / hscale);
+		p->idy = 0.5 * (1.0 - 1.0 / vscale);
+		p->interpolate = resize->kernel == VIPS_KERNEL_LINEAR ? 1 : 2; /* bilinear : bicubic */
+		if (vips_hip_affine_out_size(in->Xsize, hscale) != op->out->Xsize ||
+			vips_hip_affine_out_size(in->Ysize, vscale) != op->out->Ysize) {
+			g_free(p);
+			return 1;
+		}
+		*plan = p;
+		return 0;
+	}
+	if (hscale > 1.0 || vscale > 1.0)
+		return 1; /* one axis up, one down: whole image */
 	/* "Don't let either axis drop below 1 px." (resize.c:197-200) */
 	hscale = VIPS_MAX(hscale, 1.0 / in->Xsize);
 	vscale = VIPS_MAX(vscale, 1.0 / in->Ysize);
