@@ -25,6 +25,14 @@ struct ReducePos {
 	int phase;
 };
 
+// one coefficient of a long double mask (x87 extended: 64 bits of mantissa) as the device's
+// soft-float takes it: value = (-1)^sign * mant * 2^(exp - 63), mant normalised (bit 63) or 0
+struct ReduceTap80 {
+	unsigned long long mant;
+	int exp;
+	int sign;
+};
+
 } // namespace vh
 
 struct _VipsHipReduce {
@@ -49,5 +57,8 @@ namespace vh {
 void reduce_make_mask(double *c, int kernel, int n_points, double shrink, double x);
 void reduce_positions(const _VipsHipReduce *r, int start, int count, int tile,
 	std::vector<ReducePos> &pos);
+// positions and per-output long double masks of the double-image path (resample_host.cpp)
+void reduce_notab_masks(const _VipsHipReduce *r, int start, int count, int tile, std::vector<ReducePos> &pos,
+	std::vector<ReduceTap80> &taps);
 
 } // namespace vh

@@ -17,6 +17,7 @@
 //   float          double coefficients, double sum, separate mul and add in
 //                  tap order, then (float)              templates.h:550-578
 #include "resample.h"
+#include "x80.h"
 #include "reduce_u8.h"
 
 #include <climits>
@@ -432,6 +433,88 @@ const ReducePos *reduce_device_positions(_VipsHipReduce *r, int start, int count
 	return d;
 }
 
+// ------------------------------------------------------------ double images
+//
+// reduceh_notab / reducev_notab (reduceh.cpp:196-213, reducev.cpp:497-515; reduce_sum<T, IT>,
+// templates.h:533-554): sum += c[i] * in[i] in LONG DOUBLE, the coefficients a long double mask
+// made for the output's exact position (resample_host.cpp reduce_notab_masks), the result cast
+// to double.  The x87 extended format on the device: a value is (sign, exponent, 64-bit mantissa
+// with its leading one explicit); a product is the 128-bit integer product rounded to 64 bits, a
+// sum is aligned in 128 bits with the shifted-out bits jammed into the last one, renormalised and
+// rounded to 64 bits -- round to nearest even, once per operation, like fmul / faddp.  The
+// extended exponent range (15 bits) cannot be left by sums of doubles times coefficients of
+// magnitude <= 1.2, so no overflow / underflow handling is needed in between.
+// One thread per output element.  VERTICAL: the mask belongs to the output row and the taps walk
+// down a column; else it belongs to the output column and the taps walk along the row.
+template <bool VERTICAL>
+__global__ void __launch_bounds__(256)
+reduce_notab_f64(RegionArgs in, RegionArgs out, int epp, int n_point, const ReducePos *__restrict__ pos,
+	const ReduceTap80 *__restrict__ taps)
+{
+	const int e = blockIdx.x * blockDim.x + threadIdx.x;
+	const int y = blockIdx.y;
+	if (e >= out.width * epp || y >= out.height)
+		return;
+	const int x = e / epp;
+	const int b = e - x * epp;
+	const int which = VERTICAL ? y : x;
+	const ReducePos p = pos[which];
+	const ReduceTap80 *c = taps + (size_t) which * n_point;
+	X80 sum = { 0, 0, 0 };
+	double plain = 0.0; // the sum in double: what an inf or NaN operand turns the result into
+	bool finite = true;
+	for (int i = 0; i < n_point; i++) {
+		double v;
+		if (VERTICAL) {
+			const int row = clampi(p.first + i, 0, in.im_height - 1) - in.top;
+			v = ((const double *) (in.data + (long long) row * in.stride))[(long long) (out.left - in.left) * epp + e];
+		}
+		else {
+			const int colx = clampi(p.first + i, 0, in.im_width - 1) - in.left;
+			v = ((const double *) (in.data + (long long) (out.top + y - in.top) * in.stride))[(long long) colx * epp + b];
+		}
+		X80 ci = { c[i].mant, c[i].exp, c[i].sign };
+		if (!(fabs(v) <= 1.7976931348623157e308)) // inf or NaN
+			finite = false;
+		if (finite)
+			sum = x80_add(sum, x80_mul(ci, x80_from_double(v)));
+		plain += x80_to_double(ci) * v;
+	}
+	((double *) (out.data + (long long) y * out.stride))[e] = finite ? x80_to_double(sum) : plain;
+}
+
+static int launch_reduce_notab(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out, int tile,
+	bool vertical)
+{
+	if (out->height > 65535) {
+		error(vertical ? "reducev" : "reduceh", "double images taller than 65535 rows per call are not supported");
+		return -1;
+	}
+	std::vector<ReducePos> pos;
+	std::vector<ReduceTap80> taps;
+	reduce_notab_masks(r, vertical ? out->top : out->left, vertical ? out->height : out->width, tile, pos, taps);
+	ReducePos *d_pos = (ReducePos *) upload(pos.data(), pos.size() * sizeof(ReducePos));
+	ReduceTap80 *d_taps = (ReduceTap80 *) upload(taps.data(), taps.size() * sizeof(ReduceTap80));
+	int result = -1;
+	if (d_pos && d_taps) {
+		const int epp = region_elems_per_pel(out);
+		const int ne = out->width * epp;
+		dim3 block(256, 1, 1), grid((ne + 255) / 256, out->height, 1);
+		Gate gate(vertical ? "reducev_notab_f64" : "reduceh_notab_f64");
+		if (vertical)
+			hipLaunchKernelGGL(reduce_notab_f64<true>, grid, block, 0, stream(), region_args(in), region_args(out), epp,
+				r->n_point, d_pos, d_taps);
+		else
+			hipLaunchKernelGGL(reduce_notab_f64<false>, grid, block, 0, stream(), region_args(in), region_args(out), epp,
+				r->n_point, d_pos, d_taps);
+		result = hipGetLastError() == hipSuccess ? 0 : hip_failed(hipErrorUnknown, "reduce_notab_f64 launch");
+	}
+	// (the pool orders reuse of these blocks behind the kernel: same thread, same stream)
+	vips_hip_free(d_pos);
+	vips_hip_free(d_taps);
+	return result;
+}
+
 static int reduce_check(const char *domain, const _VipsHipReduce *r, const VipsHipRegion *in,
 	const VipsHipRegion *out, bool vertical)
 {
@@ -485,12 +568,8 @@ static int reduce_gen(const char *domain, const VipsHipReduce *reduce, const Vip
 
 	const int fmt = format_real(out->format);
 	const bool want_float = fmt == VIPS_HIP_FORMAT_FLOAT;
-	if (fmt == VIPS_HIP_FORMAT_DOUBLE) {
-		// reduceh_notab / reducev_notab (reduceh.cpp:198-213): long double
-		// accumulation with a per-pixel mask; not implemented on the device.
-		error(domain, "double images are not supported by the HIP reduce path");
-		return -1;
-	}
+	if (fmt == VIPS_HIP_FORMAT_DOUBLE) // reduceh_notab / reducev_notab: no table, long double
+		return launch_reduce_notab(r, in, out, tile, vertical);
 	const void *table;
 	if (reduce_tables(r, want_float, &table))
 		return -1;

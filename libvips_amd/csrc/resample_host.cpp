@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 namespace vh {
 
@@ -92,8 +93,10 @@ static double filter_value(int kernel, double x)
 	}
 }
 
-// vips_reduce_make_mask<double> -> calculate_coefficients (templates.h:453-531)
-void reduce_make_mask(double *c, int kernel, int n_points, double shrink, double x)
+// vips_reduce_make_mask<T> -> calculate_coefficients<T> (templates.h:453-531): the filter is
+// evaluated in double whatever T is; the sum and the normalising division are T's.
+template <typename T>
+static void make_mask(T *c, int kernel, int n_points, double shrink, double x)
 {
 	if (kernel == VIPS_HIP_KERNEL_NEAREST) {
 		c[0] = 1.0;
@@ -102,7 +105,7 @@ void reduce_make_mask(double *c, int kernel, int n_points, double shrink, double
 
 	const double half = x + n_points / 2.0 - 1;
 	const double scale = 1.0 / shrink;
-	double sum = 0.0;
+	T sum = 0.0;
 	for (int i = 0; i < n_points; i++) {
 		const double xp = (i - half) * scale;
 		double l = filter_value(kernel, xp);
@@ -111,6 +114,62 @@ void reduce_make_mask(double *c, int kernel, int n_points, double shrink, double
 	}
 	for (int i = 0; i < n_points; i++)
 		c[i] /= sum;
+}
+
+void reduce_make_mask(double *c, int kernel, int n_points, double shrink, double x)
+{
+	make_mask<double>(c, kernel, n_points, shrink, x);
+}
+
+// Double images take the reference's "ultra-high-quality" path (reduceh.cpp:196-213,
+// reducev.cpp:497-515): no coefficient table -- a mask made for the exact fractional position of
+// every output column (row), in LONG DOUBLE (LongT<double>, templates.h:556-560), and a long
+// double sum.  On x86-64 that is the x87 extended format: 64 bits of mantissa.  The masks are made
+// here, on the host, with the same arithmetic (this file is built by the same compiler for the
+// same ABI), and handed to the device as (sign, exponent, 64-bit mantissa) triples; the device
+// adds and multiplies them with integer instructions, rounding to 64 bits of mantissa after every
+// operation exactly as the x87 does (resample.hip x80_*).
+#if !defined(__HIP_DEVICE_COMPILE__) // (this file also passes through the device compiler, whose long double is a double)
+static_assert(sizeof(long double) == 16 && __LDBL_MANT_DIG__ == 64, "the host's long double is not the x87 extended format");
+#endif
+
+void reduce_notab_masks(const _VipsHipReduce *r, int start, int count, int tile, std::vector<ReducePos> &pos,
+	std::vector<ReduceTap80> &taps)
+{
+	const int n = r->n_point;
+	pos.resize(count);
+	taps.resize((size_t) count * n);
+	if (tile <= 0)
+		tile = count;
+	std::vector<long double> cx(n);
+	for (int t0 = 0; t0 < count; t0 += tile) {
+		const int m = count - t0 < tile ? count - t0 : tile;
+		double X = (start + t0 + 0.5) * r->shrink - 0.5 - r->offset;
+		for (int k = 0; k < m; k++) {
+			const int ix = (int) X;
+			pos[t0 + k].first = ix - r->embed;
+			pos[t0 + k].phase = 0;
+			make_mask<long double>(cx.data(), r->kernel, n, r->shrink, X - ix);
+			for (int i = 0; i < n; i++) {
+				unsigned char raw[16];
+				memcpy(raw, &cx[i], sizeof(long double));
+				unsigned long long mant;
+				unsigned short se;
+				memcpy(&mant, raw, 8);
+				memcpy(&se, raw + 8, 2);
+				ReduceTap80 &tap = taps[(size_t) (t0 + k) * n + i];
+				tap.mant = mant;
+				tap.sign = se >> 15;
+				tap.exp = (int) (se & 0x7fff) - 16383;
+				if (mant && !(mant >> 63)) { // a denormal extended value: normalise
+					const int lz = __builtin_clzll(mant);
+					tap.mant = mant << lz;
+					tap.exp = -16382 - lz;
+				}
+			}
+			X += r->shrink;
+		}
+	}
 }
 
 // One generate call's position walk, reduceh.cpp:254-276,326 (and the same

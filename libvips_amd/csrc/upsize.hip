@@ -90,7 +90,26 @@ UP_TRAITS(short, true, true, SHRT_MIN, SHRT_MAX)
 UP_TRAITS(unsigned int, false, false, 0, INT_MAX)
 UP_TRAITS(int, false, true, INT_MIN, INT_MAX)
 UP_TRAITS(float, false, true, 0, 0)
+UP_TRAITS(double, false, true, 0, 0)
 #undef UP_TRAITS
+
+// calculate_coefficients_catmull (templates.h:296-320), every operation rounded: what the
+// no-table bicubic of double images evaluates per output pixel (bicubic.cpp:419-480)
+static __device__ __forceinline__ void catmull_device(double c[4], const double x)
+{
+	const double cr1 = __dsub_rn(1.0, x);
+	const double cr2 = __dmul_rn(-0.5, x);
+	const double cr3 = __dmul_rn(cr1, cr2);
+	const double cone = __dmul_rn(cr1, cr3);
+	const double cfou = __dmul_rn(x, cr3);
+	const double cr4 = __dsub_rn(cfou, cone);
+	const double ctwo = __dadd_rn(__dsub_rn(cr1, cone), cr4);
+	const double cthr = __dsub_rn(__dsub_rn(x, cfou), cr4);
+	c[0] = cone;
+	c[3] = cfou;
+	c[1] = ctwo;
+	c[2] = cthr;
+}
 
 // a * b + c * d + e * f + g * h, left to right, every operation rounded (cubic_float)
 static __device__ __forceinline__ double dot4(double c0, double v0, double c1, double v1, double c2,
@@ -191,6 +210,14 @@ upsize_kernel(UpsizeArgs a)
 			else {
 				const double *cx = a.tables->mf[tx];
 				const double *cy = a.tables->mf[ty];
+				double nx[4], ny[4];
+				if (std::is_same<T, double>::value) {
+					// double images: no table, the coefficients of the exact offsets (bicubic_notab)
+					catmull_device(nx, __dsub_rn(x, (double) ix));
+					catmull_device(ny, __dsub_rn(y, (double) iy));
+					cx = nx;
+					cy = ny;
+				}
 				for (int z = 0; z < a.bands; z++) {
 					double r[4];
 #pragma unroll
@@ -198,7 +225,7 @@ upsize_kernel(UpsizeArgs a)
 						r[j] = dot4(cx[0], (double) fetch<T>(a, ix - 1, iy - 1 + j, z), cx[1],
 							(double) fetch<T>(a, ix, iy - 1 + j, z), cx[2], (double) fetch<T>(a, ix + 1, iy - 1 + j, z),
 							cx[3], (double) fetch<T>(a, ix + 2, iy - 1 + j, z));
-						if (std::is_floating_point<T>::value)
+						if (std::is_same<T, float>::value)
 							r[j] = (double) (float) r[j]; // cubic_float<float> returns a float
 					}
 					double v = dot4(cy[0], r[0], cy[1], r[1], cy[2], r[2], cy[3], r[3]);
@@ -423,6 +450,8 @@ static int fill_args(const char *domain, const VipsHipRegion *in, const VipsHipR
 	case VIPS_HIP_FORMAT_INT: return CALL(int); \
 	case VIPS_HIP_FORMAT_FLOAT: \
 	case VIPS_HIP_FORMAT_COMPLEX: return CALL(float); \
+	case VIPS_HIP_FORMAT_DOUBLE: \
+	case VIPS_HIP_FORMAT_DPCOMPLEX: return CALL(double); \
 	default: break; \
 	}
 
@@ -498,7 +527,7 @@ int vips_hip_upsize_gen(const VipsHipRegion *in, const VipsHipRegion *out, doubl
 #define CALL(T) launch_upsize<T>(a, interpolate)
 	UP_DISPATCH(in->format, CALL)
 #undef CALL
-	error(domain, "band format %d is outside the HIP path (double images use the no-table bicubic)", in->format);
+	error(domain, "band format %d is outside the HIP path", in->format);
 	return -1;
 }
 

@@ -156,6 +156,47 @@ def test_error_behaviour():
         im.resize(-0.5)
 
 
+@pytest.mark.skipif(not helpers.have_ref(), reason="needs oracle/_ref: the x87 long double sums are the reference's")
+@pytest.mark.parametrize("op,args", [
+    ("reduceh", "hshrink=3.1"), ("reducev", "vshrink=2.5,kernel=cubic"), ("reduce", "hshrink=8,vshrink=8"),
+    ("reduce", "hshrink=1.7,vshrink=4.3,kernel=lanczos2"), ("reduce", "hshrink=2,vshrink=2,kernel=linear"),
+    ("reduce", "hshrink=3.3,vshrink=1.2,kernel=mks2021"), ("reducev", "vshrink=5,kernel=nearest"),
+    ("resize", "scale=0.37"), ("resize", "scale=0.125,kernel=mitchell"),
+    # upsizing: the no-table bicubic (bicubic.cpp:419-480: Catmull-Rom coefficients of the exact
+    # offsets, all in double), bilinear, nearest
+    ("resize", "scale=2.2"), ("resize", "scale=2.5,kernel=cubic"), ("resize", "scale=1.7,kernel=linear"),
+    ("resize", "scale=3,kernel=nearest"),
+])
+@pytest.mark.parametrize("bands", [1, 3])
+def test_reduce_double_vs_reference(op, args, bands):
+    """Double images: the reference's "ultra-high-quality" path (reduceh.cpp:196-213,
+    reducev.cpp:497-515): no coefficient table, a LONG DOUBLE mask per output position and a long
+    double sum.  The device does that arithmetic -- x87 extended: 64 bits of mantissa, one rounding
+    per operation -- with integers (x80.h); the masks are made on the host in long double.  Bit for
+    bit against the compiled reference, values over a wide range of magnitudes and signs."""
+    rng = np.random.default_rng(5)
+    w, h = 403, 297
+    src = (rng.standard_normal((h, w, bands)) * np.exp2(rng.integers(-20, 20, size=(h, w, bands)))).astype(np.float64)
+    src[3, 5] = 0.0
+    src[7, 11] = 5e-324          # a denormal
+    want = Ref.run(op, src, args)
+    im = Image.new_from_array(src)
+    kw = dict(kv.split("=") for kv in args.split(","))
+    kernel = kw.pop("kernel", "lanczos3")
+    kw = {k: float(v) for k, v in kw.items()}
+    if op == "reduceh":
+        got = im.reduceh(kw["hshrink"], kernel=kernel)
+    elif op == "reducev":
+        got = im.reducev(kw["vshrink"], kernel=kernel)
+    elif op == "reduce":
+        got = im.reduce(kw["hshrink"], kw["vshrink"], kernel=kernel)
+    else:
+        got = im.resize(kw["scale"], kernel=kernel)
+    got = got.numpy()
+    assert got.dtype == np.float64 and got.shape == want.shape
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
 def test_c2_quarter_size_vs_reference_checksum():
     # SURVEY.md 8(c) golden: 4096^2 x4 LCG -> 512^2, checksum 16793779256
     src = helpers.lcg_image(4096, 4096, 4, np.uint8, 12345)
