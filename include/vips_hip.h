@@ -470,6 +470,10 @@ VIPS_HIP_API VipsHipImage *vips_hip_image_new_from_memory(const void *host_data,
 VIPS_HIP_API VipsHipImage *vips_hip_image_new_from_device(void *device_data,
 	int width, int height, int bands, int format, int interpretation);
 VIPS_HIP_API void vips_hip_image_unref(VipsHipImage *image);
+/* vips_hip_image_unref() on images[0 .. n) (NULL entries are skipped), each entry set to NULL:
+ * what a caller of the batch entry points does with a batch's results (VIPS_UNREF in a loop,
+ * g_object_unref, gobject/gobject.c). */
+VIPS_HIP_API void vips_hip_image_unref_many(VipsHipImage **images, int n);
 VIPS_HIP_API int vips_hip_image_write_to_memory(const VipsHipImage *image, void *host_data);
 VIPS_HIP_API void *vips_hip_image_get_data(const VipsHipImage *image);
 /* the device the pixels live on (-1 for a NULL image) */

@@ -188,6 +188,7 @@ _SIGNATURES = {
     "vips_hip_image_new_from_memory": (c_void_p, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "vips_hip_image_new_from_device": (c_void_p, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "vips_hip_image_unref": (None, [c_void_p]),
+    "vips_hip_image_unref_many": (None, [P(c_void_p), c_int]),
     "vips_hip_image_write_to_memory": (c_int, [c_void_p, c_void_p]),
     "vips_hip_image_get_data": (c_void_p, [c_void_p]),
     "vips_hip_image_get_device": (c_int, [c_void_p]),

@@ -1022,6 +1022,16 @@ void vips_hip_image_unref(VipsHipImage *image)
 	delete image; // library memory goes back to the pool with its last holder
 }
 
+void vips_hip_image_unref_many(VipsHipImage **images, int n)
+{
+	if (!images)
+		return;
+	for (int i = 0; i < n; i++) {
+		vips_hip_image_unref(images[i]);
+		images[i] = nullptr;
+	}
+}
+
 int vips_hip_image_write_to_memory(const VipsHipImage *image, void *host_data)
 {
 	if (!image || !host_data) {

@@ -83,8 +83,12 @@ const char *hipGetErrorString(hipError_t) { return "mock hip error"; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 
+static long g_mallocs = 0;
+long mock_hip_mallocs(void) { return g_mallocs; }
+
 hipError_t hipMalloc(void **p, size_t size)
 {
+	__sync_fetch_and_add(&g_mallocs, 1);
 	*p = malloc(size ? size : 1);
 	return *p ? hipSuccess : hipErrorOutOfMemory;
 }

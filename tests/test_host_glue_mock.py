@@ -254,6 +254,23 @@ assert mock.mock_hip_launches() - n0 == 2
 mixed = ims[:3] + [Image.new_from_array(np.zeros((64, 700, 3), np.uint8), interpretation="srgb")]
 outs = libvips_amd.resize_sharpen_batch(mixed, 0.125, threads=2)
 assert [(o.width, o.height) for o in outs] == [(86, 8)] * 3 + [(88, 8)]
+# the C caller's side of a batch: arrays in, arrays out, the results released in one call (their
+# memory goes back to the pool: the next batch allocates nothing new)
+from libvips_amd._ffi import lib
+n = len(ims)
+hin = (ctypes.c_void_p * n)(*[im._h.value for im in ims])
+hout = (ctypes.c_void_p * n)()
+mock.mock_hip_mallocs.restype = ctypes.c_long
+for rep in range(3):
+    assert lib.vips_hip_resize_sharpen_batch(hin, n, hout, 0.125, 5, 2.0, 0.5, 2.0, 10.0, 20.0, 0.0, 3.0, 4) == 0
+    assert all(hout[i] for i in range(n))
+    if rep == 1:
+        m0 = mock.mock_hip_mallocs()
+    lib.vips_hip_image_unref_many(hout, n)
+    assert not any(hout[i] for i in range(n))
+assert mock.mock_hip_mallocs() == m0, (m0, mock.mock_hip_mallocs())
+lib.vips_hip_image_unref_many(hout, n)   # all NULL: nothing to do
+lib.vips_hip_image_unref_many(None, 5)
 ''', tmp_path)
 
 

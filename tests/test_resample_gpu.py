@@ -613,3 +613,17 @@ def test_resize_sharpen_batch():
     bad = ims[:2] + [Image.new_from_array(helpers.lcg_image(64, 48, 2, np.uint8, 70))] + ims[2:4]
     with pytest.raises(libvips_amd.VipsHipError):
         libvips_amd.resize_sharpen_batch(bad, 0.125, threads=2)  # a 2-band image has no route to LabS
+    # as a C caller drives it (bench.py's C4 step): handle arrays, results released in one call
+    import ctypes
+
+    from libvips_amd._ffi import lib
+
+    n = len(ims)
+    hin = (ctypes.c_void_p * n)(*[im._h.value for im in ims])
+    hout = (ctypes.c_void_p * n)()
+    for _ in range(2):
+        lib.vips_hip_image_unref_many(hout, n)
+        assert lib.vips_hip_resize_sharpen_batch(hin, n, hout, 0.125, 5, 2.0, 0.5, 2.0, 10.0, 20.0, 0.0, 3.0, 4) == 0
+    got = [Image(h) for h in hout]
+    for im, out in zip(ims, got):
+        assert np.array_equal(out.numpy(), im.resize(0.125).sharpen().numpy())
