@@ -19,7 +19,13 @@
 //   retires per pair into LDS.  Row registers are refilled in place with the next pair's rows, so
 //   2 vs loads per lane are always in flight.  Nothing is read twice within a segment.
 //   horizontal, every 7 retired rows: shrinkh box sums from that LDS slab into a second one, then
-//   the 13 reduceh taps from there, bytes stored straight to the output image.
+//   the 13 reduceh taps from there, bytes stored straight to the output image.  While a block is
+//   in its horizontal pass it issues no loads, so the pass is kept short: when a box is whole
+//   dwords (hs * bands a multiple of 4, e.g. 4 x RGB = 12 bytes) its sums are v_dot4_u32_u8 of
+//   the slab's dwords with 0/1 byte masks (band b of dword j), the shrunk pixels go to the second
+//   slab as 16-bit lanes, band-planar, indexed by UNCLAMPED column (edge columns are written
+//   twice), and a reduceh output is 7 v_dot2_i32_i16 per row on consecutive dwords (HF below;
+//   any other geometry takes the byte-by-byte form).
 //
 // The 1/vs-size and the two further intermediate images of the chain never exist: an 8192 x 8192 x 3
 // image is read once (201 MB) and 3 MB are written.  Every rounding is the separate operations'
@@ -50,11 +56,14 @@ struct StreamArgs {
 	int n_h;                     // horizontal taps (<= 13)
 	int tw, seg;                 // output columns per strip, output rows per segment
 	int s_pitch;                 // bytes per row of the shrinkh slab
-	int debug;                   // $VIPS_HIP_STREAM_DEBUG: 1 skip the horizontal pass (timing only)
+	int debug;                   // $VIPS_HIP_STREAM_DEBUG: 1 skip the horizontal pass, 2 skip its stores (HF form) (timing only)
 	int nstrips, nsegs, n_images; // the launch: strips x segments x images
 	int grouped;                  // the strips of a (segment, image) on one XCD
 	unsigned int cv[RS_NP];      // vertical taps (2q, 2q + 1) as i16 pairs
-	short ch[16];                // horizontal taps
+	short ch[16];                // horizontal taps (those past n_h are 0: read in pairs by the HF pass)
+	int s_len;                   // HF: dwords per band and row of the shrinkh slab
+	int o_pitch, burst;          // HF: bytes per staged output row, slabs the stage holds (0: store row by row)
+	int window;                  // HF: the staged rows leave when the 100 MHz clock crosses a multiple of 2^window ticks
 };
 
 struct StreamPtrs {
@@ -110,7 +119,11 @@ static __device__ __forceinline__ unsigned int rs_box2(unsigned int sums, unsign
 // registers, twice the waves)
 // NP = coefficient pairs of the vertical reduce = output rows in flight per column = rows per
 // slab: 7 (13 taps: lanczos3), 5 (9 taps: lanczos2, cubic, mitchell), 3 (5 taps: linear)
-template <int VS, int DW, int NP>
+// HF = the dword form of the horizontal pass (see the head of the file)
+// (the compiler gathers a pair's 2 VS refills in front of the pair: 2 VS to 4 VS loads in flight per
+// lane; pinned behind their rows' uses -- 2 VS at all times -- the kernel ran 0.5 % faster, within
+// what the boxes differ by: profiles/r03_probes.txt)
+template <int VS, int DW, int NP, bool HF>
 __global__ void __launch_bounds__(RS_SPAN / (4 * DW))
 resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 {
@@ -119,6 +132,9 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 	extern __shared__ __attribute__((aligned(16))) unsigned int rs_lds[];
 	unsigned char *T = reinterpret_cast<unsigned char *>(rs_lds); // NP rows of RS_SPAN bytes
 	unsigned char *S = T + NP * RS_SPAN;                        // NP rows of s_pitch bytes
+	unsigned int *HM = reinterpret_cast<unsigned int *>(S + NP * a.s_pitch); // HF: byte masks [band][dword of a box]
+	unsigned int *CLK = HM + 32;                                             // HF: the clock slot every wave of the block acts on
+	unsigned char *O = reinterpret_cast<unsigned char *>(HM + 36);           // HF: burst * NP staged output rows
 	(void) ptrs_by_value;
 	// the image pointers where they lie in the kernarg segment (a by-value array indexed
 	// dynamically would be copied to scratch)
@@ -162,6 +178,19 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 
 	const int t = threadIdx.x;
 	const int B = a.bands;
+	if constexpr (HF) {
+		// byte i of dword j of a box belongs to band (4 j + i) % B (ordered before its readers by
+		// the first slab's barrier)
+		if (t < 32) {
+			const int b = t >> 3, j = t & 7;
+			unsigned int m = 0;
+#pragma unroll
+			for (int i = 0; i < 4; i++)
+				if ((4 * j + i) % B == b)
+					m |= 1u << (8 * i);
+			HM[t] = m;
+		}
+	}
 	const int x0 = strip * a.tw, nx = min(a.tw, a.out_width - x0);
 	const int y0 = seg_i * a.seg, ny = min(a.seg, a.out_height - y0);
 	// columns of the shrinkh image the strip's taps touch, and the input bytes under them
@@ -220,6 +249,19 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 		for (int k = 0; k < VS; k++)
 			ring[h][k] = load(r0 - 2 + h, k);
 
+	// HF: output rows wait in LDS and leave `burst` slabs at a time -- a trickle of small writes
+	// into the streaming read costs a fifth of its rate on this part (the stores of 1.5 % of the
+	// bytes: 0.0404 -> 0.0337 ms per image without them), a burst now and then far less (the same
+	// finding as reduce_u8.hip's output stage)
+	//
+	// ... and the bursts of ALL blocks fall together: a block writes what it holds when the chip-wide
+	// 100 MHz clock (s_memrealtime) crosses a multiple of 2^window ticks (and when its stage is
+	// full, and at its end).  HBM pays for every change of direction on a channel; output rows are
+	// spread over all channels, so only writes that arrive together from the whole chip share
+	// those turnarounds (tools/c4_load_probe: the stores of this kernel cost 18 % of the read rate
+	// trickling, 10 % in per-block bursts, 6 % in chip-wide windows 82 us apart).
+	int staged = 0, flushed = 0;
+	unsigned int slot = 0; // (the first slab's reading differs: a first, short burst)
 	const int nbody = (ny + NP - 1) / NP + 1;
 	for (int n = 0; n < nbody; n++) {
 #pragma unroll
@@ -289,57 +331,165 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 		// hoisted out of the row loop it would sit in ~30 registers through the vertical pass)
 		int th = t;
 		asm volatile("" : "+v"(th));
-		// shrinkh: thread = one band element of the shrunk rows, all slab rows
-		{
-			const int per_row = ncol * B;
-			const unsigned int magic = (65536u + B - 1) / B;
-			for (int e = th; e < per_row; e += NT) {
-				const int c = (int) ((e * magic) >> 16);
-				const int b = e - c * B;
-				const int px0 = (c_lo + c) * a.hs;
-				const unsigned char *src = T + b - start_al;
+		if constexpr (!HF) {
+			// shrinkh: thread = one band element of the shrunk rows, all slab rows
+			{
+				const int per_row = ncol * B;
+				const unsigned int magic = (65536u + B - 1) / B;
+				for (int e = th; e < per_row; e += NT) {
+					const int c = (int) ((e * magic) >> 16);
+					const int b = e - c * B;
+					const int px0 = (c_lo + c) * a.hs;
+					const unsigned char *src = T + b - start_al;
+					unsigned int sum[NP];
+	#pragma unroll
+					for (int r = 0; r < NP; r++)
+						sum[r] = (unsigned int) (a.hs / 2);
+	#pragma unroll 4
+					for (int k = 0; k < a.hs; k++) {
+						const int off = min(px0 + k, a.width - 1) * B;
+	#pragma unroll
+						for (int r = 0; r < NP; r++)
+							sum[r] += src[r * RS_SPAN + off];
+					}
+	#pragma unroll
+					for (int r = 0; r < NP; r++)
+						S[r * a.s_pitch + e] = (unsigned char) ((sum[r] * a.mult_h) >> 24);
+				}
+			}
+			__syncthreads();
+			// reduceh: thread = one band element of the output rows (nx * B <= 256), all slab rows
+			if (th < nx * B) {
+				const unsigned int magic = (65536u + B - 1) / B;
+				const int x = (int) ((th * magic) >> 16);
+				const int b = th - x * B;
+				const int f = 2 * (x0 + x) + a.fh;
+				int sum[NP];
+	#pragma unroll
+				for (int r = 0; r < NP; r++)
+					sum[r] = 0;
+	#pragma unroll
+				for (int k = 0; k < 13; k++) {
+					if (k < a.n_h) {
+						const int off = (min(max(f + k, 0), a.w3 - 1) - c_lo) * B + b;
+						const int ck = a.ch[k];
+	#pragma unroll
+						for (int r = 0; r < NP; r++)
+							sum[r] += ck * (int) S[r * a.s_pitch + off];
+					}
+				}
+				const GlobalOut dst = out + (long long) (y0 + yb) * a.out_stride + (long long) x0 * B + th;
+	#pragma unroll
+				for (int r = 0; r < NP; r++)
+					if (r < nr)
+						dst[(long long) r * a.out_stride] = (unsigned char) rs_fin(sum[r]);
+			}
+		}
+		else {
+			// shrinkh: thread = one band of one UNCLAMPED shrunk column u (column 2 x0 + fh + u of
+			// the shrunk image, clamped into it: reduceh's edge taps then read plain consecutive
+			// columns), band-major so that a wave's lanes walk consecutive boxes; all slab rows
+			const int len = 2 * nx + a.n_h - 1;
+			const int total = len * B;
+			const int ndw = (a.hs * B) >> 2;
+			unsigned short *S16 = reinterpret_cast<unsigned short *>(S);
+			const int band_pitch = 2 * a.s_len; // 16-bit lanes per band and row
+			for (int e = th; e < total; e += NT) {
+				const int b = (e >= len) + (e >= 2 * len) + (e >= 3 * len);
+				const int u = e - b * len;
+				const int col = min(max(2 * x0 + a.fh + u, 0), a.w3 - 1);
+				const unsigned int *src = reinterpret_cast<const unsigned int *>(T + col * a.hs * B - start_al);
 				unsigned int sum[NP];
 #pragma unroll
 				for (int r = 0; r < NP; r++)
 					sum[r] = (unsigned int) (a.hs / 2);
-#pragma unroll 4
-				for (int k = 0; k < a.hs; k++) {
-					const int off = min(px0 + k, a.width - 1) * B;
 #pragma unroll
-					for (int r = 0; r < NP; r++)
-						sum[r] += src[r * RS_SPAN + off];
-				}
+				for (int j = 0; j < 8; j++)
+					if (j < ndw) {
+						const unsigned int m = HM[b * 8 + j];
+#pragma unroll
+						for (int r = 0; r < NP; r++)
+							sum[r] = __builtin_amdgcn_udot4(src[r * (RS_SPAN / 4) + j], m, sum[r], false);
+					}
 #pragma unroll
 				for (int r = 0; r < NP; r++)
-					S[r * a.s_pitch + e] = (unsigned char) ((sum[r] * a.mult_h) >> 24);
+					S16[(r * B + b) * band_pitch + u] = (unsigned short) ((sum[r] * a.mult_h) >> 24);
 			}
-		}
-		__syncthreads();
-		// reduceh: thread = one band element of the output rows (nx * B <= 256), all slab rows
-		if (th < nx * B) {
-			const unsigned int magic = (65536u + B - 1) / B;
-			const int x = (int) ((th * magic) >> 16);
-			const int b = th - x * B;
-			const int f = 2 * (x0 + x) + a.fh;
-			int sum[NP];
+			// (ONE reading of the clock per block and slab: waves that read it for themselves could
+			// disagree about the slot, and about the barrier below)
+			if (th == 0)
+				*CLK = (unsigned int) (__builtin_amdgcn_s_memrealtime() >> a.window);
+			__syncthreads();
+			// reduceh: thread = one band element of the output rows; taps (2 q, 2 q + 1) of output
+			// x are the two lanes of dword x + q of the band's row
+			if (th < nx * B) {
+				const unsigned int magic = (65536u + B - 1) / B;
+				const int x = (int) ((th * magic) >> 16);
+				const int b = th - x * B;
+				const unsigned int *row = reinterpret_cast<const unsigned int *>(S) + b * a.s_len + x;
+				const int nq = (a.n_h + 1) >> 1;
+				int sum[NP];
 #pragma unroll
-			for (int r = 0; r < NP; r++)
-				sum[r] = 0;
+				for (int r = 0; r < NP; r++)
+					sum[r] = 0;
 #pragma unroll
-			for (int k = 0; k < 13; k++) {
-				if (k < a.n_h) {
-					const int off = (min(max(f + k, 0), a.w3 - 1) - c_lo) * B + b;
-					const int ck = a.ch[k];
+				for (int q = 0; q < 7; q++)
+					if (q < nq) {
+						const unsigned int ck = (unsigned int) (unsigned short) a.ch[2 * q] |
+							((unsigned int) (unsigned short) a.ch[2 * q + 1] << 16);
+#pragma unroll
+						for (int r = 0; r < NP; r++)
+							sum[r] = rs_dot2(row[r * B * a.s_len + q], ck, sum[r]);
+					}
+				if (a.burst > 0) {
+					// into the stage, every row at the byte offset its global address has in a dword
+					// (the burst then moves whole dwords)
+					const unsigned int lo = (unsigned int) (unsigned long long) (out + (long long) x0 * B);
 #pragma unroll
 					for (int r = 0; r < NP; r++)
-						sum[r] += ck * (int) S[r * a.s_pitch + off];
+						if (r < nr) {
+							const unsigned int mis = (lo + (unsigned int) (y0 + yb + r) * (unsigned int) a.out_stride) & 3u;
+							O[(staged + r) * a.o_pitch + mis + th] = (unsigned char) rs_fin(sum[r]);
+						}
+				}
+				else {
+					const GlobalOut dst = out + (long long) (y0 + yb) * a.out_stride + (long long) x0 * B + th;
+#pragma unroll
+					for (int r = 0; r < NP; r++)
+						if (r < nr && !(a.debug & 2)) // (debug 2: everything but the stores -- timing only)
+							dst[(long long) r * a.out_stride] = (unsigned char) rs_fin(sum[r]);
 				}
 			}
-			const GlobalOut dst = out + (long long) (y0 + yb) * a.out_stride + (long long) x0 * B + th;
-#pragma unroll
-			for (int r = 0; r < NP; r++)
-				if (r < nr)
-					dst[(long long) r * a.out_stride] = (unsigned char) rs_fin(sum[r]);
+			if (a.burst > 0) {
+				staged += nr;
+				const unsigned int now = *CLK;
+				if (now != slot || staged + NP > a.burst * NP || n == nbody - 1) {
+					slot = now;
+					__syncthreads();
+					// a wave per row, a lane per dword of the row's window [address & ~3, ...): whole
+					// dwords inside the fragment as dwords, its ragged ends byte by byte
+					const int nb = nx * B;
+					for (int row = th >> 6; row < staged; row += NT / 64) {
+						const long long first = (long long) (y0 + flushed + row) * a.out_stride + (long long) x0 * B;
+						const int mis = (int) ((unsigned int) (unsigned long long) (out + first) & 3u);
+						const GlobalOut g = out + first - mis;
+						const unsigned char *src = O + row * a.o_pitch;
+						for (int d = th & 63; 4 * d < mis + nb; d += 64) {
+							const int b0 = 4 * d;
+							if (a.debug & 2)
+								continue;
+							if (b0 >= mis && b0 + 4 <= mis + nb)
+								*(unsigned int __attribute__((address_space(1))) *) (g + b0) = *reinterpret_cast<const unsigned int *>(src + b0);
+							else
+								for (int k = 0; k < 4; k++)
+									if (b0 + k >= mis && b0 + k < mis + nb)
+										g[b0 + k] = src[b0 + k];
+						}
+					}
+					flushed += staged;
+					staged = 0;
+				}
+			}
 		}
 	}
 }
@@ -360,23 +510,25 @@ bool stream_regular(const std::vector<ReducePos> &pos, int *first0, int *phase)
 }
 
 template <int VS, int NP>
-void stream_launch_np(const StreamArgs &a, const StreamPtrs &p, dim3 grid, size_t lds, int dw)
+void stream_launch_np(const StreamArgs &a, const StreamPtrs &p, dim3 grid, size_t lds, int dw, bool hf)
 {
 	if (dw == 2 && NP == RS_NP)
-		hipLaunchKernelGGL((resize_stream_u8<VS, NP == RS_NP ? 2 : 1, NP>), grid, dim3(RS_SPAN / 8, 1, 1), lds, stream(), a, p);
+		hipLaunchKernelGGL((resize_stream_u8<VS, NP == RS_NP ? 2 : 1, NP, false>), grid, dim3(RS_SPAN / 8, 1, 1), lds, stream(), a, p);
+	else if (hf)
+		hipLaunchKernelGGL((resize_stream_u8<VS, 1, NP, true>), grid, dim3(RS_SPAN / 4, 1, 1), lds, stream(), a, p);
 	else
-		hipLaunchKernelGGL((resize_stream_u8<VS, 1, NP>), grid, dim3(RS_SPAN / 4, 1, 1), lds, stream(), a, p);
+		hipLaunchKernelGGL((resize_stream_u8<VS, 1, NP, false>), grid, dim3(RS_SPAN / 4, 1, 1), lds, stream(), a, p);
 }
 
 template <int VS>
-void stream_launch(const StreamArgs &a, const StreamPtrs &p, dim3 grid, size_t lds, int dw, int np)
+void stream_launch(const StreamArgs &a, const StreamPtrs &p, dim3 grid, size_t lds, int dw, int np, bool hf)
 {
 	if (np == 7)
-		stream_launch_np<VS, 7>(a, p, grid, lds, dw);
+		stream_launch_np<VS, 7>(a, p, grid, lds, dw, hf);
 	else if (np == 5)
-		stream_launch_np<VS, 5>(a, p, grid, lds, dw);
+		stream_launch_np<VS, 5>(a, p, grid, lds, dw, hf);
 	else
-		stream_launch_np<VS, 3>(a, p, grid, lds, dw);
+		stream_launch_np<VS, 3>(a, p, grid, lds, dw, hf);
 }
 
 } // namespace
@@ -454,6 +606,26 @@ int resize_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh, int hs,
 		return 0;
 	a.tw = tw;
 	a.s_pitch = ((2 * tw + a.n_h - 1) * B + 3) & ~3;
+	// the dword form of the horizontal pass: boxes of whole dwords (at most 8), none clipped by the
+	// right edge of the image (the byte form clamps pixel by pixel there)
+	int dw = getenv("VIPS_HIP_STREAM_DW") ? atoi(getenv("VIPS_HIP_STREAM_DW")) : 1;
+	if (row_bytes < RS_SPAN)
+		dw = 1; // (a row shorter than the span: lanes beyond it clamp dword by dword)
+	const char *hf_env = getenv("VIPS_HIP_STREAM_HF");
+	const bool hf = dw == 1 && (hs * B) % 4 == 0 && hs * B <= 32 && i0->width % hs == 0 && !(hf_env && atoi(hf_env) == 0);
+	if (hf) {
+		// 2 tw + n_h - 1 columns and the lane a last odd tap's partner reads; an odd number of dwords
+		// per band (the three bands of a wave's lanes then fall on different banks)
+		a.s_len = ((2 * tw + a.n_h - 1 + 1 + 1) / 2) | 1;
+		a.s_pitch = B * a.s_len * 4;
+		a.o_pitch = (tw * B + 3 + 3) & ~3;
+		a.burst = getenv("VIPS_HIP_STREAM_BURST") ? atoi(getenv("VIPS_HIP_STREAM_BURST")) : 14;
+		if (a.burst < 0 || a.burst > 32)
+			a.burst = 14;
+		a.window = getenv("VIPS_HIP_STREAM_WINDOW") ? atoi(getenv("VIPS_HIP_STREAM_WINDOW")) : 13;
+		if (a.window < 4 || a.window > 40)
+			a.window = 13;
+	}
 	const int nstrips = (o0->width + tw - 1) / tw;
 	// segments: enough blocks to fill the chip several times, but tall (a segment re-reads 6 pairs)
 	long long want = getenv("VIPS_HIP_STREAM_BLOCKS") ? atoll(getenv("VIPS_HIP_STREAM_BLOCKS")) : 2048;
@@ -475,10 +647,13 @@ int resize_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh, int hs,
 	const short *chs = &rh->matrixs[(size_t) phase_h * rh->n_point];
 	for (int k = 0; k < rh->n_point; k++)
 		a.ch[k] = chs[k];
-	const size_t lds = (size_t) np * RS_SPAN + (size_t) np * a.s_pitch;
-	int dw = getenv("VIPS_HIP_STREAM_DW") ? atoi(getenv("VIPS_HIP_STREAM_DW")) : 1;
-	if (row_bytes < RS_SPAN)
-		dw = 1; // (a row shorter than the span: lanes beyond it clamp dword by dword)
+	// ($VIPS_HIP_STREAM_LDSPAD: unused LDS bytes per block, to hold the blocks per CU down in experiments)
+	// (the stage shrinks until the block's LDS is within the 64 KB a launch gets without asking)
+	while (hf && a.burst > 1 && (size_t) np * RS_SPAN + (size_t) np * a.s_pitch + 144 + (size_t) a.burst * np * a.o_pitch > 65536)
+		a.burst--;
+	const size_t lds = (size_t) np * RS_SPAN + (size_t) np * a.s_pitch +
+		(hf ? 36 * sizeof(unsigned int) + (size_t) a.burst * np * a.o_pitch : 0) +
+		(getenv("VIPS_HIP_STREAM_LDSPAD") ? (size_t) atoi(getenv("VIPS_HIP_STREAM_LDSPAD")) : 0);
 
 	Gate gate("resize_stream_u8");
 	for (int base = 0; base < n; base += RS_MAXB) {
@@ -502,25 +677,25 @@ int resize_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh, int hs,
 		const dim3 grid((unsigned int) blocks, 1, 1);
 		switch (vs) {
 		case 1:
-			stream_launch<1>(a, p, grid, lds, dw, np);
+			stream_launch<1>(a, p, grid, lds, dw, np, hf);
 			break;
 		case 2:
-			stream_launch<2>(a, p, grid, lds, dw, np);
+			stream_launch<2>(a, p, grid, lds, dw, np, hf);
 			break;
 		case 3:
-			stream_launch<3>(a, p, grid, lds, dw, np);
+			stream_launch<3>(a, p, grid, lds, dw, np, hf);
 			break;
 		case 4:
-			stream_launch<4>(a, p, grid, lds, dw, np);
+			stream_launch<4>(a, p, grid, lds, dw, np, hf);
 			break;
 		case 5:
-			stream_launch<5>(a, p, grid, lds, dw, np);
+			stream_launch<5>(a, p, grid, lds, dw, np, hf);
 			break;
 		case 6:
-			stream_launch<6>(a, p, grid, lds, dw, np);
+			stream_launch<6>(a, p, grid, lds, dw, np, hf);
 			break;
 		default:
-			stream_launch<8>(a, p, grid, lds, dw, np);
+			stream_launch<8>(a, p, grid, lds, dw, np, hf);
 			break;
 		}
 		if (hipGetLastError() != hipSuccess) {

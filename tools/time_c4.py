@@ -14,7 +14,7 @@ from libvips_amd import Image, lib  # noqa: E402
 
 KNOBS = ("VIPS_HIP_NO_RESIZE_TAIL", "VIPS_HIP_NO_FUSED_SHARPEN", "VIPS_HIP_TAIL_TH", "VIPS_HIP_TAIL_TW",
          "VIPS_HIP_NO_RESIZE_STREAM", "VIPS_HIP_NO_BATCH_LAUNCH", "VIPS_HIP_STREAM_BLOCKS", "VIPS_HIP_STREAM_SEG",
-         "VIPS_HIP_STREAM_DEBUG", "VIPS_HIP_BATCH_OVERLAP", "VIPS_HIP_STREAM_DW")
+         "VIPS_HIP_STREAM_DEBUG", "VIPS_HIP_BATCH_OVERLAP", "VIPS_HIP_STREAM_DW", "VIPS_HIP_STREAM_HF")
 n, count = 8192, int(os.environ.get("C4_IMAGES", "64"))
 scale = float(os.environ.get("C4_SCALE", "0.125"))
 libvips_amd.init(0)
