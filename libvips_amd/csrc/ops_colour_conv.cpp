@@ -863,8 +863,8 @@ static int resize_sharpen_batch_here(VipsHipImage *const *in, int n, VipsHipImag
 	// runs on a stream masked to 3/4 of the CUs of every XCD (hipExtStreamCreateWithCUMask) next to
 	// the sharpen of chunk k on the other quarter -- measured on the MI355X (tools/c4_cumask.py):
 	// resize 0.0405 ms per image on 256 CUs, 0.0440 on 192; sharpen x 4 on 64 CUs = about the same
-	// time, so a pair of chunks takes what the resize alone takes on 192 CUs.  The last chunk's
-	// sharpen has nothing to hide behind and runs on every CU.  $VIPS_HIP_BATCH_OVERLAP=0: one
+	// time, so a pair of chunks takes what the resize alone takes on 192 CUs.  The first chunk's
+	// resize and the last chunk's sharpen have nothing to run beside and take every CU.  $VIPS_HIP_BATCH_OVERLAP=0: one
 	// stream, one stage after the other.
 	if (n > 0 && !getenv("VIPS_HIP_NO_BATCH_LAUNCH")) {
 		const int chunk = 64;
@@ -889,10 +889,17 @@ static int resize_sharpen_batch_here(VipsHipImage *const *in, int n, VipsHipImag
 			if (!ev || hipStreamWaitEvent(bs->resize, ev, 0) != hipSuccess || hipStreamWaitEvent(bs->sharpen, ev, 0) != hipSuccess)
 				bad = 1;
 		}
+		// the first chunk's resize has no sharpen to run beside: it takes every CU (the caller's
+		// stream), and the resize partition starts behind it
 		int r = 0;
+		hipEvent_t first_done = nullptr;
 		if (!bad) {
-			ScopedStream on(bs ? bs->resize : nullptr); // (a null stream leaves the thread's own)
 			r = vh::resize_batch_u8(in, first, ps.data(), scale, kernel, gap);
+			if (bs && r == 0) {
+				first_done = event_on(main_stream);
+				if (!first_done || hipStreamWaitEvent(bs->resize, first_done, 0) != hipSuccess)
+					bad = 1;
+			}
 		}
 		if (r < 0 || bad) {
 			for (hipEvent_t ev : events)
@@ -927,7 +934,7 @@ static int resize_sharpen_batch_here(VipsHipImage *const *in, int n, VipsHipImag
 				hipStream_t sharpen_on = nullptr;
 				if (bs) {
 					sharpen_on = last ? main_stream : bs->sharpen;
-					hipEvent_t ev = event_on(bs->resize);
+					hipEvent_t ev = base == 0 ? first_done : event_on(bs->resize);
 					if (!ev || hipStreamWaitEvent(sharpen_on, ev, 0) != hipSuccess)
 						bad = 1;
 				}
