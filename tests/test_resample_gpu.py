@@ -490,6 +490,43 @@ def test_resize_stream_fused(bands, size, scale, vscale, monkeypatch):
     assert np.array_equal(got, im.resize(scale, **kw).numpy())
 
 
+@pytest.mark.parametrize("burst,window,hf", [(0, 13, 1), (1, 13, 1), (2, 4, 1), (14, 40, 1), (5, 9, 1), (14, 13, 0)])
+@pytest.mark.parametrize("bands,size,scale,vscale", [
+    (3, (8192, 2563), 0.125, None), (3, (4104, 1203), 0.125, None), (4, (4096, 1607), 1.0 / 16.0, None),
+    (4, (2052, 1202), 0.25, 0.125), (1, (4096, 900), 0.125, 0.25), (2, (2048, 1537), 0.25, None),
+    (4, (2050, 801), 0.125, None)])
+def test_resize_stream_output_stage(bands, size, scale, vscale, burst, window, hf, monkeypatch):
+    """The output stage of resize_stream's dword horizontal pass: rows wait in LDS (`burst` slabs,
+    0 = written as they are made) and leave when the chip-wide clock crosses a multiple of
+    2^window ticks -- every stage size and window length, also windows shorter than a slab (a
+    write after every slab) and longer than a launch (only the full stage and the segment's end
+    write), gives the byte-by-byte pass's pixels and the port's: when a row leaves cannot change
+    what is in it.  The last case (2050 wide: the box does not divide the row) takes the byte form."""
+    w, h = size
+    src = helpers.lcg_image(w, h, bands, np.uint8, 83)
+    kw = {} if vscale is None else {"vscale": vscale}
+    im = Image.new_from_array(src)
+    want = Port.resize(src, scale, **kw)
+    monkeypatch.setenv("VIPS_HIP_STREAM_BURST", str(burst))
+    monkeypatch.setenv("VIPS_HIP_STREAM_WINDOW", str(window))
+    monkeypatch.setenv("VIPS_HIP_STREAM_HF", str(hf))
+    for blocks in ("4096", None):  # short segments, then one tall segment per strip
+        if blocks:
+            monkeypatch.setenv("VIPS_HIP_STREAM_BLOCKS", blocks)
+        else:
+            monkeypatch.delenv("VIPS_HIP_STREAM_BLOCKS")
+        libvips_amd.lib.vips_hip_gate_reset()
+        libvips_amd.lib.vips_hip_gate_enable(1)
+        try:
+            got = im.resize(scale, **kw).numpy()
+            report = libvips_amd.gate_report()
+        finally:
+            libvips_amd.lib.vips_hip_gate_enable(0)
+            libvips_amd.lib.vips_hip_gate_reset()
+        assert list(report) == ["resize_stream_u8"], report
+        assert_same(got, want, str((bands, size, scale, vscale, burst, window, hf, blocks)))
+
+
 @pytest.mark.parametrize("kernel", ["linear", "cubic", "mitchell", "lanczos2", "mks2013"])
 @pytest.mark.parametrize("bands,size,scale", [(3, (2048, 1203), 0.125), (1, (4104, 777), 0.25), (4, (2560, 1004), 0.1)])
 def test_resize_stream_other_kernels(kernel, bands, size, scale, monkeypatch):
