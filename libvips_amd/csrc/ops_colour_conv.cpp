@@ -799,9 +799,11 @@ static int sharpen_fused_images(VipsHipImage *const *in, int n_images, VipsHipIm
 	double y2, double y3, double m1, double m2);
 
 // The two CU partitions of the batched pipeline (see vips_hip_resize_sharpen_batch): streams
-// restricted to 3/4 and 1/4 of the CUs.  Bit i of a CU mask is CU i / xcds of XCD i % xcds on this
-// part, so a run of consecutive bits takes the same share of every XCD.  Made once per device and
-// kept (a masked stream is a hardware queue with a fixed mask).
+// restricted to 3/4 and 1/4 of the CUs: the low and the high run of consecutive mask bits.  (What
+// the runtime honours on this part, measured by tools/c4_masks.py: runs of at least 8 consecutive
+// bits restrict a queue, in effect in groups of 32 CUs -- 48 or 56 bits behave like 32; masks
+// interleaved finer than that leave it on every CU.)  Made once per device and kept (a masked
+// stream is a hardware queue with a fixed mask).
 struct BatchStreams {
 	hipStream_t resize = nullptr, sharpen = nullptr;
 };
