@@ -418,13 +418,13 @@ sharpen_kernel(SharpenArgs a)
 // image -- colourspace(LABS), extract L, convsep of a 3..5-tap integer gaussian (two passes),
 // the LUT step (sharpen.c:116-168), colourspace(sRGB) -- each a kernel that is over before the
 // launch latency is (BASELINE config 4: 0.06 ms of the 0.14 ms per thumbnail).  Here a block
-// owns a 64 x 16 pixel tile: it converts the tile and its halo to LabS into LDS (route code of
+// owns a 64 x 32 (or 64 x 16) pixel tile: it converts the tile and its halo to LabS into LDS (route code of
 // colour_device.h, image edges clamped = the embed of the convolution), runs the horizontal
 // and the vertical pass on L in LDS with the convi C-path arithmetic and its rounding to short
 // between the passes ((sum + scale / 2) / scale, C division: convi.c:698-716), applies the LUT
 // and converts back: one read of the image, one write.
-constexpr int SF_TW = 64, SF_TH = 16, SF_MAXHALF = 2;
-constexpr int SF_RW = SF_TW + 2 * SF_MAXHALF, SF_RH = SF_TH + 2 * SF_MAXHALF;
+constexpr int SF_TW = 64, SF_MAXHALF = 2;
+constexpr int SF_RW = SF_TW + 2 * SF_MAXHALF;
 
 constexpr int SF_MAXB = 64; // images per launch
 
@@ -462,9 +462,13 @@ static __device__ __forceinline__ int sf_convi_fin(int sum, const SharpenFusedAr
 	return min(max(q, -32768), 32767);
 }
 
+// SF_TH = rows of a tile: 16 rows per pass of the block's 256 threads (4 pixels each), SF_TH / 16
+// passes; the halo ring and the tables a block loads are shared by all of them
+template <int SF_TH>
 __global__ void __launch_bounds__(256)
 sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 {
+	constexpr int SF_RH = SF_TH + 2 * SF_MAXHALF;
 	__shared__ short s_lab[SF_RH][SF_RW][3];
 	__shared__ short s_h[SF_RH][SF_TW];
 	// the two 8-bit colour tables in LDS: six of a pixel's table reads stay off the vector memory path
@@ -491,8 +495,8 @@ sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 	// 1. the tile and its halo: sRGB uchar -> LabS.
 	// 1a. the tile itself, 4 pixels per thread (the mapping of step 3): 12 bytes as three dwords
 	// when the row allows it, the four conversions side by side (their table reads overlap)
-	{
-		const int row = t >> 4, quad = t & 15;
+	for (int pass = 0; pass < SF_TH / 16; pass++) {
+		const int row = (t >> 4) + 16 * pass, quad = t & 15;
 		const int y = min(y0 + row, a.height - 1);
 		const int x = x0 + 4 * quad;
 		const GlobalIn line = in + (long long) y * a.in_stride;
@@ -566,8 +570,8 @@ sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 	}
 	__syncthreads();
 	// 3. vertical pass, the LUT, back to sRGB: 4 pixels per thread, three dword stores
-	{
-		const int row = t >> 4, quad = t & 15;
+	for (int pass = 0; pass < SF_TH / 16; pass++) {
+		const int row = (t >> 4) + 16 * pass, quad = t & 15;
 		const int y = y0 + row;
 		if (y < a.height) {
 			unsigned char o[12];
@@ -672,8 +676,18 @@ int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const
 			p.in[i] = (const unsigned char *) ins[base + i]->data;
 			p.out[i] = (unsigned char *) outs[base + i]->data;
 		}
-		dim3 grid((a.width + SF_TW - 1) / SF_TW, (a.height + SF_TH - 1) / SF_TH, count);
-		hipLaunchKernelGGL(sharpen_fused_u8_kernel, grid, dim3(256, 1, 1), 0, stream(), p, a);
+		// 32-row tiles: the halo ring and the block's table loads are shared by twice the pixels
+		// (2 % faster than 16-row tiles in the C4 batch, 64-row tiles slower again);
+		// $VIPS_HIP_SHARPEN_TH=16 for the other
+		const int th = getenv("VIPS_HIP_SHARPEN_TH") ? atoi(getenv("VIPS_HIP_SHARPEN_TH")) : 32;
+		if (th != 16 && a.height > 16) {
+			dim3 grid((a.width + SF_TW - 1) / SF_TW, (a.height + 31) / 32, count);
+			hipLaunchKernelGGL(sharpen_fused_u8_kernel<32>, grid, dim3(256, 1, 1), 0, stream(), p, a);
+		}
+		else {
+			dim3 grid((a.width + SF_TW - 1) / SF_TW, (a.height + 15) / 16, count);
+			hipLaunchKernelGGL(sharpen_fused_u8_kernel<16>, grid, dim3(256, 1, 1), 0, stream(), p, a);
+		}
 		VH_CHECK(hipGetLastError());
 	}
 	return 0;
