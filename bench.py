@@ -720,9 +720,11 @@ def run_c4(ctx, steps, warmup, images, verify=True, cpu=True, size=8192):
     def step():
         # the previous step's thumbnails go back to the pool; then one launch per 64 images for the
         # whole resize chain and one for the sharpen (resize_stream.hip, colour.hip sharpen_fused_u8)
+        # (the QUEUED form: like the C2 launches of this file, a step is enqueued and the region ends
+        # with a fence -- the host prepares batch k + 1 while batch k runs, as a thumbnail service would)
         lib.vips_hip_image_unref_many(handles_out, count)
-        if lib.vips_hip_resize_sharpen_batch(handles_in, count, handles_out, 0.125, lanczos3, 2.0, 0.5, 2.0, 10.0,
-                                             20.0, 0.0, 3.0, 8):
+        if lib.vips_hip_resize_sharpen_batch_queue(handles_in, count, handles_out, 0.125, lanczos3, 2.0, 0.5, 2.0,
+                                                   10.0, 20.0, 0.0, 3.0, 8):
             _ffi.check(-1)
 
     elapsed, _ = ctx.timed(step, steps, warmup)

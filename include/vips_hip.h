@@ -641,6 +641,15 @@ VIPS_HIP_API int vips_hip_conv_strips(VipsHipStrips *strips, VipsHipImage **out,
 VIPS_HIP_API int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage **out,
 	double scale, int kernel, double gap,
 	double sigma, double x1, double y2, double y3, double m1, double m2, int n_threads);
+/* The same, QUEUED: a batch the library runs in batch launches on the caller's device (same-sized
+ * uchar images, a 1 / (2 k) resize) returns as soon as its work is queued -- the results are
+ * ordered on the calling thread's stream like those of every single-image operation (use them in
+ * stream order, or vips_hip_synchronize()) and the host can prepare the next batch meanwhile: what
+ * libvips' pipelines do between a sink's two buffers (iofuncs/sinkdisc.c:177-220).  Any other
+ * batch, and any failure, completes before the return as above. */
+VIPS_HIP_API int vips_hip_resize_sharpen_batch_queue(VipsHipImage *const *in, int n, VipsHipImage **out,
+	double scale, int kernel, double gap,
+	double sigma, double x1, double y2, double y3, double m1, double m2, int n_threads);
 VIPS_HIP_API int vips_hip_colourspace(VipsHipImage *in, VipsHipImage **out, int space);
 /* vips_gaussblur() then vips_colourspace() (convolution/gaussblur.c:71-116,
  * colour/colourspace.c:551-612) as one call: on 3-band float images both blur passes and

@@ -236,6 +236,8 @@ _SIGNATURES = {
     "vips_hip_conv_strips": (c_int, [c_void_p, P(c_void_p), P(c_double), c_int, c_int, c_double, c_double, c_int]),
     "vips_hip_resize_sharpen_batch": (c_int, [P(c_void_p), c_int, P(c_void_p), c_double, c_int, c_double,
                                              c_double, c_double, c_double, c_double, c_double, c_double, c_int]),
+    "vips_hip_resize_sharpen_batch_queue": (c_int, [P(c_void_p), c_int, P(c_void_p), c_double, c_int, c_double,
+                                             c_double, c_double, c_double, c_double, c_double, c_double, c_int]),
     "vips_hip_gaussblur_colourspace": (c_int, [c_void_p, P(c_void_p), c_double, c_double, c_int, c_int]),
     "vips_hip_cast": (c_int, [c_void_p, P(c_void_p), c_int]),
     "vips_hip_premultiply": (c_int, [c_void_p, P(c_void_p), c_int]),

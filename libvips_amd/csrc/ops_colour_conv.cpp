@@ -846,8 +846,10 @@ static BatchStreams *batch_streams()
 // NULL; the first error message is left in the caller's error buffer); all work is complete
 // on return.
 // ... on the device the calling thread drives (every image of `in` lives there)
+// wait = false: a uniform batch returns as soon as it is queued (everything it queued is ordered on
+// the calling thread's stream: the join below); any other batch, and every failure, waits as before
 static int resize_sharpen_batch_here(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel,
-	double gap, double sigma, double x1, double y2, double y3, double m1, double m2, int n_threads)
+	double gap, double sigma, double x1, double y2, double y3, double m1, double m2, int n_threads, bool wait = true)
 {
 	if (n_threads < 1)
 		n_threads = 1;
@@ -963,10 +965,16 @@ static int resize_sharpen_batch_here(VipsHipImage *const *in, int n, VipsHipImag
 						bad = 1;
 				}
 			}
-			if (vips_hip_synchronize())
-				bad = 1;
-			if (bs && (hipStreamSynchronize(bs->resize) != hipSuccess || hipStreamSynchronize(bs->sharpen) != hipSuccess))
-				bad = 1;
+			// (queued form: the intermediate thumbnails go back to the pool below while the device
+			// still reads them -- the pool hands a block to this thread's later work only, and that
+			// work is queued behind the join; an event destroyed before it completes is released
+			// when it does)
+			if (wait || bad) {
+				if (vips_hip_synchronize())
+					bad = 1;
+				if (bs && (hipStreamSynchronize(bs->resize) != hipSuccess || hipStreamSynchronize(bs->sharpen) != hipSuccess))
+					bad = 1;
+			}
 			for (hipEvent_t ev : events)
 				(void) hipEventDestroy(ev);
 			if (bad) {
@@ -1034,8 +1042,8 @@ static int resize_sharpen_batch_here(VipsHipImage *const *in, int n, VipsHipImag
 // several devices (whoever loaded them dealt them out: vips_hip_devices()); each device's share
 // runs on a host thread bound to that device -- its own pool, plan caches and streams -- with no
 // data moving between devices.  One device: the calling thread does the work itself.
-int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel,
-	double gap, double sigma, double x1, double y2, double y3, double m1, double m2, int n_threads)
+static int resize_sharpen_batch_any(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel,
+	double gap, double sigma, double x1, double y2, double y3, double m1, double m2, int n_threads, bool wait)
 {
 	if (!in || !out || n < 0) {
 		error("resize_sharpen_batch", "null argument");
@@ -1049,7 +1057,7 @@ int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage *
 	if (by_device.size() <= 1) {
 		if (n > 0 && vh::bind_to(in[by_device.begin()->second[0]]))
 			return -1;
-		return resize_sharpen_batch_here(in, n, out, scale, kernel, gap, sigma, x1, y2, y3, m1, m2, n_threads);
+		return resize_sharpen_batch_here(in, n, out, scale, kernel, gap, sigma, x1, y2, y3, m1, m2, n_threads, wait);
 	}
 	for (int i = 0; i < n; i++)
 		out[i] = nullptr;
@@ -1084,6 +1092,22 @@ int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage *
 	if (!first_error.empty())
 		error("resize_sharpen_batch", "%s", first_error.c_str());
 	return failed.load() == n ? -1 : failed.load();
+}
+
+int vips_hip_resize_sharpen_batch(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel,
+	double gap, double sigma, double x1, double y2, double y3, double m1, double m2, int n_threads)
+{
+	return resize_sharpen_batch_any(in, n, out, scale, kernel, gap, sigma, x1, y2, y3, m1, m2, n_threads, true);
+}
+
+// ... returning as soon as the batch is QUEUED when it is one the library runs in batch launches on
+// the caller's device (the usual case of a thumbnail service: same-sized uchar images): the results
+// are then ordered on the calling thread's stream like any other operation's -- use them in stream
+// order, or vips_hip_synchronize() -- and the host prepares the next batch while this one runs.
+int vips_hip_resize_sharpen_batch_queue(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel,
+	double gap, double sigma, double x1, double y2, double y3, double m1, double m2, int n_threads)
+{
+	return resize_sharpen_batch_any(in, n, out, scale, kernel, gap, sigma, x1, y2, y3, m1, m2, n_threads, false);
 }
 
 // vips_extract_area (conversion/extract.c:137-187): a rectangle of the image, as a new image

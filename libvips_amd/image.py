@@ -366,15 +366,16 @@ class Image(object):
 
 
 def resize_sharpen_batch(images, scale, kernel="lanczos3", gap=2.0, sharpen=True, sigma=0.5, x1=2.0, y2=10.0,
-                         y3=20.0, m1=0.0, m2=3.0, threads=8):
+                         y3=20.0, m1=0.0, m2=3.0, threads=8, wait=True):
     """BASELINE config 4: ``im.resize(scale).sharpen()`` over a batch of images, ``threads`` images
-    in flight on their own streams (vips_hip_resize_sharpen_batch).  Returns a list of Images."""
+    in flight on their own streams (vips_hip_resize_sharpen_batch; ``wait=False``: the queued
+    form, vips_hip_resize_sharpen_batch_queue).  Returns a list of Images."""
     n = len(images)
     ins = (ctypes.c_void_p * n)(*[im._h for im in images])
     outs = (ctypes.c_void_p * n)()
-    failed = lib.vips_hip_resize_sharpen_batch(ins, n, outs, float(scale), _enum(KERNELS, kernel, "kernel"), float(gap),
-                                               float(sigma) if sharpen else -1.0, float(x1), float(y2), float(y3),
-                                               float(m1), float(m2), int(threads))
+    fn = lib.vips_hip_resize_sharpen_batch if wait else lib.vips_hip_resize_sharpen_batch_queue
+    failed = fn(ins, n, outs, float(scale), _enum(KERNELS, kernel, "kernel"), float(gap),
+                float(sigma) if sharpen else -1.0, float(x1), float(y2), float(y3), float(m1), float(m2), int(threads))
     result = [Image(h) if h else None for h in outs]
     if failed:
         check(-1)

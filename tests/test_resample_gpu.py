@@ -664,3 +664,33 @@ def test_resize_sharpen_batch():
     got = [Image(h) for h in hout]
     for im, out in zip(ims, got):
         assert np.array_equal(out.numpy(), im.resize(0.125).sharpen().numpy())
+
+
+def test_resize_sharpen_batch_queued():
+    """vips_hip_resize_sharpen_batch_queue: a uniform batch of more than one launch's worth returns
+    when it is queued; three batches back to back, each releasing the one before while the device
+    may still be working on it (the pool hands those blocks to work queued behind it), then one
+    synchronize: the last batch's thumbnails are the synchronous form's, pixel for pixel."""
+    import ctypes
+
+    from libvips_amd._ffi import lib
+
+    srcs = [helpers.lcg_image(1024 + 8 * (k % 3 == 0) * 0, 768, 3, np.uint8, 90 + k) for k in range(70)]
+    ims = [Image.new_from_array(s, interpretation="srgb") for s in srcs]
+    want = libvips_amd.resize_sharpen_batch(ims, 0.125, threads=4)
+    n = len(ims)
+    hin = (ctypes.c_void_p * n)(*[im._h.value for im in ims])
+    hout = (ctypes.c_void_p * n)()
+    for _ in range(3):
+        lib.vips_hip_image_unref_many(hout, n)
+        assert lib.vips_hip_resize_sharpen_batch_queue(hin, n, hout, 0.125, 5, 2.0, 0.5, 2.0, 10.0, 20.0, 0.0, 3.0, 4) == 0
+    libvips_amd.synchronize()
+    got = [Image(h) for h in hout]
+    for k in range(n):
+        assert np.array_equal(got[k].numpy(), want[k].numpy()), k
+    # the Python mirror's spelling, and a batch the library runs image by image (it completes before the return)
+    outs = libvips_amd.resize_sharpen_batch(ims[:5] + [Image.new_from_array(helpers.lcg_image(640, 480, 3, np.uint8, 7),
+                                                                            interpretation="srgb")], 0.125, wait=False)
+    for k in range(5):
+        assert np.array_equal(outs[k].numpy(), want[k].numpy()), k
+    assert outs[5].width == 80
