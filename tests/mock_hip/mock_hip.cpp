@@ -81,7 +81,13 @@ hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_tR0600 *prop, int)
 
 const char *hipGetErrorString(hipError_t) { return "mock hip error"; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
-hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+static long g_syncs = 0; // host waits: device / stream / event synchronize
+long mock_hip_syncs(void) { return g_syncs; }
+hipError_t hipDeviceSynchronize(void)
+{
+	__sync_fetch_and_add(&g_syncs, 1);
+	return hipSuccess;
+}
 
 static long g_mallocs = 0;
 long mock_hip_mallocs(void) { return g_mallocs; }
@@ -158,7 +164,11 @@ hipError_t hipStreamDestroy(hipStream_t s)
 // how many streams are alive: lets the tests see a leak
 int mock_hip_live_streams(void) { return g_streams; }
 
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t)
+{
+	__sync_fetch_and_add(&g_syncs, 1);
+	return hipSuccess;
+}
 
 hipError_t hipEventCreate(hipEvent_t *e)
 {
@@ -180,7 +190,11 @@ hipError_t hipEventDestroy(hipEvent_t e)
 
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int) { return hipSuccess; }
-hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t)
+{
+	__sync_fetch_and_add(&g_syncs, 1);
+	return hipSuccess;
+}
 
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t)
 {

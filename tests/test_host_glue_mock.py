@@ -271,6 +271,19 @@ for rep in range(3):
 assert mock.mock_hip_mallocs() == m0, (m0, mock.mock_hip_mallocs())
 lib.vips_hip_image_unref_many(hout, n)   # all NULL: nothing to do
 lib.vips_hip_image_unref_many(None, 5)
+# the queued form of a uniform batch returns without a single host wait (the synchronous form
+# waits for the caller's stream and the two partitions); a mixed batch completes before the return
+mock.mock_hip_syncs.restype = ctypes.c_long
+s0 = mock.mock_hip_syncs()
+assert lib.vips_hip_resize_sharpen_batch_queue(hin, n, hout, 0.125, 5, 2.0, 0.5, 2.0, 10.0, 20.0, 0.0, 3.0, 4) == 0
+assert mock.mock_hip_syncs() == s0, (s0, mock.mock_hip_syncs())
+lib.vips_hip_image_unref_many(hout, n)
+assert lib.vips_hip_resize_sharpen_batch(hin, n, hout, 0.125, 5, 2.0, 0.5, 2.0, 10.0, 20.0, 0.0, 3.0, 4) == 0
+assert mock.mock_hip_syncs() >= s0 + 1
+lib.vips_hip_image_unref_many(hout, n)
+s1 = mock.mock_hip_syncs()
+outs = libvips_amd.resize_sharpen_batch(mixed, 0.125, threads=2, wait=False)
+assert mock.mock_hip_syncs() > s1 and [(o.width, o.height) for o in outs] == [(86, 8)] * 3 + [(88, 8)]
 ''', tmp_path)
 
 
