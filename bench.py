@@ -979,6 +979,158 @@ def c5_entry(line):
     }
 
 
+# ------------------------------------------------------------------------------------- ops
+
+def ops_table():
+    """The single calls of the path a libvips user makes one at a time (north_star's list), each
+    on its own synthetic image: (name, input spec, device call, reference chain / mask call).
+    Input spec = (edge, bands, dtype, interpretation, how it is made)."""
+    k3 = np.array([[-1, -1, -1], [-1, 16, -1], [-1, -1, -1]], dtype=np.float64)  # the 3 x 3 sharpen mask of conv.c's doc
+    b5 = np.array([1, 4, 6, 4, 1], dtype=np.float64)
+    k5 = np.outer(b5, b5)  # 5 x 5 binomial, scale 256
+    ops = []
+
+    def chain(name, spec, call, chain_text, **kw):
+        ops.append(dict(name=name, spec=spec, call=call, chain=chain_text, **kw))
+
+    def masked(name, spec, call, nick, mask, scale, args, **kw):
+        ops.append(dict(name=name, spec=spec, call=call, mask=(nick, mask, scale, args), **kw))
+
+    rgb8 = (8192, 3, "u8", "srgb", "lcg")
+    rgb16 = (8192, 3, "u16", "rgb16", "lcg")
+    rgba8 = (8192, 4, "u8", "srgb", "lcg")
+    rgba16 = (16384, 4, "u16", "rgb16", "lcg")
+    rgbf = (8192, 3, "f32", "srgb", "lcg")
+    chain("reducev_8", rgb8, lambda im: im.reducev(8), "reducev:vshrink=8,kernel=lanczos3")
+    chain("reduceh_8", rgb8, lambda im: im.reduceh(8), "reduceh:hshrink=8,kernel=lanczos3")
+    chain("reduce_rgb_8", rgb8, lambda im: im.reduce(8, 8), "reduce:hshrink=8,vshrink=8,kernel=lanczos3")
+    chain("reduce_rgb_7.3", rgb8, lambda im: im.reduce(7.3, 7.3), "reduce:hshrink=7.3,vshrink=7.3,kernel=lanczos3")
+    chain("shrinkv_4", rgb8, lambda im: im.shrinkv(4), "shrinkv:vshrink=4")
+    chain("shrinkh_4", rgb8, lambda im: im.shrinkh(4), "shrinkh:hshrink=4")
+    masked("convi_3x3_u8", rgb8, lambda im: im.conv(k3, scale=8, precision="integer"), "conv", k3, 8.0, "precision=integer")
+    masked("convi_5x5_u8", rgb8, lambda im: im.conv(k5, scale=256, precision="integer"), "conv", k5, 256.0, "precision=integer")
+    masked("convi_3x3_u16", rgb16, lambda im: im.conv(k3, scale=8, precision="integer"), "conv", k3, 8.0, "precision=integer")
+    masked("convi_5x5_u16", rgb16, lambda im: im.conv(k5, scale=256, precision="integer"), "conv", k5, 256.0, "precision=integer")
+    chain("gaussblur_s2_u8", rgb8, lambda im: im.gaussblur(2.0), "gaussblur:sigma=2")
+    chain("gaussblur_s8_u8", rgb8, lambda im: im.gaussblur(8.0), "gaussblur:sigma=8")
+    chain("gaussblur_s2_f32", rgbf, lambda im: im.gaussblur(2.0, precision="float"), "gaussblur:sigma=2,precision=float",
+          float_out=True)
+    chain("colourspace_srgb_lab_u8", rgb8, lambda im: im.colourspace("lab"), "colourspace:space=lab", float_out=True)
+    chain("colourspace_srgb_lab_f32", rgbf, lambda im: im.colourspace("lab"), "colourspace:space=lab", float_out=True)
+    chain("colourspace_srgb_labs_u8", rgb8, lambda im: im.colourspace("labs"), "colourspace:space=labs")
+    chain("colourspace_lab_srgb_f32", (8192, 3, "f32", "lab", "lab"), lambda im: im.colourspace("srgb"),
+          "colourspace:space=srgb")
+    chain("sharpen_u8", rgb8, lambda im: im.sharpen(), "sharpen:")
+    chain("cast_u8_f32", rgb8, lambda im: im.cast("float"), "cast:format=float", float_out=True)
+    chain("premultiply_u8", rgba8, lambda im: im.premultiply(), "premultiply:", float_out=True)
+    chain("reduce_rgba16_8", rgba16, lambda im: im.reduce(8, 8), "reduce:hshrink=8,vshrink=8,kernel=lanczos3")
+    chain("shrink_rgba16_4", rgba16, lambda im: im.shrink(4, 4), "shrink:hshrink=4,vshrink=4")
+    return ops
+
+
+def run_ops(ctx, steps, warmup, verify=True, cpu=True, only=None):
+    """One entry per single call of the path: ms per call (HIP events around `steps` calls on the
+    library's stream), algorithmic bytes (every input byte read once, every output byte written
+    once), the fraction of the 8 TB/s HBM roofline, the kernels that ran (gates), the WHOLE output
+    compared with the compiled reference, and the reference's own time on this box's cores."""
+    torch = ctx.torch
+    from libvips_amd import Image
+
+    helpers = ref_or_none()
+    dtypes = {"u8": torch.uint8, "u16": torch.uint16, "f32": torch.float32}
+    cores = os.cpu_count() or 1
+    entries = []
+    made = {}
+    for op in ops_table():
+        if only and not any(s in op["name"] for s in only):
+            continue
+        edge, bands, dt, interp, how = op["spec"]
+        key = op["spec"]
+        if key not in made:
+            made.clear()  # one input image alive at a time
+            ctx.trim()
+            with torch.cuda.stream(ctx.stream):
+                if dt == "u16":
+                    src = lcg_image_device(torch, edge, edge, 2 * bands, 12345, ctx.device).view(torch.uint16)
+                    src = src.reshape(edge, edge, bands)
+                elif how == "lab":
+                    u8 = lcg_image_device(torch, edge, edge, bands, 12345, ctx.device)
+                    lab = Image.new_from_tensor(u8, interpretation="srgb").colourspace("lab")
+                    src = torch.from_numpy(lab.numpy()).to(ctx.device)
+                    del lab, u8
+                else:
+                    src = lcg_image_device(torch, edge, edge, bands, 12345, ctx.device)
+                    if dt == "f32":
+                        src = src.float()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            made[key] = src
+        src = made[key]
+        im = Image.new_from_tensor(src, interpretation=interp)
+        call = op["call"]
+
+        def step():
+            return call(im)
+
+        elapsed, out = ctx.timed(step, steps, warmup)
+        ms = ctx.event_ms / steps
+        report = ctx.gates(step, 2)
+        out_bytes = out.width * out.height * out.bands * {"uchar": 1, "char": 1, "ushort": 2, "short": 2, "uint": 4,
+                                                           "int": 4, "float": 4, "double": 8}.get(out.format, 4)
+        alg = src.numel() * src.element_size() + out_bytes
+        dominant = max(report.items(), key=lambda kv: kv[1][1])[0] if report else None
+        entry = {
+            "name": op["name"],
+            "input": "%dx%dx%d %s" % (edge, edge, bands, dt),
+            "output": "%dx%dx%d %s" % (out.width, out.height, out.bands, out.format),
+            "ms": round(ms, 4),
+            "steps": steps,
+            "algorithmic_bytes": alg,
+            "GBps": round(alg / (ms * 1e-3) / 1e9, 1),
+            "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "mpixels_per_s": round(float(edge) * edge / (ms * 1e-3) / 1e6, 1),
+            "kernel": dominant,
+            "kernels": kernels_of(report),
+        }
+        if helpers is not None and (verify or cpu):
+            host = src.cpu().numpy()
+            ri = helpers.INTERP[interp]
+            t1 = time.perf_counter()
+            if "chain" in op:
+                want = helpers.Ref.run_chain(op["chain"], host, ri)
+            else:
+                nick, mask, scale, margs = op["mask"]
+                want = helpers.Ref.run_mask(nick, host, mask, scale, 0.0, margs, ri)
+            secs = time.perf_counter() - t1
+            if verify:
+                got = out.numpy()
+                if op.get("float_out"):
+                    ok, ulp = same_float(got, want)
+                    entry["parity"] = {"against": "oracle/_ref, whole output", "bit_exact": bool(ok), "max_ulp": ulp,
+                                       "tolerance_ulp": 1}
+                    bad = ulp is None or ulp > 1
+                else:
+                    ok = got.shape == want.shape and got.dtype == want.dtype and bool(np.array_equal(got, want))
+                    entry["parity"] = {"against": "oracle/_ref, whole output", "bit_exact": ok}
+                    bad = not ok
+                if bad:
+                    raise SystemExit("bench.py: ops[%s] differs from the reference: %r" % (op["name"], entry["parity"]))
+                del got
+            if cpu:
+                if "chain" in op:
+                    secs = helpers.Ref.time_chain(op["chain"], host, repeats=2, interpretation=ri, concurrency=cores)
+                entry["cpu_baseline"] = {"value": round(float(edge) * edge / secs / 1e6, 1), "unit": "Mpixels/s",
+                                         "cores": helpers.Ref.concurrency(), "kind": "reference",
+                                         "sample": "the whole image, %s" % ("best of 2" if "chain" in op else
+                                                                              "one run incl. the copy out")}
+            del host, want
+        del im, out
+        entries.append(entry)
+    made.clear()
+    ctx.trim()
+    return entries
+
+
 def entry_as_line(entry, ctx, steps, warmup, metric, scaling="weak"):
     """A configs[] entry promoted to the bench line (--config c3 / c4 / c5slab)."""
     bound = entry.get("bound", "hbm")
@@ -1018,7 +1170,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5slab", "c5"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5slab", "c5", "ops"])
+    ap.add_argument("--ops", default=None, help="ops: comma-separated substrings of the entries to run (default all)")
     ap.add_argument("--size", type=int, default=None, help="image edge (default: the BASELINE size of the config)")
     ap.add_argument("--images", type=int, default=None, help="c4: images per GPU (default 1024 at N=1 -- the whole "
                                                              "BASELINE batch, 206 GB, on one GPU -- and 1024 / N at N>1)")
@@ -1045,6 +1198,7 @@ def main():
                 run_c5slab(ctx, max(2, min(args.steps, 4)), 2, verify, cpu),
                 c5_entry(run_c5(ctx, 2, 1, verify)),
             ]
+            line["ops"] = run_ops(ctx, 5, 2, verify, cpu)
             if verify and cpu:
                 e2e = run_module_e2e(ctx, line["roofline"]["kernel_ms"] if line.get("roofline") else None)
                 if e2e:
@@ -1063,6 +1217,20 @@ def main():
         e = run_c5slab(ctx, args.steps, args.warmup, verify, cpu, width=size, rows=max(size // 8, 64), im_height=size)
         line = entry_as_line(e, ctx, args.steps, args.warmup,
                              "Mpixels/s, vips_conv 31x31 float mask on a 65536x8192 ushort slab (+halos)")
+    elif args.config == "ops":
+        ops = run_ops(ctx, args.steps, args.warmup, verify, cpu, only=args.ops.split(",") if args.ops else None)
+        worst = min(ops, key=lambda e: e["frac"])
+        line = {
+            "metric": "fraction of the HBM roofline of the slowest single call of the path (table in `ops`)",
+            "value": worst["frac"], "unit": "fraction of 8 TB/s", "n_gpus": ctx.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": worst["ms"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/u16/f32 per entry", "data": "synthetic (LCG bytes, seed 12345)",
+            "config": {"workload": "every single call of the path on its own image, slowest: %s" % worst["name"]},
+            "roofline": {"bound": "hbm", "achieved": worst["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": worst["frac"], "traffic": None, "kernel": worst["kernel"]},
+            "cpu_baseline": worst.get("cpu_baseline"),
+            "ops": ops,
+        }
     else:
         size = args.size or 65536
         line = run_c5(ctx, args.steps, args.warmup, verify, width=size, im_height=size)
