@@ -5,6 +5,8 @@
 
 #include <vector>
 
+struct _VipsHipReduce;
+
 namespace vh {
 
 // vips_cast of bands [in_first, in_first + take) of `in` into bands
@@ -20,6 +22,17 @@ int colour_route(const int *steps, int n_steps, double alpha_scale, const VipsHi
 int sharpen_fused_u8(const VipsHipRegion *const *in, const VipsHipRegion *const *out, int n_images,
 	const int *to_steps, int n_to, const int *from_steps, int n_from, const int *coef, int n, int scale,
 	const int *lut);
+
+// host copies of the 8-bit sRGB tables (256 floats, 257 ints) and the cube-root table (100000
+// floats), as the device tables are made (LabQ2sRGB.c:130-160, XYZ2Lab.c:92-106)
+void colour_tables_host(std::vector<float> &v2Y_8, std::vector<int> &Y2v_8, std::vector<float> &cbrt);
+
+// vips_resize's downsizing chain then vips_sharpen on n 3-band uchar sRGB images of one geometry in
+// ONE streaming kernel (resize_sharpen.hip); arguments as resize_stream_u8_try + the blur mask as
+// convi's integers and sharpen.c's LUT (host).  1 = handled, 0 = not its case, -1 = error
+int resize_sharpen_stream_u8_try(_VipsHipReduce *rv, int vshrink, _VipsHipReduce *rh, int hshrink, int shrunk_height,
+	int shrunk_width, const VipsHipRegion *const *in, const VipsHipRegion *const *out, int n, int tile, const int *coef,
+	int ncoef, int scale, const int *lut);
 
 int premultiply_region(const VipsHipRegion *in, const VipsHipRegion *out, double max_alpha, int uchar,
 	int inverse);

@@ -74,6 +74,27 @@ static void calcul_tables(int range, std::vector<int> &Y2v, std::vector<float> &
 	}
 }
 
+static void cbrt_table(std::vector<float> &cb)
+{
+	// table_init(), XYZ2Lab.c:92-106
+	const int QUANT_ELEMENTS = 100000;
+	cb.resize(QUANT_ELEMENTS);
+	for (int i = 0; i < QUANT_ELEMENTS; i++) {
+		float Y = (double) i / QUANT_ELEMENTS;
+
+		if (Y < 0.008856)
+			cb[i] = 7.787F * Y + (16.0F / 116.0F);
+		else
+			cb[i] = cbrtf(Y);
+	}
+}
+
+void colour_tables_host(std::vector<float> &v2Y_8, std::vector<int> &Y2v_8, std::vector<float> &cbrt)
+{
+	calcul_tables(256, Y2v_8, v2Y_8);
+	cbrt_table(cbrt);
+}
+
 static int ensure_tables()
 {
 	std::lock_guard<std::mutex> lock(g_tables_mutex);
@@ -87,17 +108,8 @@ static int ensure_tables()
 	calcul_tables(65536, Y2v, v2Y);
 	g_tables.Y2v_16 = (int *) upload(Y2v.data(), Y2v.size() * sizeof(int));
 	g_tables.v2Y_16 = (float *) upload(v2Y.data(), v2Y.size() * sizeof(float));
-	// table_init(), XYZ2Lab.c:92-106
-	const int QUANT_ELEMENTS = 100000;
-	std::vector<float> cb(QUANT_ELEMENTS);
-	for (int i = 0; i < QUANT_ELEMENTS; i++) {
-		float Y = (double) i / QUANT_ELEMENTS;
-
-		if (Y < 0.008856)
-			cb[i] = 7.787F * Y + (16.0F / 116.0F);
-		else
-			cb[i] = cbrtf(Y);
-	}
+	std::vector<float> cb;
+	cbrt_table(cb);
 	float *cbrt = (float *) upload(cb.data(), cb.size() * sizeof(float));
 	if (!g_tables.Y2v_8 || !g_tables.v2Y_8 || !g_tables.Y2v_16 || !g_tables.v2Y_16 || !cbrt)
 		return -1;

@@ -1,0 +1,84 @@
+// Names for the gfx950 instructions, address spaces and block-level primitives the streaming
+// kernel bodies (*_body.h) are written in.  A body only uses what is declared here, so that the
+// same source also runs, thread by thread on host fibers, under tests/emul/gcn.h -- the CPU suite
+// checks a body's indexing and arithmetic against the oracle without a GPU (test infrastructure
+// only: the product is built with THIS header).
+#ifndef VH_GCN_H
+#define VH_GCN_H
+
+#include <hip/hip_runtime.h>
+
+#define VH_DEV static __device__ __forceinline__
+
+namespace vh {
+
+// global memory: a uniform base (SGPR pair) + a 32-bit lane offset is the saddr form of
+// global_load / global_store (one VGPR per address instead of two and a 64-bit add)
+typedef const unsigned char __attribute__((address_space(1))) *gptr_in;
+typedef unsigned char __attribute__((address_space(1))) *gptr_out;
+
+VH_DEV gptr_in gptr_in_of(unsigned long long v) { return (gptr_in) v; }
+VH_DEV gptr_out gptr_out_of(unsigned long long v) { return (gptr_out) v; }
+VH_DEV unsigned int gptr_low(gptr_out p) { return (unsigned int) (unsigned long long) p; }
+VH_DEV unsigned int gload32(gptr_in base, unsigned int off)
+{
+	return *(const unsigned int __attribute__((address_space(1))) *) (base + off);
+}
+VH_DEV void gstore32(gptr_out p, unsigned int v) { *(unsigned int __attribute__((address_space(1))) *) p = v; }
+VH_DEV void gstore8(gptr_out p, unsigned char v) { *p = v; }
+
+// the image pointers of a batch where they lie in the kernarg segment (a by-value array indexed
+// dynamically would be copied to scratch): 64-bit words at `offset` bytes into the segment
+struct KernargWords {
+	int offset;
+	__device__ __forceinline__ unsigned long long operator[](int i) const
+	{
+		typedef const unsigned long long __attribute__((address_space(4))) *Words;
+		return ((Words) ((const char __attribute__((address_space(4))) *) __builtin_amdgcn_kernarg_segment_ptr() + offset))[i];
+	}
+};
+
+VH_DEV int tid() { return (int) threadIdx.x; }
+VH_DEV void barrier() { __syncthreads(); }
+// the chip-wide 100 MHz clock
+VH_DEV unsigned long long realtime() { return __builtin_amdgcn_s_memrealtime(); }
+VH_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+VH_DEV void opaque(int &v) { asm volatile("" : "+v"(v)); }
+VH_DEV void opaque(unsigned int &v) { asm volatile("" : "+v"(v)); }
+
+// v_perm_b32: byte k of the result is byte sel[k] of {hi, lo} (0-3 lo, 4-7 hi, 0x0c zero)
+VH_DEV unsigned int perm(unsigned int hi, unsigned int lo, unsigned int sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+typedef short gcn_short2 __attribute__((ext_vector_type(2)));
+// v_dot2_i32_i16: acc + lo16(a) * lo16(b) + hi16(a) * hi16(b), signed
+VH_DEV int dot2(unsigned int a, unsigned int b, int acc)
+{
+	return __builtin_amdgcn_sdot2(__builtin_bit_cast(gcn_short2, a), __builtin_bit_cast(gcn_short2, b), acc, false);
+}
+// the same with the coefficient pair in an SGPR and a fresh accumulator register
+VH_DEV int dot2_s(unsigned int a, unsigned int b_uniform, int acc)
+{
+	int r;
+	asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(acc));
+	return r;
+}
+// v_dot4_u32_u8
+VH_DEV unsigned int udot4(unsigned int a, unsigned int b, unsigned int acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
+// v_sat_pk_u8_i16: {0, 0, sat_u8(hi16), sat_u8(lo16)}
+VH_DEV unsigned int sat_pk_u8_i16(unsigned int both)
+{
+	unsigned int r;
+	asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(both));
+	return r;
+}
+VH_DEV unsigned int umulhi(unsigned int a, unsigned int b) { return __umulhi(a, b); }
+// x - floor(x)
+VH_DEV float fract(float x) { return __builtin_amdgcn_fractf(x); }
+// round to nearest even, as rintf
+VH_DEV float rne(float x) { return __builtin_rintf(x); }
+// v_cvt_pk_u8_f32 of an integer-valued float in 0..255 into byte `byte` of `old`
+VH_DEV unsigned int cvt_pk_u8(float v, unsigned int byte, unsigned int old) { return __builtin_amdgcn_cvt_pk_u8_f32(v, byte, old); }
+
+} // namespace vh
+
+#endif // VH_GCN_H

@@ -139,20 +139,10 @@ struct LutKey {
 typedef std::shared_ptr<int> LutPtr;
 std::list<std::pair<LutKey, LutPtr>> &g_lut_cache = *new std::list<std::pair<LutKey, LutPtr>>;
 
-LutPtr sharpen_lut_cached(double x1, double y2, double y3, double m1, double m2)
+// sharpen.c:230-257
+void sharpen_lut_host(double x1, double y2, double y3, double m1, double m2, std::vector<int> &lut)
 {
-	if (ensure_init())
-		return LutPtr();
-	LutKey key = { current_device(), { x1, y2, y3, m1, m2 } };
-	{
-		std::lock_guard<std::mutex> lock(g_conv_mutex);
-		for (auto it = g_lut_cache.begin(); it != g_lut_cache.end(); ++it)
-			if (it->first == key) {
-				g_lut_cache.splice(g_lut_cache.begin(), g_lut_cache, it);
-				return g_lut_cache.front().second;
-			}
-	}
-	std::vector<int> lut(65536);
+	lut.resize(65536);
 	for (int i = 0; i < 65536; i++) {
 		double v = (i - 32767) / 327.67;
 		double y;
@@ -171,6 +161,23 @@ LutPtr sharpen_lut_cached(double x1, double y2, double y3, double m1, double m2)
 
 		lut[i] = rint(y * 327.67);
 	}
+}
+
+LutPtr sharpen_lut_cached(double x1, double y2, double y3, double m1, double m2)
+{
+	if (ensure_init())
+		return LutPtr();
+	LutKey key = { current_device(), { x1, y2, y3, m1, m2 } };
+	{
+		std::lock_guard<std::mutex> lock(g_conv_mutex);
+		for (auto it = g_lut_cache.begin(); it != g_lut_cache.end(); ++it)
+			if (it->first == key) {
+				g_lut_cache.splice(g_lut_cache.begin(), g_lut_cache, it);
+				return g_lut_cache.front().second;
+			}
+	}
+	std::vector<int> lut;
+	sharpen_lut_host(x1, y2, y3, m1, m2, lut);
 	int *d_lut = (int *) upload(lut.data(), lut.size() * sizeof(int));
 	if (!d_lut)
 		return LutPtr();
@@ -798,6 +805,37 @@ int vips_hip_gaussblur_colourspace(VipsHipImage *in, VipsHipImage **out, double 
 static int sharpen_fused_images(VipsHipImage *const *in, int n_images, VipsHipImage **out, double sigma, double x1,
 	double y2, double y3, double m1, double m2);
 
+// vips_sharpen's blur mask as the convi C path's integers (sharpen.c:214-218, convi.c:886-915) when
+// it has at most 5 taps -- the case of the fused sharpen kernels; false: a wider mask (or an error,
+// which the unfused path then reports)
+static bool sharpen_small_mask(double sigma, std::vector<int> &coef, int *scale)
+{
+	const int n = vips_hip_gaussmat(sigma, 0.1, 1, VIPS_HIP_PRECISION_INTEGER, nullptr, 0, nullptr);
+	if (n < 1 || n > 5)
+		return false;
+	std::vector<double> mask(n);
+	double s = 1.0;
+	if (vips_hip_gaussmat(sigma, 0.1, 1, VIPS_HIP_PRECISION_INTEGER, mask.data(), n, &s) < 0) {
+		vips_hip_error_clear();
+		return false;
+	}
+	coef.resize(n);
+	for (int k = 0; k < n; k++)
+		coef[k] = (int) rint(mask[k]);
+	*scale = (int) rint(s);
+	return true;
+}
+
+static bool sharpen_images_fusable(VipsHipImage *const *in, int n)
+{
+	for (int i = 0; i < n; i++)
+		if (!in[i] || in[i]->format != VIPS_HIP_FORMAT_UCHAR || in[i]->bands != 3 ||
+			in[i]->interpretation != VIPS_HIP_INTERPRETATION_sRGB || in[i]->width != in[0]->width ||
+			in[i]->height != in[0]->height)
+			return false;
+	return n > 0;
+}
+
 // The two CU partitions of the batched pipeline (see vips_hip_resize_sharpen_batch): streams
 // restricted to 3/4 and 1/4 of the CUs: the low and the high run of consecutive mask bits.  (What
 // the runtime honours on this part, measured by tools/c4_masks.py: runs of at least 8 consecutive
@@ -872,11 +910,40 @@ static int resize_sharpen_batch_here(VipsHipImage *const *in, int n, VipsHipImag
 	// stream, one stage after the other.
 	if (n > 0 && !getenv("VIPS_HIP_NO_BATCH_LAUNCH")) {
 		const int chunk = 64;
+		// resize and sharpen of 3-band sRGB images in ONE kernel (resize_sharpen.hip): nothing to
+		// partition, no thumbnail in memory between the two
+		std::vector<int> coef;
+		int mask_scale = 1;
+		const bool small_mask = sigma >= 0.0 && sharpen_small_mask(sigma, coef, &mask_scale);
+		const bool fusable = small_mask && sharpen_images_fusable(in, n);
+		if (fusable && !getenv("VIPS_HIP_NO_RESIZE_SHARPEN")) {
+			std::vector<int> lut;
+			sharpen_lut_host(x1, y2, y3, m1, m2, lut);
+			const int r = vh::resize_sharpen_batch_u8(in, n, out, scale, kernel, gap, coef.data(), (int) coef.size(),
+				mask_scale, lut.data());
+			if (r < 0)
+				return -1;
+			if (r == 0) {
+				if (wait && vips_hip_synchronize()) {
+					for (int i = 0; i < n; i++) {
+						vips_hip_image_unref(out[i]);
+						out[i] = nullptr;
+					}
+					return -1;
+				}
+				return 0;
+			}
+		}
 		std::vector<ImageRef> small(n); // held to the end: several streams read and write them
 		std::vector<VipsHipImage *> ps(n, nullptr);
 		const int first = n < chunk ? n : chunk;
 		const char *ov = getenv("VIPS_HIP_BATCH_OVERLAP");
-		BatchStreams *bs = sigma >= 0.0 && n > chunk && !(ov && atoi(ov) == 0) ? batch_streams() : nullptr;
+		// (the partitions only when the ONE-kernel sharpen will run on them: the unfused sharpen takes
+		// its temporaries from the pool, which orders reuse within one stream only)
+		BatchStreams *bs = sigma >= 0.0 && n > chunk && fusable && !getenv("VIPS_HIP_NO_FUSED_SHARPEN") &&
+				!(ov && atoi(ov) == 0)
+			? batch_streams()
+			: nullptr;
 		hipStream_t main_stream = stream();
 		std::vector<hipEvent_t> events;
 		auto event_on = [&](hipStream_t s) -> hipEvent_t {
@@ -948,9 +1015,17 @@ static int resize_sharpen_batch_here(VipsHipImage *const *in, int n, VipsHipImag
 					ScopedStream on(sharpen_on);
 					int done = sharpen_fused_images(ps.data() + base, cnt, out + base, sigma, x1, y2, y3, m1, m2);
 					if (done > 0) {
+						// not the one-kernel sharpen's case after all: the separate operations take pool
+						// blocks for their temporaries, which are only ordered within ONE stream -- so
+						// nothing else of the batch may be in flight around them
+						if (bs && (hipStreamSynchronize(bs->resize) != hipSuccess || hipStreamSynchronize(bs->sharpen) != hipSuccess ||
+									  hipStreamSynchronize(main_stream) != hipSuccess))
+							bad = 1;
 						done = 0;
-						for (int i = base; i < base + cnt && !done; i++)
+						for (int i = base; i < base + cnt && !done && !bad; i++)
 							done = vips_hip_sharpen(ps[i], &out[i], sigma, x1, y2, y3, m1, m2);
+						if (bs && hipStreamSynchronize(sharpen_on ? sharpen_on : main_stream) != hipSuccess)
+							bad = 1;
 					}
 					if (done)
 						bad = 1;

@@ -5,6 +5,7 @@
 // on a 288 GB device the natural "tile" is the image.
 #include "internal.h"
 #include "resample.h"
+#include "colour.h"
 #include "reduce_u8.h"
 
 #include <cmath>
@@ -431,6 +432,59 @@ int resize_batch_u8(VipsHipImage *const *in, int n, VipsHipImage **out, double s
 	if (done <= 0)
 		return done;
 	return resize_down_u8_tail_batch(in, n, out, pv, ph, shrunk_width, kernel);
+}
+
+// vips_resize(scale) then vips_sharpen (blur mask `coef` / `mask_scale` as convi's integers, LUT
+// `lut`: 65536 host ints) of n 3-band uchar sRGB images of one size, ONE kernel for both
+// (resize_sharpen.hip): 0 = done, 1 = not that kernel's case (nothing done), -1 = error
+int resize_sharpen_batch_u8(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel, double gap,
+	const int *coef, int ncoef, int mask_scale, const int *lut)
+{
+	if (n < 1 || !in[0] || in[0]->format != VIPS_HIP_FORMAT_UCHAR || in[0]->bands != 3 || kernel == VIPS_HIP_KERNEL_NEAREST)
+		return 1;
+	if (gap < 0.0)
+		gap = 2.0; // resize.c:397
+	if (!(scale > 0.0) || scale >= 1.0 || scale < 1.0 / in[0]->width || scale < 1.0 / in[0]->height)
+		return 1;
+	for (int i = 1; i < n; i++)
+		if (!in[i] || in[i]->width != in[0]->width || in[i]->height != in[0]->height || in[i]->bands != 3 ||
+			in[i]->format != VIPS_HIP_FORMAT_UCHAR)
+			return 1;
+	AxisPlan pv, ph;
+	if (plan_axis("reducev", in[0]->height, 1.0 / scale, kernel, gap, &pv) ||
+		plan_axis("reduceh", in[0]->width, 1.0 / scale, kernel, gap, &ph))
+		return -1;
+	if (pv.size <= 0 || ph.size <= 0 || pv.residual != 2.0 || ph.residual != 2.0)
+		return 1;
+	const int shrunk_width = ph.int_shrink > 1 ? vips_hip_shrink_out_size(in[0]->width, ph.int_shrink, 1) : in[0]->width;
+	const int shrunk_height = pv.int_shrink > 1 ? vips_hip_shrink_out_size(in[0]->height, pv.int_shrink, 1) : in[0]->height;
+	if (shrunk_width <= 0 || shrunk_height <= 0)
+		return 1;
+	ReducePtr rv = reduce_cached(kernel, pv.residual, shrunk_height, pv.size, pv.extra_pixels);
+	ReducePtr rh = rv ? reduce_cached(kernel, ph.residual, shrunk_width, ph.size, ph.extra_pixels) : ReducePtr();
+	if (!rv || !rh)
+		return -1;
+	std::vector<ImageRef> o(n);
+	std::vector<VipsHipRegion> ri(n), ro(n);
+	std::vector<const VipsHipRegion *> pi(n), po(n);
+	for (int i = 0; i < n; i++) {
+		o[i].im = like(in[i], ph.size, pv.size);
+		if (!o[i].im)
+			return -1;
+		vips_hip_image_region(in[i], &ri[i]);
+		vips_hip_image_region(o[i].im, &ro[i]);
+		pi[i] = &ri[i];
+		po[i] = &ro[i];
+	}
+	const int done = resize_sharpen_stream_u8_try(rv.get(), pv.int_shrink, rh.get(), ph.int_shrink, shrunk_height,
+		shrunk_width, pi.data(), po.data(), n, g_fatstrip_height, coef, ncoef, mask_scale, lut);
+	if (done < 0)
+		return -1;
+	if (done == 0)
+		return 1;
+	for (int i = 0; i < n; i++)
+		out[i] = o[i].release();
+	return 0;
 }
 
 } // namespace vh

@@ -35,5 +35,9 @@ int resize_streamg_u8_try(_VipsHipReduce *rv, int vshrink, _VipsHipReduce *rh, i
 	int shrunk_width, const VipsHipRegion *const *in, const VipsHipRegion *const *out, int n, int tile);
 // the same from images (ops_resample.cpp); 0 = done, 1 = not its case, -1 = error
 int resize_batch_u8(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel, double gap);
+// ... followed by vips_sharpen, in ONE kernel (resize_sharpen.hip); the blur mask as convi's integers,
+// sharpen.c's LUT as 65536 host ints; 0 = done, 1 = not its case, -1 = error
+int resize_sharpen_batch_u8(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel, double gap,
+	const int *coef, int ncoef, int mask_scale, const int *lut);
 
 } // namespace vh

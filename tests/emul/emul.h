@@ -1,0 +1,21 @@
+// TEST INFRASTRUCTURE: a workgroup on host fibers.  run_block() runs `threads` copies of a
+// function, each on its own ucontext stack, switching only at barrier(); a block is correct here
+// exactly when it is correct under any interleaving that respects its barriers only if it has no
+// data race between barriers -- which is what the bodies promise.  To shake out ordering
+// assumptions the fibers of a block are resumed in a different order after every barrier.
+#ifndef VH_EMUL_H
+#define VH_EMUL_H
+
+#include <functional>
+
+namespace emul {
+
+int current_tid();
+void barrier();
+unsigned long long clock_ticks();
+// run `fn` as `threads` fibers (one block); fn reads current_tid()
+void run_block(int threads, const std::function<void()> &fn);
+
+} // namespace emul
+
+#endif

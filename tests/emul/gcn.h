@@ -1,0 +1,104 @@
+// TEST INFRASTRUCTURE (CPU suite only; never part of the product): the names of
+// libvips_amd/csrc/gcn.h for the host, so that a kernel body (*_body.h) runs thread by thread on
+// fibers (emul.h) and its indexing and arithmetic can be compared with the oracle without a GPU.
+// Each function restates the instruction's documented semantics.
+#ifndef VH_GCN_H
+#define VH_GCN_H
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include "emul.h"
+
+#define VH_DEV static inline
+#ifndef __device__
+#define __device__
+#endif
+#ifndef __forceinline__
+#define __forceinline__ inline
+#endif
+
+namespace vh {
+
+using std::max;
+using std::min;
+
+typedef const unsigned char *gptr_in;
+typedef unsigned char *gptr_out;
+
+VH_DEV gptr_in gptr_in_of(unsigned long long v) { return (gptr_in) (uintptr_t) v; }
+VH_DEV gptr_out gptr_out_of(unsigned long long v) { return (gptr_out) (uintptr_t) v; }
+VH_DEV unsigned int gptr_low(gptr_out p) { return (unsigned int) (uintptr_t) p; }
+VH_DEV unsigned int gload32(gptr_in base, unsigned int off)
+{
+	unsigned int v;
+	memcpy(&v, base + off, 4);
+	return v;
+}
+VH_DEV void gstore32(gptr_out p, unsigned int v) { memcpy(p, &v, 4); }
+VH_DEV void gstore8(gptr_out p, unsigned char v) { *p = v; }
+
+struct KernargWords {
+	const unsigned long long *words;
+	unsigned long long operator[](int i) const { return words[i]; }
+};
+
+VH_DEV int tid() { return emul::current_tid(); }
+VH_DEV void barrier() { emul::barrier(); }
+VH_DEV unsigned long long realtime() { return emul::clock_ticks(); }
+VH_DEV void sched_fence() {}
+VH_DEV void opaque(int &) {}
+VH_DEV void opaque(unsigned int &) {}
+
+VH_DEV unsigned int perm(unsigned int hi, unsigned int lo, unsigned int sel)
+{
+	const unsigned long long both = ((unsigned long long) hi << 32) | lo;
+	unsigned int r = 0;
+	for (int k = 0; k < 4; k++) {
+		const unsigned int s = (sel >> (8 * k)) & 0xffu;
+		unsigned int byte;
+		if (s <= 7)
+			byte = (unsigned int) (both >> (8 * s)) & 0xffu;
+		else if (s == 0x0c)
+			byte = 0;
+		else if (s >= 0x0d)
+			byte = 0xff;
+		else // 8..11: sign of a 16-bit half, not used by the bodies
+			byte = ((both >> (16 * (s - 8) + 15)) & 1) ? 0xff : 0;
+		r |= byte << (8 * k);
+	}
+	return r;
+}
+VH_DEV int dot2(unsigned int a, unsigned int b, int acc)
+{
+	return acc + (int) (short) (a & 0xffff) * (int) (short) (b & 0xffff) + (int) (short) (a >> 16) * (int) (short) (b >> 16);
+}
+VH_DEV int dot2_s(unsigned int a, unsigned int b, int acc) { return dot2(a, b, acc); }
+VH_DEV unsigned int udot4(unsigned int a, unsigned int b, unsigned int acc)
+{
+	for (int k = 0; k < 4; k++)
+		acc += ((a >> (8 * k)) & 0xffu) * ((b >> (8 * k)) & 0xffu);
+	return acc;
+}
+VH_DEV unsigned int sat_pk_u8_i16(unsigned int both)
+{
+	const int lo = (short) (both & 0xffff), hi = (short) (both >> 16);
+	return (unsigned int) min(max(lo, 0), 255) | ((unsigned int) min(max(hi, 0), 255) << 8);
+}
+VH_DEV unsigned int umulhi(unsigned int a, unsigned int b) { return (unsigned int) (((unsigned long long) a * b) >> 32); }
+VH_DEV float fract(float x) { return x - floorf(x); }
+VH_DEV float rne(float x) { return rintf(x); }
+VH_DEV unsigned int cvt_pk_u8(float v, unsigned int byte, unsigned int old)
+{
+	const float r = rintf(v);
+	const unsigned int u = r <= 0.0f ? 0u : r >= 255.0f ? 255u : (unsigned int) r;
+	return (old & ~(0xffu << (8 * byte))) | (u << (8 * byte));
+}
+
+} // namespace vh
+
+#endif // VH_GCN_H

@@ -550,13 +550,16 @@ def test_resize_stream_other_kernels(kernel, bands, size, scale, monkeypatch):
     assert np.array_equal(got, im.resize(scale, kernel=kernel).numpy())
 
 
-@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("overlap", [False, True, None])
 def test_resize_stream_batch_chunks(overlap, monkeypatch):
     """More images than one launch of the streaming resize / the one-kernel sharpen holds (64):
     every image of the batch equals the pipeline run on it alone; also with the sharpen of a
-    chunk on a second stream next to the next chunk's resize ($VIPS_HIP_BATCH_OVERLAP)."""
+    chunk on a second stream next to the next chunk's resize ($VIPS_HIP_BATCH_OVERLAP).
+    overlap None: resize AND sharpen in one kernel (resize_sharpen.hip), the default."""
     if overlap:
         monkeypatch.setenv("VIPS_HIP_BATCH_OVERLAP", "1")
+    if overlap is not None:
+        monkeypatch.setenv("VIPS_HIP_NO_RESIZE_SHARPEN", "1")
     srcs = [helpers.lcg_image(688, 96, 3, np.uint8, 900 + k) for k in range(70)]
     ims = [Image.new_from_array(s, interpretation="srgb") for s in srcs]
     libvips_amd.lib.vips_hip_gate_reset()
@@ -567,7 +570,7 @@ def test_resize_stream_batch_chunks(overlap, monkeypatch):
     finally:
         libvips_amd.lib.vips_hip_gate_enable(0)
         libvips_amd.lib.vips_hip_gate_reset()
-    assert sorted(report) == ["resize_stream_u8", "sharpen_fused_u8"], report
+    assert sorted(report) == (["resize_sharpen_u8"] if overlap is None else ["resize_stream_u8", "sharpen_fused_u8"]), report
     for k in (0, 1, 63, 64, 69):
         assert np.array_equal(outs[k].numpy(), ims[k].resize(0.125).sharpen().numpy()), k
         assert np.array_equal(outs[k].numpy(), helpers.PortCC.sharpen(Port.resize(srcs[k], 0.125)))
@@ -633,6 +636,67 @@ def test_resize_batch_any_scale(scale, env, want, monkeypatch):
         assert np.array_equal(outs[k].numpy(), ims[k].resize(scale).sharpen().numpy()), k
     for k in (0, 69):
         assert np.array_equal(outs[k].numpy(), helpers.PortCC.sharpen(Port.resize(srcs[k], scale)))
+
+
+RSH_CASES = [
+    # (width, height, images, scale, sigma, sharpen arguments, environment): the cases of
+    # tests/test_emul_resize_sharpen.py (where the same kernel body runs on host fibers)
+    (704, 512, 2, 0.125, 0.5, {}, {}),
+    (1408, 776, 1, 0.125, 0.5, {}, {}),
+    (2048, 1000, 2, 0.125, 1.0, {}, {}),
+    (2112, 640, 1, 0.0625, 0.5, {}, {}),
+    (4096, 256, 1, 0.125, 0.5, {}, {}),
+    (4000, 184, 1, 0.125, 0.7, {}, {}),
+    (1408, 512, 1, 0.125, 0.5, {"flat": True}, {}),
+    (1408, 512, 1, 0.125, 0.5, {"flat": True, "m1": 1.0, "m2": 2.0, "x1": 1.0, "y2": 4.0, "y3": 6.0}, {}),
+    (704, 320, 1, 0.125, 1.0, {"m2": 5.0, "y2": 30.0, "y3": 40.0}, {}),
+    (1408, 776, 1, 0.125, 0.5, {}, {"VIPS_HIP_STREAM_SEG": "7", "VIPS_HIP_RSH_TW": "9", "VIPS_HIP_STREAM_BURST": "2"}),
+    (1408, 776, 1, 0.125, 1.0, {}, {"VIPS_HIP_STREAM_SEG": "7", "VIPS_HIP_RSH_TW": "9", "VIPS_HIP_STREAM_BURST": "2"}),
+    (1408, 776, 2, 0.125, 0.5, {}, {"VIPS_HIP_STREAM_SEG": "49", "VIPS_HIP_RSH_TW": "61"}),
+    # the BASELINE config 4 and config 1 image sizes
+    (8192, 8192, 1, 0.125, 0.5, {}, {}),
+    (4096, 4096, 3, 0.125, 0.5, {}, {}),
+]
+
+
+@pytest.mark.parametrize("case", range(len(RSH_CASES)))
+def test_resize_sharpen_one_kernel(case, monkeypatch):
+    """vips_resize(1 / (2k)) -> vips_sharpen of 3-band sRGB images in ONE kernel
+    (resize_sharpen.hip): ran alone, bit-exact against the compiled reference (or the port) --
+    strips, segments, halo rows and columns, 3- and 5-tap blurs, LUT arguments, flat and dark
+    areas, the BASELINE config 1 and 4 image sizes."""
+    w, h, n, scale, sigma, kw, env = RSH_CASES[case]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    srcs = [helpers.lcg_image(w, h, 3, np.uint8, 100 + i) for i in range(n)]
+    kw = dict(kw)
+    if kw.pop("flat", False):
+        for s in srcs:
+            s[: h // 2, : w // 2] = (s[: h // 2, : w // 2] // 32).astype(np.uint8)
+            s[h // 2:, w // 2:] = 250
+    ims = [Image.new_from_array(s, interpretation="srgb") for s in srcs]
+    libvips_amd.lib.vips_hip_gate_reset()
+    libvips_amd.lib.vips_hip_gate_enable(1)
+    try:
+        outs = libvips_amd.resize_sharpen_batch(ims, scale, sigma=sigma, **kw)
+        report = libvips_amd.gate_report()
+    finally:
+        libvips_amd.lib.vips_hip_gate_enable(0)
+        libvips_amd.lib.vips_hip_gate_reset()
+    assert list(report) == ["resize_sharpen_u8"], report
+    chain = "resize:scale=%r;sharpen:sigma=%r" % (scale, sigma) + "".join(",%s=%r" % kv for kv in sorted(kw.items()))
+    for s, o, im in zip(srcs, outs, ims):
+        got = o.numpy()
+        if helpers.have_ref():
+            want = helpers.Ref.run_chain(chain, s, helpers.INTERP["srgb"])
+        else:
+            want = helpers.PortCC.sharpen(Port.resize(s, scale), sigma=sigma, **kw)
+        assert got.shape == want.shape
+        bad = np.argwhere(got != want)
+        assert len(bad) == 0, (len(bad), bad[:4])
+    # ... and equal to the two operations run one after the other on the device
+    monkeypatch.setenv("VIPS_HIP_NO_RESIZE_SHARPEN", "1")
+    assert np.array_equal(outs[0].numpy(), ims[0].resize(scale).sharpen(sigma=sigma, **kw).numpy())
 
 
 def test_resize_sharpen_batch():
