@@ -27,6 +27,11 @@ int sharpen_fused_u8(const VipsHipRegion *const *in, const VipsHipRegion *const 
 // floats), as the device tables are made (LabQ2sRGB.c:130-160, XYZ2Lab.c:92-106)
 void colour_tables_host(std::vector<float> &v2Y_8, std::vector<int> &Y2v_8, std::vector<float> &cbrt);
 
+// the LDS-sized exact form of the cube-root table (cbrt_exact.h) on the calling thread's device;
+// nullptr when this host's cbrtf does not fit the scheme
+struct CbrtExact;
+const CbrtExact *cbrt_exact_tables();
+
 // vips_resize's downsizing chain then vips_sharpen on n 3-band uchar sRGB images of one geometry in
 // ONE streaming kernel (resize_sharpen.hip); arguments as resize_stream_u8_try + the blur mask as
 // convi's integers and sharpen.c's LUT (host).  1 = handled, 0 = not its case, -1 = error

@@ -14,6 +14,8 @@
 // every multiply and add below is a separate IEEE operation (__fmul_rn/__fadd_rn,
 // __dmul_rn/...; the file is also built with -ffp-contract=off).
 #include "colour_device.h"
+#define VH_CBRT_FN static __host__ __device__ __forceinline__
+#include "cbrt_exact.h"
 
 #include <climits>
 #include <cstdlib>
@@ -93,6 +95,72 @@ void colour_tables_host(std::vector<float> &v2Y_8, std::vector<int> &Y2v_8, std:
 {
 	calcul_tables(256, Y2v_8, v2Y_8);
 	cbrt_table(cbrt);
+}
+
+// The tables of cbrt_exact.h for the calling thread's device: made from the cube-root table this
+// host's libm produces, every entry checked to come out of cbrt_pair() bit for bit.  nullptr: the
+// scheme does not fit this host's cbrtf (callers then read the table itself), or an upload failed.
+const CbrtExact *cbrt_exact_tables()
+{
+	static std::mutex mutex;
+	static CbrtExact by_device[64];
+	static int state[64]; // 0 not tried, 1 ready, -1 unusable
+	std::lock_guard<std::mutex> lock(mutex);
+	const int dev = current_device() < 0 ? 0 : current_device() & 63;
+	if (state[dev])
+		return state[dev] > 0 ? &by_device[dev] : nullptr;
+	state[dev] = -1;
+	std::vector<float> cb;
+	cbrt_table(cb);
+	std::vector<CbrtBlockD> bd(CBRT_BLOCKS + 1);
+	std::vector<CbrtBlockI> bi(CBRT_BLOCKS + 1);
+	std::vector<unsigned int> res(CBRT_RES_WORDS, 0x55555555u); // residual 0 everywhere
+	for (int k = 0; k <= CBRT_BLOCKS; k++) {
+		bi[k].i0 = 0;
+		bi[k].count = 0;
+	}
+	for (int i = 1; i < CBRT_N + 4096; i++) { // (one block past the table's last)
+		const int k = (int) (cbrt_bits((float) i) >> 18) - CBRT_KEY0;
+		if (k < 0 || k > CBRT_BLOCKS)
+			continue;
+		if (!bi[k].count)
+			bi[k].i0 = i;
+		bi[k].count++;
+	}
+	for (int k = 0; k <= CBRT_BLOCKS; k++) {
+		if (!bi[k].count)
+			return nullptr;
+		bd[k].c0 = cbrt((double) bi[k].i0 / CBRT_N);
+		bd[k].inv = 1.0 / bi[k].i0;
+	}
+	for (int i = CBRT_LINEAR; i < CBRT_N; i++) {
+		const int k = (int) (cbrt_bits((float) i) >> 18) - CBRT_KEY0;
+		if (k < 0 || k >= CBRT_BLOCKS)
+			return nullptr;
+		const long long r = (long long) cbrt_bits(cb[i]) - (long long) cbrt_predict(bd[k], bi[k], i);
+		if (r < -1 || r > 1)
+			return nullptr;
+		res[i >> 4] = (res[i >> 4] & ~(3u << (2 * (i & 15)))) | ((unsigned int) (r + 1) << (2 * (i & 15)));
+	}
+	// every pair a kernel can ask for, against the table the reference would read
+	{
+		CbrtExact host = { bd.data(), bi.data(), res.data() };
+		for (int i = 0; i + 1 < CBRT_N; i++) {
+			float t0, dt;
+			cbrt_pair(host, i, &t0, &dt);
+			const float want_dt = cb[i + 1] - cb[i];
+			if (memcmp(&t0, &cb[i], 4) || memcmp(&dt, &want_dt, 4))
+				return nullptr;
+		}
+	}
+	CbrtExact &t = by_device[dev];
+	t.bd = (const CbrtBlockD *) upload(bd.data(), bd.size() * sizeof(CbrtBlockD));
+	t.bi = (const CbrtBlockI *) upload(bi.data(), bi.size() * sizeof(CbrtBlockI));
+	t.res = (const unsigned int *) upload(res.data(), res.size() * sizeof(unsigned int));
+	if (!t.bd || !t.bi || !t.res)
+		return nullptr;
+	state[dev] = 1;
+	return &t;
 }
 
 static int ensure_tables()

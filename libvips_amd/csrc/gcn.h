@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #define VH_DEV static __device__ __forceinline__
+#define VH_CBRT_FN static __host__ __device__ __forceinline__ // (cbrt_exact.h: the host checks what the device runs)
 
 namespace vh {
 

@@ -911,12 +911,16 @@ static int resize_sharpen_batch_here(VipsHipImage *const *in, int n, VipsHipImag
 	if (n > 0 && !getenv("VIPS_HIP_NO_BATCH_LAUNCH")) {
 		const int chunk = 64;
 		// resize and sharpen of 3-band sRGB images in ONE kernel (resize_sharpen.hip): nothing to
-		// partition, no thumbnail in memory between the two
+		// partition, no thumbnail in memory between the two.  Bit-exact, but on the MI355X the
+		// sharpen's arithmetic inside the streaming blocks costs more than the partition it removes
+		// (0.051 ms per 8192 x 8192 image against 0.043: DESIGN.md 3.2), so it runs on request only:
+		// $VIPS_HIP_RESIZE_SHARPEN=1
 		std::vector<int> coef;
 		int mask_scale = 1;
 		const bool small_mask = sigma >= 0.0 && sharpen_small_mask(sigma, coef, &mask_scale);
 		const bool fusable = small_mask && sharpen_images_fusable(in, n);
-		if (fusable && !getenv("VIPS_HIP_NO_RESIZE_SHARPEN")) {
+		const char *one_kernel = getenv("VIPS_HIP_RESIZE_SHARPEN");
+		if (fusable && one_kernel && atoi(one_kernel) > 0) {
 			std::vector<int> lut;
 			sharpen_lut_host(x1, y2, y3, m1, m2, lut);
 			const int r = vh::resize_sharpen_batch_u8(in, n, out, scale, kernel, gap, coef.data(), (int) coef.size(),

@@ -24,16 +24,16 @@
 //            stage's burst when the chip-wide write window says so; then reduceh(s) -> the
 //            resized slab R[s & 1]
 //
-// F and B each issue their table gathers BEFORE a pair's row work and use them after it, so the
-// gathers' latency sits under the pair's and the row loads issued meanwhile stay in flight
-// (vmcnt is in order: a gather issued after the row loads could only be waited for together with
-// them).  A block never stops loading while it sharpens; the ALU work of the sharpen runs in
-// what was the block's wait for its loads.
+// F and B read NO table from global memory: a wave's gather from an L2-resident table costs ~146
+// cycles of its CU's L1 fill path (tools/gather_probe.hip) -- the path the row loads need -- and
+// the first build of this kernel, with XYZ2Lab's cube-root table and a per-L table gathered, ran
+// 0.066 ms per image against 0.041 for the resize alone.  Everything the sharpen looks up is in
+// LDS: the two 8-bit sRGB tables, the bending part of sharpen's LUT, and the cube-root table in
+// the exact 30 KB form of cbrt_exact.h.  A block never stops loading while it sharpens; the ALU
+// work of the sharpen runs in what was the block's wait for its loads.
 //
 // Arithmetic: every rounding is the separate operations' own (the result is theirs bit for bit),
 // with the per-pixel work cut to what is not a function of one small integer:
-//   * L' (15 bits) -> the Y chain of Lab2XYZ and XYZ2scRGB is a 32768-entry table {fy, the three
-//     matrix products of Y / 100} made on the host with the reference's own operations;
 //   * a / 500 with a = A / 256: A / 128000 (the same real number, correctly rounded once);
 //   * X / 100.0 in double then float == the correctly rounded FLOAT quotient (no double rounding:
 //     100 m for a float midpoint m needs 29 bits; tools/c4_identities.c checks every float);
@@ -42,6 +42,8 @@
 
 #include "gcn.h"
 
+#include "cbrt_exact.h"
+
 namespace vh {
 
 constexpr int RSH_SPAN = 2048; // bytes of a row a strip covers
@@ -49,13 +51,6 @@ constexpr int RSH_NT = 512;
 constexpr int RSH_MAXB = 64;   // images per launch
 constexpr int RSH_NP = 7;      // coefficient pairs of the vertical reduce = rows per slab
 constexpr int RSH_RING = 16;   // rows of the LabS and blur rings
-
-// Lab2XYZ.c:84-109 + LabQ2sRGB.c:263-283 for one LabS L: fy, and Y / 100 times the matrix column
-struct RshLEntry {
-	double fy;
-	float c0, c1, c2;
-	float pad[3];
-};
 
 struct RshPair {
 	float x, y;
@@ -89,16 +84,14 @@ struct RshArgs {
 	const short *lut;         // lut_n entries between
 	const float *v2Y;         // 256: sRGB2scRGB
 	const RshPair *Y2v;       // 256: scRGB2sRGB as {l0, l1 - l0}
-	const RshPair *cbrt;      // 99999: XYZ2Lab's table as {t[i], t[i + 1] - t[i]}
-	const RshLEntry *ltab;    // 32768
+	CbrtExact cbrt;           // XYZ2Lab's table, cbrt_exact.h (copied to LDS)
 	// ---- LDS layout, byte offsets (T at 0)
-	int off_S, off_HM, off_O, off_R, off_L, off_AB, off_H, off_v2Y, off_Y2v, off_lut;
+	int off_S, off_HM, off_O, off_R, off_L, off_AB, off_H, off_v2Y, off_Y2v, off_lut, off_cres, off_cbd, off_cbi;
 	int s_pitch;  // bytes per row of S
 	int r_pitch;  // bytes per row of R (and per buffer NP rows)
 	int l_pitch;  // shorts per row of the L ring
 	int ab_pitch; // dwords per row of the (a, b) ring
 	int h_pitch;  // shorts per row of the H ring
-	int pad_;
 };
 
 struct RshPtrs {
@@ -203,6 +196,10 @@ static __device__ __forceinline__ void resize_sharpen_body(const RshArgs &a, con
 	float *const v2Y = reinterpret_cast<float *>(lds8 + a.off_v2Y);
 	RshPair *const Y2v = reinterpret_cast<RshPair *>(lds8 + a.off_Y2v);
 	short *const LUT = reinterpret_cast<short *>(lds8 + a.off_lut);
+	unsigned int *const CRES = reinterpret_cast<unsigned int *>(lds8 + a.off_cres);
+	CbrtBlockD *const CBD = reinterpret_cast<CbrtBlockD *>(lds8 + a.off_cbd);
+	CbrtBlockI *const CBI = reinterpret_cast<CbrtBlockI *>(lds8 + a.off_cbi);
+	const CbrtExact cbrt = { CBD, CBI, CRES };
 
 	// block -> (strip, segment, image), the strips of one (segment, image) on one XCD (see resize_stream.hip)
 	int strip, unit;
@@ -240,6 +237,12 @@ static __device__ __forceinline__ void resize_sharpen_body(const RshArgs &a, con
 	}
 	for (int i = t; i < a.lut_n; i += NT)
 		LUT[i] = a.lut[i];
+	for (int i = t; i < CBRT_RES_WORDS; i += NT)
+		CRES[i] = a.cbrt.res[i];
+	if (t <= CBRT_BLOCKS) {
+		CBD[t] = a.cbrt.bd[t];
+		CBI[t] = a.cbrt.bi[t];
+	}
 
 	const int h = a.half;
 	const int x0 = strip * a.tw, nx = min(a.tw, a.out_width - x0);
@@ -290,13 +293,7 @@ static __device__ __forceinline__ void resize_sharpen_body(const RshArgs &a, con
 	const unsigned int out_lo = gptr_low(out + (long long) x0 * B);
 
 	// ---- F: resized pixel idx of slab sf -> LabS
-	struct FState {
-		float f[3];
-		RshPair p[3];
-		int slot_u; // ring row * 1 (slot) in the high half, column in the low half; -1: nothing
-	};
-	auto f_pre = [&](int sf, int idx, FState &st) {
-		st.slot_u = -1;
+	auto f_stage = [&](int sf, int idx) {
 		const int rows = min(NP, nyr - NP * sf);
 		const int r = (int) (((unsigned int) idx * magic_nxr) >> 20);
 		const int u = idx - r * nxr;
@@ -308,32 +305,25 @@ static __device__ __forceinline__ void resize_sharpen_body(const RshArgs &a, con
 		const float X = (0.4124F * Rl + 0.3576F * Gl) + 0.1805F * Bl;
 		const float Y = (0.2126F * Rl + 0.7152F * Gl) + 0.0722F * Bl;
 		const float Z = (0.0193F * Rl + 0.1192F * Gl) + 0.9505F * Bl;
-		// XYZ2Lab.c:109-138: nX = QUANT_ELEMENTS * X / X0 in double, to float; index, fraction
+		// XYZ2Lab.c:109-138: nX = QUANT_ELEMENTS * X / X0 in double, to float; index, fraction, lerp
 		const float n0 = (float) RSH_DIV((double) (100000.0f * X), 95.0470);
 		const float n1 = (float) RSH_DIV((double) (100000.0f * Y), 100.0);
 		const float n2 = (float) RSH_DIV((double) (100000.0f * Z), 108.8827);
-		const int i0 = min(max((int) n0, 0), 100000 - 2);
-		const int i1 = min(max((int) n1, 0), 100000 - 2);
-		const int i2 = min(max((int) n2, 0), 100000 - 2);
-		st.f[0] = n0 - (float) i0;
-		st.f[1] = n1 - (float) i1;
-		st.f[2] = n2 - (float) i2;
-		st.p[0] = a.cbrt[i0];
-		st.p[1] = a.cbrt[i1];
-		st.p[2] = a.cbrt[i2];
-		st.slot_u = ((((NP * sf + r) & (RSH_RING - 1))) << 16) | u;
-	};
-	auto f_post = [&](const FState &st) {
-		if (st.slot_u < 0)
-			return;
-		const int slot = st.slot_u >> 16, u = st.slot_u & 0xffff;
-		const float cbx = st.p[0].x + st.f[0] * st.p[0].y;
-		const float cby = st.p[1].x + st.f[1] * st.p[1].y;
-		const float cbz = st.p[2].x + st.f[2] * st.p[2].y;
+		const int i0 = min(max((int) n0, 0), CBRT_N - 2);
+		const int i1 = min(max((int) n1, 0), CBRT_N - 2);
+		const int i2 = min(max((int) n2, 0), CBRT_N - 2);
+		const int slot = (NP * sf + r) & (RSH_RING - 1);
+		float t0, dt;
+		cbrt_pair(cbrt, i1, &t0, &dt);
+		const float cby = t0 + (n1 - (float) i1) * dt;
 		const int L = rsh_labs(116.0F * cby - 16.0F, 32767.0 / 100.0, 0.0);
 		LR[slot * a.l_pitch + u] = (short) L;
 		const int x = u - h;
 		if (x >= 0 && x < nx) {
+			cbrt_pair(cbrt, i0, &t0, &dt);
+			const float cbx = t0 + (n0 - (float) i0) * dt;
+			cbrt_pair(cbrt, i2, &t0, &dt);
+			const float cbz = t0 + (n2 - (float) i2) * dt;
 			const int A = rsh_labs(500.0F * (cbx - cby), 32768.0 / 128.0, -32768.0);
 			const int Bv = rsh_labs(200.0F * (cby - cbz), 32768.0 / 128.0, -32768.0);
 			ABR[slot * a.ab_pitch + x] = ((unsigned int) A & 0xffffu) | ((unsigned int) Bv << 16);
@@ -342,13 +332,7 @@ static __device__ __forceinline__ void resize_sharpen_body(const RshArgs &a, con
 
 	// ---- B: output pixel idx of batch bb -> the stage
 	int staged = 0, flushed = 0; // rows in the stage; output rows already written
-	struct BState {
-		RshLEntry e;
-		int A, Bv;
-		int o_off; // byte offset in the stage; -1: nothing
-	};
-	auto b_pre = [&](int bb, int idx, BState &st) {
-		st.o_off = -1;
+	auto b_stage = [&](int bb, int idx) {
 		const int r = (int) (((unsigned int) idx * magic_nx) >> 20);
 		const int x = idx - r * nx;
 		const int first = max(NP * bb - h, rho0);
@@ -373,18 +357,17 @@ static __device__ __forceinline__ void resize_sharpen_body(const RshArgs &a, con
 			lv = LUT[d];
 		const int sharp = min(max(v1 + lv, 0), 32767);
 		const unsigned int ab = ABR[slot * a.ab_pitch + x];
-		st.A = (int) (short) (ab & 0xffffu);
-		st.Bv = (int) ab >> 16;
-		st.e = a.ltab[sharp];
-		const unsigned int mis = (out_lo + (unsigned int) y * (unsigned int) a.out_stride) & 3u;
-		st.o_off = (staged + rho - first) * a.o_pitch + (int) mis + 3 * x;
-	};
-	auto b_post = [&](const BState &st) {
-		if (st.o_off < 0)
-			return;
-		// Lab2XYZ.c:84-109 with a = A / 256, b = B / 256 (LabS2Lab.c:55-69)
-		const double fx = RSH_DIV((double) st.A, 128000.0) + st.e.fy;
-		const double fz = st.e.fy - RSH_DIV((double) st.Bv, 51200.0);
+		const int A = (int) (short) (ab & 0xffffu), Bv = (int) ab >> 16;
+		// LabS2Lab.c:55-69 and Lab2XYZ.c:84-109 (a = A / 256, b = B / 256: exact)
+		const float Lf = (float) RSH_DIV((double) sharp, 32767.0 / 100.0);
+		double fy = RSH_DIV((double) Lf + 16.0, 116.0);
+		float Y = (float) (((100.0 * fy) * fy) * fy);
+		if (Lf < 8.0f) {
+			Y = (float) RSH_DIV((double) Lf * 100.0, 903.3);
+			fy = 7.787 * RSH_DIV((double) Y, 100.0) + 16.0 / 116.0;
+		}
+		const double fx = RSH_DIV((double) A, 128000.0) + fy;
+		const double fz = fy - RSH_DIV((double) Bv, 51200.0);
 		float X = (float) (((95.0470 * fx) * fx) * fx);
 		float Z = (float) (((108.8827 * fz) * fz) * fz);
 		if (fx < 0.2069)
@@ -392,14 +375,15 @@ static __device__ __forceinline__ void resize_sharpen_body(const RshArgs &a, con
 		if (fz < 0.2069)
 			Z = (float) RSH_DIV(108.8827 * (fz - 0.13793), 7.787);
 		// LabQ2sRGB.c:263-283
-		const float Xn = rsh_divf100(X), Zn = rsh_divf100(Z);
-		const float r = (3.240625F * Xn + st.e.c0) + -0.498629F * Zn;
-		const float g = (-0.968931F * Xn + st.e.c1) + 0.041518F * Zn;
-		const float b = (0.055710F * Xn + st.e.c2) + 1.056996F * Zn;
-		unsigned int px = rsh_channel(Y2v, r, 0, 0u);
-		px = rsh_channel(Y2v, g, 1, px);
-		px = rsh_channel(Y2v, b, 2, px);
-		unsigned char *o = O + st.o_off;
+		const float Xn = rsh_divf100(X), Yn = rsh_divf100(Y), Zn = rsh_divf100(Z);
+		const float rl = (3.240625F * Xn + -1.537208F * Yn) + -0.498629F * Zn;
+		const float gl = (-0.968931F * Xn + 1.875756F * Yn) + 0.041518F * Zn;
+		const float bl = (0.055710F * Xn + -0.204021F * Yn) + 1.056996F * Zn;
+		unsigned int px = rsh_channel(Y2v, rl, 0, 0u);
+		px = rsh_channel(Y2v, gl, 1, px);
+		px = rsh_channel(Y2v, bl, 2, px);
+		const unsigned int mis = (out_lo + (unsigned int) y * (unsigned int) a.out_stride) & 3u;
+		unsigned char *o = O + (staged + rho - first) * a.o_pitch + (int) mis + 3 * x;
 		o[0] = (unsigned char) px;
 		o[1] = (unsigned char) (px >> 8);
 		o[2] = (unsigned char) (px >> 16);
@@ -413,20 +397,13 @@ static __device__ __forceinline__ void resize_sharpen_body(const RshArgs &a, con
 		const bool do_f = sf >= 0 && sf < ns, do_b = bb >= 0 && bb < nb;
 		const int nfpix = do_f ? nxr * min(NP, nyr - NP * sf) : 0;
 		const int nbpix = do_b ? nx * NP : 0;
-		FState fs;
-		BState bs;
 		if (n <= ns) {
 #pragma unroll
 			for (int p = 0; p < NP; p++) {
 				const int j = NP * n + p - 1;
-				// the sharpen stages of this step, each around one pair's row work
+				// the sharpen stages of this step, each behind one pair's row work
 				const bool f_now = (p == 1 || p == NP - 2), b_now = (p == 2 || p == NP - 1);
 				const int rd = p >= NP - 2 ? 1 : 0; // second round: pixels 512 ...
-				if (f_now && rd * NT < nfpix)
-					f_pre(sf, rd * NT + t, fs);
-				if (b_now && rd * NT < nbpix)
-					b_pre(bb, rd * NT + t, bs);
-				sched_fence();
 				unsigned int sb[2][2];
 #pragma unroll
 				for (int hh = 0; hh < 2; hh++) {
@@ -459,22 +436,18 @@ static __device__ __forceinline__ void resize_sharpen_body(const RshArgs &a, con
 				*reinterpret_cast<unsigned int *>(T + p * RSH_SPAN + 4 * t) = packed;
 				sched_fence();
 				if (f_now && rd * NT < nfpix)
-					f_post(fs);
+					f_stage(sf, rd * NT + t);
 				if (b_now && rd * NT < nbpix)
-					b_post(bs);
+					b_stage(bb, rd * NT + t);
 				sched_fence();
 			}
 		}
 		else {
 			// the segment's rows are all made: the stages still in flight, without row work
-			for (int rd = 0; rd * NT < nfpix; rd++) {
-				f_pre(sf, rd * NT + t, fs);
-				f_post(fs);
-			}
-			for (int rd = 0; rd * NT < nbpix; rd++) {
-				b_pre(bb, rd * NT + t, bs);
-				b_post(bs);
-			}
+			for (int rd = 0; rd * NT < nfpix; rd++)
+				f_stage(sf, rd * NT + t);
+			for (int rd = 0; rd * NT < nbpix; rd++)
+				b_stage(bb, rd * NT + t);
 		}
 		if (n == 0)
 			continue;

@@ -26,8 +26,7 @@ namespace {
 // (colour.hip: calcul_tables = LabQ2sRGB.c:130-160, table_init = XYZ2Lab.c:92-106)
 struct RshTables {
 	float *v2Y = nullptr;
-	RshPair *Y2v = nullptr, *cbrt = nullptr;
-	RshLEntry *ltab = nullptr;
+	RshPair *Y2v = nullptr;
 };
 
 const RshTables *rsh_tables()
@@ -38,49 +37,21 @@ const RshTables *rsh_tables()
 	const int device = current_device();
 	auto it = by_device.find(device);
 	if (it != by_device.end())
-		return it->second.ltab ? &it->second : nullptr;
+		return it->second.Y2v ? &it->second : nullptr;
 	RshTables &tb = by_device[device];
 	std::vector<float> v2Y, cb;
 	std::vector<int> Y2v;
 	colour_tables_host(v2Y, Y2v, cb);
-	std::vector<RshPair> y2(256), c2(cb.size() - 1);
+	std::vector<RshPair> y2(256);
 	for (int i = 0; i < 256; i++) {
 		y2[i].x = (float) Y2v[i];
 		y2[i].y = (float) (Y2v[i + 1] - Y2v[i]);
 	}
-	for (size_t i = 0; i + 1 < cb.size(); i++) {
-		c2[i].x = cb[i];
-		c2[i].y = cb[i + 1] - cb[i];
-	}
-	// LabS2Lab.c:55-69, Lab2XYZ.c:84-109, LabQ2sRGB.c:263-283 for every L the coding holds
-	std::vector<RshLEntry> lt(32768);
-	const double Y0 = 100.0;
-	for (int i = 0; i < 32768; i++) {
-		const float L = (float) ((double) i / (32767.0 / 100.0));
-		double cby;
-		float Y;
-		if (L < 8.0) {
-			Y = (float) (((double) L * Y0) / 903.3);
-			cby = 7.787 * ((double) Y / Y0) + 16.0 / 116.0;
-		}
-		else {
-			cby = ((double) L + 16.0) / 116.0;
-			Y = (float) (((Y0 * cby) * cby) * cby);
-		}
-		const float Yn = (float) ((double) Y / 100.0);
-		memset(&lt[i], 0, sizeof(RshLEntry));
-		lt[i].fy = cby;
-		lt[i].c0 = -1.537208F * Yn;
-		lt[i].c1 = 1.875756F * Yn;
-		lt[i].c2 = -0.204021F * Yn;
-	}
 	tb.v2Y = (float *) upload(v2Y.data(), 256 * sizeof(float));
-	tb.Y2v = (RshPair *) upload(y2.data(), y2.size() * sizeof(RshPair));
-	tb.cbrt = (RshPair *) upload(c2.data(), c2.size() * sizeof(RshPair));
-	RshLEntry *lp = (RshLEntry *) upload(lt.data(), lt.size() * sizeof(RshLEntry));
-	if (!tb.v2Y || !tb.Y2v || !tb.cbrt || !lp)
+	RshPair *yp = (RshPair *) upload(y2.data(), y2.size() * sizeof(RshPair));
+	if (!tb.v2Y || !yp)
 		return nullptr;
-	tb.ltab = lp;
+	tb.Y2v = yp;
 	return &tb;
 }
 
@@ -159,7 +130,7 @@ int resize_sharpen_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh,
 	const VipsHipRegion *const *in, const VipsHipRegion *const *out, int n, int tile, const int *coef, int ncoef,
 	int scale, const int *lut)
 {
-	if (getenv("VIPS_HIP_NO_RESIZE_SHARPEN") || n < 1)
+	if (n < 1)
 		return 0;
 	const VipsHipRegion *i0 = in[0], *o0 = out[0];
 	for (int i = 0; i < n; i++) {
@@ -216,6 +187,11 @@ int resize_sharpen_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh,
 	const RshTables *tb = rsh_tables();
 	if (!tb)
 		return -1;
+	const CbrtExact *cx = cbrt_exact_tables();
+	if (!cx) {
+		vips_hip_error_clear();
+		return 0; // (this host's cbrtf does not fit cbrt_exact.h: the separate kernels read the table itself)
+	}
 
 	RshArgs a;
 	memset(&a, 0, sizeof(a));
@@ -252,8 +228,7 @@ int resize_sharpen_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh,
 	a.lut = l->d;
 	a.v2Y = tb->v2Y;
 	a.Y2v = tb->Y2v;
-	a.cbrt = tb->cbrt;
-	a.ltab = tb->ltab;
+	a.cbrt = *cx;
 
 	// the widest strip whose span fits: (2 (tw + 2 half) + n_h - 1) shrunk columns of hs pixels, + 3 bytes
 	// of alignment; then strips of equal width
@@ -302,6 +277,12 @@ int resize_sharpen_stream_u8_try(_VipsHipReduce *rv, int vs, _VipsHipReduce *rh,
 	off = align16(off + 256 * sizeof(RshPair));
 	a.off_lut = (int) off;
 	off = align16(off + (size_t) (a.lut_n + 1) * sizeof(short));
+	a.off_cres = (int) off;
+	off = align16(off + (size_t) CBRT_RES_WORDS * sizeof(unsigned int));
+	a.off_cbd = (int) off;
+	off = align16(off + (size_t) (CBRT_BLOCKS + 1) * sizeof(CbrtBlockD));
+	a.off_cbi = (int) off;
+	off = align16(off + (size_t) (CBRT_BLOCKS + 1) * sizeof(CbrtBlockI));
 	a.off_O = (int) off;
 	// the stage takes what is left of half a CU's LDS (two blocks per CU), at most 14 slabs
 	const size_t budget = (size_t) rsh_env("VIPS_HIP_RSH_LDS", 80 * 1024);

@@ -68,7 +68,7 @@ def _run(cases, tmp_path, extra_env=None):
     script = os.path.join(str(tmp_path), "child.py")
     with open(script, "w") as f:
         f.write(CHILD % {"root": helpers.ROOT, "cases": cases})
-    env = dict(os.environ, LD_PRELOAD=MOCK_SO, VIPS_HIP_LIBRARY=EMUL_SO)
+    env = dict(os.environ, LD_PRELOAD=MOCK_SO, VIPS_HIP_LIBRARY=EMUL_SO, VIPS_HIP_RESIZE_SHARPEN="1")
     env.update(extra_env or {})
     proc = subprocess.run([sys.executable, script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                           env=env, timeout=1200)

@@ -220,10 +220,10 @@ assert mock.mock_hip_launches() > 0
 
 def test_uniform_batch_takes_the_batch_launches(tmp_path):
     """vips_hip_resize_sharpen_batch on a uniform batch of more than one launch's worth of images:
-    ONE launch per 64 images (resize + sharpen in one kernel, on the caller's stream); with that
-    kernel switched off one resize launch and one sharpen launch per 64 images (on the two
-    CU-masked streams the library keeps per device, or with $VIPS_HIP_BATCH_OVERLAP=0 on the
-    caller's); thumbnails of the right geometry; a mixed batch goes image by image."""
+    one resize launch and one sharpen launch per 64 images (on the two CU-masked streams the
+    library keeps per device, or with $VIPS_HIP_BATCH_OVERLAP=0 on the caller's); with
+    $VIPS_HIP_RESIZE_SHARPEN=1 ONE launch per 64 images (resize + sharpen in one kernel, on the
+    caller's stream); thumbnails of the right geometry; a mixed batch goes image by image."""
     run_child(r'''
 import ctypes, os
 import numpy as np
@@ -237,11 +237,12 @@ ims = [Image.new_from_array(np.zeros((64, 688, 3), np.uint8), interpretation="sr
 ims[0].resize(0.125)
 s0 = mock.mock_hip_live_streams()
 n0 = mock.mock_hip_launches()
+os.environ["VIPS_HIP_RESIZE_SHARPEN"] = "1"
 outs = libvips_amd.resize_sharpen_batch(ims, 0.125, threads=4)
 assert mock.mock_hip_launches() - n0 == 2, mock.mock_hip_launches() - n0   # 2 chunks x one kernel
 assert mock.mock_hip_live_streams() == s0
 assert all((o.width, o.height, o.bands) == (86, 8, 3) for o in outs)
-os.environ["VIPS_HIP_NO_RESIZE_SHARPEN"] = "1"
+del os.environ["VIPS_HIP_RESIZE_SHARPEN"]
 libvips_amd.resize_sharpen_batch(ims, 0.125, threads=4)
 before = mock.mock_hip_live_streams()
 assert before == s0 + 2, (s0, before)  # the two CU partitions, made once and kept
@@ -255,7 +256,6 @@ for overlap in ("", "0"):
     assert mock.mock_hip_live_streams() == before
     assert all((o.width, o.height, o.bands) == (86, 8, 3) for o in outs)
 os.environ.pop("VIPS_HIP_BATCH_OVERLAP", None)
-del os.environ["VIPS_HIP_NO_RESIZE_SHARPEN"]
 n0 = mock.mock_hip_launches()
 outs = libvips_amd.resize_sharpen_batch(ims, 0.125, sharpen=False, threads=4)
 assert mock.mock_hip_launches() - n0 == 2
@@ -280,7 +280,7 @@ assert mock.mock_hip_mallocs() == m0, (m0, mock.mock_hip_mallocs())
 lib.vips_hip_image_unref_many(hout, n)   # all NULL: nothing to do
 lib.vips_hip_image_unref_many(None, 5)
 # the queued form of a uniform batch returns without a single host wait (the synchronous form
-# waits for the caller's stream); a mixed batch completes before the return
+# waits for the caller's stream and the two partitions); a mixed batch completes before the return
 mock.mock_hip_syncs.restype = ctypes.c_long
 s0 = mock.mock_hip_syncs()
 assert lib.vips_hip_resize_sharpen_batch_queue(hin, n, hout, 0.125, 5, 2.0, 0.5, 2.0, 10.0, 20.0, 0.0, 3.0, 4) == 0

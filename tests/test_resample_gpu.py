@@ -555,11 +555,11 @@ def test_resize_stream_batch_chunks(overlap, monkeypatch):
     """More images than one launch of the streaming resize / the one-kernel sharpen holds (64):
     every image of the batch equals the pipeline run on it alone; also with the sharpen of a
     chunk on a second stream next to the next chunk's resize ($VIPS_HIP_BATCH_OVERLAP).
-    overlap None: resize AND sharpen in one kernel (resize_sharpen.hip), the default."""
+    overlap None: resize AND sharpen in one kernel (resize_sharpen.hip, $VIPS_HIP_RESIZE_SHARPEN=1)."""
     if overlap:
         monkeypatch.setenv("VIPS_HIP_BATCH_OVERLAP", "1")
-    if overlap is not None:
-        monkeypatch.setenv("VIPS_HIP_NO_RESIZE_SHARPEN", "1")
+    if overlap is None:
+        monkeypatch.setenv("VIPS_HIP_RESIZE_SHARPEN", "1")
     srcs = [helpers.lcg_image(688, 96, 3, np.uint8, 900 + k) for k in range(70)]
     ims = [Image.new_from_array(s, interpretation="srgb") for s in srcs]
     libvips_amd.lib.vips_hip_gate_reset()
@@ -662,10 +662,11 @@ RSH_CASES = [
 @pytest.mark.parametrize("case", range(len(RSH_CASES)))
 def test_resize_sharpen_one_kernel(case, monkeypatch):
     """vips_resize(1 / (2k)) -> vips_sharpen of 3-band sRGB images in ONE kernel
-    (resize_sharpen.hip): ran alone, bit-exact against the compiled reference (or the port) --
+    (resize_sharpen.hip, on request: $VIPS_HIP_RESIZE_SHARPEN=1): ran alone, bit-exact against the compiled reference (or the port) --
     strips, segments, halo rows and columns, 3- and 5-tap blurs, LUT arguments, flat and dark
     areas, the BASELINE config 1 and 4 image sizes."""
     w, h, n, scale, sigma, kw, env = RSH_CASES[case]
+    monkeypatch.setenv("VIPS_HIP_RESIZE_SHARPEN", "1")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     srcs = [helpers.lcg_image(w, h, 3, np.uint8, 100 + i) for i in range(n)]
@@ -695,7 +696,7 @@ def test_resize_sharpen_one_kernel(case, monkeypatch):
         bad = np.argwhere(got != want)
         assert len(bad) == 0, (len(bad), bad[:4])
     # ... and equal to the two operations run one after the other on the device
-    monkeypatch.setenv("VIPS_HIP_NO_RESIZE_SHARPEN", "1")
+    monkeypatch.delenv("VIPS_HIP_RESIZE_SHARPEN")
     assert np.array_equal(outs[0].numpy(), ims[0].resize(scale).sharpen(sigma=sigma, **kw).numpy())
 
 
