@@ -46,6 +46,11 @@ int convsep_f32_fused(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHi
 int convsep_stream_fused(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConv *pass1,
 	double offset2, const int *route_steps, int n_route);
 
+// conv_u8.hip: integer convolution of uchar images on packed bytes (v_dot4_i32_i8), streaming: both
+// passes of a separable mask, or a two-dimensional mask of up to 7 x 9.  1 = not their case.
+int conv_u8_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConv *pass1, double offset2);
+int conv_u8_2d_try(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConv *c);
+
 // approx.hip: both passes of a convasep plan through the fused kernel above; 1 when not covered.
 int convasep_fused(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConva *plan);
 

@@ -25,6 +25,7 @@ VH_DEV unsigned int gload32(gptr_in base, unsigned int off)
 {
 	return *(const unsigned int __attribute__((address_space(1))) *) (base + off);
 }
+VH_DEV unsigned char gload8(gptr_in base, unsigned int off) { return base[off]; }
 VH_DEV void gstore32(gptr_out p, unsigned int v) { *(unsigned int __attribute__((address_space(1))) *) p = v; }
 VH_DEV void gstore8(gptr_out p, unsigned char v) { *p = v; }
 
@@ -39,7 +40,23 @@ struct KernargWords {
 	}
 };
 
+// the value lane - 1 / lane + 1 / lane + delta of the wave holds (lane 0 / 63: unspecified)
+VH_DEV unsigned int lane_prev(unsigned int v) { return (unsigned int) __builtin_amdgcn_update_dpp(0, (int) v, 0x138, 0xf, 0xf, false); }
+VH_DEV unsigned int lane_next(unsigned int v) { return (unsigned int) __builtin_amdgcn_update_dpp(0, (int) v, 0x130, 0xf, 0xf, false); }
+VH_DEV unsigned int lane_from(unsigned int v, int delta)
+{
+	return (unsigned int) __builtin_amdgcn_ds_bpermute((int) ((threadIdx.x + delta) & 63) << 2, (int) v);
+}
 VH_DEV int tid() { return (int) threadIdx.x; }
+// the next work item of a persistent block: one atomic per block, handed to every thread through `slot` (LDS)
+VH_DEV int next_item(int *counter, int *slot)
+{
+	__syncthreads();
+	if (threadIdx.x == 0)
+		*slot = atomicAdd(counter, 1);
+	__syncthreads();
+	return __builtin_amdgcn_readfirstlane(*slot);
+}
 VH_DEV void barrier() { __syncthreads(); }
 // the chip-wide 100 MHz clock
 VH_DEV unsigned long long realtime() { return __builtin_amdgcn_s_memrealtime(); }
@@ -65,6 +82,8 @@ VH_DEV int dot2_s(unsigned int a, unsigned int b_uniform, int acc)
 }
 // v_dot4_u32_u8
 VH_DEV unsigned int udot4(unsigned int a, unsigned int b, unsigned int acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
+// v_dot4_i32_i8: acc + the four products of signed bytes
+VH_DEV int dot4(unsigned int a, unsigned int b, int acc) { return __builtin_amdgcn_sdot4((int) a, (int) b, acc, false); }
 // v_sat_pk_u8_i16: {0, 0, sat_u8(hi16), sat_u8(lo16)}
 VH_DEV unsigned int sat_pk_u8_i16(unsigned int both)
 {

@@ -199,6 +199,18 @@ int conv_image(VipsHipImage *in, VipsHipImage **out, const double *mask, int mw,
 	ImageRef o(vips_hip_image_new(in->width, in->height, in->bands, fmt, in->interpretation));
 	if (!o.im)
 		return -1;
+	// uchar, integer precision, a small mask: the packed-byte streaming kernel (conv_u8.hip)
+	// (not with the Highway variant of convi selected: that one has its own arithmetic)
+	if (in->format == VIPS_HIP_FORMAT_UCHAR && precision == VIPS_HIP_PRECISION_INTEGER && !vips_hip_vector_isenabled() &&
+		mh > 1 && mw > 1) {
+		const int r = vh::conv_u8_2d_try(in, o.im, c.get());
+		if (r < 0)
+			return -1;
+		if (r == 0) {
+			*out = o.release();
+			return 0;
+		}
+	}
 	VipsHipRegion ri, ro;
 	vips_hip_image_region(in, &ri);
 	vips_hip_image_region(o.im, &ro);
@@ -556,6 +568,8 @@ int vips_hip_convsep(VipsHipImage *in, VipsHipImage **out, const double *mask, i
 		if (!o.im)
 			return -1;
 		int r = vh::convsep_stream_fused(in, o.im, c.get(), 0.0, nullptr, 0);
+		if (r == 1)
+			r = vh::conv_u8_sep_try(in, o.im, c.get(), 0.0);
 		if (r == 1)
 			r = vh::convsep_f32_fused(in, o.im, c.get(), 0.0);
 		if (r < 0)

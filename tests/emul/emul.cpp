@@ -22,6 +22,7 @@ thread_local ucontext_t g_main;
 thread_local int g_tid = 0;
 thread_local const std::function<void()> *g_fn = nullptr;
 thread_local unsigned long long g_ticks = 0;
+thread_local std::vector<unsigned int> *g_exchange = nullptr;
 
 void trampoline()
 {
@@ -42,8 +43,19 @@ void barrier()
 	swapcontext(&f.ctx, &g_main);
 }
 
+unsigned int exchange(unsigned int value, int src)
+{
+	(*g_exchange)[g_tid] = value;
+	barrier();
+	const unsigned int got = (*g_exchange)[src];
+	barrier();
+	return got;
+}
+
 void run_block(int threads, const std::function<void()> &fn)
 {
+	std::vector<unsigned int> xchg(threads, 0u);
+	g_exchange = &xchg;
 	const size_t stack_bytes = 256 * 1024;
 	std::vector<Fiber> fibers(threads);
 	g_fibers = &fibers;

@@ -13,6 +13,8 @@ namespace emul {
 int current_tid();
 void barrier();
 unsigned long long clock_ticks();
+// every thread of the block hands in a value and gets the one thread `src` handed in (two barriers)
+unsigned int exchange(unsigned int value, int src);
 // run `fn` as `threads` fibers (one block); fn reads current_tid()
 void run_block(int threads, const std::function<void()> &fn);
 

@@ -39,6 +39,7 @@ VH_DEV unsigned int gload32(gptr_in base, unsigned int off)
 	memcpy(&v, base + off, 4);
 	return v;
 }
+VH_DEV unsigned char gload8(gptr_in base, unsigned int off) { return base[off]; }
 VH_DEV void gstore32(gptr_out p, unsigned int v) { memcpy(p, &v, 4); }
 VH_DEV void gstore8(gptr_out p, unsigned char v) { *p = v; }
 
@@ -47,7 +48,23 @@ struct KernargWords {
 	unsigned long long operator[](int i) const { return words[i]; }
 };
 
+// cross-lane moves: every thread of the block must make the same calls (the bodies do)
+VH_DEV unsigned int lane_from(unsigned int v, int delta)
+{
+	const int t = emul::current_tid();
+	return emul::exchange(v, (t & ~63) + ((t + delta) & 63));
+}
+VH_DEV unsigned int lane_prev(unsigned int v) { return lane_from(v, -1); }
+VH_DEV unsigned int lane_next(unsigned int v) { return lane_from(v, 1); }
 VH_DEV int tid() { return emul::current_tid(); }
+VH_DEV int next_item(int *counter, int *slot)
+{
+	emul::barrier();
+	if (emul::current_tid() == 0)
+		*slot = __sync_fetch_and_add(counter, 1);
+	emul::barrier();
+	return *slot;
+}
 VH_DEV void barrier() { emul::barrier(); }
 VH_DEV unsigned long long realtime() { return emul::clock_ticks(); }
 VH_DEV void sched_fence() {}
@@ -82,6 +99,12 @@ VH_DEV unsigned int udot4(unsigned int a, unsigned int b, unsigned int acc)
 {
 	for (int k = 0; k < 4; k++)
 		acc += ((a >> (8 * k)) & 0xffu) * ((b >> (8 * k)) & 0xffu);
+	return acc;
+}
+VH_DEV int dot4(unsigned int a, unsigned int b, int acc)
+{
+	for (int k = 0; k < 4; k++)
+		acc += (int) (signed char) (a >> (8 * k)) * (int) (signed char) (b >> (8 * k));
 	return acc;
 }
 VH_DEV unsigned int sat_pk_u8_i16(unsigned int both)
