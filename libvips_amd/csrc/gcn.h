@@ -25,7 +25,36 @@ VH_DEV unsigned int gload32(gptr_in base, unsigned int off)
 {
 	return *(const unsigned int __attribute__((address_space(1))) *) (base + off);
 }
+// 8 bytes at a 4-byte aligned offset: global_load_dwordx2
+VH_DEV void gload64(gptr_in base, unsigned int off, unsigned int (&w)[2])
+{
+	typedef unsigned int gcn_uint2 __attribute__((ext_vector_type(2)));
+	const gcn_uint2 v = *(const gcn_uint2 __attribute__((address_space(1), aligned(4))) *) (base + off);
+	w[0] = v.x;
+	w[1] = v.y;
+}
+// 16 bytes at a 4-byte aligned offset: global_load_dwordx4
+VH_DEV void gload128(gptr_in base, unsigned int off, unsigned int (&w)[4])
+{
+	typedef unsigned int gcn_uint4 __attribute__((ext_vector_type(4)));
+	const gcn_uint4 v = *(const gcn_uint4 __attribute__((address_space(1), aligned(4))) *) (base + off);
+	w[0] = v.x;
+	w[1] = v.y;
+	w[2] = v.z;
+	w[3] = v.w;
+}
+VH_DEV void gstore128(gptr_out p, const unsigned int (&w)[4])
+{
+	typedef unsigned int gcn_uint4 __attribute__((ext_vector_type(4)));
+	const gcn_uint4 v = { w[0], w[1], w[2], w[3] };
+	*(gcn_uint4 __attribute__((address_space(1), aligned(4))) *) p = v;
+}
 VH_DEV unsigned char gload8(gptr_in base, unsigned int off) { return base[off]; }
+VH_DEV unsigned int gload16(gptr_in base, unsigned int off)
+{
+	return *(const unsigned short __attribute__((address_space(1))) *) (base + off);
+}
+VH_DEV void gstore16(gptr_out p, unsigned short v) { *(unsigned short __attribute__((address_space(1))) *) p = v; }
 VH_DEV void gstore32(gptr_out p, unsigned int v) { *(unsigned int __attribute__((address_space(1))) *) p = v; }
 VH_DEV void gstore8(gptr_out p, unsigned char v) { *p = v; }
 
@@ -48,6 +77,22 @@ VH_DEV unsigned int lane_from(unsigned int v, int delta)
 	return (unsigned int) __builtin_amdgcn_ds_bpermute((int) ((threadIdx.x + delta) & 63) << 2, (int) v);
 }
 VH_DEV int tid() { return (int) threadIdx.x; }
+// *p for a wave-uniform p into memory nobody writes while the kernel runs: scalar loads (through a
+// plain pointer the compiler loads per lane and reads the first lane back)
+template <typename T>
+VH_DEV T uniform_load(const T *p)
+{
+	static_assert(sizeof(T) % 4 == 0, "whole dwords");
+	typedef const unsigned int __attribute__((address_space(4))) *Words;
+	const Words w = (Words) (unsigned long long) p;
+	unsigned int buf[sizeof(T) / 4];
+#pragma unroll
+	for (unsigned int i = 0; i < sizeof(T) / 4; i++)
+		buf[i] = w[i];
+	T v;
+	__builtin_memcpy(&v, buf, sizeof(T));
+	return v;
+}
 // the next work item of a persistent block: one atomic per block, handed to every thread through `slot` (LDS)
 VH_DEV int next_item(int *counter, int *slot)
 {

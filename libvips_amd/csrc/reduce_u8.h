@@ -40,4 +40,11 @@ int resize_batch_u8(VipsHipImage *const *in, int n, VipsHipImage **out, double s
 int resize_sharpen_batch_u8(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel, double gap,
 	const int *coef, int ncoef, int mask_scale, const int *lut);
 
+// resample16.hip: the ushort streaming kernels (whole images); 1 = handled, 0 = not their case
+int reducev16_stream_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out, int tile);
+int reduceh16_stream_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out, const ReducePos *pos,
+	const short *table);
+int shrinkv16_stream_try(int vshrink, const VipsHipRegion *in, const VipsHipRegion *out);
+int shrinkh16_stream_try(int hshrink, const VipsHipRegion *in, const VipsHipRegion *out);
+
 } // namespace vh

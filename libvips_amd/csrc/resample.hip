@@ -588,6 +588,14 @@ static int reduce_gen(const char *domain, const VipsHipReduce *reduce, const Vip
 			return 0;
 	}
 
+	if (fmt == VIPS_HIP_FORMAT_USHORT && !format_iscomplex(out->format)) {
+		int done = vertical ? reducev16_stream_try(r, in, out, tile) : reduceh16_stream_try(r, in, out, pos, (const short *) table);
+		if (done < 0)
+			return -1;
+		if (done > 0)
+			return 0;
+	}
+
 #define DISPATCH(FN) \
 	switch (fmt) { \
 	case VIPS_HIP_FORMAT_UCHAR: return FN<unsigned char>(r, in, out, pos, table); \
@@ -830,6 +838,13 @@ static int shrink_gen(const char *domain, int shrink, const VipsHipRegion *in,
 	const int fmt = format_real(out->format);
 	if (fmt == VIPS_HIP_FORMAT_UCHAR && vertical) {
 		int done = shrinkv_u8_try(shrink, in, out);
+		if (done < 0)
+			return -1;
+		if (done > 0)
+			return 0;
+	}
+	if (fmt == VIPS_HIP_FORMAT_USHORT) {
+		int done = vertical ? shrinkv16_stream_try(shrink, in, out) : shrinkh16_stream_try(shrink, in, out);
 		if (done < 0)
 			return -1;
 		if (done > 0)

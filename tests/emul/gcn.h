@@ -39,7 +39,17 @@ VH_DEV unsigned int gload32(gptr_in base, unsigned int off)
 	memcpy(&v, base + off, 4);
 	return v;
 }
+VH_DEV void gload64(gptr_in base, unsigned int off, unsigned int (&w)[2]) { memcpy(w, base + off, 8); }
+VH_DEV void gload128(gptr_in base, unsigned int off, unsigned int (&w)[4]) { memcpy(w, base + off, 16); }
+VH_DEV void gstore128(gptr_out p, const unsigned int (&w)[4]) { memcpy(p, w, 16); }
 VH_DEV unsigned char gload8(gptr_in base, unsigned int off) { return base[off]; }
+VH_DEV unsigned int gload16(gptr_in base, unsigned int off)
+{
+	unsigned short v;
+	memcpy(&v, base + off, 2);
+	return v;
+}
+VH_DEV void gstore16(gptr_out p, unsigned short v) { memcpy(p, &v, 2); }
 VH_DEV void gstore32(gptr_out p, unsigned int v) { memcpy(p, &v, 4); }
 VH_DEV void gstore8(gptr_out p, unsigned char v) { *p = v; }
 
@@ -57,6 +67,11 @@ VH_DEV unsigned int lane_from(unsigned int v, int delta)
 VH_DEV unsigned int lane_prev(unsigned int v) { return lane_from(v, -1); }
 VH_DEV unsigned int lane_next(unsigned int v) { return lane_from(v, 1); }
 VH_DEV int tid() { return emul::current_tid(); }
+template <typename T>
+VH_DEV T uniform_load(const T *p)
+{
+	return *p;
+}
 VH_DEV int next_item(int *counter, int *slot)
 {
 	emul::barrier();
