@@ -365,23 +365,24 @@ def run_c2(ctx, args):
                 "algorithmic_bytes": alg_bytes[key],
                 "kernels": kernels_of(report),
             }
-            # also against what this box's HBM delivers -- a device-to-device copy of
-            # the same 1 GiB (read + write traffic), timed with events on the same stream
+            # also against what this box's HBM delivers to a kernel of the same shape --
+            # a READ of the same 1 GiB (the reduce reads 64 bytes for every byte it writes; a copy,
+            # half of whose traffic is writes, is the wrong yardstick): a sum over the image, timed
+            # with events on the same stream
             try:
                 with torch.cuda.stream(ctx.stream):
-                    dst = torch.empty_like(src)
+                    flat = src.view(-1).view(torch.int64)
                     e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
-                    dst.copy_(src)
-                    best_copy = 1e9
+                    flat.sum()
+                    best_read = 1e9
                     for _ in range(5):
                         e0.record(ctx.stream)
-                        dst.copy_(src)
+                        flat.sum()
                         e1.record(ctx.stream)
                         e1.synchronize()
-                        best_copy = min(best_copy, e0.elapsed_time(e1))
-                    del dst
-                roofline["measured_copy_GBps"] = round(2 * src.numel() / (best_copy * 1e-3) / 1e9, 1)
-                roofline["frac_of_measured_copy"] = round(achieved / roofline["measured_copy_GBps"], 4)
+                        best_read = min(best_read, e0.elapsed_time(e1))
+                roofline["measured_read_GBps"] = round(src.numel() / (best_read * 1e-3) / 1e9, 1)
+                roofline["frac_of_measured_read"] = round(achieved / roofline["measured_read_GBps"], 4)
             except Exception:  # the reference rates are a courtesy, never a reason to fail the bench
                 pass
 
@@ -670,12 +671,8 @@ def run_c3(ctx, steps, warmup, verify=True, cpu=True, size=32768):
         if cpu:
             srows = 512
             host = src[n // 2:n // 2 + srows].cpu().numpy()
-            secs = helpers.Ref.time_chain(chain, host, repeats=1, interpretation=interp,
-                                          concurrency=os.cpu_count() or 1)
-            entry["cpu_baseline"] = {
-                "value": round(float(n) * srows / secs / 1e6, 1), "unit": "Mpixels/s",
-                "cores": helpers.Ref.concurrency(), "kind": "reference",
-                "sample": "%d rows x %d x 3 f32 of the same image, whole pipeline, one run" % (srows, n)}
+            entry["cpu_baseline"] = cpu_baselines(helpers, chain, host, float(n) * srows, interp, repeats=5, single_rows=64,
+                                                  what="%d rows x %d x 3 f32 of the same image, whole pipeline" % (srows, n))
     del im, src, out
     ctx.trim()
     return entry
@@ -729,6 +726,15 @@ def run_c4(ctx, steps, warmup, images, verify=True, cpu=True, size=8192):
 
     elapsed, _ = ctx.timed(step, steps, warmup)
     ms = elapsed / steps * 1e3
+    # every rank's own rate (events on its stream): a straggler shows as MIN well under MAX
+    own = len(mine) * steps / (ctx.event_ms * 1e-3)
+    rank_rates = {"min": own, "max": own}
+    if ctx.dist is not None:
+        lo = torch.tensor([own], dtype=torch.float64, device=ctx.device)
+        hi = lo.clone()
+        ctx.dist.all_reduce(lo, op=ctx.dist.ReduceOp.MIN)
+        ctx.dist.all_reduce(hi, op=ctx.dist.ReduceOp.MAX)
+        rank_rates = {"min": float(lo.item()), "max": float(hi.item())}
     # the kernels of one step, HIP events around each gate, as time per image of the batch
     report = {k: (v[0], v[1] / len(ims)) for k, v in ctx.gates(step, 1).items()}
     outs = [Image(h) if h else None for h in handles_out]  # (the objects now own the last step's results)
@@ -744,6 +750,7 @@ def run_c4(ctx, steps, warmup, images, verify=True, cpu=True, size=8192):
         "ms_per_image": round(ms / len(ims), 4),
         "steps": steps,
         "images_per_s": round(total / (ms * 1e-3), 1),
+        "images_per_s_per_rank": {"min": round(rank_rates["min"], 1), "max": round(rank_rates["max"], 1)},
         "mpixels_per_s": round(float(n) * n * total / (ms * 1e-3) / 1e6, 1),
         "algorithmic_bytes": alg,
         "bound": "hbm",
@@ -864,13 +871,30 @@ def run_c5slab(ctx, steps, warmup, verify=True, cpu=True, width=65536, rows=8192
         if cpu:
             srows = 64
             host = window[:srows + 30].cpu().numpy()
-            t1 = time.perf_counter()
-            helpers.Ref.run_mask("conv", host, mask, scale, 0.0, "precision=float")
-            secs = time.perf_counter() - t1
+            cores = os.cpu_count() or 1
+
+            def best_of(rows, reps):
+                sample = np.ascontiguousarray(host[:rows])
+                best = 1e30
+                for _ in range(reps):
+                    t1 = time.perf_counter()
+                    helpers.Ref.run_mask("conv", sample, mask, scale, 0.0, "precision=float")
+                    best = min(best, time.perf_counter() - t1)
+                return best
+
+            helpers.Ref.lib().ref_init(cores)
+            secs = best_of(srows + 30, 5)
+            used = helpers.Ref.concurrency()
+            helpers.Ref.lib().ref_init(1)
+            rows1 = 34  # (4 output rows' worth of windows: one core takes ~1 s per 16 rows of 65536)
+            secs1 = best_of(rows1, 3)
+            helpers.Ref.lib().ref_init(cores)
             entry["cpu_baseline"] = {
                 "value": round(float(width) * (srows + 30) / secs / 1e6, 1), "unit": "Mpixels/s",
-                "cores": helpers.Ref.concurrency(), "kind": "reference",
-                "sample": "%d rows x %d u16 of the same window, one run" % (srows + 30, width)}
+                "cores": used, "kind": "reference",
+                "sample": "%d rows x %d u16 of the same window, best of 5; libvips 8.19.0 scalar C path" % (srows + 30, width),
+                "single_core": {"value": round(float(width) * rows1 / secs1 / 1e6, 1), "unit": "Mpixels/s", "cores": 1,
+                                "sample": "%d rows of it, best of 3, VIPS_CONCURRENCY=1" % rows1}}
     del window, out
     ctx.trim()
     return entry
@@ -1158,7 +1182,8 @@ def entry_as_line(entry, ctx, steps, warmup, metric, scaling="weak"):
         "vs_baseline": None,
         "dtype": entry["dtype"],
         "data": "synthetic (LCG bytes, seed 12345 + image index, generated on device)",
-        "config": {k: entry[k] for k in ("workload", "images_per_gpu", "ms_per_image", "images_per_s") if k in entry},
+        "config": {k: entry[k] for k in ("workload", "images_per_gpu", "ms_per_image", "images_per_s",
+                                         "images_per_s_per_rank") if k in entry},
         "roofline": roof,
         "parity": entry.get("parity"),
         "cpu_baseline": entry.get("cpu_baseline"),

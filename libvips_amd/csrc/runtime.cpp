@@ -26,8 +26,13 @@ static thread_local int tls_device = -1;
 // (vips_hip_set_stream) of its current binding
 constexpr int MAX_DEVICES = 64;
 static thread_local hipStream_t tls_own_stream[MAX_DEVICES];
-static thread_local hipStream_t tls_external = nullptr;
-static thread_local bool tls_stream_external = false;
+// (an external stream belongs to the device the thread was bound to when it set it: one slot per
+// device, so that a thread that visits another device -- ScopedDevice in strips.cpp, bind_to() --
+// finds its stream again when it comes back instead of silently continuing on the library's own)
+static thread_local hipStream_t tls_external_dev[MAX_DEVICES];
+static thread_local bool tls_stream_external_dev[MAX_DEVICES];
+#define tls_external tls_external_dev[tls_device < 0 ? 0 : tls_device]
+#define tls_stream_external tls_stream_external_dev[tls_device < 0 ? 0 : tls_device]
 
 static std::mutex g_mutex;
 static bool g_checked[MAX_DEVICES]; // gfx950 confirmed
@@ -171,8 +176,10 @@ void release_thread_stream()
 		}
 	if (bound >= 0)
 		(void) hipSetDevice(bound);
-	tls_external = nullptr;
-	tls_stream_external = false;
+	for (int d = 0; d < MAX_DEVICES; d++) {
+		tls_external_dev[d] = nullptr;
+		tls_stream_external_dev[d] = false;
+	}
 }
 
 ScopedStream::ScopedStream(hipStream_t s)
@@ -218,7 +225,8 @@ int check_region(const char *domain, const VipsHipRegion *r)
 
 // ---------------------------------------------------------------- the pool
 //
-// Size-bucketed free lists (power-of-two classes from 256 B, 2 MB granules above 1 GiB).
+// Size-bucketed free lists (power-of-two classes from 256 B, eight classes per octave above 64 MiB,
+// 2 MB granules above 1 GiB).
 // A freed block goes to the FREEING THREAD's own list and is handed out again only to that
 // thread: every thread queues its work on one stream, so a block whose last kernel is still
 // in flight can only be reused behind that kernel on the same stream (stream-ordered reuse
@@ -262,6 +270,11 @@ struct Pool {
 		size_t b = 256;
 		while (b < size)
 			b <<= 1;
+		// above 64 MiB eight classes per octave: a 600 MB strip window costs 640 MB, not 1 GiB
+		if (b > ((size_t) 64 << 20)) {
+			const size_t step = b >> 4; // an eighth of the octave below b
+			return (size + step - 1) / step * step;
+		}
 		return b;
 	}
 
@@ -323,14 +336,10 @@ struct Pool {
 			live_bytes -= b;
 			cached_bytes += b;
 		}
-		if (current_device() != device) {
-			// freed by a thread bound to another device: that thread queues nothing on this
-			// device, so the block waits in the global list (blocks cross devices and threads
-			// only after a synchronize, see above)
-			std::lock_guard<std::mutex> lock(mutex);
-			free_lists[b].push_back(p);
-			return;
-		}
+		// (also when the thread is bound to another device right now: it may have work of its own
+		// queued on this device from before it re-bound -- its stream there orders the reuse, as
+		// for any block it frees; the block leaves the thread only through trim / thread exit,
+		// which synchronise)
 		Local &l = local();
 		l.pool = this;
 		l.lists[b].push_back(p);
@@ -500,12 +509,7 @@ int vips_hip_init(int device)
 		int none = -1;
 		g_device.compare_exchange_strong(none, device); // the default of threads that never ask
 	}
-	if (tls_device != device) {
-		// an external stream belongs to the device it was made on
-		tls_external = nullptr;
-		tls_stream_external = false;
-	}
-	tls_device = device;
+	tls_device = device; // (the thread's external stream of THIS device, if it set one, is current again)
 	return 0;
 }
 

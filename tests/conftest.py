@@ -30,6 +30,19 @@ def _exact_float(_built):
     (test_conv_colour_gpu.py::test_c5_*_default_mode, bench.py's parity checks, smoke())."""
     from libvips_amd import lib
 
+    before = lib.vips_hip_get_exact_float()
     lib.vips_hip_set_exact_float(1)
     yield
+    lib.vips_hip_set_exact_float(before)
+
+
+@pytest.fixture(params=["exact", "default"])
+def float_mode(request, _exact_float):
+    """Run a float-convolution parity test in both modes of the library: "exact" (bit for bit against
+    the reference) and "default" (the shipped mode: fused multiply-adds, within 1 ULP -- the
+    tolerance BASELINE.json's north_star grants float paths)."""
+    from libvips_amd import lib
+
+    lib.vips_hip_set_exact_float(1 if request.param == "exact" else 0)
+    yield request.param
     lib.vips_hip_set_exact_float(1)

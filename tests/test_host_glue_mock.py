@@ -407,6 +407,77 @@ assert lib.vips_hip_current_device() == 0
 ''', tmp_path, {"MOCK_HIP_DEVICES": "2", "VIPS_HIP_DEVICES": "0,1"})
 
 
+def test_eight_devices_uneven_strips_and_streams(tmp_path):
+    """EIGHT fake devices (the node BASELINE's multi-GPU configs name): worker threads dealt over all
+    eight; a batch spread over them comes back where its inputs live; an image of 1003 rows as 8
+    strips of uneven heights (1003 = 3 x 126 + 5 x 125) with 15-row halos moved by peer copies --
+    every window holds exactly the image's rows, 14 boundaries x 2 directions; and a caller's own
+    stream (vips_hip_set_stream) survives the library's visits to the other devices (ADVICE r3:
+    ScopedDevice used to drop it)."""
+    run_child(r'''
+import ctypes, os, threading
+import numpy as np
+import libvips_amd
+from libvips_amd import Image, _ffi
+from libvips_amd._ffi import Region, lib
+from tests import helpers
+
+mock = ctypes.CDLL(os.environ["LD_PRELOAD"])
+for f in ("mock_hip_peer_copies", "mock_hip_peer_bytes"):
+    getattr(mock, f).restype = ctypes.c_long
+assert lib.vips_hip_device_count() == 8
+seen = []
+def worker():
+    Image.new_from_array(np.zeros((8, 8, 3), np.uint8))
+    seen.append(lib.vips_hip_current_device())
+ts = [threading.Thread(target=worker) for _ in range(16)]
+for t in ts:
+    t.start()
+    t.join()
+assert sorted(seen) == sorted(list(range(8)) * 2), seen
+
+ims = []
+for k in range(20):
+    libvips_amd.init(k % 8)
+    ims.append(Image.new_from_array(np.zeros((64, 688, 3), np.uint8), interpretation="srgb"))
+libvips_amd.init(3)
+# the caller's own stream on device 3
+lib.vips_hip_stream_new.restype = ctypes.c_void_p
+mine = ctypes.c_void_p(lib.vips_hip_stream_new())
+assert lib.vips_hip_set_stream(mine) == 0 and lib.vips_hip_get_stream() == mine.value
+outs = libvips_amd.resize_sharpen_batch(ims, 0.125, threads=2)
+assert [lib.vips_hip_image_get_device(o._h) for o in outs] == [k % 8 for k in range(20)]
+assert lib.vips_hip_current_device() == 3 and lib.vips_hip_get_stream() == mine.value
+
+H, W, halo = 1003, 20, 15
+full = helpers.lcg_image(W, H, 1, np.uint16, 93)
+devices = (ctypes.c_int * 8)(*range(8))
+strips = _ffi.check_handle(lib.vips_hip_strips_new(W, H, 1, 2, 8, devices, halo))
+heights, wins = [], []
+for k in range(8):
+    dev, own, win = ctypes.c_int(), Region(), Region()
+    assert lib.vips_hip_strips_region(strips, k, ctypes.byref(dev), ctypes.byref(own), ctypes.byref(win)) == 0
+    assert dev.value == k
+    heights.append(own.height)
+    rows = np.ascontiguousarray(full[own.top:own.top + own.height])
+    ctypes.memmove(own.data, rows.ctypes.data, rows.nbytes)
+    wins.append((win.top, win.height, win.data))
+assert heights == [126, 126, 126, 125, 125, 125, 125, 125] and sum(heights) == H
+n0, b0 = mock.mock_hip_peer_copies(), mock.mock_hip_peer_bytes()
+assert lib.vips_hip_strips_exchange(strips) == 0
+for top, height, data in wins:
+    got = np.frombuffer((ctypes.c_char * (height * W * 2)).from_address(data), dtype=np.uint16).reshape(height, W, 1)
+    assert np.array_equal(got, full[top:top + height]), top
+assert mock.mock_hip_peer_copies() - n0 == 7 * 2
+assert mock.mock_hip_peer_bytes() - b0 == 7 * 2 * halo * W * 2
+# ... the visit to eight devices left the caller where it was, on its own stream
+assert lib.vips_hip_current_device() == 3 and lib.vips_hip_get_stream() == mine.value
+lib.vips_hip_strips_free(strips)
+lib.vips_hip_set_stream(None)
+lib.vips_hip_stream_free(mine)
+''', tmp_path, {"MOCK_HIP_DEVICES": "8", "VIPS_HIP_DEVICES": "0,1,2,3,4,5,6,7"})
+
+
 @pytest.mark.skipif(not helpers.have_module(), reason="oracle/_ref or host/_build missing")
 def test_module_plumbing_through_libvips(tmp_path):
     """The *_hip operations driven through the reference's own operation API: build(), the

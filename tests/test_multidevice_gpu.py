@@ -1,8 +1,10 @@
-"""The one-process, several-devices paths of the C library on the GPU box, which has ONE device:
-every logical slot is device 0 (VIPS_HIP_DEVICES=0,0 / devices [0, 0, 0]), so the worker threads,
-the per-device pools and plan caches, the batch scatter, the strip windows and the peer copies all
-run for real and the pixels must be the single-device pixels.  (The host logic against two
-distinct fake devices is tests/test_host_glue_mock.py::test_two_devices_in_one_process.)"""
+"""The one-process, several-devices paths of the C library on the GPU box.  With ONE visible device
+(the round's boxes) every logical slot is device 0 (VIPS_HIP_DEVICES=0,0 / devices [0, 0, 0]): the
+worker threads, the per-device pools and plan caches, the batch scatter, the strip windows and the
+peer copies all run for real and the pixels must be the single-device pixels.  With SEVERAL visible
+devices (the first multi-GPU lease) the slots are dealt over all of them -- slots() below -- so the
+same tests then move real pixels between devices with hipMemcpyPeerAsync, with no new code.  (The
+host logic against distinct fake devices is tests/test_host_glue_mock.py.)"""
 import ctypes
 import os
 import subprocess
@@ -14,6 +16,14 @@ import pytest
 from tests import helpers
 
 pytestmark = pytest.mark.gpu
+
+
+def slots(n):
+    """n logical slots over the visible devices: 0, 1, ... round-robin (all 0 on a one-GPU box)."""
+    import torch
+
+    count = max(torch.cuda.device_count(), 1)
+    return [k % count for k in range(n)]
 
 
 def test_conv_strips_on_one_device_match_whole_image():
@@ -30,7 +40,7 @@ def test_conv_strips_on_one_device_match_whole_image():
     mask, scale = libvips_amd.gaussmat(5, 0.01, False, "float")
     whole = Image.new_from_array(full).conv(mask, scale=scale, precision="float").numpy()
     n = 3
-    devices = (ctypes.c_int * n)(*([0] * n))
+    devices = (ctypes.c_int * n)(*slots(n))
     strips = _ffi.check_handle(lib.vips_hip_strips_new(width, height, 1, 2, n, devices, halo))
     try:
         for k in range(n):
@@ -73,10 +83,12 @@ def worker(i):
 ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
 for t in ts: t.start()
 for t in ts: t.join()
+want_devs = %(devs)r
 for i in range(4):
-    assert results[i][1] == 0 and np.array_equal(results[i][0], want), i
+    assert results[i][1] in want_devs and np.array_equal(results[i][0], want), i
+assert sorted(set(r[1] for r in results.values())) == sorted(set(want_devs))   # every slot took work
 devs = (libvips_amd._ffi.c_int * 4)()
-assert lib.vips_hip_devices(devs, 4) == 2 and list(devs[:2]) == [0, 0]
+assert lib.vips_hip_devices(devs, 4) == 2 and list(devs[:2]) == want_devs
 # the batch entry point over the configured slots
 ims = [Image.new_from_array(helpers.lcg_image(1024, 768, 3, np.uint8, 60 + k), interpretation="srgb") for k in range(5)]
 outs = libvips_amd.resize_sharpen_batch(ims, 0.125, threads=2)
@@ -88,10 +100,11 @@ print("CHILD-OK")
 
 
 def test_worker_threads_dealt_over_vips_hip_devices():
-    """VIPS_HIP_DEVICES=0,0: threads that never call vips_hip_init() are bound round-robin to the
+    """VIPS_HIP_DEVICES=<two slots>: threads that never call vips_hip_init() are bound round-robin to the
     listed slots, each with its own stream; identical pixels from every thread."""
-    env = dict(os.environ, VIPS_HIP_DEVICES="0,0")
-    proc = subprocess.run([sys.executable, "-c", CHILD % {"root": helpers.ROOT}], stdout=subprocess.PIPE,
+    two = slots(2)
+    env = dict(os.environ, VIPS_HIP_DEVICES=",".join(str(d) for d in two))
+    proc = subprocess.run([sys.executable, "-c", CHILD % {"root": helpers.ROOT, "devs": two}], stdout=subprocess.PIPE,
                           stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
     assert proc.returncode == 0 and "CHILD-OK" in proc.stdout, proc.stdout[-3000:]
 
@@ -122,7 +135,7 @@ def test_module_with_vips_hip_devices():
     """The libvips module in a process whose worker pool is spread over VIPS_HIP_DEVICES=0,0:
     libvips' own threads evaluate and generate, whichever slot they were dealt; the pixels are the
     built-in operations' (VERDICT round 2, item 5)."""
-    env = dict(os.environ, VIPS_HIP_DEVICES="0,0")
+    env = dict(os.environ, VIPS_HIP_DEVICES=",".join(str(d) for d in slots(2)))
     proc = subprocess.run([sys.executable, "-c", MODULE_CHILD % {"root": helpers.ROOT}], stdout=subprocess.PIPE,
                           stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
     assert proc.returncode == 0 and "CHILD-OK" in proc.stdout, proc.stdout[-3000:]
