@@ -46,6 +46,7 @@ struct CbrtExact {
 	const CbrtBlockD *bd;
 	const CbrtBlockI *bi;
 	const unsigned int *res;
+	const float *lin; // the 886 entries of the linear arm as they are, or NULL: computed
 };
 
 VH_CBRT_FN unsigned int cbrt_bits(float f)
@@ -106,9 +107,9 @@ VH_CBRT_FN void cbrt_pair(const CbrtExact &t, int i, float *t0, float *dt)
 	unsigned int b1 = cbrt_bits((float) c1) + ((rr >> 2) & 3u) - 1u;
 	float v0 = cbrt_float(b0), v1 = cbrt_float(b1);
 	if (i < CBRT_LINEAR) {
-		v0 = cbrt_linear(i);
+		v0 = t.lin ? t.lin[i] : cbrt_linear(i);
 		if (i + 1 < CBRT_LINEAR)
-			v1 = cbrt_linear(i + 1);
+			v1 = t.lin ? t.lin[i + 1] : cbrt_linear(i + 1);
 	}
 	*t0 = v0;
 	*dt = v1 - v0;

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <cmath>
 #include <mutex>
+#include <type_traits>
 
 namespace vh {
 
@@ -144,7 +145,8 @@ const CbrtExact *cbrt_exact_tables()
 	}
 	// every pair a kernel can ask for, against the table the reference would read
 	{
-		CbrtExact host = { bd.data(), bi.data(), res.data() };
+		for (int pass = 0; pass < 2; pass++) {
+		CbrtExact host = { bd.data(), bi.data(), res.data(), pass ? cb.data() : nullptr };
 		for (int i = 0; i + 1 < CBRT_N; i++) {
 			float t0, dt;
 			cbrt_pair(host, i, &t0, &dt);
@@ -152,12 +154,14 @@ const CbrtExact *cbrt_exact_tables()
 			if (memcmp(&t0, &cb[i], 4) || memcmp(&dt, &want_dt, 4))
 				return nullptr;
 		}
+		}
 	}
 	CbrtExact &t = by_device[dev];
 	t.bd = (const CbrtBlockD *) upload(bd.data(), bd.size() * sizeof(CbrtBlockD));
 	t.bi = (const CbrtBlockI *) upload(bi.data(), bi.size() * sizeof(CbrtBlockI));
 	t.res = (const unsigned int *) upload(res.data(), res.size() * sizeof(unsigned int));
-	if (!t.bd || !t.bi || !t.res)
+	t.lin = (const float *) upload(cb.data(), CBRT_LINEAR * sizeof(float));
+	if (!t.bd || !t.bi || !t.res || !t.lin)
 		return nullptr;
 	state[dev] = 1;
 	return &t;
@@ -252,6 +256,88 @@ colour_route_x4_kernel(RouteArgs a)
 		route_pixel<TIN, TOUT, ROUTE>(a, s_v2Y, s_Y2v, v0.v[3], v1.v[0], v1.v[1], r0.v[3], r1.v[0], r1.v[1]);
 		route_pixel<TIN, TOUT, ROUTE>(a, s_v2Y, s_Y2v, v1.v[2], v1.v[3], v2.v[0], r1.v[2], r1.v[3], r2.v[0]);
 		route_pixel<TIN, TOUT, ROUTE>(a, s_v2Y, s_Y2v, v2.v[1], v2.v[2], v2.v[3], r2.v[1], r2.v[2], r2.v[3]);
+		q[0] = r0;
+		q[1] = r1;
+		q[2] = r2;
+	}
+}
+
+// sRGB -> Lab / LabS of 3-band uchar or float images with XYZ2Lab's cube-root table in LDS
+// (cbrt_exact.h: every entry bit for bit from 34 KB): a lane that gathers from the 400 KB table in
+// global memory pulls a 128-byte line through its CU's L1 fill path per channel (~146 cycles of that
+// path per wave instruction, tools/gather_probe.hip), which bounded colour_route_x4_kernel on these
+// routes; here a pixel reads nothing but its own bytes.  Persistent blocks (the tables are copied
+// once per block), 4 pixels per thread, rows dealt round the grid.
+template <typename TIN, bool LABS>
+__global__ void __launch_bounds__(256)
+colour_lab_lds_kernel(RouteArgs a, CbrtExact cx)
+{
+	__shared__ float s_v2Y[256];
+	__shared__ unsigned int s_res[CBRT_RES_WORDS];
+	__shared__ CbrtBlockD s_bd[CBRT_BLOCKS + 1];
+	__shared__ CbrtBlockI s_bi[CBRT_BLOCKS + 1];
+	__shared__ float s_lin[CBRT_LINEAR];
+	const int t = threadIdx.x;
+	s_v2Y[t] = a.tables.v2Y_8[t];
+	for (int i = t; i < CBRT_RES_WORDS; i += 256)
+		s_res[i] = cx.res[i];
+	for (int i = t; i < CBRT_LINEAR; i += 256)
+		s_lin[i] = cx.lin[i];
+	if (t <= CBRT_BLOCKS) {
+		s_bd[t] = cx.bd[t];
+		s_bi[t] = cx.bi[t];
+	}
+	__syncthreads();
+	const CbrtExact lds = { s_bd, s_bi, s_res, s_lin };
+	const int x4 = blockIdx.x * blockDim.x + t;
+	if (x4 * 4 >= a.width)
+		return;
+	typedef typename std::conditional<LABS, short, float>::type TOUT;
+	for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
+		const Vec4<TIN> *p = (const Vec4<TIN> *) (a.in + (long long) y * a.in_stride) + (long long) x4 * 3;
+		Vec4<TOUT> *q = (Vec4<TOUT> *) (a.out + (long long) y * a.out_stride) + (long long) x4 * 3;
+		const Vec4<TIN> v0 = p[0], v1 = p[1], v2 = p[2];
+		const TIN in[12] = { v0.v[0], v0.v[1], v0.v[2], v0.v[3], v1.v[0], v1.v[1], v1.v[2], v1.v[3], v2.v[0], v2.v[1], v2.v[2],
+			v2.v[3] };
+		TOUT out[12];
+#pragma unroll
+		for (int m = 0; m < 4; m++) {
+			// sRGB2scRGB.c:72-90 (vips_colour_code_build casts to uchar), scRGB2XYZ.c:58-82
+			Px v;
+			v.a = s_v2Y[load_as_uchar_like<TIN>(in[3 * m], 255)];
+			v.b = s_v2Y[load_as_uchar_like<TIN>(in[3 * m + 1], 255)];
+			v.c = s_v2Y[load_as_uchar_like<TIN>(in[3 * m + 2], 255)];
+			v = step_scRGB2XYZ(v);
+			// XYZ2Lab.c:109-138 on small finite values
+			const float n0 = (float) DIV_CONST_F((double) __fmul_rn(100000.0f, v.a), 95.0470);
+			const float n1 = (float) DIV_CONST_F((double) __fmul_rn(100000.0f, v.b), 100.0);
+			const float n2 = (float) DIV_CONST_F((double) __fmul_rn(100000.0f, v.c), 108.8827);
+			const int i0 = min(max(__float2int_rz(n0), 0), CBRT_N - 2);
+			const int i1 = min(max(__float2int_rz(n1), 0), CBRT_N - 2);
+			const int i2 = min(max(__float2int_rz(n2), 0), CBRT_N - 2);
+			float t0, dt;
+			cbrt_pair(lds, i0, &t0, &dt);
+			const float cbx = __fadd_rn(t0, __fmul_rn(__fsub_rn(n0, (float) i0), dt));
+			cbrt_pair(lds, i1, &t0, &dt);
+			const float cby = __fadd_rn(t0, __fmul_rn(__fsub_rn(n1, (float) i1), dt));
+			cbrt_pair(lds, i2, &t0, &dt);
+			const float cbz = __fadd_rn(t0, __fmul_rn(__fsub_rn(n2, (float) i2), dt));
+			const float L = __fsub_rn(__fmul_rn(116.0F, cby), 16.0F);
+			const float A = __fmul_rn(500.0F, __fsub_rn(cbx, cby));
+			const float B = __fmul_rn(200.0F, __fsub_rn(cby, cbz));
+			if constexpr (LABS) {
+				out[3 * m] = lab2labs_finite(L, 32767.0 / 100.0, 0.0);
+				out[3 * m + 1] = lab2labs_finite(A, 32768.0 / 128.0, -32768.0);
+				out[3 * m + 2] = lab2labs_finite(B, 32768.0 / 128.0, -32768.0);
+			}
+			else {
+				out[3 * m] = L;
+				out[3 * m + 1] = A;
+				out[3 * m + 2] = B;
+			}
+		}
+		Vec4<TOUT> r0 = { { out[0], out[1], out[2], out[3] } }, r1 = { { out[4], out[5], out[6], out[7] } },
+				   r2 = { { out[8], out[9], out[10], out[11] } };
 		q[0] = r0;
 		q[1] = r1;
 		q[2] = r2;
@@ -1101,6 +1187,28 @@ int colour_route(const int *steps, int n_steps, double alpha_scale, const VipsHi
 		if (n_steps == kStaticRoutes[r][0] && !memcmp(steps, &kStaticRoutes[r][1], sizeof(int) * n_steps))
 			route_id = r;
 	bool launched = false;
+	// sRGB -> Lab / LabS from uchar or float: the cube-root table from LDS (colour_lab_lds_kernel)
+	if ((route_id == 1 || route_id == 2) && !getenv("VIPS_HIP_NO_LAB_LDS") &&
+		(in->format == VIPS_HIP_FORMAT_UCHAR || in->format == VIPS_HIP_FORMAT_FLOAT)) {
+		const CbrtExact *cx = cbrt_exact_tables();
+		if (cx) {
+			const int gx = (a.width / 4 + 255) / 256;
+			int gy = (256 * 4 + gx - 1) / gx; // four 34 KB blocks per CU, each walking its share of the rows
+			gy = gy > a.height ? a.height : gy;
+			const dim3 gridp(gx, gy, 1);
+			if (route_id == 1 && in->format == VIPS_HIP_FORMAT_UCHAR)
+				hipLaunchKernelGGL((colour_lab_lds_kernel<unsigned char, false>), gridp, block, 0, stream(), a, *cx);
+			else if (route_id == 1)
+				hipLaunchKernelGGL((colour_lab_lds_kernel<float, false>), gridp, block, 0, stream(), a, *cx);
+			else if (in->format == VIPS_HIP_FORMAT_UCHAR)
+				hipLaunchKernelGGL((colour_lab_lds_kernel<unsigned char, true>), gridp, block, 0, stream(), a, *cx);
+			else
+				hipLaunchKernelGGL((colour_lab_lds_kernel<float, true>), gridp, block, 0, stream(), a, *cx);
+			launched = true;
+		}
+		else
+			vips_hip_error_clear();
+	}
 #define STATIC_ROUTE(R, TIN, FIN, TOUT, FOUT) \
 	if (!launched && route_id == R && in->format == FIN && want_out == FOUT) { \
 		hipLaunchKernelGGL((colour_route_x4_kernel<TIN, TOUT, R>), grid4, block, 0, stream(), a); \
