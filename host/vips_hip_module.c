@@ -109,15 +109,11 @@ hip_link_producer(VipsImage *image, HipDeviceFn *device)
 
 /* ------------------------------------------------------------------ base class */
 
-/* HBM budget (bytes of input + output an operation may hold on the device at once) above
- * which strip-capable operations work through the image in row strips.
- * $VIPS_HIP_BUDGET, with an optional k / m / g suffix; default 64 GiB.
- */
 static guint64
-hip_budget(void)
+hip_env_bytes(const char *name, guint64 fallback)
 {
-	const char *env = g_getenv("VIPS_HIP_BUDGET");
-	guint64 budget = (guint64) 64 << 30;
+	const char *env = g_getenv(name);
+	guint64 budget = fallback;
 
 	if (env && *env) {
 		char *end = NULL;
@@ -136,6 +132,28 @@ hip_budget(void)
 	return budget;
 }
 
+/* HBM budget (bytes of input + output an operation may hold on the device at once) above
+ * which strip-capable operations work through the image in row strips.
+ * $VIPS_HIP_BUDGET, with an optional k / m / g suffix; default 64 GiB.
+ */
+static guint64
+hip_budget(void)
+{
+	return hip_env_bytes("VIPS_HIP_BUDGET", (guint64) 64 << 30);
+}
+
+/* Host budget: the bytes of a result this module keeps on the HOST at once (plus the two
+ * staging buffers of the strip loop).  A result that fits is kept whole; a larger one is held as
+ * a ring of row strips that the consumer walks through -- what the reference's sinks do with
+ * their two buffers (iofuncs/sinkdisc.c:177-220, sink.c:428-441).
+ * $VIPS_HIP_HOST_BUDGET, with an optional k / m / g suffix; default 2 GiB.
+ */
+static guint64
+hip_host_budget(void)
+{
+	return hip_env_bytes("VIPS_HIP_HOST_BUDGET", (guint64) 2 << 30);
+}
+
 typedef struct _VipsHipOp {
 	VipsOperation parent_instance;
 
@@ -150,15 +168,25 @@ typedef struct _VipsHipOp {
 
 	/* Evaluation state, all under `lock`. */
 	GMutex lock;
+	GCond cond;             /* the cache changed / the producer has something to do */
 	gboolean evaluated;
+	gboolean evaluating;    /* a thread is inside hip_eval() (which may wait, lock released, for the
+	                         * strip producer's plan): everybody else waits for it */
 	char *eval_error;       /* non-NULL: evaluation failed, with this message */
-	VipsHipImage *result;   /* the result on the device (NULL after a strip-mined run) */
-	VipsPel *host;          /* the result on the host, for generate */
-	gboolean host_pinned;   /* ... in pinned memory (vips_hip_malloc_host) */
-	/* A device result comes down in bands of rows, each on its first touch: a consumer that asks
-	 * for one tile of a 17 GB result pays for one band, not for the image. */
-	int band_rows;          /* rows per band (0: `host` is complete) */
-	guint8 *band_done;      /* per band: already downloaded */
+	VipsHipImage *result;   /* the result on the device (NULL for a strip-mined run) */
+
+	/* The host side of the result, for generate: a cache of row items.  A device result comes
+	 * down in bands of rows, each on its first touch (a consumer that asks for one tile of a
+	 * 17 GB result pays for one band, not for the image); a strip-mined result is made strip by
+	 * strip by the producer thread below, and generate calls are served as their strips land. */
+	struct _HipCache *cache;
+	gboolean striped;       /* items are strips from the producer thread */
+	GThread *producer;
+	gboolean producer_running;
+	gboolean producer_quit;
+	int setup;              /* the producer's first run: 0 pending, 1 ready, 2 no region form, -1 failed */
+	guint64 budget;         /* the HBM budget the strips were sized for */
+	int device;             /* the device the first producer run was dealt */
 } VipsHipOp;
 
 typedef struct _VipsHipOpClass {
@@ -245,15 +273,199 @@ hip_check_header(VipsHipOp *op, int width, int height, int bands, int format)
 	return 0;
 }
 
-/* ---- the strip loop: images over the HBM budget
+/* ---- the host side of a result: a bounded cache of row items
  *
  * The reference evaluates any pipeline with bounded memory: a sink asks for tiles, threads
- * compute them (iofuncs/sink.c:469, thread.c:301-325) and sinkdisc.c:177-220 writes one buffer
- * behind the one being filled.  Here the unit is a row strip of gigabytes and the stages are
- * pull (libvips' own threaded evaluation of the upstream pipeline, straight into PINNED
- * memory), upload, kernels, download: strip k + 1 is pulled while strip k's upload, kernels
- * and download run on the device, strips alternate between two streams and two pinned input
- * buffers, and the result lands in one pinned host image that generate serves rows from.
+ * compute them (iofuncs/sink.c:469, thread.c:301-325), sinkdisc.c:177-220 writes one buffer behind
+ * the one being filled, and progress is reported per tile (sink.c:428-441).  Here the unit is a
+ * row item of megabytes to gigabytes -- a strip of a strip-mined result, a band of a device
+ * result -- and the host holds `n_slots` of them: every item when the result fits the host
+ * budget, else a ring that follows the consumer.  generate calls are served as soon as the item
+ * they touch has landed; an item that has left the ring is made (or downloaded) again when
+ * somebody comes back for it, the way the reference recomputes a tile that fell out of its cache.
+ * Everything below is under op->lock unless it says otherwise.
+ */
+enum {
+	HIP_SLOT_EMPTY = 0,
+	HIP_SLOT_FILLING, /* claimed: being pulled / queued / downloaded */
+	HIP_SLOT_ISSUED,  /* its download is queued: `event` says when the pixels are there */
+	HIP_SLOT_READY
+};
+
+typedef struct _HipCache {
+	int item_rows; /* rows per item (the last one may be shorter) */
+	int n_items;
+	int n_slots;
+	size_t ls;     /* bytes per row */
+	gboolean pinned; /* slots are vips_hip_malloc_host() memory */
+	VipsPel **mem; /* per slot, allocated on first use */
+	int *slot_item;
+	guint8 *slot_state;
+	int *slot_pins;      /* generate calls copying out of the slot right now */
+	guint64 *slot_tick;  /* last use */
+	void **slot_event;   /* ISSUED: recorded behind the slot's download; made by the producer on the
+	                      * slot's first use, kept for the cache's life */
+	int *item_slot;      /* the slot an item is in, or -1 */
+	int *want;           /* per item: generate calls waiting for it */
+	guint64 tick;
+	int hi_seen;         /* the highest item a consumer has asked for */
+} HipCache;
+
+/* what the module holds on the host right now / at most so far (the tests ask: is it bounded?) */
+static GMutex hip_host_lock;
+static guint64 hip_host_now = 0, hip_host_peak = 0;
+/* generate calls served while their operation's producer was still making strips; producer
+ * (re)starts (the tests ask: does the output stream? was an evicted strip made again?) */
+static volatile gint hip_served_early = 0, hip_producer_starts = 0;
+
+static void
+hip_host_account(gint64 delta)
+{
+	g_mutex_lock(&hip_host_lock);
+	hip_host_now += delta;
+	hip_host_peak = VIPS_MAX(hip_host_peak, hip_host_now);
+	g_mutex_unlock(&hip_host_lock);
+}
+
+/* stats[0] = peak host bytes, [1] = host bytes now, [2] = requests served while strips were
+ * still being made, [3] = producer starts; reset != 0 restarts the peak from the current level */
+G_MODULE_EXPORT void
+vips_hip_module_stream_stats(guint64 stats[4], int reset)
+{
+	g_mutex_lock(&hip_host_lock);
+	stats[0] = hip_host_peak;
+	stats[1] = hip_host_now;
+	if (reset)
+		hip_host_peak = hip_host_now;
+	g_mutex_unlock(&hip_host_lock);
+	stats[2] = (guint64) g_atomic_int_get(&hip_served_early);
+	stats[3] = (guint64) g_atomic_int_get(&hip_producer_starts);
+}
+
+static HipCache *
+hip_cache_new(int total_rows, int item_rows, size_t ls, guint64 host_bytes, gboolean pinned)
+{
+	HipCache *c = g_new0(HipCache, 1);
+	const guint64 item_bytes = (guint64) item_rows * ls;
+
+	c->item_rows = item_rows;
+	c->n_items = (total_rows + item_rows - 1) / item_rows;
+	c->ls = ls;
+	c->pinned = pinned;
+	/* everything when it fits; else a ring of at least three: the item being read, the one a
+	 * region may straddle into, the one being made */
+	if ((guint64) c->n_items * item_bytes <= host_bytes)
+		c->n_slots = c->n_items;
+	else
+		c->n_slots = (int) VIPS_CLIP(3, host_bytes / item_bytes, (guint64) c->n_items);
+	c->mem = g_new0(VipsPel *, c->n_slots);
+	c->slot_item = g_new(int, c->n_slots);
+	c->slot_state = g_new0(guint8, c->n_slots);
+	c->slot_pins = g_new0(int, c->n_slots);
+	c->slot_tick = g_new0(guint64, c->n_slots);
+	c->slot_event = g_new0(void *, c->n_slots);
+	c->item_slot = g_new(int, c->n_items);
+	c->want = g_new0(int, c->n_items);
+	for (int i = 0; i < c->n_slots; i++)
+		c->slot_item[i] = -1;
+	for (int i = 0; i < c->n_items; i++)
+		c->item_slot[i] = -1;
+	c->hi_seen = -1;
+
+	return c;
+}
+
+static void
+hip_cache_free(HipCache *c)
+{
+	if (!c)
+		return;
+	for (int i = 0; i < c->n_slots; i++)
+		if (c->mem[i]) {
+			if (c->pinned)
+				vips_hip_free_host(c->mem[i]);
+			else
+				g_free(c->mem[i]);
+			hip_host_account(-(gint64) ((guint64) c->item_rows * c->ls));
+		}
+	for (int i = 0; i < c->n_slots; i++)
+		vips_hip_event_free(c->slot_event[i]);
+	g_free(c->mem);
+	g_free(c->slot_item);
+	g_free(c->slot_state);
+	g_free(c->slot_pins);
+	g_free(c->slot_tick);
+	g_free(c->slot_event);
+	g_free(c->item_slot);
+	g_free(c->want);
+	g_free(c);
+}
+
+/* a slot for a new item: an empty one, else the least recently used READY one nobody is copying
+ * out of or waiting for; -1 when there is none right now */
+static int
+hip_cache_victim(HipCache *c)
+{
+	int best = -1;
+
+	for (int i = 0; i < c->n_slots; i++) {
+		if (c->slot_state[i] == HIP_SLOT_EMPTY)
+			return i;
+		if (c->slot_state[i] == HIP_SLOT_READY && c->slot_pins[i] == 0 && c->want[c->slot_item[i]] == 0 &&
+			(best < 0 || c->slot_tick[i] < c->slot_tick[best]))
+			best = i;
+	}
+
+	return best;
+}
+
+static void
+hip_cache_claim(HipCache *c, int slot, int item)
+{
+	if (c->slot_item[slot] >= 0)
+		c->item_slot[c->slot_item[slot]] = -1;
+	c->slot_item[slot] = item;
+	c->item_slot[item] = slot;
+	c->slot_state[slot] = HIP_SLOT_FILLING;
+	c->slot_tick[slot] = ++c->tick;
+}
+
+static void
+hip_cache_drop(HipCache *c, int slot)
+{
+	if (c->slot_item[slot] >= 0)
+		c->item_slot[c->slot_item[slot]] = -1;
+	c->slot_item[slot] = -1;
+	c->slot_state[slot] = HIP_SLOT_EMPTY;
+}
+
+/* the slot's memory, allocated on its first use (no lock needed: the slot is claimed) */
+static VipsPel *
+hip_cache_mem(HipCache *c, int slot)
+{
+	const size_t bytes = (size_t) c->item_rows * c->ls;
+
+	if (!c->mem[slot]) {
+		if (c->pinned && !(c->mem[slot] = (VipsPel *) vips_hip_malloc_host(bytes)))
+			vips_hip_error_clear(); /* too large to pin: ordinary memory, its download simply does not overlap */
+		if (!c->mem[slot])
+			c->mem[slot] = (VipsPel *) g_try_malloc(bytes);
+		if (c->mem[slot])
+			hip_host_account((gint64) bytes);
+	}
+
+	return c->mem[slot];
+}
+
+/* ---- the strip loop: images over the HBM budget
+ *
+ * The stages are pull (libvips' own threaded evaluation of the upstream pipeline, straight into
+ * PINNED memory), upload, kernels, download, serve.  One producer thread per evaluating
+ * operation walks the strips in the order the consumer asks for them: strip k + 1 is pulled while
+ * strip k's upload, kernels and download run on the device, strips alternate between two streams,
+ * two pinned staging buffers and two device windows, and each result lands in a slot of the host
+ * cache above, where the generate calls that wait for it pick it up -- libvips' workers run
+ * beside the device instead of sleeping until the last strip is down.
  */
 
 /* pull target: rows [top, top + rows) of an image into a buffer */
@@ -328,7 +540,7 @@ hip_halo_run(VipsHipOp *op, HaloStrip *plan, const VipsHipRegion *in, const Vips
 	return result;
 }
 
-static const VipsPel *hip_host_pixels(VipsHipOp *op, VipsImage **mem);
+static const VipsPel *hip_host_in_place(VipsHipOp *op);
 
 /* how many bands of device results have been downloaded in this process (the tests ask: did a
  * small request pay for the whole image?) */
@@ -340,7 +552,7 @@ vips_hip_module_bands_done(void)
 	return g_atomic_int_get(&hip_bands_done);
 }
 
-/* how many strips the loop below has run in this process (the tests ask: was it strip-mined?) */
+/* how many strips the producers have made in this process (the tests ask: was it strip-mined?) */
 static volatile gint hip_strips_done = 0;
 
 G_MODULE_EXPORT int
@@ -349,48 +561,48 @@ vips_hip_module_strips_done(void)
 	return g_atomic_int_get(&hip_strips_done);
 }
 
-static int
-hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
+static void
+hip_producer_fail(VipsHipOp *op, const char *domain)
 {
+	/* (called without the lock; the message is what every waiting generate call reports) */
+	if (vips_hip_error_buffer()[0])
+		hip_fail(domain);
+	g_mutex_lock(&op->lock);
+	if (!op->eval_error)
+		op->eval_error = g_strdup(vips_error_buffer()[0] ? vips_error_buffer() : "evaluation failed");
+	g_cond_broadcast(&op->cond);
+	g_mutex_unlock(&op->lock);
+}
+
+/* The producer: one run = open the plan, make strips for as long as somebody wants one that is
+ * not on the host, hand the device and the staging memory back.  A later request for a strip that
+ * has left the ring starts another run. */
+static void *
+hip_producer(void *data)
+{
+	VipsHipOp *op = (VipsHipOp *) data;
 	VipsHipOpClass *hclass = VIPS_HIP_OP_GET_CLASS(op);
 	const char *nick = VIPS_OBJECT_GET_CLASS(op)->nickname;
+	VipsImage *in = op->ready;
 	VipsImage *out = op->out;
 	const size_t ls = VIPS_IMAGE_SIZEOF_LINE(out);
 	const size_t in_ls = VIPS_IMAGE_SIZEOF_LINE(in);
 	const gboolean generic = hclass->halo != NULL && !hclass->strip_open;
-	VipsImage *resident_mem = NULL;
+	const guint64 budget = op->budget;
+	const guint64 host_budget = hip_host_budget();
 	const VipsPel *resident = NULL;
 	HaloStrip halo = { 0, 0 };
 	void *plan = NULL;
-	VipsPel *host = NULL;
-	gboolean pinned = TRUE;
 	VipsPel *stage[2] = { NULL, NULL };
 	void *stream[2] = { NULL, NULL };
-	void *computed[2] = { NULL, NULL }, *finished[2] = { NULL, NULL };
+	void *computed[2] = { NULL, NULL }, *uploaded[2] = { NULL, NULL };
+	gboolean upload_seen[2] = { FALSE, FALSE };
 	VipsHipImage *dev_in[2] = { NULL, NULL }, *dev_out[2] = { NULL, NULL };
-	int rows, max_in_rows = 0;
-	int result;
-
-	if (generic) {
-		if ((result = hclass->halo(op, in, &halo.above, &halo.below)))
-			return result;
-	}
-	else {
-		if (!hclass->strip_open || !hclass->strip_need || !hclass->strip_run)
-			return 1;
-		if ((result = hclass->strip_open(op, in, &plan)))
-			return result;
-	}
-
-	/* an input that already is host memory is uploaded from where it lies: nothing to pull */
-	if (op->in->dtype == VIPS_IMAGE_SETBUF || op->in->dtype == VIPS_IMAGE_SETBUF_FOREIGN ||
-		op->in->dtype == VIPS_IMAGE_MMAPIN || op->in->dtype == VIPS_IMAGE_MMAPINRW) {
-		resident = hip_host_pixels(op, &resident_mem);
-		if (resident_mem) { /* (it was not usable as it lies after all: pull like any other image) */
-			VIPS_UNREF(resident_mem);
-			resident = NULL;
-		}
-	}
+	HipCache *c = NULL;
+	int rows = 0, max_in_rows = 0;
+	int setup = -1;
+	int cursor = 0, pulled = -1, issues = 0, pending = -1;
+	gboolean failed = FALSE;
 
 #define STRIP_NEED(TOP, N, IN_TOP, IN_ROWS) \
 	do { \
@@ -407,15 +619,60 @@ hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
 		*(IN_ROWS) = VIPS_MIN(*(IN_ROWS), in->Ysize - *(IN_TOP)); \
 	} while (0)
 
-	/* the tallest strip (a multiple of 16 lines: the reference's fat-strip height, which the
-	 * vertical reduce re-seeds its position on) of which TWO -- one being pulled and uploaded,
-	 * one being computed and downloaded -- fit with their input rows */
-	for (rows = VIPS_ROUND_UP(out->Ysize, 16); rows > 16; rows = VIPS_ROUND_UP(rows / 2, 16)) {
-		int in_top, in_rows;
+	g_atomic_int_inc(&hip_producer_starts);
 
-		STRIP_NEED(0, VIPS_MIN(rows, out->Ysize), &in_top, &in_rows);
-		if (2 * ((guint64) in_rows * in_ls + (guint64) rows * ls) <= budget)
-			break;
+	/* NULL selects the library's own per-thread stream (and deals this thread a device; a later
+	 * run goes back to the first run's: the slot events live there) */
+	if ((op->cache && vips_hip_init(op->device)) || vips_hip_set_stream(NULL))
+		goto setup_done;
+	if (generic) {
+		const int r = hclass->halo(op, in, &halo.above, &halo.below);
+
+		if (r) {
+			setup = r > 0 ? 2 : -1;
+			goto setup_done;
+		}
+	}
+	else {
+		int r;
+
+		if (!hclass->strip_open || !hclass->strip_need || !hclass->strip_run) {
+			setup = 2;
+			goto setup_done;
+		}
+		if ((r = hclass->strip_open(op, in, &plan))) {
+			plan = NULL;
+			setup = r > 0 ? 2 : -1;
+			goto setup_done;
+		}
+	}
+
+	/* an input that already is host memory is uploaded from where it lies: nothing to pull */
+	resident = hip_host_in_place(op);
+
+	if (op->cache) /* a later run: the geometry is the first run's */
+		rows = op->cache->item_rows;
+	else {
+		const gboolean whole_fits = (guint64) ls * out->Ysize <= host_budget;
+
+		/* the tallest strip (a multiple of 16 lines: the reference's fat-strip height, which the
+		 * vertical reduce re-seeds its position on) of which TWO -- one being pulled and uploaded,
+		 * one being computed and downloaded -- fit the HBM budget with their input rows (the
+		 * generic form also holds the window's result and the operation's own temporaries: counted
+		 * as two more windows), and of which three, with the two staging buffers, fit the host
+		 * budget when the whole result does not */
+		for (rows = VIPS_ROUND_UP(out->Ysize, 16); rows > 16; rows = VIPS_ROUND_UP(rows / 2, 16)) {
+			int in_top, in_rows;
+			guint64 dev, host;
+
+			STRIP_NEED(0, VIPS_MIN(rows, out->Ysize), &in_top, &in_rows);
+			dev = 2 * ((guint64) in_rows * in_ls + (guint64) rows * ls);
+			if (generic)
+				dev += 2 * (guint64) in_rows * VIPS_MAX(ls, in_ls);
+			host = 3 * (guint64) rows * ls + (resident ? 0 : 2 * (guint64) in_rows * in_ls);
+			if (dev <= budget && (whole_fits || host <= host_budget))
+				break;
+		}
 	}
 	for (int top = 0; top < out->Ysize; top += rows) {
 		int in_top, in_rows;
@@ -424,93 +681,227 @@ hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
 		max_in_rows = VIPS_MAX(max_in_rows, in_rows);
 	}
 
-	/* the host result and the two staging buffers, pinned (a result too large to pin is
-	 * ordinary memory: its downloads then simply do not overlap); two input windows and two
-	 * output strips on the device, kept for the whole loop */
-	if (!(host = (VipsPel *) vips_hip_malloc_host(ls * out->Ysize))) {
-		vips_hip_error_clear();
-		pinned = FALSE;
-		host = (VipsPel *) g_try_malloc(ls * out->Ysize);
-	}
-	result = host ? 0 : -1;
-	if (!host)
-		vips_error(nick, "%s", "out of memory for the result");
-	for (int i = 0; i < 2 && !result; i++)
+	/* two staging buffers, pinned; two input windows and two output strips on the device, kept
+	 * for the whole run */
+	for (int i = 0; i < 2; i++) {
 		if ((!resident && !(stage[i] = (VipsPel *) vips_hip_malloc_host((size_t) max_in_rows * in_ls))) ||
 			!(stream[i] = vips_hip_stream_new()) ||
-			!(computed[i] = vips_hip_event_new()) || !(finished[i] = vips_hip_event_new()) ||
+			!(computed[i] = vips_hip_event_new()) || !(uploaded[i] = vips_hip_event_new()) ||
 			!(dev_in[i] = vips_hip_image_new(in->Xsize, max_in_rows, in->Bands, in->BandFmt, in->Type)) ||
 			!(dev_out[i] = vips_hip_image_new(out->Xsize, VIPS_MIN(rows, out->Ysize), out->Bands, out->BandFmt, out->Type)))
-			result = hip_fail(nick);
-
-	if (!result && !resident) {
-		int in_top, in_rows;
-
-		STRIP_NEED(0, VIPS_MIN(rows, out->Ysize), &in_top, &in_rows);
-		result = hip_pull_rows(in, in_top, in_rows, stage[0]);
+			goto setup_done;
+		if (stage[i])
+			hip_host_account((gint64) ((guint64) max_in_rows * in_ls));
 	}
-	for (int top = 0, k = 0; top < out->Ysize && !result; top += rows, k++) {
-		const int b = k & 1;
-		const int n = VIPS_MIN(rows, out->Ysize - top);
-		VipsHipRegion ri, ro;
-		int in_top, in_rows;
+	op->device = vips_hip_image_get_device(dev_in[0]);
+	setup = 1;
 
-		STRIP_NEED(top, n, &in_top, &in_rows);
-		if (vips_image_iskilled(out)) {
-			vips_error(nick, "%s", "killed");
-			result = -1;
+setup_done:
+	if (setup < 0)
+		hip_producer_fail(op, nick);
+	g_mutex_lock(&op->lock);
+	if (setup == 1 && !op->cache) {
+		const guint64 stage_bytes = resident ? 0 : 2 * (guint64) max_in_rows * in_ls;
+
+		op->cache = hip_cache_new(out->Ysize, rows, ls, host_budget > stage_bytes ? host_budget - stage_bytes : 0, TRUE);
+	}
+	if (!op->setup)
+		op->setup = setup;
+	g_cond_broadcast(&op->cond);
+	c = op->cache;
+
+	/* ---- the loop (lock held at the top of every turn) */
+	while (setup == 1) {
+		const int ahead = VIPS_MAX(1, c->n_slots - 2);
+		gboolean can;
+		int w = -1, slot = -1;
+
+		if (op->producer_quit || op->eval_error)
 			break;
-		}
-		/* strip k on stream b: its upload may run beside strip k - 1's kernels and download (the
-		 * other stream); its KERNELS wait for strip k - 1's -- the operation's temporaries come
-		 * from a pool that orders reuse within one stream, and kernels of two strips have nothing
-		 * to gain from running side by side */
-		if (vips_hip_set_stream(stream[b]) ||
-			vips_hip_memcpy_h2d_async(vips_hip_image_get_data(dev_in[b]),
-				resident ? resident + (size_t) in_top * in_ls : stage[b], (size_t) in_rows * in_ls) ||
-			(k > 0 && vips_hip_stream_wait_event(computed[1 - b]))) {
-			result = hip_fail(nick);
-			break;
-		}
-		vips_hip_image_region(dev_in[b], &ri);
-		ri.top = in_top;
-		ri.height = in_rows;
-		ri.im_width = in->Xsize;
-		ri.im_height = in->Ysize;
-		vips_hip_image_region(dev_out[b], &ro);
-		ro.top = top;
-		ro.height = n;
-		ro.im_width = out->Xsize;
-		ro.im_height = out->Ysize;
-		if ((generic ? hip_halo_run(op, &halo, &ri, &ro) : hclass->strip_run(op, plan, &ri, &ro)) ||
-			vips_hip_event_record(computed[b]) ||
-			(pinned ? vips_hip_memcpy_d2h_async(host + (size_t) top * ls, vips_hip_image_get_data(dev_out[b]), (size_t) n * ls)
-					: vips_hip_memcpy_d2h(host + (size_t) top * ls, vips_hip_image_get_data(dev_out[b]), (size_t) n * ls)) ||
-			vips_hip_event_record(finished[b])) {
-			result = hip_fail(nick);
-			break;
-		}
-		g_atomic_int_inc(&hip_strips_done);
-		/* meanwhile, on the host: strip k + 1 is pulled into the buffer strip k - 1 was uploaded
-		 * from (that strip is complete: its stream comes next) */
-		if (!resident && top + rows < out->Ysize) {
-			if (k > 0 && vips_hip_event_synchronize(finished[1 - b])) {
-				result = hip_fail(nick);
+		/* the lowest strip somebody waits for that is neither here nor on its way: when the walk
+		 * will not reach it soon, go there */
+		for (int i = 0; i < c->n_items; i++)
+			if (c->want[i] > 0 && c->item_slot[i] < 0) {
+				w = i;
 				break;
 			}
-			STRIP_NEED(top + rows, VIPS_MIN(rows, out->Ysize - top - rows), &in_top, &in_rows);
-			result = hip_pull_rows(in, in_top, in_rows, stage[1 - b]);
+		if (w >= 0 && (w < cursor || w >= cursor + c->n_slots))
+			cursor = w;
+		/* skip what is already here (after a jump back) */
+		while (cursor < c->n_items && c->item_slot[cursor] >= 0)
+			cursor++;
+		/* not further ahead of the consumer than the ring can hold beside what it is reading */
+		can = cursor < c->n_items && (c->n_slots >= c->n_items || cursor <= VIPS_MAX(c->hi_seen, 0) + ahead);
+		if (can)
+			slot = hip_cache_victim(c);
+		if (slot < 0) {
+			if (pending >= 0) {
+				/* nothing to queue: make the last strip visible, then look again */
+				void *ev = c->slot_event[pending];
+				const int p = pending;
+
+				pending = -1;
+				g_mutex_unlock(&op->lock);
+				if (vips_hip_event_synchronize(ev)) {
+					hip_producer_fail(op, nick);
+					failed = TRUE;
+				}
+				g_mutex_lock(&op->lock);
+				if (!failed && c->slot_state[p] == HIP_SLOT_ISSUED)
+					c->slot_state[p] = HIP_SLOT_READY;
+				g_cond_broadcast(&op->cond);
+				if (failed)
+					break;
+				continue;
+			}
+			if (cursor >= c->n_items && w < 0)
+				break; /* every strip made, nobody waiting: the device goes back */
+			g_cond_wait(&op->cond, &op->lock);
+			continue;
 		}
+		hip_cache_claim(c, slot, cursor);
+		g_mutex_unlock(&op->lock);
+
+		/* ---- strip `cursor` into `slot`, without the lock */
+		{
+			const int k = cursor;
+			const int b = issues & 1;
+			const int top = k * rows;
+			const int n = VIPS_MIN(rows, out->Ysize - top);
+			VipsPel *mem = hip_cache_mem(c, slot);
+			VipsHipRegion ri, ro;
+			int in_top, in_rows;
+
+			STRIP_NEED(top, n, &in_top, &in_rows);
+			if (!mem) {
+				vips_error(nick, "%s", "out of memory for the result");
+				failed = TRUE;
+			}
+			else if (vips_image_iskilled(out)) {
+				vips_error(nick, "%s", "killed");
+				failed = TRUE;
+			}
+			/* its input rows: prefetched during the previous strip, or pulled now (the first
+			 * strip, or after a jump) into the staging buffer this turn uploads from -- once the
+			 * upload that last read that buffer is through */
+			if (!failed && !resident && pulled != k) {
+				if ((upload_seen[b] && vips_hip_event_synchronize(uploaded[b])) ||
+					hip_pull_rows(in, in_top, in_rows, stage[b]))
+					failed = TRUE;
+				pulled = k;
+			}
+			if (!c->slot_event[slot] && !(c->slot_event[slot] = vips_hip_event_new()))
+				failed = TRUE;
+			/* strip k on stream b: its upload may run beside the previous strip's kernels and
+			 * download (the other stream); its KERNELS wait for the previous strip's -- the
+			 * operation's temporaries come from a pool that orders reuse within one stream, and
+			 * kernels of two strips have nothing to gain from running side by side */
+			if (!failed &&
+				(vips_hip_set_stream(stream[b]) ||
+					vips_hip_memcpy_h2d_async(vips_hip_image_get_data(dev_in[b]),
+						resident ? resident + (size_t) in_top * in_ls : stage[b], (size_t) in_rows * in_ls) ||
+					vips_hip_event_record(uploaded[b]) ||
+					(issues > 0 && vips_hip_stream_wait_event(computed[1 - b]))))
+				failed = TRUE;
+			upload_seen[b] = TRUE;
+			if (!failed) {
+				vips_hip_image_region(dev_in[b], &ri);
+				ri.top = in_top;
+				ri.height = in_rows;
+				ri.im_width = in->Xsize;
+				ri.im_height = in->Ysize;
+				vips_hip_image_region(dev_out[b], &ro);
+				ro.top = top;
+				ro.height = n;
+				ro.im_width = out->Xsize;
+				ro.im_height = out->Ysize;
+				if ((generic ? hip_halo_run(op, &halo, &ri, &ro) : hclass->strip_run(op, plan, &ri, &ro)) ||
+					vips_hip_event_record(computed[b]) ||
+					vips_hip_memcpy_d2h_async(mem, vips_hip_image_get_data(dev_out[b]), (size_t) n * ls) ||
+					vips_hip_event_record(c->slot_event[slot]))
+					failed = TRUE;
+			}
+			if (failed) {
+				hip_producer_fail(op, nick);
+				g_mutex_lock(&op->lock);
+				hip_cache_drop(c, slot);
+				break;
+			}
+			issues++;
+			cursor = k + 1;
+			g_atomic_int_inc(&hip_strips_done);
+
+			g_mutex_lock(&op->lock);
+			c->slot_state[slot] = HIP_SLOT_ISSUED;
+			g_cond_broadcast(&op->cond);
+			g_mutex_unlock(&op->lock);
+
+			/* the strip before this one has had a whole turn: make it visible (a generate call
+			 * that wanted it sooner has waited on its event itself) */
+			if (pending >= 0) {
+				if (vips_hip_event_synchronize(c->slot_event[pending])) {
+					hip_producer_fail(op, nick);
+					g_mutex_lock(&op->lock);
+					break;
+				}
+				g_mutex_lock(&op->lock);
+				if (c->slot_state[pending] == HIP_SLOT_ISSUED)
+					c->slot_state[pending] = HIP_SLOT_READY;
+				g_cond_broadcast(&op->cond);
+				g_mutex_unlock(&op->lock);
+			}
+			pending = slot;
+
+			/* meanwhile, on the host: the next strip's rows into the other staging buffer (the
+			 * upload that read it, two strips ago, first) -- unless the consumers are elsewhere */
+			if (!resident && cursor < c->n_items) {
+				const int nb = issues & 1;
+				gboolean go;
+
+				g_mutex_lock(&op->lock);
+				go = !op->producer_quit && c->item_slot[cursor] < 0 &&
+					(c->n_slots >= c->n_items || cursor <= VIPS_MAX(c->hi_seen, 0) + ahead);
+				for (int i = 0; i < c->n_items && go; i++)
+					if (c->want[i] > 0 && c->item_slot[i] < 0 && (i < cursor || i >= cursor + c->n_slots))
+						go = FALSE;
+				g_mutex_unlock(&op->lock);
+				if (go) {
+					const int ntop = cursor * rows;
+
+					STRIP_NEED(ntop, VIPS_MIN(rows, out->Ysize - ntop), &in_top, &in_rows);
+					if ((upload_seen[nb] && vips_hip_event_synchronize(uploaded[nb])) ||
+						hip_pull_rows(in, in_top, in_rows, stage[nb])) {
+						hip_producer_fail(op, nick);
+						g_mutex_lock(&op->lock);
+						break;
+					}
+					pulled = cursor;
+				}
+			}
+		}
+		g_mutex_lock(&op->lock);
 	}
 #undef STRIP_NEED
 
-	/* everything queued must finish before its memory goes back (also on the failure paths) */
-	for (int i = 0; i < 2; i++) {
+	/* (lock held) this run is over.  Whatever is still queued (a run that was told to quit, or
+	 * failed) lands before its memory goes back; then a request that finds no producer running
+	 * starts the next run. */
+	for (int i = 0; i < 2; i++)
 		if (stream[i]) {
 			(void) vips_hip_set_stream(stream[i]);
-			if (vips_hip_synchronize() && !result)
-				result = hip_fail(nick);
+			(void) vips_hip_synchronize();
 		}
+	for (int i = 0; c && i < c->n_slots; i++) {
+		if (c->slot_state[i] == HIP_SLOT_ISSUED && !op->eval_error)
+			c->slot_state[i] = HIP_SLOT_READY;
+		else if (c->slot_state[i] == HIP_SLOT_ISSUED || c->slot_state[i] == HIP_SLOT_FILLING)
+			hip_cache_drop(c, i);
+	}
+	op->producer_running = FALSE;
+	g_cond_broadcast(&op->cond);
+	g_mutex_unlock(&op->lock);
+
+	for (int i = 0; i < 2; i++) {
 		vips_hip_image_unref(dev_in[i]);
 		vips_hip_image_unref(dev_out[i]);
 	}
@@ -518,23 +909,85 @@ hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
 	for (int i = 0; i < 2; i++) {
 		vips_hip_stream_free(stream[i]);
 		vips_hip_event_free(computed[i]);
-		vips_hip_event_free(finished[i]);
-		vips_hip_free_host(stage[i]);
+		vips_hip_event_free(uploaded[i]);
+		if (stage[i]) {
+			vips_hip_free_host(stage[i]);
+			hip_host_account(-(gint64) ((guint64) max_in_rows * in_ls));
+		}
 	}
-	if (!generic && hclass->strip_close)
+	if (!generic && plan && hclass->strip_close)
 		hclass->strip_close(op, plan);
-	VIPS_UNREF(resident_mem);
-	if (result) {
-		if (pinned)
-			vips_hip_free_host(host);
-		else
-			g_free(host);
+	vips_hip_error_clear();
+	vips_thread_shutdown();
+
+	return NULL;
+}
+
+/* (lock held) start a producer run; the previous run's thread, if any, has set
+ * producer_running = FALSE and touches nothing of the operation any more */
+static int
+hip_producer_start(VipsHipOp *op)
+{
+	if (op->producer) {
+		GThread *old = op->producer;
+
+		op->producer = NULL;
+		g_mutex_unlock(&op->lock);
+		g_thread_join(old);
+		g_mutex_lock(&op->lock);
+		if (op->producer_running) /* (somebody else started the next run meanwhile) */
+			return 0;
+	}
+	op->producer_running = TRUE;
+	op->producer_quit = FALSE;
+	if (!(op->producer = vips_g_thread_new("vips-hip strips", hip_producer, op))) {
+		op->producer_running = FALSE;
 		return -1;
 	}
-	op->host = host;
-	op->host_pinned = pinned;
 
 	return 0;
+}
+
+/* (lock held) An image over the HBM budget: start the producer and wait for its plan.  0: the
+ * strips are on their way; 1: this instance has no region form; -1: failed. */
+static int
+hip_eval_strips(VipsHipOp *op, guint64 budget)
+{
+	VipsHipOpClass *hclass = VIPS_HIP_OP_GET_CLASS(op);
+
+	if (!hclass->halo && !(hclass->strip_open && hclass->strip_need && hclass->strip_run))
+		return 1;
+	op->budget = budget;
+	op->setup = 0;
+	if (hip_producer_start(op)) {
+		vips_error(VIPS_OBJECT_GET_CLASS(op)->nickname, "%s", "unable to start the strip producer");
+		return -1;
+	}
+	while (!op->setup)
+		g_cond_wait(&op->cond, &op->lock);
+	if (op->setup == 1) {
+		op->striped = TRUE;
+		return 0;
+	}
+
+	return op->setup == 2 ? 1 : -1;
+}
+
+/* An input that already IS host memory (vips_image_new_from_memory(), a loaded-to-memory file,
+ * a mapped .v), usable where it lies: its pixels, else NULL.  Costs nothing. */
+static const VipsPel *
+hip_host_in_place(VipsHipOp *op)
+{
+	VipsImage *raw = op->in;
+
+	if (raw->Coding == VIPS_CODING_NONE && raw->Xsize == op->ready->Xsize && raw->Ysize == op->ready->Ysize &&
+		raw->Bands == op->ready->Bands && raw->BandFmt == op->ready->BandFmt &&
+		(raw->dtype == VIPS_IMAGE_SETBUF || raw->dtype == VIPS_IMAGE_SETBUF_FOREIGN ||
+			raw->dtype == VIPS_IMAGE_MMAPIN || raw->dtype == VIPS_IMAGE_MMAPINRW) &&
+		!vips_image_wio_input(raw) && raw->data)
+		return (const VipsPel *) raw->data;
+
+	return NULL;
 }
 
 /* The input's pixels on the host.  An image that already IS memory (vips_image_new_from_memory(),
@@ -546,15 +999,11 @@ hip_eval_strips(VipsHipOp *op, VipsImage *in, guint64 budget)
 static const VipsPel *
 hip_host_pixels(VipsHipOp *op, VipsImage **mem)
 {
-	VipsImage *raw = op->in;
+	const VipsPel *in_place = hip_host_in_place(op);
 
 	*mem = NULL;
-	if (raw->Coding == VIPS_CODING_NONE && raw->Xsize == op->ready->Xsize && raw->Ysize == op->ready->Ysize &&
-		raw->Bands == op->ready->Bands && raw->BandFmt == op->ready->BandFmt &&
-		(raw->dtype == VIPS_IMAGE_SETBUF || raw->dtype == VIPS_IMAGE_SETBUF_FOREIGN ||
-			raw->dtype == VIPS_IMAGE_MMAPIN || raw->dtype == VIPS_IMAGE_MMAPINRW) &&
-		!vips_image_wio_input(raw) && raw->data)
-		return (const VipsPel *) raw->data;
+	if (in_place)
+		return in_place;
 	if (!(*mem = vips_image_copy_memory(op->ready)))
 		return NULL;
 
@@ -589,6 +1038,20 @@ hip_input(VipsHipOp *op, VipsHipImage **fresh)
 }
 
 static void hip_eval(VipsHipOp *op);
+
+/* (lock held) evaluate, once, whoever comes first */
+static void
+hip_ensure_eval(VipsHipOp *op)
+{
+	while (op->evaluating)
+		g_cond_wait(&op->cond, &op->lock);
+	if (!op->evaluated) {
+		op->evaluating = TRUE;
+		hip_eval(op);
+		op->evaluating = FALSE;
+		g_cond_broadcast(&op->cond);
+	}
+}
 
 /* This operation fused with the one that makes its input, when the class has a hook for the
  * pair and nobody has evaluated the upstream operation yet (if somebody asks for it later it
@@ -681,7 +1144,7 @@ hip_eval(VipsHipOp *op)
 		const guint64 budget = hip_budget();
 
 		if (bytes > budget) {
-			const int r = hip_eval_strips(op, in, budget);
+			const int r = hip_eval_strips(op, budget);
 
 			if (r < 0)
 				hip_eval_fail(op, class->nickname);
@@ -750,12 +1213,143 @@ vips_hip_op_device(GObject *producer)
 	VipsHipImage *result;
 
 	g_mutex_lock(&op->lock);
-	if (!op->evaluated)
-		hip_eval(op);
+	hip_ensure_eval(op);
 	result = op->result;
 	g_mutex_unlock(&op->lock);
 
 	return result;
+}
+
+/* (lock held) The host copy of a device result: address space for the cache now, pixels band by
+ * band as they are first asked for (~32 MB bands: large enough for the link, small enough to
+ * skip), at most the host budget of them at once. */
+static int
+hip_bands_open(VipsHipOp *op)
+{
+	VipsImage *out = op->out;
+	const size_t ls = VIPS_IMAGE_SIZEOF_LINE(out);
+	const int band_rows = VIPS_CLIP(16, (int) (((size_t) 32 << 20) / ls), out->Ysize);
+
+	op->cache = hip_cache_new(out->Ysize, band_rows, ls, hip_host_budget(), FALSE);
+
+	return 0;
+}
+
+/* Rows of item @item for a generate call: its slot (pinned until hip_cache_put) and memory, or
+ * NULL with the error set.  Waits for a strip that is on its way; downloads a band of a device
+ * result itself. */
+static const VipsPel *
+hip_cache_get(VipsHipOp *op, int item, int *slot_out)
+{
+	const char *nick = VIPS_OBJECT_GET_CLASS(op)->nickname;
+	HipCache *c = op->cache;
+	VipsImage *out = op->out;
+	int s;
+
+	g_mutex_lock(&op->lock);
+	if (item > c->hi_seen) {
+		c->hi_seen = item; /* (the producer may walk further now) */
+		g_cond_broadcast(&op->cond);
+	}
+	for (;;) {
+		if (op->eval_error) {
+			vips_error(nick, "%s", op->eval_error);
+			g_mutex_unlock(&op->lock);
+			return NULL;
+		}
+		if (vips_image_iskilled(out)) {
+			g_mutex_unlock(&op->lock);
+			return NULL;
+		}
+		s = c->item_slot[item];
+		if (s >= 0 && c->slot_state[s] == HIP_SLOT_READY)
+			break;
+		if (s >= 0 && c->slot_state[s] == HIP_SLOT_ISSUED) {
+			/* its download is queued: wait for it here rather than for the producer's next turn */
+			void *ev = c->slot_event[s];
+			int r;
+
+			c->slot_pins[s]++;
+			g_mutex_unlock(&op->lock);
+			r = vips_hip_event_synchronize(ev);
+			g_mutex_lock(&op->lock);
+			c->slot_pins[s]--;
+			if (r) {
+				g_mutex_unlock(&op->lock);
+				hip_fail(nick);
+				return NULL;
+			}
+			if (c->slot_item[s] == item && c->slot_state[s] == HIP_SLOT_ISSUED)
+				c->slot_state[s] = HIP_SLOT_READY;
+			g_cond_broadcast(&op->cond);
+			continue;
+		}
+		if (op->striped) {
+			/* a strip that is being pulled, or is not on the host (any more): the producer makes it */
+			c->want[item]++;
+			if (!op->producer_running && hip_producer_start(op)) {
+				c->want[item]--;
+				g_mutex_unlock(&op->lock);
+				vips_error(nick, "%s", "unable to start the strip producer");
+				return NULL;
+			}
+			g_cond_broadcast(&op->cond);
+			g_cond_wait(&op->cond, &op->lock);
+			c->want[item]--;
+			continue;
+		}
+		/* a band of a device result: this thread downloads it (another thread may be at it) */
+		if (s >= 0 || (s = hip_cache_victim(c)) < 0) {
+			g_cond_wait(&op->cond, &op->lock);
+			continue;
+		}
+		hip_cache_claim(c, s, item);
+		g_mutex_unlock(&op->lock);
+		{
+			const int top = item * c->item_rows;
+			const int rows = VIPS_MIN(c->item_rows, out->Ysize - top);
+			VipsPel *mem = hip_cache_mem(c, s);
+			int r = 0;
+
+			if (!mem) {
+				vips_error(nick, "%s", "out of memory for the result");
+				r = -1;
+			}
+			/* (vips_hip_memcpy_d2h binds nothing: run where the result lives) */
+			else if (vips_hip_init(vips_hip_image_get_device(op->result)) ||
+				vips_hip_memcpy_d2h(mem,
+					(const char *) vips_hip_image_get_data(op->result) + (size_t) top * vips_hip_image_get_stride(op->result),
+					(size_t) rows * c->ls))
+				r = hip_fail(nick);
+			g_mutex_lock(&op->lock);
+			if (r) {
+				hip_cache_drop(c, s);
+				g_cond_broadcast(&op->cond);
+				g_mutex_unlock(&op->lock);
+				return NULL;
+			}
+			c->slot_state[s] = HIP_SLOT_READY;
+			g_atomic_int_inc(&hip_bands_done);
+			g_cond_broadcast(&op->cond);
+		}
+	}
+	c->slot_pins[s]++;
+	c->slot_tick[s] = ++c->tick;
+	if (op->striped && op->producer_running)
+		g_atomic_int_inc(&hip_served_early);
+	g_mutex_unlock(&op->lock);
+	*slot_out = s;
+
+	return c->mem[s];
+}
+
+static void
+hip_cache_put(VipsHipOp *op, int slot)
+{
+	g_mutex_lock(&op->lock);
+	op->cache->slot_pins[slot]--;
+	g_cond_broadcast(&op->cond); /* (the slot may be what the producer is waiting for) */
+	g_mutex_unlock(&op->lock);
 }
 
 static int
@@ -765,60 +1359,42 @@ vips_hip_op_gen(VipsRegion *out_region, void *seq, void *a, void *b, gboolean *s
 	VipsRect *r = &out_region->valid;
 	VipsImage *out = out_region->im;
 	const size_t ps = VIPS_IMAGE_SIZEOF_PEL(out);
-	const size_t ls = VIPS_IMAGE_SIZEOF_LINE(out);
+	HipCache *c;
 
 	if (vips_image_iskilled(out))
 		return -1;
 
-	/* First demand: evaluate, then bring the device result to the host, once. */
+	/* First demand: evaluate.  A result that fits HBM is made here and now (then its bands come
+	 * down as they are asked for); an image over the budget only gets its producer started. */
 	g_mutex_lock(&op->lock);
-	if (!op->evaluated)
-		hip_eval(op);
+	hip_ensure_eval(op);
 	if (op->eval_error) {
 		vips_error(VIPS_OBJECT_GET_CLASS(op)->nickname, "%s", op->eval_error);
 		g_mutex_unlock(&op->lock);
 		return -1;
 	}
-	if (!op->host) {
-		/* the host copy of a device result: address space now, pixels band by band as they are
-		 * first asked for (~32 MB bands: large enough for the link, small enough to skip) */
-		const int band_rows = VIPS_CLIP(16, (int) (((size_t) 32 << 20) / ls), out->Ysize);
-		const int n_bands = (out->Ysize + band_rows - 1) / band_rows;
-
-		op->band_done = g_new0(guint8, n_bands);
-		if (!(op->host = (VipsPel *) g_try_malloc(ls * out->Ysize))) {
-			g_mutex_unlock(&op->lock);
-			vips_error(VIPS_OBJECT_GET_CLASS(op)->nickname, "%s", "out of memory for the result");
-			return -1;
-		}
-		op->band_rows = band_rows;
+	if (!op->cache && hip_bands_open(op)) {
+		g_mutex_unlock(&op->lock);
+		return -1;
 	}
-	if (op->band_rows) {
-		const int first = r->top / op->band_rows, last = (r->top + r->height - 1) / op->band_rows;
-
-		for (int band = first; band <= last; band++)
-			if (!op->band_done[band]) {
-				const int top = band * op->band_rows;
-				const int rows = VIPS_MIN(op->band_rows, out->Ysize - top);
-
-				/* (vips_hip_memcpy_d2h binds nothing: run where the result lives) */
-				if (vips_hip_init(vips_hip_image_get_device(op->result)) ||
-					vips_hip_memcpy_d2h(op->host + (size_t) top * ls,
-						(const char *) vips_hip_image_get_data(op->result) + (size_t) top * vips_hip_image_get_stride(op->result),
-						(size_t) rows * ls)) {
-					g_mutex_unlock(&op->lock);
-					return hip_fail(VIPS_OBJECT_GET_CLASS(op)->nickname);
-				}
-				op->band_done[band] = 1;
-				g_atomic_int_inc(&hip_bands_done);
-			}
-	}
+	c = op->cache;
 	g_mutex_unlock(&op->lock);
 
-	for (int y = 0; y < r->height; y++)
-		memcpy(VIPS_REGION_ADDR(out_region, r->left, r->top + y),
-			op->host + (size_t) (r->top + y) * ls + (size_t) r->left * ps,
-			(size_t) r->width * ps);
+	for (int item = r->top / c->item_rows; item <= (r->top + r->height - 1) / c->item_rows; item++) {
+		const int top = item * c->item_rows;
+		const int y0 = VIPS_MAX(r->top, top);
+		const int y1 = VIPS_MIN(r->top + r->height, top + c->item_rows);
+		int slot;
+		const VipsPel *rows = hip_cache_get(op, item, &slot);
+
+		if (!rows)
+			return -1;
+		for (int y = y0; y < y1; y++)
+			memcpy(VIPS_REGION_ADDR(out_region, r->left, y),
+				rows + (size_t) (y - top) * c->ls + (size_t) r->left * ps,
+				(size_t) r->width * ps);
+		hip_cache_put(op, slot);
+	}
 
 	return 0;
 }
@@ -937,12 +1513,17 @@ vips_hip_op_dispose(GObject *gobject)
 {
 	VipsHipOp *op = VIPS_HIP_OP(gobject);
 
-	if (op->host_pinned)
-		vips_hip_free_host(op->host);
-	else
-		g_free(op->host);
-	op->host = NULL;
-	VIPS_FREE(op->band_done);
+	/* the producer holds no reference: it ends here, before anything it reads goes away */
+	g_mutex_lock(&op->lock);
+	op->producer_quit = TRUE;
+	g_cond_broadcast(&op->cond);
+	g_mutex_unlock(&op->lock);
+	if (op->producer) {
+		g_thread_join(op->producer);
+		op->producer = NULL;
+	}
+	hip_cache_free(op->cache);
+	op->cache = NULL;
 	VIPS_FREE(op->eval_error);
 	if (op->result) {
 		vips_hip_image_unref(op->result);
@@ -977,6 +1558,7 @@ static void
 vips_hip_op_init(VipsHipOp *op)
 {
 	g_mutex_init(&op->lock);
+	g_cond_init(&op->cond);
 }
 
 /* ------------------------------------------------------------------ subclasses */

@@ -117,8 +117,19 @@ hipError_t hipHostFree(void *p)
 	return hipSuccess;
 }
 
-hipError_t hipMemcpyAsync(void *dst, const void *src, size_t size, hipMemcpyKind, hipStream_t)
+// $MOCK_HIP_FAIL_D2H_AFTER=N: the N + 1-th device-to-host copy from now on fails (the tests ask:
+// does a failure inside a worker thread reach the caller?).  Read per call; counted per process.
+static long g_d2h = 0;
+
+hipError_t hipMemcpyAsync(void *dst, const void *src, size_t size, hipMemcpyKind kind, hipStream_t)
 {
+	if (kind == hipMemcpyDeviceToHost) {
+		const char *e = getenv("MOCK_HIP_FAIL_D2H_AFTER");
+		if (!e)
+			g_d2h = 0;
+		else if (__sync_fetch_and_add(&g_d2h, 1) >= atol(e))
+			return hipErrorUnknown;
+	}
 	if (size)
 		memmove(dst, src, size);
 	return hipSuccess;
