@@ -309,9 +309,9 @@ colour_lab_lds_kernel(RouteArgs a, CbrtExact cx)
 			v.c = s_v2Y[load_as_uchar_like<TIN>(in[3 * m + 2], 255)];
 			v = step_scRGB2XYZ(v);
 			// XYZ2Lab.c:109-138 on small finite values
-			const float n0 = (float) DIV_CONST_F((double) __fmul_rn(100000.0f, v.a), 95.0470);
-			const float n1 = (float) DIV_CONST_F((double) __fmul_rn(100000.0f, v.b), 100.0);
-			const float n2 = (float) DIV_CONST_F((double) __fmul_rn(100000.0f, v.c), 108.8827);
+			const float n0 = quant_div_finite<0>(__fmul_rn(100000.0f, v.a));
+			const float n1 = quant_div_finite<1>(__fmul_rn(100000.0f, v.b));
+			const float n2 = quant_div_finite<2>(__fmul_rn(100000.0f, v.c));
 			const int i0 = min(max(__float2int_rz(n0), 0), CBRT_N - 2);
 			const int i1 = min(max(__float2int_rz(n1), 0), CBRT_N - 2);
 			const int i2 = min(max(__float2int_rz(n2), 0), CBRT_N - 2);

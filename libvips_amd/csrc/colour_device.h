@@ -62,20 +62,38 @@ static __device__ __forceinline__ double div_const_finite(double a, double y, do
 }
 #define DIV_CONST_F(A, Y) div_const_finite((A), (Y), 1.0 / (Y))
 
+// (float) ((double) A / C) for C = X0, Y0, Z0 of D65 (WHICH = 0, 1, 2) in two single-precision
+// operations.  With R = 1 / C cut into two floats, fmaf(A, Rhi, RN(A * Rlo)) rounds
+// A * (Rhi + Rlo) + (an error below 2^-47 of it) once, to float; A / C for a 24-bit A and
+// C = 95047 / 1000, 100, 1088827 / 10000 is never closer than 2^-44 (relative) to the midpoint of two
+// floats, and the reference's own double quotient is within 2^-52 of it: the same float.  Checked
+// against the double division for EVERY float A in [2^-8, 2^27) and the three constants (8 M
+// mantissas x 35 exponents, tools/div_f32_check.py); the XYZ of a uchar pixel gives A = 0 or
+// 58 <= A < 1.1e7.
+template <int WHICH>
+static __device__ __forceinline__ float quant_div_finite(float A)
+{
+	constexpr double C = WHICH == 0 ? 95.0470 : WHICH == 1 ? 100.0 : 108.8827;
+	constexpr float rhi = (float) (1.0 / C);
+	constexpr float rlo = (float) (1.0 / C - (double) rhi);
+	return __builtin_fmaf(A, rhi, __fmul_rn(A, rlo));
+}
+
 // vips_col_XYZ2Lab_helper, XYZ2Lab.c:109-138 (D65: include/vips/colour.h:58-60)
 // FINITE: v is known to be a small finite number (XYZ of a uchar pixel): no inf / NaN handling
 template <int WHICH, bool FINITE = false>
 static __device__ __forceinline__ float cbrt_lerp(const float *__restrict__ table, float v)
 {
 	// nX = QUANT_ELEMENTS * X / X0: (int * float) in float, then / double, back to float
-	const double num = (double) __fmul_rn(100000.0f, v);
+	const float fnum = __fmul_rn(100000.0f, v);
 	float n;
 	if (FINITE)
-		n = (float) (WHICH == 0 ? DIV_CONST_F(num, 95.0470) : WHICH == 1 ? DIV_CONST_F(num, 100.0)
-																	 : DIV_CONST_F(num, 108.8827));
-	else
+		n = quant_div_finite<WHICH>(fnum);
+	else {
+		const double num = (double) fnum;
 		n = (float) (WHICH == 0 ? DIV_CONST(num, 95.0470) : WHICH == 1 ? DIV_CONST(num, 100.0)
 																   : DIV_CONST(num, 108.8827));
+	}
 	// VIPS_CLIP(0, (int) nX, QUANT_ELEMENTS - 2); (int) of NaN / overflow is the x86
 	// "integer indefinite" INT_MIN, which the clip turns into 0
 	// (v_cvt_i32_f32 saturates and turns NaN into 0: after the clip only n >= 2^31 -- INT_MAX

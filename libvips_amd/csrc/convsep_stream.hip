@@ -86,6 +86,7 @@ struct StreamArgs {
 	int spw;          // staged pixels per (row, band) plane: pxw + SS_SLACK
 	int step_rows, step_px; // block size / pxw and % pxw: the epilogue walks its items without dividing
 	int ring;         // staged-row buffers in LDS (2..4): the LDS-DMA runs ring - 1 steps ahead
+	int order;        // with an epilogue: 1 = request a phase's rows after the epilogue, 0 = before
 	int strips, segs, seg_rows;
 	int has_scale;    // scale != 1 (an integer for the kernel to test: a scalar compare and branch;
 	                  // the f64 compare makes a lane mask that is kept -- spilled -- for every use)
@@ -416,17 +417,20 @@ convsep_stream(StreamArgs a, RouteArgs route)
 			// Keep the compiler from hoisting every derived address out of the phase loop: held
 			// across the loop they spill; re-deriving them costs a few adds per phase.
 			asm volatile("" : "+v"(goff[0]), "+v"(goff[1]), "+v"(h_in_off), "+v"(h_x_off), "+v"(tt));
-			// the rows of step p + 1 start travelling into the buffer the horizontal pass of
-			// step p - 1 read before the barrier
-			if (p + a.ring - 1 < steps)
-				dma_rows(p + a.ring - 1, dslot);
-			dslot = dslot + 1 == a.ring ? 0 : dslot + 1;
-			// ---- vertical pass of step p - 1
-			if (p >= 1 && p - 1 < steps && active) {
-				const int q = p - 1;
-				ss_vpass<MODE, NG, EPI, Q4>(a, kc, acc, s_x + (q & 1) * x_buf + tt, s_o + (q & 1) * x_buf + tt, q,
-					rows_out, y0, e0, tt, tt < ne);
-			}
+			// The rows of step p + ring - 1 start travelling into the buffer the horizontal pass of
+			// step p - 1 read before the barrier.  With an epilogue they are requested AFTER it: the
+			// epilogue's table gathers and stores wait with s_waitcnt vmcnt(0) -- the compiler does
+			// not know about the LDS-DMA -- so requested first, every wave sat out the HBM latency of
+			// the rows it had just asked for, once per phase.
+			auto request_rows = [&]() __attribute__((always_inline)) {
+				if (p + a.ring - 1 < steps)
+					dma_rows(p + a.ring - 1, dslot);
+				dslot = dslot + 1 == a.ring ? 0 : dslot + 1;
+			};
+			if (!EPI || a.order == 0)
+				request_rows();
+			// (the epilogue of step p - 2 reads the blurred rows the vertical pass wrote in the phase
+			// before; the vertical pass below writes the other buffer)
 			// ---- colour epilogue of step p - 2: blurred rows (LDS) -> the route -> the final image.
 			// One pixel per item, items dealt round the block (a 4-pixels-per-thread form with
 			// wide loads and stores measured slower: a third of the threads idle while the rest
@@ -472,6 +476,14 @@ convsep_stream(StreamArgs a, RouteArgs route)
 						dst[2] = o2;
 					}
 				}
+			}
+			if (EPI && a.order != 0)
+				request_rows();
+			// ---- vertical pass of step p - 1
+			if (p >= 1 && p - 1 < steps && active) {
+				const int q = p - 1;
+				ss_vpass<MODE, NG, EPI, Q4>(a, kc, acc, s_x + (q & 1) * x_buf + tt, s_o + (q & 1) * x_buf + tt, q,
+					rows_out, y0, e0, tt, tt < ne);
 			}
 			// ---- horizontal pass of step p
 			if (p < steps && active)
@@ -648,6 +660,10 @@ int convsep_stream_fused(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 	while (ring > 2 && ring * in_bytes + x_bytes > (size_t) SS_LDS_MAX)
 		ring--;
 	a.ring = ring;
+	{
+		const char *order_env = getenv("VIPS_HIP_STREAM_ORDER");
+		a.order = order_env ? atoi(order_env) : 1;
+	}
 	const size_t lds = ring * in_bytes + x_bytes;
 	if (lds > (size_t) SS_LDS_MAX)
 		return 1;

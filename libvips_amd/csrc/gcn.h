@@ -49,6 +49,34 @@ VH_DEV void gstore128(gptr_out p, const unsigned int (&w)[4])
 	const gcn_uint4 v = { w[0], w[1], w[2], w[3] };
 	*(gcn_uint4 __attribute__((address_space(1), aligned(4))) *) p = v;
 }
+// N dwords (1..4) at a 4-byte aligned offset / address: one global_load / global_store _dword[xN]
+template <int N>
+VH_DEV void gload_dwords(gptr_in base, unsigned int off, unsigned int (&w)[N])
+{
+	if constexpr (N == 1)
+		w[0] = gload32(base, off);
+	else {
+		typedef unsigned int gcn_uintn __attribute__((ext_vector_type(N)));
+		const gcn_uintn v = *(const gcn_uintn __attribute__((address_space(1), aligned(4))) *) (base + off);
+#pragma unroll
+		for (int i = 0; i < N; i++)
+			w[i] = v[i];
+	}
+}
+template <int N>
+VH_DEV void gstore_dwords(gptr_out p, const unsigned int (&w)[N])
+{
+	if constexpr (N == 1)
+		*(unsigned int __attribute__((address_space(1))) *) p = w[0];
+	else {
+		typedef unsigned int gcn_uintn __attribute__((ext_vector_type(N)));
+		gcn_uintn v;
+#pragma unroll
+		for (int i = 0; i < N; i++)
+			v[i] = w[i];
+		*(gcn_uintn __attribute__((address_space(1), aligned(4))) *) p = v;
+	}
+}
 VH_DEV unsigned char gload8(gptr_in base, unsigned int off) { return base[off]; }
 VH_DEV unsigned int gload16(gptr_in base, unsigned int off)
 {

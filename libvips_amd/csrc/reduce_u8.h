@@ -46,5 +46,7 @@ int reduceh16_stream_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsH
 	const short *table);
 int shrinkv16_stream_try(int vshrink, const VipsHipRegion *in, const VipsHipRegion *out);
 int shrinkh16_stream_try(int hshrink, const VipsHipRegion *in, const VipsHipRegion *out);
+// shrinkh_u8.hip: vips_shrinkh on uchar, packed bytes (whole rows); 1 = handled, 0 = not its case
+int shrinkh_u8_stream_try(int hshrink, const VipsHipRegion *in, const VipsHipRegion *out);
 
 } // namespace vh

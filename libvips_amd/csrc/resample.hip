@@ -843,6 +843,13 @@ static int shrink_gen(const char *domain, int shrink, const VipsHipRegion *in,
 		if (done > 0)
 			return 0;
 	}
+	if (fmt == VIPS_HIP_FORMAT_UCHAR && !vertical) {
+		int done = shrinkh_u8_stream_try(shrink, in, out);
+		if (done < 0)
+			return -1;
+		if (done > 0)
+			return 0;
+	}
 	if (fmt == VIPS_HIP_FORMAT_USHORT) {
 		int done = vertical ? shrinkv16_stream_try(shrink, in, out) : shrinkh16_stream_try(shrink, in, out);
 		if (done < 0)

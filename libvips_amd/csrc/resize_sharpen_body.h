@@ -138,6 +138,12 @@ VH_DEV double rsh_div(double a, double y, double r)
 	return __builtin_fma(e, r, q0);
 }
 #define RSH_DIV(A, Y) rsh_div((A), (Y), 1.0 / (Y))
+// (float) ((double) a / c) for the XYZ of a uchar pixel: see colour_device.h quant_div_finite
+#define rsh_quant(A, C) rsh_quant_((A), (float) (1.0 / (C)), (float) (1.0 / (C) - (double) (float) (1.0 / (C))))
+VH_DEV float rsh_quant_(float a, float rhi, float rlo)
+{
+	return __builtin_fmaf(a, rhi, a * rlo);
+}
 VH_DEV float rsh_divf100(float a)
 {
 	const float r = 1.0f / 100.0f;
@@ -306,9 +312,10 @@ static __device__ __forceinline__ void resize_sharpen_body(const RshArgs &a, con
 		const float Y = (0.2126F * Rl + 0.7152F * Gl) + 0.0722F * Bl;
 		const float Z = (0.0193F * Rl + 0.1192F * Gl) + 0.9505F * Bl;
 		// XYZ2Lab.c:109-138: nX = QUANT_ELEMENTS * X / X0 in double, to float; index, fraction, lerp
-		const float n0 = (float) RSH_DIV((double) (100000.0f * X), 95.0470);
-		const float n1 = (float) RSH_DIV((double) (100000.0f * Y), 100.0);
-		const float n2 = (float) RSH_DIV((double) (100000.0f * Z), 108.8827);
+		// (the double quotient in two float operations: colour_device.h quant_div_finite)
+		const float n0 = rsh_quant(100000.0f * X, 95.0470);
+		const float n1 = rsh_quant(100000.0f * Y, 100.0);
+		const float n2 = rsh_quant(100000.0f * Z, 108.8827);
 		const int i0 = min(max((int) n0, 0), CBRT_N - 2);
 		const int i1 = min(max((int) n1, 0), CBRT_N - 2);
 		const int i2 = min(max((int) n2, 0), CBRT_N - 2);

@@ -42,6 +42,10 @@ VH_DEV unsigned int gload32(gptr_in base, unsigned int off)
 VH_DEV void gload64(gptr_in base, unsigned int off, unsigned int (&w)[2]) { memcpy(w, base + off, 8); }
 VH_DEV void gload128(gptr_in base, unsigned int off, unsigned int (&w)[4]) { memcpy(w, base + off, 16); }
 VH_DEV void gstore128(gptr_out p, const unsigned int (&w)[4]) { memcpy(p, w, 16); }
+template <int N>
+VH_DEV void gload_dwords(gptr_in base, unsigned int off, unsigned int (&w)[N]) { memcpy(w, base + off, 4 * N); }
+template <int N>
+VH_DEV void gstore_dwords(gptr_out p, const unsigned int (&w)[N]) { memcpy(p, w, 4 * N); }
 VH_DEV unsigned char gload8(gptr_in base, unsigned int off) { return base[off]; }
 VH_DEV unsigned int gload16(gptr_in base, unsigned int off)
 {
