@@ -46,6 +46,9 @@ int reduceh16_stream_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsH
 	const short *table);
 int shrinkv16_stream_try(int vshrink, const VipsHipRegion *in, const VipsHipRegion *out);
 int shrinkh16_stream_try(int hshrink, const VipsHipRegion *in, const VipsHipRegion *out);
+// reduceh_u8.hip: vips_reduceh on uchar with one coefficient row and first taps 4 or 8 pixels apart,
+// packed bytes (whole rows); 1 = handled, 0 = not its case
+int reduceh_u8p_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out, int tile);
 // shrinkh_u8.hip: vips_shrinkh on uchar, packed bytes (whole rows); 1 = handled, 0 = not its case
 int shrinkh_u8_stream_try(int hshrink, const VipsHipRegion *in, const VipsHipRegion *out);
 

@@ -162,7 +162,8 @@ class TestStreamOnGpu(object):
 
         want = run(ref_op)
         os.environ["VIPS_HIP_BUDGET"] = "300k"
-        os.environ["VIPS_HIP_HOST_BUDGET"] = "%d" % max(48 * 1024, want.nbytes // 6)
+        host_budget = max(48 * 1024, want.nbytes // 6)
+        os.environ["VIPS_HIP_HOST_BUDGET"] = "%d" % host_budget
         before, s0 = module.vips_hip_module_strips_done(), _stats(module, 1)
         try:
             got = run(hip_op)
@@ -173,7 +174,7 @@ class TestStreamOnGpu(object):
         assert module.vips_hip_module_strips_done() - before >= 3, "not strip-mined"
         assert got.shape == want.shape and got.dtype == want.dtype
         assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
-        assert s1[0] - s0[1] < want.nbytes // 2, ("host peak", s1, s0, want.nbytes)
+        assert s1[0] - s0[1] <= host_budget, ("host peak over the budget", s1, s0, want.nbytes)
         assert s1[1] == s0[1], "host memory not given back"
 
     def test_random_access_over_a_ring(self):

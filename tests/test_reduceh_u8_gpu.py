@@ -1,0 +1,44 @@
+"""GPU: the packed-byte vips_reduceh on uchar (libvips_amd/csrc/reduceh_u8.hip) against the compiled
+reference, whole image, bit for bit -- the cases of tests/test_emul_reduceh_u8.py on the device, plus
+larger images and the two-axis vips_reduce on 3 bands that now ends in it."""
+import numpy as np
+import pytest
+
+import libvips_amd
+from libvips_amd import Image
+from tests import helpers
+from tests.test_emul_reduceh_u8 import CASES
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not helpers.have_ref(), reason="oracle/_ref missing")]
+
+
+@pytest.mark.parametrize("w,h,bands,shrink,kernel,gate", CASES + [(8192, 300, 3, 8.0, "lanczos3", "reduceh_u8_packed"),
+                                                                  (16384, 70, 4, 4.0, "lanczos3", "reduceh_u8_packed")])
+def test_reduceh_u8_vs_reference(w, h, bands, shrink, kernel, gate):
+    lib = libvips_amd.lib
+    src = helpers.lcg_image(w, h, bands, np.uint8, 11 + w)
+    src[: h // 3, : w // 2] = 255
+    src[h // 3: h // 2, w // 2:] = 0
+    im = Image.new_from_array(src)
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    got = im.reduceh(shrink, kernel=kernel).numpy()
+    report = libvips_amd.gate_report()
+    lib.vips_hip_gate_enable(0)
+    want = helpers.Ref.run_chain("reduceh:hshrink=%r,kernel=%s" % (shrink, kernel), src)
+    assert list(report) == [gate], report
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert np.array_equal(got, want)
+
+
+def test_reduce_rgb_both_axes():
+    src = helpers.lcg_image(4096, 2048, 3, np.uint8, 3)
+    lib = libvips_amd.lib
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    got = Image.new_from_array(src).reduce(8.0, 8.0).numpy()
+    report = libvips_amd.gate_report()
+    lib.vips_hip_gate_enable(0)
+    want = helpers.Ref.run_chain("reduce:hshrink=8.0,vshrink=8.0", src)
+    assert "reduceh_u8_packed" in report, report
+    assert np.array_equal(got, want)

@@ -7,7 +7,7 @@
 
 #define REP8(X) X X X X X X X X
 
-// 8 independent chains per lane, 8 instructions per turn of the loop
+// 8 independent chains per lane, 8 x 8 instructions per turn of the loop
 template <int OP>
 __global__ void k(double *out, int n, double seed)
 {
@@ -25,6 +25,8 @@ __global__ void k(double *out, int n, double seed)
 	typedef float vf4 __attribute__((ext_vector_type(4)));
 	vf4 q0 = { 0, 0, 0, 0 };
 	for (int it = 0; it < n; it++) {
+#pragma unroll
+	for (int rep = 0; rep < 8; rep++) {
 		if (OP == 0) { // v_fma_f64
 #define I(A) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(A) : "v"(y), "v"(x));
 			I(a0) I(a1) I(a2) I(a3) I(a4) I(a5) I(a6) I(a7)
@@ -105,6 +107,7 @@ __global__ void k(double *out, int n, double seed)
 #undef I
 		}
 	}
+	}
 	out[blockIdx.x * blockDim.x + threadIdx.x] =
 		a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7 + sacc;
 }
@@ -117,7 +120,7 @@ void run(const char *name)
 	hipEvent_t a, b;
 	hipEventCreate(&a);
 	hipEventCreate(&b);
-	const int n = 2048;
+	const int n = 256;
 	double cyc[2];
 	for (int mode = 0; mode < 2; mode++) {
 		// mode 0: 8 waves per SIMD (2048 blocks of 256 over 256 CUs); mode 1: one wave per SIMD
@@ -130,7 +133,7 @@ void run(const char *name)
 		hipEventSynchronize(b);
 		float ms;
 		hipEventElapsedTime(&ms, a, b);
-		const double wi = (double) blocks * 4 / 1024 * n * 8; // wave-instructions per SIMD
+		const double wi = (double) blocks * 4 / 1024 * n * 64; // wave-instructions per SIMD
 		cyc[mode] = ms * 1e6 / wi * 2.4;
 	}
 	printf("%-28s %6.2f cycles per wave-instr per SIMD (8 waves), %6.2f (1 wave)\n", name, cyc[0], cyc[1]);
