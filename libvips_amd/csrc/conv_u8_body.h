@@ -118,11 +118,8 @@ VH_DEV void cu8_load(const Cu8Args &a, int row, int px0, unsigned int (&w)[B])
 {
 	const int rc = min(max(row, 0), a.height - 1);
 	const gptr_in line = gptr_in_of((unsigned long long) a.in) + (long long) rc * a.in_stride;
-	if (px0 >= 0 && px0 + 4 <= a.width) {
-#pragma unroll
-		for (int d = 0; d < B; d++)
-			w[d] = gload32(line, (unsigned int) (px0 * B + 4 * d));
-	}
+	if (px0 >= 0 && px0 + 4 <= a.width)
+		gload_dwords<B>(line, (unsigned int) (px0 * B), w); // (one load of B dwords, not B loads 4 B apart)
 	else {
 #pragma unroll
 		for (int d = 0; d < B; d++) {
@@ -143,11 +140,8 @@ template <int B>
 VH_DEV void cu8_store(const Cu8Args &a, int row, int px0, int px_end, const unsigned int (&w)[B])
 {
 	const gptr_out line = gptr_out_of((unsigned long long) a.out) + (long long) row * a.out_stride;
-	if (px0 + 4 <= px_end) {
-#pragma unroll
-		for (int d = 0; d < B; d++)
-			gstore32(line + (px0 * B + 4 * d), w[d]);
-	}
+	if (px0 + 4 <= px_end)
+		gstore_dwords<B>(line + px0 * B, w);
 	else {
 #pragma unroll
 		for (int d = 0; d < B; d++)
