@@ -1445,6 +1445,13 @@ hip_twin_header(VipsHipOp *op, VipsImage *out)
 		return -1;
 	vips_argument_map(VIPS_OBJECT(op), hip_copy_argument, twin, NULL);
 	if (vips_object_build(VIPS_OBJECT(twin))) {
+		/* the original's own words (it validates the arguments), under THIS operation's name */
+		char *said = g_strdup(vips_error_buffer());
+
+		vips_error_clear();
+		g_strchomp(said);
+		vips_error(nick, "%s", said);
+		g_free(said);
 		vips_object_unref_outputs(VIPS_OBJECT(twin));
 		g_object_unref(twin);
 		return -1;
