@@ -168,7 +168,8 @@ typedef struct _VipsHipOp {
 
 	/* Evaluation state, all under `lock`. */
 	GMutex lock;
-	GCond cond;             /* the cache changed / the producer has something to do */
+	GCond cond;             /* generate calls wait here: a strip (band) changed state, the evaluation is over */
+	GCond pcond;            /* the strip producer waits here: a new demand, a slot nobody reads any more */
 	gboolean evaluated;
 	gboolean evaluating;    /* a thread is inside hip_eval() (which may wait, lock released, for the
 	                         * strip producer's plan): everybody else waits for it */
@@ -756,7 +757,7 @@ setup_done:
 			}
 			if (cursor >= c->n_items && w < 0)
 				break; /* every strip made, nobody waiting: the device goes back */
-			g_cond_wait(&op->cond, &op->lock);
+			g_cond_wait(&op->pcond, &op->lock);
 			continue;
 		}
 		hip_cache_claim(c, slot, cursor);
@@ -1249,7 +1250,7 @@ hip_cache_get(VipsHipOp *op, int item, int *slot_out)
 	g_mutex_lock(&op->lock);
 	if (item > c->hi_seen) {
 		c->hi_seen = item; /* (the producer may walk further now) */
-		g_cond_broadcast(&op->cond);
+		g_cond_signal(&op->pcond);
 	}
 	for (;;) {
 		if (op->eval_error) {
@@ -1279,9 +1280,10 @@ hip_cache_get(VipsHipOp *op, int item, int *slot_out)
 				hip_fail(nick);
 				return NULL;
 			}
-			if (c->slot_item[s] == item && c->slot_state[s] == HIP_SLOT_ISSUED)
+			if (c->slot_item[s] == item && c->slot_state[s] == HIP_SLOT_ISSUED) {
 				c->slot_state[s] = HIP_SLOT_READY;
-			g_cond_broadcast(&op->cond);
+				g_cond_broadcast(&op->cond);
+			}
 			continue;
 		}
 		if (op->striped) {
@@ -1293,7 +1295,7 @@ hip_cache_get(VipsHipOp *op, int item, int *slot_out)
 				vips_error(nick, "%s", "unable to start the strip producer");
 				return NULL;
 			}
-			g_cond_broadcast(&op->cond);
+			g_cond_signal(&op->pcond);
 			g_cond_wait(&op->cond, &op->lock);
 			c->want[item]--;
 			continue;
@@ -1346,9 +1348,18 @@ hip_cache_get(VipsHipOp *op, int item, int *slot_out)
 static void
 hip_cache_put(VipsHipOp *op, int slot)
 {
+	HipCache *c = op->cache;
+
 	g_mutex_lock(&op->lock);
-	op->cache->slot_pins[slot]--;
-	g_cond_broadcast(&op->cond); /* (the slot may be what the producer is waiting for) */
+	/* the slot is a candidate for eviction again -- news only for whoever waits for a slot, and
+	 * only when the ring is smaller than the result (waking every waiting worker on every tile
+	 * served was a thundering herd: 256 workers, thousands of tiles) */
+	if (--c->slot_pins[slot] == 0 && c->n_slots < c->n_items) {
+		if (op->striped)
+			g_cond_signal(&op->pcond);
+		else
+			g_cond_broadcast(&op->cond);
+	}
 	g_mutex_unlock(&op->lock);
 }
 
@@ -1445,12 +1456,31 @@ hip_twin_header(VipsHipOp *op, VipsImage *out)
 		return -1;
 	vips_argument_map(VIPS_OBJECT(op), hip_copy_argument, twin, NULL);
 	if (vips_object_build(VIPS_OBJECT(twin))) {
-		/* the original's own words (it validates the arguments), under THIS operation's name */
+		/* the original's own words (it validates the arguments); where it names itself, THIS
+		 * operation's name */
 		char *said = g_strdup(vips_error_buffer());
+		char **line = g_strsplit(said, "\n", -1);
+		char *own = g_strdup_printf("%s: ", base);
+		gboolean names_itself = FALSE;
 
-		vips_error_clear();
-		g_strchomp(said);
-		vips_error(nick, "%s", said);
+		for (int i = 0; line[i]; i++)
+			names_itself |= g_str_has_prefix(line[i], own);
+		g_free(own);
+		if (names_itself) /* (else the buffer stays exactly as the original left it) */
+			vips_error_clear();
+		for (int i = 0; names_itself && line[i]; i++) {
+			char *colon = strstr(line[i], ": ");
+
+			if (!line[i][0])
+				continue;
+			if (colon) {
+				*colon = '\0';
+				vips_error(strcmp(line[i], base) == 0 ? nick : line[i], "%s", colon + 2);
+			}
+			else
+				vips_error(nick, "%s", line[i]);
+		}
+		g_strfreev(line);
 		g_free(said);
 		vips_object_unref_outputs(VIPS_OBJECT(twin));
 		g_object_unref(twin);
@@ -1524,6 +1554,7 @@ vips_hip_op_dispose(GObject *gobject)
 	g_mutex_lock(&op->lock);
 	op->producer_quit = TRUE;
 	g_cond_broadcast(&op->cond);
+	g_cond_signal(&op->pcond);
 	g_mutex_unlock(&op->lock);
 	if (op->producer) {
 		g_thread_join(op->producer);
@@ -1566,6 +1597,7 @@ vips_hip_op_init(VipsHipOp *op)
 {
 	g_mutex_init(&op->lock);
 	g_cond_init(&op->cond);
+	g_cond_init(&op->pcond);
 }
 
 /* ------------------------------------------------------------------ subclasses */

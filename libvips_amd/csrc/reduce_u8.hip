@@ -1339,6 +1339,12 @@ int reducev_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsH
 		if (done != 0)
 			return done;
 	}
+	{
+		// a coefficient row per output row: stream down the rows once (resample16.hip)
+		const int done = reducev8_stream_try(const_cast<_VipsHipReduce *>(r), in, out, tile);
+		if (done != 0)
+			return done;
+	}
 	VerticalArgs a;
 	int dw;
 	if (!vertical_args(in, out, &a, &dw))

@@ -12,6 +12,13 @@ reducev16(R16VArgs a)
 }
 
 __global__ void __launch_bounds__(R16_NT)
+reducev8(R16VArgs a)
+{
+	__shared__ unsigned int r16_slot[4];
+	reducev8_block(a, r16_slot);
+}
+
+__global__ void __launch_bounds__(R16_NT)
 shrinkv16(R16VArgs a)
 {
 	shrinkv16_body(a, (int) blockIdx.x, (int) blockIdx.y, (int) gridDim.y);
@@ -42,6 +49,8 @@ static int r16_launch_v(int which, const R16VArgs &a, int gx, int gy)
 {
 	if (which == 0)
 		hipLaunchKernelGGL(reducev16, dim3(gx), dim3(R16_NT), 0, stream(), a);
+	else if (which == 2)
+		hipLaunchKernelGGL(reducev8, dim3(gx), dim3(R16_NT), 0, stream(), a);
 	else
 		hipLaunchKernelGGL(shrinkv16, dim3(gx, gy, 1), dim3(R16_NT), 0, stream(), a);
 	return hipGetLastError() != hipSuccess ? -1 : 0;

@@ -184,6 +184,101 @@ static __device__ __forceinline__ void shrinkv16_body(const R16VArgs &a, int bx,
 	}
 }
 
+// ---- reducev on UCHAR images with a coefficient row per output row (any shrink, any kernel): the
+// same walk down a segment from the same kind of schedule.  A lane owns 8 byte columns (one 8-byte
+// load per row); the pair of rows of a column is one dword of two 16-bit lanes (the bytes zero
+// extended: v_perm), every output row in flight takes its two taps from it with one
+// v_dot2_i32_i16.  Sums start at 2048 (templates.h:152-157's rounding term; no bias: a byte is a
+// non-negative 16-bit value), retire as clip(sum >> 12) to 0 .. 255.  reducev_u8_kernel
+// (reduce_u8.hip) gives a thread one output row and re-reads its n_point input rows through L2.
+static __device__ __forceinline__ void reducev8_body(const R16VArgs &a, int item)
+{
+	const int t = tid();
+	const int strip = item % a.strips, seg = item / a.strips;
+	const int col = strip * (R16_NT * 8) + 8 * t;
+	const bool live = col < a.row_bytes;
+	const unsigned int off = (unsigned int) (live ? col : a.row_bytes - 8);
+	const int ya = seg * a.seg_rows, yb = min(ya + a.seg_rows, a.out_height);
+	const int p0 = uniform_load(a.seg_pairs + 2 * seg), p1 = uniform_load(a.seg_pairs + 2 * seg + 1);
+
+	auto load = [&](int row, unsigned int (&w)[2]) {
+		const int rc = min(max(row, 0), a.in_height - 1);
+		const gptr_in line = gptr_in_of((unsigned long long) a.in) + (long long) rc * a.in_stride;
+		gload64(line, off, w);
+	};
+	unsigned int raw[R16_PF][2][2];
+#pragma unroll
+	for (int k = 0; k < R16_PF; k++) {
+		load(a.r_base + 2 * (p0 + k), raw[k][0]);
+		load(a.r_base + 2 * (p0 + k) + 1, raw[k][1]);
+	}
+	int acc[R16_SLOTS][8];
+#pragma unroll
+	for (int j = 0; j < R16_SLOTS; j++)
+#pragma unroll
+		for (int e = 0; e < 8; e++)
+			acc[j][e] = 0;
+	for (int p = p0; p <= p1; p++) {
+		const R16Pair rec = uniform_load(a.sched + p);
+		// the pair's 8 columns: (row, row + 1) as two 16-bit lanes
+		unsigned int pk[8];
+#pragma unroll
+		for (int e = 0; e < 8; e++)
+			pk[e] = perm(raw[0][1][e >> 2], raw[0][0][e >> 2], 0x0c000c00u | (unsigned int) (e & 3) | ((4u + (e & 3)) << 16));
+#pragma unroll
+		for (int k = 0; k + 1 < R16_PF; k++)
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				raw[k][h][0] = raw[k + 1][h][0];
+				raw[k][h][1] = raw[k + 1][h][1];
+			}
+		if (p + R16_PF <= p1) {
+			load(a.r_base + 2 * (p + R16_PF), raw[R16_PF - 1][0]);
+			load(a.r_base + 2 * (p + R16_PF) + 1, raw[R16_PF - 1][1]);
+		}
+		const unsigned int start = rec.start_mask, ret = rec.ret_mask;
+#pragma unroll
+		for (int j = 0; j < R16_SLOTS; j++) {
+			if (start & (1u << j)) {
+				const int v = rec.init[j];
+#pragma unroll
+				for (int e = 0; e < 8; e++)
+					acc[j][e] = v;
+			}
+			const unsigned int c2 = rec.c2[j];
+#pragma unroll
+			for (int e = 0; e < 8; e++)
+				acc[j][e] = dot2(pk[e], c2, acc[j][e]);
+			if (ret & (1u << j)) {
+				const int y = rec.yret[j];
+				if (y >= ya && y < yb && live) {
+					unsigned int o[2] = { 0, 0 };
+#pragma unroll
+					for (int e = 0; e < 8; e++) {
+						int v = acc[j][e] >> 12;
+						opaque(v); // (shift and clamp kept apart: v_ashr_pk_u8_i32, NOTES 3.1 "toolchain findings")
+						o[e >> 2] |= (unsigned int) min(max(v, 0), 255) << (8 * (e & 3));
+					}
+					const gptr_out line = gptr_out_of((unsigned long long) a.out) + (long long) y * a.out_stride;
+					gstore32(line + col, o[0]);
+					gstore32(line + col + 4, o[1]);
+				}
+			}
+		}
+	}
+}
+
+static __device__ __forceinline__ void reducev8_block(const R16VArgs &a, unsigned int *lds)
+{
+	int *slot = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(lds) + a.off_slot);
+	for (;;) {
+		const int item = next_item(a.counter, slot);
+		if (item >= a.strips * a.segs)
+			return;
+		reducev8_body(a, item);
+	}
+}
+
 static __device__ __forceinline__ void reducev16_block(const R16VArgs &a, unsigned int *lds)
 {
 	int *slot = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(lds) + a.off_slot);

@@ -61,13 +61,14 @@ int r16_counter(int **counter)
 
 // the schedule of a vertical reduce to `out_height` rows in segments of seg_rows: built once per plan
 // and segment height, kept with the plan's other device tables (pos_cache, freed with the plan)
-const R16Sched *r16_schedule(_VipsHipReduce *r, int out_height, int tile, int seg_rows)
+// (bias: what a sample is stored less -- 32768 for the ushort kernel's signed 16-bit lanes, 0 for bytes)
+const R16Sched *r16_schedule(_VipsHipReduce *r, int out_height, int tile, int seg_rows, unsigned int bias = 32768u)
 {
 	static std::mutex mutex;
 	static std::map<const void *, R16Sched> host; // by device blob
 	std::lock_guard<std::mutex> lock(mutex);
 	std::lock_guard<std::mutex> plan_lock(r->mutex);
-	const auto key = std::make_tuple(-16 - seg_rows, out_height, tile);
+	const auto key = std::make_tuple((bias ? -16 : -(1 << 24)) - seg_rows, out_height, tile);
 	auto it = r->pos_cache.find(key);
 	if (it != r->pos_cache.end()) {
 		auto h = host.find(it->second);
@@ -110,7 +111,7 @@ const R16Sched *r16_schedule(_VipsHipReduce *r, int out_height, int tile, int se
 			sched[p].c2[slot] = lo | (hi << 16);
 		}
 		sched[ps].start_mask |= 1u << slot;
-		sched[ps].init[slot] = (int) (2048u + 32768u * (unsigned int) csum);
+		sched[ps].init[slot] = (int) (2048u + bias * (unsigned int) csum);
 		sched[pe].ret_mask |= 1u << slot;
 		sched[pe].yret[slot] = y;
 		const int seg = y / seg_rows;
@@ -143,14 +144,14 @@ const R16Sched *r16_schedule(_VipsHipReduce *r, int out_height, int tile, int se
 	return &host[blob];
 }
 
-void r16_v_geometry(R16VArgs *a, const VipsHipRegion *in, const VipsHipRegion *out, int seg_rows)
+void r16_v_geometry(R16VArgs *a, const VipsHipRegion *in, const VipsHipRegion *out, int seg_rows, int elem_bytes = 2)
 {
 	memset(a, 0, sizeof(*a));
 	a->in = (const unsigned char *) in->data;
 	a->out = (unsigned char *) out->data;
 	a->in_stride = (long long) in->stride;
 	a->out_stride = (long long) out->stride;
-	a->row_bytes = in->width * in->bands * 2;
+	a->row_bytes = in->width * in->bands * elem_bytes;
 	a->in_height = in->height;
 	a->out_height = out->height;
 	a->strips = (a->row_bytes + R16_NT * 8 - 1) / (R16_NT * 8);
@@ -199,6 +200,41 @@ int reducev16_stream_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsH
 	const int items = a.strips * a.segs;
 	Gate gate("reducev_u16_stream");
 	const int rc = r16_launch_v(0, a, items < 256 * 8 ? items : 256 * 8, 1);
+	vips_hip_free(a.counter);
+	return rc ? -1 : 1;
+}
+
+// the same walk for uchar images whose rows take a coefficient row each (a fractional shrink)
+int reducev8_stream_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out, int tile)
+{
+	if (getenv("VIPS_HIP_NO_STREAM8"))
+		return 0;
+	if (in->format != VIPS_HIP_FORMAT_UCHAR || out->format != VIPS_HIP_FORMAT_UCHAR || in->bands != out->bands ||
+		in->bands < 1 || in->bands > 4)
+		return 0;
+	if (in->left || in->top || out->left || out->top || in->width != in->im_width || in->height != in->im_height ||
+		out->width != out->im_width || out->height != out->im_height || in->width != out->width)
+		return 0;
+	if ((((uintptr_t) in->data | in->stride | (uintptr_t) out->data | out->stride) & 3) || (in->width * in->bands) % 8)
+		return 0;
+	const int strips = (in->width * in->bands + R16_NT * 8 - 1) / (R16_NT * 8);
+	int min_rows = (int) (4.0 * r->n_point / r->shrink) + 1;
+	const int seg_rows = r16_seg_rows(out->height, strips, min_rows);
+	const R16Sched *s = r16_schedule(r, out->height, tile, seg_rows, 0u);
+	if (!s)
+		return -1;
+	if (!s->ok)
+		return 0;
+	R16VArgs a;
+	r16_v_geometry(&a, in, out, seg_rows, 1);
+	a.r_base = s->r_base;
+	a.sched = s->d_sched;
+	a.seg_pairs = s->d_seg_pairs;
+	if (r16_counter(&a.counter))
+		return -1;
+	const int items = a.strips * a.segs;
+	Gate gate("reducev_u8_stream");
+	const int rc = r16_launch_v(2, a, items < 256 * 8 ? items : 256 * 8, 1);
 	vips_hip_free(a.counter);
 	return rc ? -1 : 1;
 }

@@ -629,12 +629,23 @@ void vips_hip_free(void *ptr)
 
 // Pinned host memory is expensive to make (the pages are locked and mapped: ~0.1 s per GiB), and
 // the strip loop of the libvips module wants the same few staging buffers for every evaluation:
-// freed blocks are kept -- a handful, by exact size -- and handed out again.
+// freed blocks are kept -- a handful, by exact size -- and handed out again.  The cache is what a
+// long-running libvips process keeps page-locked between evaluations, so it is small: the two
+// staging buffers and the ring slots of one strip loop under the module's default budgets
+// ($VIPS_HIP_POOL_PINNED bytes overrides it; vips_hip_pool_trim() empties it).
 static std::mutex &g_pinned_mutex = *new std::mutex;
 static std::unordered_map<void *, size_t> &g_pinned_live = *new std::unordered_map<void *, size_t>;
 static std::vector<std::pair<size_t, void *>> &g_pinned_free = *new std::vector<std::pair<size_t, void *>>;
 constexpr size_t PINNED_CACHE_BLOCKS = 8;
-constexpr size_t PINNED_CACHE_BYTES = (size_t) 16 << 30;
+static size_t pinned_cache_bytes()
+{
+	static const size_t v = [] {
+		const char *e = getenv("VIPS_HIP_POOL_PINNED");
+		const long long n = e ? atoll(e) : 0;
+		return n > 0 ? (size_t) n : (size_t) 4 << 30;
+	}();
+	return v;
+}
 
 void *vips_hip_malloc_host(size_t size)
 {
@@ -674,7 +685,7 @@ void vips_hip_free_host(void *ptr)
 			size_t total = 0;
 			for (auto &b : g_pinned_free)
 				total += b.first;
-			while (g_pinned_free.size() > PINNED_CACHE_BLOCKS || total > PINNED_CACHE_BYTES) {
+			while (g_pinned_free.size() > PINNED_CACHE_BLOCKS || total > pinned_cache_bytes()) {
 				total -= g_pinned_free.front().first;
 				drop.push_back(g_pinned_free.front().second);
 				g_pinned_free.erase(g_pinned_free.begin());

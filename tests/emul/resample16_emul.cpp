@@ -41,6 +41,8 @@ static int r16_launch_v(int which, const R16VArgs &a, int gx, int gy)
 	r16_run(gx * gy, 64, [&](int wg, unsigned int *l) {
 		if (which == 0)
 			reducev16_block(a, l);
+		else if (which == 2)
+			reducev8_block(a, l);
 		else
 			shrinkv16_body(a, wg % gx, wg / gx, gy);
 	});

@@ -1,0 +1,37 @@
+"""GPU: the streaming vertical reduce on uchar with a coefficient row per output row
+(resample16.hip reducev8) against the compiled reference, whole image, bit for bit -- the cases of
+tests/test_emul_reducev8.py on the device, plus a large image and the two-axis fractional reduce."""
+import numpy as np
+import pytest
+
+import libvips_amd
+from libvips_amd import Image
+from tests import helpers
+from tests.test_emul_reducev8 import CASES
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not helpers.have_ref(), reason="oracle/_ref missing")]
+
+
+@pytest.mark.parametrize("w,h,bands,shrink,kernel,gate", CASES + [(8192, 2100, 3, 7.3, "lanczos3", "reducev_u8_stream")])
+def test_reducev8_vs_reference(w, h, bands, shrink, kernel, gate):
+    lib = libvips_amd.lib
+    src = helpers.lcg_image(w, h, bands, np.uint8, 11 + w)
+    src[: h // 3, : w // 2] = 255
+    src[h // 3: h // 2, w // 2:] = 0
+    im = Image.new_from_array(src)
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    got = im.reducev(shrink, kernel=kernel).numpy()
+    report = libvips_amd.gate_report()
+    lib.vips_hip_gate_enable(0)
+    want = helpers.Ref.run_chain("reducev:vshrink=%r,kernel=%s" % (shrink, kernel), src)
+    assert list(report) == [gate], report
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert np.array_equal(got, want)
+
+
+def test_reduce_fractional_both_axes():
+    src = helpers.lcg_image(4096, 2048, 3, np.uint8, 3)
+    got = Image.new_from_array(src).reduce(7.3, 7.3).numpy()
+    want = helpers.Ref.run_chain("reduce:hshrink=7.3,vshrink=7.3", src)
+    assert np.array_equal(got, want)
