@@ -48,6 +48,31 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector / matrix peak
+
+
+def fp64_stream_tflops():
+    """What a bare stream of independent v_fma_f64 reaches on this part, from the committed probe
+    (tools/valu_probe2.hip -> profiles/r04_valu_probe2.txt: cycles at 2.4 GHz per wave64
+    instruction per SIMD, 8 waves per SIMD): 128 flops per instruction x 1024 SIMDs.  A second
+    denominator beside the spec sheet's 78.6 for the two FP64-bound configurations; None when the
+    probe's output is not there."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_valu_probe2.txt")
+    try:
+        for line in open(path):
+            if line.startswith("v_fmac_f64 sgpr"):  # (the form the kernels issue: a scalar coefficient)
+                cycles = float(line.split()[2])
+                return round(128.0 / (cycles / 2.4e9) * 1024 / 1e12, 1)
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
+def with_fp64_stream(entry):
+    rate = fp64_stream_tflops()
+    if rate and entry.get("tflops"):
+        entry["fp64_stream_tflops"] = rate
+        entry["frac_of_fp64_stream"] = round(entry["tflops"] / rate, 4)
+    return entry
 M32 = 0xFFFFFFFF
 _LCG_TABLES = {}
 
@@ -675,7 +700,7 @@ def run_c3(ctx, steps, warmup, verify=True, cpu=True, size=32768):
                                                   what="%d rows x %d x 3 f32 of the same image, whole pipeline" % (srows, n))
     del im, src, out
     ctx.trim()
-    return entry
+    return with_fp64_stream(entry)
 
 
 # ------------------------------------------------------------------------------------- C4
@@ -897,7 +922,7 @@ def run_c5slab(ctx, steps, warmup, verify=True, cpu=True, width=65536, rows=8192
                                 "sample": "%d rows of it, best of 3, VIPS_CONCURRENCY=1" % rows1}}
     del window, out
     ctx.trim()
-    return entry
+    return with_fp64_stream(entry)
 
 
 def run_c5(ctx, steps, warmup, verify=True, width=65536, im_height=65536):
@@ -987,7 +1012,7 @@ def c5_entry(line):
     """The whole-image C5 line (world 1: the 65536 x 65536 image as ONE strip on this GPU) as a
     configs[] entry next to the slab."""
     roof = line["roofline"]
-    return {
+    return with_fp64_stream({
         "name": "c5",
         "workload": line["config"]["workload"] + " -- the WHOLE image on one GPU (25.8 GB in + out)",
         "ms": line["ms_per_step"],
@@ -1000,7 +1025,7 @@ def c5_entry(line):
         "frac_hbm": round(roof["algorithmic_bytes"] / (line["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "dtype": "f64 sums -> f32",
         "parity": line["parity"],
-    }
+    })
 
 
 # ------------------------------------------------------------------------------------- ops
