@@ -211,6 +211,16 @@ int conv_image(VipsHipImage *in, VipsHipImage **out, const double *mask, int mw,
 			return 0;
 		}
 	}
+	// ushort, integer precision, a mask up to 5 x 5: the streaming kernel on 16-bit lanes (conv_u16.hip)
+	if (in->format == VIPS_HIP_FORMAT_USHORT && precision == VIPS_HIP_PRECISION_INTEGER && (mh > 1 || mw > 1)) {
+		const int r = vh::conv_u16_2d_try(in, o.im, c.get());
+		if (r < 0)
+			return -1;
+		if (r == 0) {
+			*out = o.release();
+			return 0;
+		}
+	}
 	VipsHipRegion ri, ro;
 	vips_hip_image_region(in, &ri);
 	vips_hip_image_region(o.im, &ro);
