@@ -10,6 +10,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 namespace vh {
@@ -69,14 +71,25 @@ int conv_u16_2d_try(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipC
 			return 1;
 		a.mult = (unsigned int) m;
 		a.shift = l - 1;
-		// the identity, where it could break: around every multiple of the scale up to 2^31 (sampled when there are many)
-		const unsigned long long top = (1ULL << 31) - 1;
-		const unsigned long long step = top / scale > 200000 ? (top / scale) / 200000 : 1;
-		for (unsigned long long k = 1; k * scale <= top; k += step)
-			for (unsigned long long x = k * scale - 1; x <= k * scale && x <= top; x++)
-				if ((unsigned int) (((unsigned long long) (unsigned int) x * m) >> 32) >> a.shift != (unsigned int) (x / scale))
-					return 1;
-		if ((unsigned int) ((top * m) >> 32) >> a.shift != (unsigned int) (top / scale))
+		// the identity, where it could break: around every multiple of the scale up to 2^31 (sampled when
+		// there are many); once per scale and process
+		static std::mutex mutex;
+		static std::map<unsigned int, bool> checked;
+		std::lock_guard<std::mutex> lock(mutex);
+		auto it = checked.find(scale);
+		if (it == checked.end()) {
+			bool ok = true;
+			const unsigned long long top = (1ULL << 31) - 1;
+			const unsigned long long step = top / scale > 200000 ? (top / scale) / 200000 : 1;
+			for (unsigned long long k = 1; k * scale <= top && ok; k += step)
+				for (unsigned long long x = k * scale - 1; x <= k * scale && x <= top; x++)
+					if ((unsigned int) (((unsigned long long) (unsigned int) x * m) >> 32) >> a.shift != (unsigned int) (x / scale))
+						ok = false;
+			if ((unsigned int) ((top * m) >> 32) >> a.shift != (unsigned int) (top / scale))
+				ok = false;
+			it = checked.emplace(scale, ok).first;
+		}
+		if (!it->second)
 			return 1;
 	}
 	// the dense mask, row by row (zero taps were squeezed out of the plan); output c, window dword j holds the

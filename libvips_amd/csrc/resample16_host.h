@@ -135,7 +135,8 @@ const R16Sched *r16_schedule(_VipsHipReduce *r, int out_height, int tile, int se
 		s.d_sched = (const R16Pair *) ((const unsigned char *) blob + head);
 	}
 	else {
-		blob = upload(&s.ok, 16); // (a placeholder block so that the refusal is cached with the plan too)
+		static const unsigned char placeholder[16] = { 0 };
+		blob = upload(placeholder, sizeof(placeholder)); // (a block so that the refusal is cached with the plan too)
 		if (!blob)
 			return nullptr;
 	}
