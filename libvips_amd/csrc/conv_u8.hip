@@ -5,12 +5,12 @@
 namespace vh {
 
 // H: the mask's half-width when it is at most 4 (coefficient dwords without a tap are compiled out), else -1
-template <int B, int ND, int H>
+template <int B, int ND, int H, bool RG>
 __global__ void __launch_bounds__(256)
 conv_u8_sep(Cu8Args a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned int cu8_lds[];
-	conv_u8_sep_block<B, ND, H>(a, cu8_lds);
+	conv_u8_sep_block<B, ND, H, RG>(a, cu8_lds);
 }
 
 template <int B, int MH, int H>
@@ -39,7 +39,7 @@ static int cu8_go(K kernel, const Cu8Args &a, int grid, size_t lds)
 
 #define CU8_SEP(B, ND, H) \
 	if (bands == B && nd == ND && h == H) \
-		return cu8_go(conv_u8_sep<B, ND, H>, a, grid, lds);
+		return regs || ND == 3 ? cu8_go(conv_u8_sep<B, ND, H, true>, a, grid, lds) : cu8_go(conv_u8_sep<B, ND, H, false>, a, grid, lds);
 #define CU8_SEP_B(B) \
 	CU8_SEP(B, 3, 1) CU8_SEP(B, 3, 2) CU8_SEP(B, 3, -1) CU8_SEP(B, 5, -1) CU8_SEP(B, 7, -1) CU8_SEP(B, 9, -1)
 #define CU8_2D(B, MH, H) \
@@ -49,7 +49,7 @@ static int cu8_go(K kernel, const Cu8Args &a, int grid, size_t lds)
 	CU8_2D(B, 3, 1) CU8_2D(B, 3, 2) CU8_2D(B, 3, -1) CU8_2D(B, 5, 1) CU8_2D(B, 5, 2) CU8_2D(B, 5, -1) \
 	CU8_2D(B, 7, 1) CU8_2D(B, 7, 2) CU8_2D(B, 7, -1)
 
-static int cu8_launch_sep(int bands, int nd, const Cu8Args &a, int grid, size_t lds)
+static int cu8_launch_sep(int bands, int nd, bool regs, const Cu8Args &a, int grid, size_t lds)
 {
 	const int h = nd == 3 && a.half <= 2 ? a.half : -1;
 	CU8_SEP_B(1) CU8_SEP_B(3) CU8_SEP_B(4)

@@ -49,6 +49,7 @@ constexpr int CU8_MAXMH = 7;    // rows of a 2-D mask
 constexpr int CU8_CVEC = 96;    // coefficient dwords: 4 ND (separable) or MH 4 ND (2-D, ND = 3)
 constexpr int CU8_NT = 256;     // threads per block: 4 independent waves
 
+
 struct Cu8Args {
 	const unsigned char *in;
 	unsigned char *out;
@@ -187,10 +188,13 @@ VH_DEV void cu8_window(unsigned int own, unsigned int (&w)[ND])
 }
 
 // ---- separable: both passes.  One work item = a block's 4 wave strips x one segment of rows.
-template <int B, int ND, int H>
+// RG: the lanes' rings of transposed quads in registers (ND quads x B bands x 4 dwords: always for
+// ND = 3; for longer masks it trades registers -- 192 for 3 bands and ND = 9, two waves per SIMD --
+// for the 110 KB of LDS that allowed ONE block of four waves per CU)
+template <int B, int ND, int H, bool RG = true>
 static __device__ __forceinline__ void conv_u8_sep_body(const Cu8Args &a, int item, unsigned int *lds)
 {
-	constexpr bool REGS = ND == 3;
+	constexpr bool REGS = ND == 3 || RG;
 	const int t = tid(), lane = t & 63;
 	const int strip = item % a.strips, seg = item / a.strips;
 	const int X0 = (strip * (CU8_NT / 64) + (t >> 6)) * a.wout;  // the wave's first output column
@@ -378,7 +382,7 @@ static __device__ __forceinline__ void conv_u8_2d_body(const Cu8Args &a, int ite
 }
 
 // a persistent block: work items (strip, segment) until the counter runs out
-template <int B, int ND, int H>
+template <int B, int ND, int H, bool RG = true>
 static __device__ __forceinline__ void conv_u8_sep_block(const Cu8Args &a, unsigned int *lds)
 {
 	int *slot = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(lds) + a.off_slot);
@@ -386,7 +390,7 @@ static __device__ __forceinline__ void conv_u8_sep_block(const Cu8Args &a, unsig
 		const int item = next_item(a.counter, slot);
 		if (item >= a.strips * a.segs)
 			return;
-		conv_u8_sep_body<B, ND, H>(a, item, lds);
+		conv_u8_sep_body<B, ND, H, RG>(a, item, lds);
 	}
 }
 

@@ -14,7 +14,7 @@
 namespace vh {
 
 // defined by the including file; 0 on success
-static int cu8_launch_sep(int bands, int nd, const Cu8Args &a, int grid, size_t lds);
+static int cu8_launch_sep(int bands, int nd, bool regs, const Cu8Args &a, int grid, size_t lds);
 static int cu8_launch_2d(int bands, int mh, const Cu8Args &a, int grid, size_t lds);
 
 namespace {
@@ -134,8 +134,11 @@ int conv_u8_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipC
 		return 1;
 	cu8_cvec(c->coeffi.data(), n, a.hq, nd, a.cvec);
 	cu8_geometry(&a, 4, 8 * a.hq);
-	// LDS: the lanes' private rings for the longer masks (3 quads live in registers)
-	const size_t ring_bytes = nd > 3 ? (size_t) nd * in->bands * CU8_NT * 16 : 0;
+	// the lanes' private rings: in registers (3 quads always; the longer masks unless
+	// $VIPS_HIP_CONV_U8_RING=lds), else in LDS
+	const char *ring_env = getenv("VIPS_HIP_CONV_U8_RING");
+	const bool regs = nd == 3 || !(ring_env && strcmp(ring_env, "lds") == 0);
+	const size_t ring_bytes = regs ? 0 : (size_t) nd * in->bands * CU8_NT * 16;
 	a.off_ring = 0;
 	a.off_slot = (int) ring_bytes;
 	const size_t lds = ring_bytes + 16;
@@ -149,7 +152,7 @@ int conv_u8_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipC
 	if (grid > items)
 		grid = items;
 	Gate gate("conv_u8_sep");
-	const int r = cu8_launch_sep(in->bands, nd, a, grid, lds);
+	const int r = cu8_launch_sep(in->bands, nd, regs, a, grid, lds);
 	vips_hip_free(a.counter);
 	return r;
 }

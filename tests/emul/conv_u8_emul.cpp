@@ -38,7 +38,10 @@ static void cu8_run(const Cu8Args &a, int grid, size_t lds, F block)
 
 #define CU8_SEP(B, ND, H) \
 	if (bands == B && nd == ND && h == H) { \
-		cu8_run(a, grid, lds, [&](unsigned int *l) { conv_u8_sep_block<B, ND, H>(a, l); }); \
+		if (regs || ND == 3) \
+			cu8_run(a, grid, lds, [&](unsigned int *l) { conv_u8_sep_block<B, ND, H, true>(a, l); }); \
+		else \
+			cu8_run(a, grid, lds, [&](unsigned int *l) { conv_u8_sep_block<B, ND, H, false>(a, l); }); \
 		return 0; \
 	}
 #define CU8_SEP_B(B) \
@@ -52,7 +55,7 @@ static void cu8_run(const Cu8Args &a, int grid, size_t lds, F block)
 	CU8_2D(B, 3, 1) CU8_2D(B, 3, 2) CU8_2D(B, 3, -1) CU8_2D(B, 5, 1) CU8_2D(B, 5, 2) CU8_2D(B, 5, -1) \
 	CU8_2D(B, 7, 1) CU8_2D(B, 7, 2) CU8_2D(B, 7, -1)
 
-static int cu8_launch_sep(int bands, int nd, const Cu8Args &a, int grid, size_t lds)
+static int cu8_launch_sep(int bands, int nd, bool regs, const Cu8Args &a, int grid, size_t lds)
 {
 	const int h = nd == 3 && a.half <= 2 ? a.half : -1;
 	CU8_SEP_B(1) CU8_SEP_B(3) CU8_SEP_B(4)

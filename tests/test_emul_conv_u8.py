@@ -85,6 +85,12 @@ def test_gaussblur_and_convsep(tmp_path):
           ("sep", 700, 50, 3, ([1, -3, 9, -3, 1], 5)), ("sep", 260, 40, 1, ([5, 1, 5], 11))], tmp_path)
 
 
+def test_gaussblur_rings_in_lds(tmp_path):
+    # the longer masks' rings of transposed quads in LDS (the default keeps them in registers)
+    _run([("blur", 1028, 150, 3, 4.0), ("blur", 532, 140, 3, 8.0), ("blur", 600, 90, 1, 6.0)], tmp_path,
+         {"VIPS_HIP_CONV_U8_RING": "lds"})
+
+
 def test_gaussblur_short_segments(tmp_path):
     _run([("blur", 1100, 200, 3, 2.0), ("blur", 532, 200, 3, 8.0)], tmp_path, {"VIPS_HIP_CONV_U8_SEG": "3"})
     _run([("blur", 1100, 100, 3, 2.0)], tmp_path, {"VIPS_HIP_CONV_U8_SEG": "1"})
