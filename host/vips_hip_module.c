@@ -685,14 +685,16 @@ hip_producer(void *data)
 	/* two staging buffers, pinned; two input windows and two output strips on the device, kept
 	 * for the whole run */
 	for (int i = 0; i < 2; i++) {
-		if ((!resident && !(stage[i] = (VipsPel *) vips_hip_malloc_host((size_t) max_in_rows * in_ls))) ||
-			!(stream[i] = vips_hip_stream_new()) ||
+		if (!resident) {
+			if (!(stage[i] = (VipsPel *) vips_hip_malloc_host((size_t) max_in_rows * in_ls)))
+				goto setup_done;
+			hip_host_account((gint64) ((guint64) max_in_rows * in_ls));
+		}
+		if (!(stream[i] = vips_hip_stream_new()) ||
 			!(computed[i] = vips_hip_event_new()) || !(uploaded[i] = vips_hip_event_new()) ||
 			!(dev_in[i] = vips_hip_image_new(in->Xsize, max_in_rows, in->Bands, in->BandFmt, in->Type)) ||
 			!(dev_out[i] = vips_hip_image_new(out->Xsize, VIPS_MIN(rows, out->Ysize), out->Bands, out->BandFmt, out->Type)))
 			goto setup_done;
-		if (stage[i])
-			hip_host_account((gint64) ((guint64) max_in_rows * in_ls));
 	}
 	op->device = vips_hip_image_get_device(dev_in[0]);
 	setup = 1;
@@ -1260,6 +1262,7 @@ hip_cache_get(VipsHipOp *op, int item, int *slot_out)
 		}
 		if (vips_image_iskilled(out)) {
 			g_mutex_unlock(&op->lock);
+			vips_error(nick, "%s", "killed");
 			return NULL;
 		}
 		s = c->item_slot[item];
