@@ -99,11 +99,17 @@ print("CHILD-OK")
 
 @pytest.mark.skipif(_gpu_present() or not helpers.have_module() or not _build_mock() or not _build_emul(),
                     reason="a real GPU is present, or the reference / module / mock runtime / emulation cannot be built")
-def test_strips_stream_through_a_bounded_host_ring(tmp_path):
+@pytest.mark.parametrize("devices", [1, 2])
+def test_strips_stream_through_a_bounded_host_ring(tmp_path, devices):
+    """devices = 2: two fake devices dealt round-robin over the threads that never bind themselves
+    ($VIPS_HIP_DEVICES=0,1: libvips' workers AND the strip producers); a producer that is started
+    again for an evicted strip goes back to its first run's device (the slot events live there)."""
     script = os.path.join(str(tmp_path), "child.py")
     with open(script, "w") as f:
         f.write(CHILD % {"root": helpers.ROOT})
     env = dict(os.environ, LD_PRELOAD=MOCK_SO + ":" + EMUL_SO)
+    if devices > 1:
+        env.update(MOCK_HIP_DEVICES=str(devices), VIPS_HIP_DEVICES=",".join(str(d) for d in range(devices)))
     proc = subprocess.run([sys.executable, script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                           env=env, timeout=1800)
     assert proc.returncode == 0 and "CHILD-OK" in proc.stdout, proc.stdout[-3000:]
