@@ -161,10 +161,10 @@ void r16_v_geometry(R16VArgs *a, const VipsHipRegion *in, const VipsHipRegion *o
 	a->off_slot = 0;
 }
 
-int r16_seg_rows(int out_height, int strips, int min_rows)
+int r16_seg_rows(int out_height, int strips, int min_rows, int per_cu = 8)
 {
-	// ~8 blocks of 4 waves per CU
-	int want = (256 * 8 + strips - 1) / strips;
+	// ~per_cu blocks of 4 waves per CU
+	int want = (256 * per_cu + strips - 1) / strips;
 	int seg = (out_height + want - 1) / want;
 	if (seg < min_rows)
 		seg = min_rows;
@@ -219,8 +219,11 @@ int reducev8_stream_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHi
 	if ((((uintptr_t) in->data | in->stride | (uintptr_t) out->data | out->stride) & 3) || (in->width * in->bands) % 8)
 		return 0;
 	const int strips = (in->width * in->bands + R16_NT * 8 - 1) / (R16_NT * 8);
-	int min_rows = (int) (4.0 * r->n_point / r->shrink) + 1;
-	const int seg_rows = r16_seg_rows(out->height, strips, min_rows);
+	// about three blocks per CU (one round of what the kernel's registers let a CU hold), segments not
+	// shorter than twice the rows a segment re-reads: on 8192^2 x 3 by 7.3 segments of 26 / 18 / 13 / 9
+	// / 6 rows ran 0.111 / 0.092 / 0.116 / 0.105 / 0.118 ms (profiles/NOTES.md R4.8)
+	int min_rows = (int) (2.0 * r->n_point / r->shrink) + 1;
+	const int seg_rows = r16_seg_rows(out->height, strips, min_rows, 3);
 	const R16Sched *s = r16_schedule(r, out->height, tile, seg_rows, 0u);
 	if (!s)
 		return -1;
