@@ -40,6 +40,10 @@ struct CbrtBlockD {
 struct CbrtBlockI {
 	int i0, count; // first entry, entries in the block
 };
+// the same block for the single-precision form below
+struct CbrtBlockF {
+	float c0, inv; // (float) cbrt(i0 / 100000), (float) (1 / i0)
+};
 
 // what a kernel keeps in LDS (or reads through these pointers)
 struct CbrtExact {
@@ -47,6 +51,15 @@ struct CbrtExact {
 	const CbrtBlockI *bi;
 	const unsigned int *res;
 	const float *lin; // the 886 entries of the linear arm as they are, or NULL: computed
+	// The single-precision form (round 4): the block polynomial evaluated in float --
+	//     u = (float) j * inv,  p = fma(fma(fma(-10/243, u, 5/81), u, -1/9), u, 1/3),  c = fma(c0, u * p, c0)
+	// (the last operation rounds c0 (1 + u p) once, so the float it makes is within one unit of
+	// the host's cbrtf everywhere, like the double form: measured on the host's table, -1 / 0 / +1 in
+	// 13.5 / 72 / 13.5 % of the entries) and its own 2-bit residuals.  Seven float operations per entry
+	// where the double form takes eight double ones and a conversion, at half their cost each on
+	// this part (tools/valu_probe2.hip).  NULL when this host's cbrtf does not fit it.
+	const CbrtBlockF *bf;
+	const unsigned int *res32;
 };
 
 VH_CBRT_FN unsigned int cbrt_bits(float f)
@@ -83,6 +96,42 @@ VH_CBRT_FN unsigned int cbrt_predict(const CbrtBlockD &bd, const CbrtBlockI &bi,
 {
 	const double u = (double) (i - bi.i0) * bd.inv;
 	return cbrt_bits((float) (bd.c0 * cbrt_poly(u)));
+}
+
+// entry i >= 886 before its residual in the single-precision form: j = i - i0 of its block
+VH_CBRT_FN unsigned int cbrt_predict32(const CbrtBlockF &bf, int j)
+{
+	const float u = (float) j * bf.inv;
+	const float p = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf((float) (-10.0 / 243.0), u, (float) (5.0 / 81.0)), u, (float) (-1.0 / 9.0)), u,
+		(float) (1.0 / 3.0));
+	const float s = u * p;
+	return cbrt_bits(__builtin_fmaf(bf.c0, s, bf.c0));
+}
+
+// cbrt_pair() through the single-precision form (t.bf, t.res32)
+VH_CBRT_FN void cbrt_pair32(const CbrtExact &t, int i, float *t0, float *dt)
+{
+	const float fi = (float) i;
+	int k = (int) (cbrt_bits(fi) >> 18) - CBRT_KEY0;
+	k = k < 0 ? 0 : k;
+	const CbrtBlockF bf = t.bf[k];
+	const CbrtBlockI bi = t.bi[k];
+	const float next_c0 = t.bf[k + 1].c0; // (one block past the last is stored; its entry 0 is c0 itself)
+	const int j = i - bi.i0;
+	const unsigned int p0 = cbrt_predict32(bf, j);
+	const unsigned int p1s = cbrt_predict32(bf, j + 1);
+	const unsigned int p1 = j + 1 < bi.count ? p1s : cbrt_bits(next_c0);
+	const unsigned int w = (unsigned int) i >> 4;
+	const unsigned long long both = ((unsigned long long) t.res32[w + 1] << 32) | t.res32[w];
+	const unsigned int rr = (unsigned int) (both >> (2 * (i & 15)));
+	float v0 = cbrt_float(p0 + (rr & 3u) - 1u), v1 = cbrt_float(p1 + ((rr >> 2) & 3u) - 1u);
+	if (i < CBRT_LINEAR) {
+		v0 = t.lin ? t.lin[i] : cbrt_linear(i);
+		if (i + 1 < CBRT_LINEAR)
+			v1 = t.lin ? t.lin[i + 1] : cbrt_linear(i + 1);
+	}
+	*t0 = v0;
+	*dt = v1 - v0;
 }
 
 // table[i] and table[i + 1] - table[i] for 0 <= i <= 99998

@@ -156,7 +156,51 @@ const CbrtExact *cbrt_exact_tables()
 		}
 		}
 	}
+	// the single-precision form, under the same two checks; left out (kernels take the double form)
+	// when this host's cbrtf does not fit it
+	std::vector<CbrtBlockF> bf(CBRT_BLOCKS + 1);
+	std::vector<unsigned int> res32(CBRT_RES_WORDS, 0x55555555u);
+	bool have32 = !getenv("VIPS_HIP_CBRT_F64");
+	for (int k = 0; k <= CBRT_BLOCKS; k++) {
+		bf[k].c0 = (float) bd[k].c0;
+		bf[k].inv = (float) bd[k].inv;
+	}
+	for (int i = CBRT_LINEAR; i < CBRT_N && have32; i++) {
+		const int k = (int) (cbrt_bits((float) i) >> 18) - CBRT_KEY0;
+		const long long r = (long long) cbrt_bits(cb[i]) - (long long) cbrt_predict32(bf[k], i - bi[k].i0);
+		if (r < -1 || r > 1)
+			have32 = false;
+		else
+			res32[i >> 4] = (res32[i >> 4] & ~(3u << (2 * (i & 15)))) | ((unsigned int) (r + 1) << (2 * (i & 15)));
+	}
+	// (the first entry of a block must be the block's c0 itself: cbrt_pair32 reads it for the pair that straddles)
+	for (int k = 1; k <= CBRT_BLOCKS && have32; k++)
+		if (bi[k].i0 < CBRT_N && cbrt_predict32(bf[k], 0) != cbrt_bits(bf[k].c0))
+			have32 = false;
+	for (int pass = 0; pass < 2 && have32; pass++) {
+		CbrtExact host = { bd.data(), bi.data(), res.data(), pass ? cb.data() : nullptr, bf.data(), res32.data() };
+		for (int i = 0; i + 1 < CBRT_N && have32; i++) {
+			float t0, dt;
+			cbrt_pair32(host, i, &t0, &dt);
+			const float want_dt = cb[i + 1] - cb[i];
+			if (memcmp(&t0, &cb[i], 4) || memcmp(&dt, &want_dt, 4))
+				have32 = false;
+		}
+	}
+	if (getenv("VIPS_HIP_DEBUG_CBRT"))
+		fprintf(stderr, "cbrt_exact_tables: the %s form\n", have32 ? "single-precision" : "double");
 	CbrtExact &t = by_device[dev];
+	t.bf = nullptr;
+	t.res32 = nullptr;
+	if (have32) {
+		t.bf = (const CbrtBlockF *) upload(bf.data(), bf.size() * sizeof(CbrtBlockF));
+		t.res32 = (const unsigned int *) upload(res32.data(), res32.size() * sizeof(unsigned int));
+		if (!t.bf || !t.res32) {
+			t.bf = nullptr;
+			t.res32 = nullptr;
+			vips_hip_error_clear();
+		}
+	}
 	t.bd = (const CbrtBlockD *) upload(bd.data(), bd.size() * sizeof(CbrtBlockD));
 	t.bi = (const CbrtBlockI *) upload(bi.data(), bi.size() * sizeof(CbrtBlockI));
 	t.res = (const unsigned int *) upload(res.data(), res.size() * sizeof(unsigned int));
@@ -268,27 +312,32 @@ colour_route_x4_kernel(RouteArgs a)
 // path per wave instruction, tools/gather_probe.hip), which bounded colour_route_x4_kernel on these
 // routes; here a pixel reads nothing but its own bytes.  Persistent blocks (the tables are copied
 // once per block), 4 pixels per thread, rows dealt round the grid.
-template <typename TIN, bool LABS>
+// F32: the table's single-precision form (cbrt_exact.h), when the host found that its cbrtf fits it
+template <typename TIN, bool LABS, bool F32>
 __global__ void __launch_bounds__(256)
 colour_lab_lds_kernel(RouteArgs a, CbrtExact cx)
 {
 	__shared__ float s_v2Y[256];
 	__shared__ unsigned int s_res[CBRT_RES_WORDS];
-	__shared__ CbrtBlockD s_bd[CBRT_BLOCKS + 1];
+	__shared__ CbrtBlockD s_bd[F32 ? 1 : CBRT_BLOCKS + 1];
+	__shared__ CbrtBlockF s_bf[F32 ? CBRT_BLOCKS + 1 : 1];
 	__shared__ CbrtBlockI s_bi[CBRT_BLOCKS + 1];
 	__shared__ float s_lin[CBRT_LINEAR];
 	const int t = threadIdx.x;
 	s_v2Y[t] = a.tables.v2Y_8[t];
 	for (int i = t; i < CBRT_RES_WORDS; i += 256)
-		s_res[i] = cx.res[i];
+		s_res[i] = F32 ? cx.res32[i] : cx.res[i];
 	for (int i = t; i < CBRT_LINEAR; i += 256)
 		s_lin[i] = cx.lin[i];
 	if (t <= CBRT_BLOCKS) {
-		s_bd[t] = cx.bd[t];
+		if constexpr (F32)
+			s_bf[t] = cx.bf[t];
+		else
+			s_bd[t] = cx.bd[t];
 		s_bi[t] = cx.bi[t];
 	}
 	__syncthreads();
-	const CbrtExact lds = { s_bd, s_bi, s_res, s_lin };
+	const CbrtExact lds = { s_bd, s_bi, s_res, s_lin, s_bf, s_res };
 	const int x4 = blockIdx.x * blockDim.x + t;
 	if (x4 * 4 >= a.width)
 		return;
@@ -316,11 +365,20 @@ colour_lab_lds_kernel(RouteArgs a, CbrtExact cx)
 			const int i1 = min(max(__float2int_rz(n1), 0), CBRT_N - 2);
 			const int i2 = min(max(__float2int_rz(n2), 0), CBRT_N - 2);
 			float t0, dt;
-			cbrt_pair(lds, i0, &t0, &dt);
+			if constexpr (F32)
+				cbrt_pair32(lds, i0, &t0, &dt);
+			else
+				cbrt_pair(lds, i0, &t0, &dt);
 			const float cbx = __fadd_rn(t0, __fmul_rn(__fsub_rn(n0, (float) i0), dt));
-			cbrt_pair(lds, i1, &t0, &dt);
+			if constexpr (F32)
+				cbrt_pair32(lds, i1, &t0, &dt);
+			else
+				cbrt_pair(lds, i1, &t0, &dt);
 			const float cby = __fadd_rn(t0, __fmul_rn(__fsub_rn(n1, (float) i1), dt));
-			cbrt_pair(lds, i2, &t0, &dt);
+			if constexpr (F32)
+				cbrt_pair32(lds, i2, &t0, &dt);
+			else
+				cbrt_pair(lds, i2, &t0, &dt);
 			const float cbz = __fadd_rn(t0, __fmul_rn(__fsub_rn(n2, (float) i2), dt));
 			const float L = __fsub_rn(__fmul_rn(116.0F, cby), 16.0F);
 			const float A = __fmul_rn(500.0F, __fsub_rn(cbx, cby));
@@ -1196,14 +1254,23 @@ int colour_route(const int *steps, int n_steps, double alpha_scale, const VipsHi
 			int gy = (256 * 4 + gx - 1) / gx; // four 34 KB blocks per CU, each walking its share of the rows
 			gy = gy > a.height ? a.height : gy;
 			const dim3 gridp(gx, gy, 1);
+			const bool f32 = cx->bf != nullptr;
+#define LAB_LDS(TIN, LABS) \
+	do { \
+		if (f32) \
+			hipLaunchKernelGGL((colour_lab_lds_kernel<TIN, LABS, true>), gridp, block, 0, stream(), a, *cx); \
+		else \
+			hipLaunchKernelGGL((colour_lab_lds_kernel<TIN, LABS, false>), gridp, block, 0, stream(), a, *cx); \
+	} while (0)
 			if (route_id == 1 && in->format == VIPS_HIP_FORMAT_UCHAR)
-				hipLaunchKernelGGL((colour_lab_lds_kernel<unsigned char, false>), gridp, block, 0, stream(), a, *cx);
+				LAB_LDS(unsigned char, false);
 			else if (route_id == 1)
-				hipLaunchKernelGGL((colour_lab_lds_kernel<float, false>), gridp, block, 0, stream(), a, *cx);
+				LAB_LDS(float, false);
 			else if (in->format == VIPS_HIP_FORMAT_UCHAR)
-				hipLaunchKernelGGL((colour_lab_lds_kernel<unsigned char, true>), gridp, block, 0, stream(), a, *cx);
+				LAB_LDS(unsigned char, true);
 			else
-				hipLaunchKernelGGL((colour_lab_lds_kernel<float, true>), gridp, block, 0, stream(), a, *cx);
+				LAB_LDS(float, true);
+#undef LAB_LDS
 			launched = true;
 		}
 		else
