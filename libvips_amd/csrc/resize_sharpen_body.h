@@ -205,7 +205,11 @@ static __device__ __forceinline__ void resize_sharpen_body(const RshArgs &a, con
 	unsigned int *const CRES = reinterpret_cast<unsigned int *>(lds8 + a.off_cres);
 	CbrtBlockD *const CBD = reinterpret_cast<CbrtBlockD *>(lds8 + a.off_cbd);
 	CbrtBlockI *const CBI = reinterpret_cast<CbrtBlockI *>(lds8 + a.off_cbi);
-	const CbrtExact cbrt = { CBD, CBI, CRES };
+	// (the table's single-precision form when the host made one -- cbrt_exact.h: the blocks' floats
+	// take the place of the doubles, the residuals are that form's)
+	const bool c32 = a.cbrt.bf != nullptr;
+	CbrtBlockF *const CBF = reinterpret_cast<CbrtBlockF *>(lds8 + a.off_cbd);
+	const CbrtExact cbrt = { CBD, CBI, CRES, nullptr, CBF, CRES };
 
 	// block -> (strip, segment, image), the strips of one (segment, image) on one XCD (see resize_stream.hip)
 	int strip, unit;
@@ -244,9 +248,12 @@ static __device__ __forceinline__ void resize_sharpen_body(const RshArgs &a, con
 	for (int i = t; i < a.lut_n; i += NT)
 		LUT[i] = a.lut[i];
 	for (int i = t; i < CBRT_RES_WORDS; i += NT)
-		CRES[i] = a.cbrt.res[i];
+		CRES[i] = c32 ? a.cbrt.res32[i] : a.cbrt.res[i];
 	if (t <= CBRT_BLOCKS) {
-		CBD[t] = a.cbrt.bd[t];
+		if (c32)
+			CBF[t] = a.cbrt.bf[t];
+		else
+			CBD[t] = a.cbrt.bd[t];
 		CBI[t] = a.cbrt.bi[t];
 	}
 
@@ -321,15 +328,24 @@ static __device__ __forceinline__ void resize_sharpen_body(const RshArgs &a, con
 		const int i2 = min(max((int) n2, 0), CBRT_N - 2);
 		const int slot = (NP * sf + r) & (RSH_RING - 1);
 		float t0, dt;
-		cbrt_pair(cbrt, i1, &t0, &dt);
+		if (c32)
+			cbrt_pair32(cbrt, i1, &t0, &dt);
+		else
+			cbrt_pair(cbrt, i1, &t0, &dt);
 		const float cby = t0 + (n1 - (float) i1) * dt;
 		const int L = rsh_labs(116.0F * cby - 16.0F, 32767.0 / 100.0, 0.0);
 		LR[slot * a.l_pitch + u] = (short) L;
 		const int x = u - h;
 		if (x >= 0 && x < nx) {
-			cbrt_pair(cbrt, i0, &t0, &dt);
+			if (c32)
+				cbrt_pair32(cbrt, i0, &t0, &dt);
+			else
+				cbrt_pair(cbrt, i0, &t0, &dt);
 			const float cbx = t0 + (n0 - (float) i0) * dt;
-			cbrt_pair(cbrt, i2, &t0, &dt);
+			if (c32)
+				cbrt_pair32(cbrt, i2, &t0, &dt);
+			else
+				cbrt_pair(cbrt, i2, &t0, &dt);
 			const float cbz = t0 + (n2 - (float) i2) * dt;
 			const int A = rsh_labs(500.0F * (cbx - cby), 32768.0 / 128.0, -32768.0);
 			const int Bv = rsh_labs(200.0F * (cby - cbz), 32768.0 / 128.0, -32768.0);
