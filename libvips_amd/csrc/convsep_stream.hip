@@ -61,6 +61,8 @@
 // Each output sums its taps in mask order in both passes (rows arrive in tap order).
 #include "colour_device.h"
 #include "conv.h"
+#include "convsep_int_body.h"
+#include "convsep_int_host.h"
 
 #include <cmath>
 #include <cstddef>
@@ -74,6 +76,7 @@ constexpr int SS_T = 8;       // rows per step = outputs per thread in the horiz
 constexpr int SS_SLOTS = 32;  // vertical accumulators = longest mask
 constexpr int SS_SLACK = 32;  // staged pixels per plane beyond the strip's own (halo + window over-read)
 constexpr int SS_LDS_MAX = 158 * 1024;
+constexpr bool SS_INT_DEFAULT = true; // the integer horizontal pass unless $VIPS_HIP_STREAM_INT=0
 
 struct StreamArgs {
 	const float *in;
@@ -94,6 +97,11 @@ struct StreamArgs {
 	double offset1, offset2;
 	int *counter;
 	double coef[SS_SLOTS]; // taps in mask order
+	// the integer horizontal pass (convsep_int_body.h): 0 = never, 1 = for waves whose windows hold
+	// nothing but the integers 0 .. 255
+	int int_h;
+	float scale_f, rscale_f;
+	unsigned int coefi[HINT_SETS];
 };
 
 template <int MODE>
@@ -216,6 +224,33 @@ static __device__ __forceinline__ void ss_hpass(const StreamArgs &a, const doubl
 		xd[k * a.bands] = ss_fin<MODE>(hacc[k], a, 1);
 }
 
+// ---- horizontal pass on packed bytes (convsep_int_body.h) when every lane's window holds nothing
+// but the integers 0 .. 255; false (wave-uniform, nothing stored) when one does not
+static __device__ __forceinline__ bool ss_hpass_int(const StreamArgs &a, const unsigned int *kci, const float *base, float *xd)
+{
+	unsigned int w[9], bad = 0;
+#pragma unroll
+	for (int m = 0; m < 9; m++) {
+		const float4v r = *reinterpret_cast<const float4v *>(base + 4 * m);
+		w[m] = hint_pack4(r[0], r[1], r[2], r[3], bad);
+		// (three window quads in flight at a time: the 32 vertical accumulators stay live across this)
+		if (m % 3 == 2)
+			__builtin_amdgcn_sched_barrier(0);
+	}
+	if (__builtin_amdgcn_ballot_w64(bad != 0)) {
+		if (a.int_h != 2)
+			return false;
+		// ($VIPS_HIP_STREAM_INT=2, tests only: a refused window poisons its outputs instead of
+		// taking the double path, so that a clean result proves which path made it)
+#pragma unroll
+		for (int k = 0; k < SS_T; k++)
+			xd[k * a.bands] = __builtin_nanf("");
+		return true;
+	}
+	hint_outputs(w, kci, a.scale_f, a.rscale_f, xd, a.bands);
+	return true;
+}
+
 // ---- vertical pass of the 8 rows of step q (Q4 = q mod 4 fixes the slot rotation).
 // Intermediate row m = 8q + r is tap d of output row m - d, kept in slot (m - d) mod 32.  A slot
 // is handed to a new output row every 32 rows: the row that finished in it (output m - 32,
@@ -279,6 +314,7 @@ convsep_stream(StreamArgs a, RouteArgs route)
 	__shared__ int s_item;
 	__shared__ __attribute__((aligned(16))) double s_coef[SS_SLOTS];
 	__shared__ float s_v2y[EPI == 2 ? 256 : 1]; // the sRGB -> scRGB table of the spelled-out epilogue
+	__shared__ __attribute__((aligned(16))) unsigned int s_coefi[MODE == 1 ? HINT_SETS : 1];
 	const int in_row = a.bands * a.spw;   // floats per staged row (planar per band)
 	const int in_buf = SS_T * in_row;
 	const int x_buf = SS_T * a.w;
@@ -291,6 +327,8 @@ convsep_stream(StreamArgs a, RouteArgs route)
 		s_coef[t] = a.coef[t];
 	if (EPI == 2 && t < 256)
 		s_v2y[t] = route.tables.v2Y_8[t];
+	if (MODE == 1 && t < HINT_SETS)
+		s_coefi[t] = a.coefi[t];
 	const double *kc = s_coef; // (the first barrier of the work loop publishes it)
 	const int E = a.width * a.bands;
 	const int items = a.strips * a.segs;
@@ -374,6 +412,9 @@ convsep_stream(StreamArgs a, RouteArgs route)
 #pragma unroll
 		for (int sl = 0; sl < SS_SLOTS; sl++)
 			acc[sl] = 0.0;
+		// the integer horizontal pass is tried until a window of this wave fails its test (a float
+		// image proper fails in the first phase and pays for one test per work item)
+		int int_ok = MODE == 1 ? a.int_h : 0;
 
 		// The LDS-DMA runs ring - 1 steps ahead of the horizontal pass (one step ahead its
 		// latency showed: 3.4 us per step of fixed cost whatever the mask).  hslot / dslot: the
@@ -486,8 +527,15 @@ convsep_stream(StreamArgs a, RouteArgs route)
 					rows_out, y0, e0, tt, tt < ne);
 			}
 			// ---- horizontal pass of step p
-			if (p < steps && active)
-				ss_hpass<MODE, NG>(a, kc, s_in + hslot * in_buf + h_in_off, s_x + (p & 1) * x_buf + h_x_off);
+			if (p < steps && active) {
+				bool done = false;
+				if (MODE == 1 && int_ok) {
+					done = ss_hpass_int(a, s_coefi, s_in + hslot * in_buf + h_in_off, s_x + (p & 1) * x_buf + h_x_off);
+					int_ok = done;
+				}
+				if (!done)
+					ss_hpass<MODE, NG>(a, kc, s_in + hslot * in_buf + h_in_off, s_x + (p & 1) * x_buf + h_x_off);
+			}
 			hslot = hslot + 1 == a.ring ? 0 : hslot + 1;
 		};
 		for (int p0 = 0; p0 < phases; p0 += 4) {
@@ -615,6 +663,22 @@ int convsep_stream_fused(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 	a.has_scale = a.scale != 1.0;
 	a.offset1 = integer ? (double) c->offset_i : c->offset;
 	a.offset2 = integer ? (double) (int) rint(offset2) : offset2;
+	a.int_h = 0;
+	a.scale_f = a.rscale_f = 1.0f;
+	memset(a.coefi, 0, sizeof(a.coefi));
+	{
+		// $VIPS_HIP_STREAM_INT: 0 = never take the integer horizontal pass, 1 = take it where it applies
+		// (2: and poison what it refuses -- tests)
+		const char *int_env = getenv("VIPS_HIP_STREAM_INT");
+		HintTables ht;
+		if (integer && !fast && (int_env ? atoi(int_env) != 0 : SS_INT_DEFAULT) &&
+			hint_prepare(c->coeffi.data(), n, c->scale_i, c->offset_i, &ht)) {
+			a.int_h = int_env && atoi(int_env) == 2 ? 2 : 1;
+			a.scale_f = ht.scale;
+			a.rscale_f = ht.rscale;
+			memcpy(a.coefi, ht.coefi, sizeof(a.coefi));
+		}
+	}
 
 	// threads per block = widest strip: 768 (168 registers per thread, 3 waves per SIMD; the
 	// compiler spills ~130 registers outside the hot loops).  A 512-thread build (256 registers,
