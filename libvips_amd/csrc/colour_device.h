@@ -109,6 +109,23 @@ static __device__ __forceinline__ float cbrt_lerp(const float *__restrict__ tabl
 	return __fadd_rn(pair.x, __fmul_rn(f, __fsub_rn(pair.y, pair.x)));
 }
 
+// cbrt_lerp<WHICH, true> in two halves, so that a caller can have the table reads of several pixels
+// in flight before it uses the first: the index and fraction, then the interpolation.  The same
+// operations in the same order.
+template <int WHICH>
+static __device__ __forceinline__ int cbrt_index_finite(float v, float &f)
+{
+	const float n = quant_div_finite<WHICH>(__fmul_rn(100000.0f, v));
+	int i = __float2int_rz(n);
+	i = min(max(i, 0), 100000 - 2);
+	f = __fsub_rn(n, (float) i);
+	return i;
+}
+static __device__ __forceinline__ float cbrt_finish(float2 pair, float f)
+{
+	return __fadd_rn(pair.x, __fmul_rn(f, __fsub_rn(pair.y, pair.x)));
+}
+
 template <bool FINITE = false>
 static __device__ __forceinline__ Px step_XYZ2Lab(Px p, const float *__restrict__ table)
 {

@@ -306,7 +306,10 @@ static __device__ __forceinline__ void ss_vpass(const StreamArgs &a, const doubl
 	}
 }
 
-template <int MODE, int NG, int EPI, int SS_NT>
+// EPIF: the form of the colour epilogue -- 0: a thread's pixels one after the other, every wave before its
+// vertical pass; 1: side by side and staggered over the waves of a SIMD (see there).  Form 1 is built, tested
+// and measured for BASELINE config 3's instantiation (integer mask of 29 taps, sRGB -> Lab) only.
+template <int MODE, int NG, int EPI, int SS_NT, int EPIF = 0>
 __global__ void __launch_bounds__(SS_NT)
 convsep_stream(StreamArgs a, RouteArgs route)
 {
@@ -477,9 +480,78 @@ convsep_stream(StreamArgs a, RouteArgs route)
 			// wide loads and stores measured slower: a third of the threads idle while the rest
 			// run four conversions back to back; so did thread -> (row, every 96th pixel), which
 			// needs no wrap-around arithmetic but makes every wave run three turns: +4 %).
-			if (EPI && p >= 2 && p - 2 < steps) {
+			auto epilogue = [&]() __attribute__((always_inline)) {
+				if (!(EPI && p >= 2 && p - 2 < steps))
+					return;
 				const int q = p - 2;
 				const float *os = s_o + (q & 1) * x_buf;
+				if constexpr (EPI == 2 && EPIF == 1) {
+					// The items of a thread side by side (at most 3: 8 rows of <= 256 pixels dealt round
+					// 768 threads): every table read of the three pixels is in flight before the first
+					// is used.  One after the other, each item sat out its own LDS and L2 round trips
+					// (about a microsecond) with every wave of the block in step behind the barrier.
+					// An item beyond the step's rows or the strip computes on clamped indices and
+					// stores nothing: no branch between the reads.
+					constexpr int NI = 3;
+					int ir[NI], ix[NI];
+					bool ok[NI];
+					{
+						int r = er0, x = ex0, idx = tt;
+						// (re-derived in every phase: hoisted out of the phase loop, the items' store
+						// addresses are 64-bit pairs that spill)
+						asm volatile("" : "+v"(r), "+v"(x));
+#pragma unroll
+						for (int i = 0; i < NI; i++) {
+							if (x >= a.pxw) {
+								x -= a.pxw;
+								r++;
+							}
+							const int j = q * SS_T + r - SS_SLOTS;
+							ok[i] = idx < SS_T * a.pxw && j >= 0 && j < rows_out && px_base + x < a.width;
+							ir[i] = min(r, SS_T - 1);
+							ix[i] = x;
+							idx += SS_NT;
+							r += a.step_rows;
+							x += a.step_px;
+						}
+					}
+					float fx[NI], fy[NI], fz[NI];
+					float2 tx[NI], ty[NI], tz[NI];
+#pragma unroll
+					for (int i = 0; i < NI; i++) {
+						const float *src = os + ir[i] * a.w + 3 * ix[i];
+						Px v;
+						v.a = s_v2y[load_as_uchar_like<float>(src[0], 255)];
+						v.b = s_v2y[load_as_uchar_like<float>(src[1], 255)];
+						v.c = s_v2y[load_as_uchar_like<float>(src[2], 255)];
+						v = step_scRGB2XYZ(v);
+						const int jx = cbrt_index_finite<0>(v.a, fx[i]);
+						const int jy = cbrt_index_finite<1>(v.b, fy[i]);
+						const int jz = cbrt_index_finite<2>(v.c, fz[i]);
+						__builtin_memcpy(&tx[i], route.tables.cbrt + jx, sizeof(float2));
+						__builtin_memcpy(&ty[i], route.tables.cbrt + jy, sizeof(float2));
+						__builtin_memcpy(&tz[i], route.tables.cbrt + jz, sizeof(float2));
+					}
+					__builtin_amdgcn_sched_barrier(0);
+					char *row0 = reinterpret_cast<char *>(a.out) + (long long) (y0 + q * SS_T - SS_SLOTS) * a.out_stride;
+#pragma unroll
+					for (int i = 0; i < NI; i++) {
+						const float cbx = cbrt_finish(tx[i], fx[i]);
+						const float cby = cbrt_finish(ty[i], fy[i]);
+						const float cbz = cbrt_finish(tz[i], fz[i]);
+						const float o0 = __fsub_rn(__fmul_rn(116.0F, cby), 16.0F);
+						const float o1 = __fmul_rn(500.0F, __fsub_rn(cbx, cby));
+						const float o2 = __fmul_rn(200.0F, __fsub_rn(cby, cbz));
+						if (ok[i]) {
+							const unsigned int off = (unsigned int) ir[i] * (unsigned int) a.out_stride + 12u * (unsigned int) (px_base + ix[i]);
+							float *dst = reinterpret_cast<float *>(row0 + off);
+							dst[0] = o0;
+							dst[1] = o1;
+							dst[2] = o2;
+						}
+					}
+					return;
+				}
 				int r = er0, x = ex0; // (row, pixel) of item tt, stepping by one block of items
 				for (int idx = tt; idx < SS_T * a.pxw; idx += SS_NT, r += a.step_rows, x += a.step_px) {
 					if (x >= a.pxw) {
@@ -517,8 +589,19 @@ convsep_stream(StreamArgs a, RouteArgs route)
 						dst[2] = o2;
 					}
 				}
-			}
-			if (EPI && a.order != 0)
+			};
+			// (form 1: the waves of a SIMD -- wave, wave + 4, wave + 8 -- do not all wait for their table reads
+			// at once: two run the epilogue before their vertical pass, the third between its vertical and
+			// its horizontal pass; the three stages of a phase are independent of each other.  Measured on
+			// BASELINE config 3, profiles/r04_calls/r04p_c3.txt: pixels side by side alone 15.19 ms, one wave
+			// first and two between 14.34, every wave between 13.85, two first and one between 13.08 --
+			// against 13.68 for form 0)
+			const bool epi_first = EPIF == 0 || wv < 8;
+			if (EPI && a.order != 0 && !epi_first)
+				request_rows();
+			if (epi_first)
+				epilogue();
+			if (EPI && a.order != 0 && epi_first)
 				request_rows();
 			// ---- vertical pass of step p - 1
 			if (p >= 1 && p - 1 < steps && active) {
@@ -526,6 +609,8 @@ convsep_stream(StreamArgs a, RouteArgs route)
 				ss_vpass<MODE, NG, EPI, Q4>(a, kc, acc, s_x + (q & 1) * x_buf + tt, s_o + (q & 1) * x_buf + tt, q,
 					rows_out, y0, e0, tt, tt < ne);
 			}
+			if (!epi_first)
+				epilogue();
 			// ---- horizontal pass of step p
 			if (p < steps && active) {
 				bool done = false;
@@ -550,17 +635,23 @@ convsep_stream(StreamArgs a, RouteArgs route)
 	}
 }
 
-template <int MODE, int NG, int EPI, int NT>
+template <int MODE, int NG, int EPI, int NT, int EPIF = 0>
 static int ss_launch(const StreamArgs &a, const RouteArgs &route, size_t lds, int grid, const char *gate_name)
 {
+	if constexpr (MODE == 1 && NG == 8 && EPI == 2 && EPIF == 0) {
+		// $VIPS_HIP_STREAM_EPI=0: the older form of the epilogue
+		const char *form_env = getenv("VIPS_HIP_STREAM_EPI");
+		if (!form_env || atoi(form_env) != 0)
+			return ss_launch<MODE, NG, EPI, NT, 1>(a, route, lds, grid, gate_name);
+	}
 	static bool attr_done = false; // one attribute per instantiation
 	if (!attr_done) {
-		VH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&convsep_stream<MODE, NG, EPI, NT>),
+		VH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&convsep_stream<MODE, NG, EPI, NT, EPIF>),
 			hipFuncAttributeMaxDynamicSharedMemorySize, SS_LDS_MAX));
 		attr_done = true;
 	}
 	Gate gate(gate_name);
-	hipLaunchKernelGGL((convsep_stream<MODE, NG, EPI, NT>), dim3(grid), dim3(NT), lds, stream(), a, route);
+	hipLaunchKernelGGL((convsep_stream<MODE, NG, EPI, NT, EPIF>), dim3(grid), dim3(NT), lds, stream(), a, route);
 	VH_CHECK(hipGetLastError());
 	return 0;
 }

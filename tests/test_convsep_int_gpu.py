@@ -66,6 +66,20 @@ def test_integer_image_blur_colourspace(shape, sigma, space):
         assert np.array_equal(_bits(got), _bits(want)), (mode, shape, sigma, space)
 
 
+def test_epilogue_forms():
+    """BASELINE config 3's instantiation has two forms of the colour epilogue (convsep_stream.hip, EPIF):
+    the same bits from both, on an integer image and on a float image proper."""
+    for src in (_integer_image(1600, 200, 3, 96), helpers.lcg_image(1600, 200, 3, np.float32, 97)):
+        want = PortCC.colourspace(PortCC.gaussblur(src, 8.0, precision="integer"), "lab", "srgb")
+        for form in ("0", "1"):
+            os.environ["VIPS_HIP_STREAM_EPI"] = form
+            try:
+                got = Image.new_from_array(src, interpretation="srgb").gaussblur_colourspace(8.0, "lab").numpy()
+            finally:
+                del os.environ["VIPS_HIP_STREAM_EPI"]
+            assert np.array_equal(_bits(got), _bits(want)), form
+
+
 @pytest.mark.parametrize("sigma", [8.0, 2.0])
 def test_almost_integer_image(sigma):
     """Integers with everything else sprinkled in: waves whose windows hold a fraction, a negative or
