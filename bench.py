@@ -698,6 +698,22 @@ def run_c3(ctx, steps, warmup, verify=True, cpu=True, size=32768):
             host = src[n // 2:n // 2 + srows].cpu().numpy()
             entry["cpu_baseline"] = cpu_baselines(helpers, chain, host, float(n) * srows, interp, repeats=5, single_rows=64,
                                                   what="%d rows x %d x 3 f32 of the same image, whole pipeline" % (srows, n))
+    # The input holds the integers 0 .. 255 (a float image cast from uchar), so the horizontal pass runs on
+    # packed bytes (convsep_int_body.h; the test is per wave, the bits do not depend on it).  The same
+    # pipeline on a float image proper -- every pixel + 0.25, both passes in double -- beside it:
+    entry["input"] = "float pixels holding the integers 0..255 (LCG bytes cast to float): integer horizontal pass"
+    if ctx.world == 1:
+        try:
+            with torch.cuda.stream(ctx.stream):
+                src.add_(0.25)
+            torch.cuda.synchronize()
+            k2 = max(2, min(steps, 5))
+            elapsed2, out2 = ctx.timed(step, k2, 1)
+            entry["float_input"] = {"what": "the same image + 0.25 (no window of integers): horizontal pass in double",
+                                    "ms": round(elapsed2 / k2 * 1e3, 3), "steps": k2}
+            del out2
+        except Exception as exc:  # a side measurement: never lose the line over it
+            entry["float_input"] = {"error": repr(exc)}
     del im, src, out
     ctx.trim()
     return with_fp64_stream(entry)
