@@ -130,7 +130,7 @@ static __device__ __forceinline__ float ss_fin(double s, const StreamArgs &a, in
 	if constexpr (MODE == 1) {
 		double q = s;
 		int has_scale = a.has_scale;
-		asm volatile("" : "+s"(has_scale)); // (tested here, as a scalar: hoisted, the test is a lane mask that spills)
+		VH_SCALAR(has_scale); // (tested here, as a scalar: hoisted, the test is a lane mask that spills)
 		if (has_scale) {
 			asm volatile(""); // a wave-uniform branch, not two selects per output
 			q = ss_div_scale(s, a);
@@ -149,11 +149,7 @@ static __device__ __forceinline__ float ss_fin(double s, const StreamArgs &a, in
 // and restored inside the one statement (cdna_hip_programming.md, LDS-DMA recipe).
 static __device__ __forceinline__ void ss_dma_dword(const char *src, unsigned int voff, unsigned int lds_dst)
 {
-	unsigned int keep;
-	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-				 : "=&s"(keep)
-				 : "v"(voff), "s"(src), "s"(lds_dst)
-				 : "memory");
+	VH_LDS_DMA_DWORD(src, voff, lds_dst);
 }
 
 typedef const double __attribute__((address_space(4))) *SsCoefs;
@@ -196,7 +192,7 @@ static __device__ __forceinline__ void ss_hpass(const StreamArgs &a, const doubl
 			cg[ii] = kc[4 * g + ii];
 		int rem = a.rem;
 		if (g + 1 == NG)
-			asm volatile("" : "+s"(rem)); // (compared here as a scalar: hoisted, each test is a lane mask that spills)
+			VH_SCALAR(rem); // (compared here as a scalar: hoisted, each test is a lane mask that spills)
 #pragma unroll
 		for (int ii = 0; ii < 4; ii++) {
 			if (g + 1 < NG || ii < rem) { // whole groups unconditional, the last one tap by tap
@@ -292,7 +288,7 @@ static __device__ __forceinline__ void ss_vpass(const StreamArgs &a, const doubl
 			acc[slot] = ss_mac<MODE>(d == 0 ? seed : acc[slot], kr[d], dv);
 		}
 		int rem = a.rem;
-		asm volatile("" : "+s"(rem)); // (see ss_hpass)
+		VH_SCALAR(rem); // (see ss_hpass)
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
 			const int d = 4 * (NG - 1) + k;
@@ -313,7 +309,7 @@ template <int MODE, int NG, int EPI, int SS_NT, int EPIF = 0>
 __global__ void __launch_bounds__(SS_NT)
 convsep_stream(StreamArgs a, RouteArgs route)
 {
-	extern __shared__ __attribute__((aligned(16))) float ss_lds[];
+	VH_DYNAMIC_LDS(float, ss_lds);
 	__shared__ int s_item;
 	__shared__ __attribute__((aligned(16))) double s_coef[SS_SLOTS];
 	__shared__ float s_v2y[EPI == 2 ? 256 : 1]; // the sRGB -> scRGB table of the spelled-out epilogue
@@ -384,13 +380,13 @@ convsep_stream(StreamArgs a, RouteArgs route)
 		const bool first_lane = t < staged;
 		const bool second = SS_NT + wv * 64 < staged;       // wave-uniform
 		const bool second_lane = SS_NT + t < staged;
-		const unsigned int lds_in = (unsigned int) (size_t) s_in; // LDS byte address
+		const unsigned int lds_in = VH_LDS_ADDR(s_in); // LDS byte address
 		auto dma_rows = [&](int q, int slot) __attribute__((always_inline)) {
 			// (opaque copies: hoisted out of the phase loop, the eight row offsets and the eight
 			// first rows sit in scalar registers that spill, and every use is a v_readlane --
 			// re-made here they are a scalar multiply and add each)
 			int in_row_o = in_row, y_first_o = y_first;
-			asm volatile("" : "+s"(in_row_o), "+s"(y_first_o));
+			VH_SCALAR2(in_row_o, y_first_o);
 			const unsigned int buf = lds_in + (unsigned int) (slot * in_buf + wv * 64) * 4u;
 			// (the lane predicate once around the eight rows, not around each)
 			if (first && first_lane) {
@@ -444,23 +440,23 @@ convsep_stream(StreamArgs a, RouteArgs route)
 			// landed, while the younger DMA batches and stores stay in flight.
 			// (near the end of a segment the younger batches do not exist: wait for everything)
 			if (a.ring == 2 || p + a.ring - 2 >= steps)
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				VH_WAIT_VMCNT(0);
 			else if (a.ring == 3) {
 				if (second)
-					asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+					VH_WAIT_VMCNT(16);
 				else
-					asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+					VH_WAIT_VMCNT(8);
 			}
 			else {
 				if (second)
-					asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+					VH_WAIT_VMCNT(32);
 				else
-					asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+					VH_WAIT_VMCNT(16);
 			}
 			__syncthreads();
 			// Keep the compiler from hoisting every derived address out of the phase loop: held
 			// across the loop they spill; re-deriving them costs a few adds per phase.
-			asm volatile("" : "+v"(goff[0]), "+v"(goff[1]), "+v"(h_in_off), "+v"(h_x_off), "+v"(tt));
+			VH_VECTOR5(goff[0], goff[1], h_in_off, h_x_off, tt);
 			// The rows of step p + ring - 1 start travelling into the buffer the horizontal pass of
 			// step p - 1 read before the barrier.  With an epilogue they are requested AFTER it: the
 			// epilogue's table gathers and stores wait with s_waitcnt vmcnt(0) -- the compiler does
@@ -499,7 +495,7 @@ convsep_stream(StreamArgs a, RouteArgs route)
 						int r = er0, x = ex0, idx = tt;
 						// (re-derived in every phase: hoisted out of the phase loop, the items' store
 						// addresses are 64-bit pairs that spill)
-						asm volatile("" : "+v"(r), "+v"(x));
+						VH_VECTOR2(r, x);
 #pragma unroll
 						for (int i = 0; i < NI; i++) {
 							if (x >= a.pxw) {

@@ -15,6 +15,9 @@ struct Fiber {
 	ucontext_t ctx;
 	char *stack = nullptr;
 	bool done = false;
+	bool voting = false; // yielded inside ballot()
+	bool pred = false;
+	unsigned long long mask = 0;
 };
 
 thread_local std::vector<Fiber> *g_fibers = nullptr;
@@ -23,6 +26,7 @@ thread_local int g_tid = 0;
 thread_local const std::function<void()> *g_fn = nullptr;
 thread_local unsigned long long g_ticks = 0;
 thread_local std::vector<unsigned int> *g_exchange = nullptr;
+thread_local unsigned char *g_lds = nullptr;
 
 void trampoline()
 {
@@ -42,6 +46,18 @@ void barrier()
 	Fiber &f = (*g_fibers)[g_tid];
 	swapcontext(&f.ctx, &g_main);
 }
+
+unsigned long long ballot(bool pred)
+{
+	Fiber &f = (*g_fibers)[g_tid];
+	f.voting = true;
+	f.pred = pred;
+	swapcontext(&f.ctx, &g_main);
+	return f.mask;
+}
+
+void set_lds_base(unsigned char *base) { g_lds = base; }
+unsigned char *lds_base() { return g_lds; }
 
 unsigned int exchange(unsigned int value, int src)
 {
@@ -87,6 +103,32 @@ void run_block(int threads, const std::function<void()> &fn)
 			g_tid = t;
 			swapcontext(&g_main, &f.ctx);
 			alive++;
+		}
+		// votes: every fiber has now run to its next barrier, its end, or a ballot; the voters of a wave get
+		// their mask and run on (to the next ballot or the barrier) until nobody waits for a vote
+		for (;;) {
+			bool any = false;
+			for (int w0 = 0; w0 < threads; w0 += 64) {
+				unsigned long long mask = 0;
+				const int w1 = w0 + 64 < threads ? w0 + 64 : threads;
+				for (int t = w0; t < w1; t++)
+					if (fibers[t].voting && fibers[t].pred)
+						mask |= 1ull << (t - w0);
+				std::vector<int> voters;
+				for (int t = w0; t < w1; t++)
+					if (fibers[t].voting) {
+						fibers[t].voting = false;
+						fibers[t].mask = mask;
+						voters.push_back(t);
+					}
+				for (int t : voters) {
+					any = true;
+					g_tid = t;
+					swapcontext(&g_main, &fibers[t].ctx);
+				}
+			}
+			if (!any)
+				break;
 		}
 		g_ticks += 997; // (the 100 MHz clock moves between barriers)
 		round++;

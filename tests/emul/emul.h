@@ -15,6 +15,13 @@ void barrier();
 unsigned long long clock_ticks();
 // every thread of the block hands in a value and gets the one thread `src` handed in (two barriers)
 unsigned int exchange(unsigned int value, int src);
+// v_cmp + s_mov of the lane mask: the lanes of the calling thread's wave (64 consecutive threads) that make
+// this call before their next barrier (or their end) vote; a lane that goes to the barrier without voting is
+// a lane the branch had masked off.  Bit i = lane i's predicate.
+unsigned long long ballot(bool pred);
+// the block's dynamic LDS (set by whoever runs the block; convsep_stream's LDS-DMA addresses are offsets into it)
+void set_lds_base(unsigned char *base);
+unsigned char *lds_base();
 // run `fn` as `threads` fibers (one block); fn reads current_tid()
 void run_block(int threads, const std::function<void()> &fn);
 
