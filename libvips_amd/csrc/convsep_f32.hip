@@ -36,6 +36,7 @@
 // Masks with zero elements (which the reference squeezes out) and masks longer than 32
 // stay on the two-pass path.
 #include "conv.h"
+#include "gcn.h"
 
 #include <cstddef>
 
@@ -276,7 +277,7 @@ convsep_kernel(ConvSepArgs a)
 {
 	typedef typename CsTraits<MODE>::vt vt;
 	typedef typename CsTraits<MODE>::lt lt;
-	extern __shared__ __attribute__((aligned(16))) unsigned int cs_lds_raw[];
+	VH_DYNAMIC_LDS(unsigned int, cs_lds_raw);
 	lt *cs_lds = reinterpret_cast<lt *>(cs_lds_raw);
 	__shared__ int s_item;
 	const int inw = a.se + (a.n - 1) * a.bands;

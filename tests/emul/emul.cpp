@@ -27,6 +27,17 @@ thread_local const std::function<void()> *g_fn = nullptr;
 thread_local unsigned long long g_ticks = 0;
 thread_local std::vector<unsigned int> *g_exchange = nullptr;
 thread_local unsigned char *g_lds = nullptr;
+// fiber stacks are kept by the OS thread from block to block (a grid of one-thread-per-pixel kernels
+// runs tens of thousands of blocks)
+struct StackPool {
+	std::vector<char *> stacks;
+	~StackPool()
+	{
+		for (char *p : stacks)
+			free(p);
+	}
+};
+thread_local StackPool g_stacks;
 
 void trampoline()
 {
@@ -78,7 +89,9 @@ void run_block(int threads, const std::function<void()> &fn)
 	g_fn = &fn;
 	for (int t = 0; t < threads; t++) {
 		Fiber &f = fibers[t];
-		f.stack = (char *) malloc(stack_bytes);
+		if ((int) g_stacks.stacks.size() <= t)
+			g_stacks.stacks.push_back((char *) malloc(stack_bytes));
+		f.stack = g_stacks.stacks[t];
 		getcontext(&f.ctx);
 		f.ctx.uc_stack.ss_sp = f.stack;
 		f.ctx.uc_stack.ss_size = stack_bytes;
@@ -139,8 +152,6 @@ void run_block(int threads, const std::function<void()> &fn)
 			abort();
 		}
 	}
-	for (Fiber &f : fibers)
-		free(f.stack);
 	g_fibers = nullptr;
 }
 

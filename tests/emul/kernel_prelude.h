@@ -26,6 +26,7 @@
 #define VH_LDS_ADDR(p) ((unsigned int) (reinterpret_cast<unsigned char *>(p) - emul::lds_base()))
 
 using std::isnan;
+using std::isinf;
 using std::rint;
 using std::rintf;
 
@@ -38,13 +39,35 @@ using std::rintf;
 #define __launch_bounds__(...)
 #undef __restrict__
 #define __restrict__
+#define address_space(n) // (inside __attribute__(( )): every pointer is a host pointer)
 
-struct EmulThreadIdx {
-	struct X {
-		operator int() const { return emul::current_tid(); }
-	} x;
+namespace emul {
+struct Geometry {
+	dim3 grid, block, block_idx;
+	const void *kernarg;
 };
-#define threadIdx (EmulThreadIdx())
+inline Geometry &geometry()
+{
+	static thread_local Geometry g;
+	return g;
+}
+struct ThreadIdx {
+	struct X {
+		operator unsigned int() const { return (unsigned int) current_tid() % geometry().block.x; }
+	} x;
+	struct Y {
+		operator unsigned int() const { return (unsigned int) current_tid() / geometry().block.x % geometry().block.y; }
+	} y;
+	struct Z {
+		operator unsigned int() const { return (unsigned int) current_tid() / (geometry().block.x * geometry().block.y); }
+	} z;
+};
+} // namespace emul
+#define threadIdx (emul::ThreadIdx())
+#define blockIdx (emul::geometry().block_idx)
+#define blockDim (emul::geometry().block)
+#define gridDim (emul::geometry().grid)
+#define __builtin_amdgcn_kernarg_segment_ptr() (emul::geometry().kernarg)
 #define __syncthreads() emul::barrier()
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 
@@ -52,6 +75,8 @@ static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __A
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void) 0)
 #define __builtin_amdgcn_ballot_w64(p) emul::ballot(p)
+#define __all(p) (emul::ballot(!(p)) == 0)
+#define __any(p) (emul::ballot(p) != 0)
 // v_div_fixup_f64: IEEE division's special cases around a computed quotient
 static inline double emul_div_fixup(double q, double den, double num)
 {
@@ -69,6 +94,7 @@ static inline double emul_div_fixup(double q, double den, double num)
 #define __dadd_rn(a, b) ((double) (a) + (double) (b))
 #define __dsub_rn(a, b) ((double) (a) - (double) (b))
 #define __ddiv_rn(a, b) ((double) (a) / (double) (b))
+#define __fdiv_rn(a, b) ((float) (a) / (float) (b))
 #define __fma_rn(a, b, c) __builtin_fma((double) (a), (double) (b), (double) (c))
 // v_cvt_i32_f32: toward zero, saturating, NaN -> 0
 static inline int emul_float2int_rz(float v)
@@ -82,29 +108,40 @@ static inline int emul_float2int_rz(float v)
 	return (int) v;
 }
 #define __float2int_rz(v) emul_float2int_rz(v)
+// v_mul_i32_i24: the product of the operands' low 24 bits, sign-extended
+#define __mul24(a, b) ((int) (((int) ((unsigned int) (a) << 8) >> 8) * (long long) ((int) ((unsigned int) (b) << 8) >> 8)))
+#define __umulhi(a, b) ((unsigned int) (((unsigned long long) (unsigned int) (a) * (unsigned int) (b)) >> 32))
 
-// ---- the launch: `grid` persistent blocks over the host's threads, each with its own dynamic LDS
+// ---- the launch: the grid's blocks over the host's threads, each with its own dynamic LDS; the kernarg
+// segment is the first argument (what the kernels that read it read)
+#include <tuple>
 namespace emul {
 template <typename F>
-static void launch(int grid, int block, size_t lds_bytes, F body)
+static void launch(dim3 grid, dim3 block, size_t lds_bytes, const void *kernarg, F body)
 {
-	std::atomic<int> next(0);
+	const long long blocks = (long long) grid.x * grid.y * grid.z;
+	std::atomic<long long> next(0);
 	auto worker = [&]() {
 		std::vector<unsigned char> lds(lds_bytes + 64);
+		unsigned char *base = lds.data();
+		base += (16 - ((uintptr_t) base & 15)) & 15;
 		for (;;) {
-			const int wg = next.fetch_add(1);
-			if (wg >= grid)
+			const long long wg = next.fetch_add(1);
+			if (wg >= blocks)
 				break;
-			unsigned char *base = lds.data();
-			base += (16 - ((uintptr_t) base & 15)) & 15;
+			Geometry &g = geometry();
+			g.grid = grid;
+			g.block = block;
+			g.block_idx = dim3((unsigned int) (wg % grid.x), (unsigned int) (wg / grid.x % grid.y), (unsigned int) (wg / ((long long) grid.x * grid.y)));
+			g.kernarg = kernarg;
 			set_lds_base(base);
-			run_block(block, body);
+			run_block((int) (block.x * block.y * block.z), body);
 		}
 	};
-	unsigned int nthreads = std::thread::hardware_concurrency();
-	nthreads = nthreads < 1 ? 1 : nthreads > (unsigned int) grid ? (unsigned int) grid : nthreads;
+	long long nthreads = std::thread::hardware_concurrency();
+	nthreads = nthreads < 1 ? 1 : nthreads > blocks ? blocks : nthreads;
 	std::vector<std::thread> pool;
-	for (unsigned int i = 0; i < nthreads; i++)
+	for (long long i = 0; i < nthreads; i++)
 		pool.emplace_back(worker);
 	for (std::thread &t : pool)
 		t.join();
@@ -114,5 +151,6 @@ static void launch(int grid, int block, size_t lds_bytes, F body)
 #define hipLaunchKernelGGL(kernel, grid, block, lds, strm, ...) \
 	do { \
 		(void) hipStreamSynchronize(strm); \
-		emul::launch((int) (grid).x, (int) (block).x, (size_t) (lds), [&]() { kernel(__VA_ARGS__); }); \
+		auto emul_args = std::make_tuple(__VA_ARGS__); \
+		emul::launch(dim3(grid), dim3(block), (size_t) (lds), &std::get<0>(emul_args), [&]() { std::apply(kernel, emul_args); }); \
 	} while (0)

@@ -1,0 +1,42 @@
+"""CPU: the GPU parity files themselves, run against libvipship_emul.so under the mock HIP runtime.
+
+tests/emul compiles the product's kernel FILES for host fibers (kernel_prelude.h: colour.hip, conv.hip,
+convsep_f32.hip, convsep_stream.hip, resample.hip, approx.hip, upsize.hip -- the source the GPU runs, not a
+restatement -- beside the kernel bodies written against gcn.h), so a `-m gpu` test whose kernels are all in
+that set can run here, on the CPU, against the same oracle with the same assertions.  What stays GPU-only:
+the matrix-core reduce and the one-kernel resize chains (inline assembly), anything that feeds NaN or
+out-of-range values into a C cast (the device's conversions saturate, the host's are undefined), sizes
+chosen for the device.  The selection below is what passes for those reasons and no other."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from tests import helpers
+from tests.test_emul_resize_sharpen import EMUL_SO, _build_emul
+from tests.test_host_glue_mock import MOCK_SO, _build_mock, _gpu_present
+
+pytestmark = pytest.mark.skipif(_gpu_present() or not helpers.have_ref() or not _build_mock() or not _build_emul(),
+                                reason="a real GPU is present, or the reference / mock runtime / emulation cannot be built")
+
+
+def _run(files, deselect, at_least):
+    env = dict(os.environ, LD_PRELOAD=MOCK_SO, VIPS_HIP_LIBRARY=EMUL_SO)
+    cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + files
+    if deselect:
+        cmd += ["-k", " and ".join("not " + d for d in deselect)]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=helpers.ROOT,
+                          timeout=3000)
+    tail = proc.stdout[-3000:]
+    m = re.search(r"(\d+) passed", tail)
+    assert proc.returncode == 0 and m and "failed" not in tail.splitlines()[-1], tail
+    assert int(m.group(1)) >= at_least, tail
+
+
+def test_conv_colour_file_on_the_cpu():
+    """tests/test_conv_colour_gpu.py: convi / convf / convsep / gaussblur in every format, the fused blur +
+    colourspace kernel, every colour route, cast, premultiply, sharpen, the approximate convolutions --
+    all but the cases that go through vips_resize."""
+    _run(["tests/test_conv_colour_gpu.py"], ["thumbnail", "c4_pipeline"], 580)
