@@ -36,7 +36,7 @@
 // Masks with zero elements (which the reference squeezes out) and masks longer than 32
 // stay on the two-pass path.
 #include "conv.h"
-#include "gcn.h"
+#include "kernel_stmt.h"
 
 #include <cstddef>
 

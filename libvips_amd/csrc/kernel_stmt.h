@@ -1,0 +1,33 @@
+// The few statements with no C++ spelling that whole kernel FILES (convsep_stream.hip, convsep_f32.hip,
+// reduce_u8.hip ...) are written with -- register-class hints, s_waitcnt, the LDS-DMA, dynamic LDS -- under
+// names, so that the same files also compile for host fibers: tests/emul/kernel_prelude.h gives the names host
+// meanings (and defines this header's guard), the product gets the instructions.
+#ifndef VH_KERNEL_STMT_H
+#define VH_KERNEL_STMT_H
+
+// register-class hints: "hold this value in a scalar / vector register here" (stops a hoist or a merge)
+#define VH_SCALAR(x) asm volatile("" : "+s"(x))
+#define VH_SCALAR2(x, y) asm volatile("" : "+s"(x), "+s"(y))
+#define VH_VECTOR1(a) asm volatile("" : "+v"(a))
+#define VH_VECTOR2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define VH_USE2(a, b) asm volatile("" ::"v"(a), "v"(b)) // (a use the compiler cannot drop)
+#define VH_VECTOR5(a, b, c, d, e) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e))
+// at most n vector memory operations of this wave still in flight
+#define VH_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// One dword per lane from global memory straight into LDS: lane i's dword lands at LDS byte address
+// lds_dst + 4 i (lds_dst wave-uniform), read from src + voff (src wave-uniform, voff per lane).  M0 carries
+// the LDS address and belongs to the compiler: saved, written and restored inside the one statement.
+#define VH_LDS_DMA_DWORD(src, voff, lds_dst) \
+	do { \
+		unsigned int vh_keep_m0; \
+		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0" \
+					 : "=&s"(vh_keep_m0) \
+					 : "v"(voff), "s"(src), "s"(lds_dst) \
+					 : "memory"); \
+	} while (0)
+// the block's dynamic LDS, and the LDS byte address of a pointer into LDS
+#define VH_DYNAMIC_LDS(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+#define VH_LDS_ADDR(p) ((unsigned int) (size_t) (p))
+
+
+#endif // VH_KERNEL_STMT_H

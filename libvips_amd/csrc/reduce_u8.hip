@@ -26,6 +26,7 @@
 // Integer arithmetic is exact, so the i32 sums equal the reference's whatever
 // the summation order; rounding/clipping is templates.h:152-157.
 #include "reduce_u8.h"
+#include "kernel_stmt.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -52,7 +53,7 @@ static __device__ __forceinline__ int dot2(unsigned int pix, unsigned int coef, 
 static __device__ __forceinline__ int fin_u8(int s)
 {
 	s = (s + (INTERPOLATE_SCALE >> 1)) >> INTERPOLATE_SHIFT;
-	asm volatile("" : "+v"(s));
+	VH_VECTOR1(s);
 	return min(max(s, 0), 255);
 }
 
@@ -479,7 +480,7 @@ struct MfmaStep {
 		if constexpr (PROF == 16) { // profiling: loads only -- consume the rows, refill, no arithmetic
 #pragma unroll
 			for (int i = 4 * Q; i < 4 * Q + 4; i++)
-				asm volatile("" ::"v"(px[i].x), "v"(px[i].y));
+				VH_USE2(px[i].x, px[i].y);
 			if (more)
 				load_rows<4 * Q, 4>(a, px, next_row, dir, ca, cb, interior);
 			return;
@@ -511,7 +512,7 @@ struct MfmaStep {
 				if (p == 1) {
 #pragma unroll
 					for (int i = 4 * Q; i < 4 * Q + 4; i++)
-						asm volatile("" : "+v"(px[i].x), "+v"(px[i].y));
+						VH_VECTOR2(px[i].x, px[i].y);
 				}
 			}
 			else if (p == 1 && more)
@@ -619,7 +620,7 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 	typedef MfmaGeo<NTH> Geo;
 	constexpr int MFMA_PLANE = Geo::PLANE, MFMA_PLANES_BYTES = Geo::PLANES_BYTES;
 	constexpr int MFMA_STAGE_PITCH = Geo::STAGE_PITCH, FUSED_SPAN = Geo::SPAN;
-	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	VH_DYNAMIC_LDS(unsigned char, lds_raw);
 	// T planes (the horizontal walker over-reads the end of a plane by up to 8 * (D - 1)
 	// samples: into the next plane / the tables -- any byte is a finite f16 denormal), the two
 	// A-operand tables, the staged output rows of the tile

@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace emul {
@@ -17,7 +18,8 @@ struct Fiber {
 	bool done = false;
 	bool voting = false; // yielded inside ballot()
 	bool pred = false;
-	unsigned long long mask = 0;
+	unsigned char payload[16] = {};
+	const WaveData *shared = nullptr;
 };
 
 thread_local std::vector<Fiber> *g_fibers = nullptr;
@@ -58,14 +60,18 @@ void barrier()
 	swapcontext(&f.ctx, &g_main);
 }
 
-unsigned long long ballot(bool pred)
+const WaveData &wave_share(const void *payload, int bytes, bool pred)
 {
 	Fiber &f = (*g_fibers)[g_tid];
 	f.voting = true;
 	f.pred = pred;
+	if (bytes > 0)
+		memcpy(f.payload, payload, (size_t) bytes);
 	swapcontext(&f.ctx, &g_main);
-	return f.mask;
+	return *f.shared;
 }
+
+unsigned long long ballot(bool pred) { return wave_share(nullptr, 0, pred).mask; }
 
 void set_lds_base(unsigned char *base) { g_lds = base; }
 unsigned char *lds_base() { return g_lds; }
@@ -98,6 +104,7 @@ void run_block(int threads, const std::function<void()> &fn)
 		f.ctx.uc_link = &g_main;
 		makecontext(&f.ctx, trampoline, 0);
 	}
+	std::vector<WaveData> waves((threads + 63) / 64);
 	unsigned int round = 0;
 	for (;;) {
 		int alive = 0, finished = 0;
@@ -122,18 +129,23 @@ void run_block(int threads, const std::function<void()> &fn)
 		for (;;) {
 			bool any = false;
 			for (int w0 = 0; w0 < threads; w0 += 64) {
-				unsigned long long mask = 0;
 				const int w1 = w0 + 64 < threads ? w0 + 64 : threads;
-				for (int t = w0; t < w1; t++)
-					if (fibers[t].voting && fibers[t].pred)
-						mask |= 1ull << (t - w0);
+				WaveData &wd = waves[w0 / 64];
 				std::vector<int> voters;
 				for (int t = w0; t < w1; t++)
-					if (fibers[t].voting) {
-						fibers[t].voting = false;
-						fibers[t].mask = mask;
+					if (fibers[t].voting)
 						voters.push_back(t);
-					}
+				if (voters.empty())
+					continue;
+				wd.voters = wd.mask = 0;
+				for (int t : voters) {
+					wd.voters |= 1ull << (t - w0);
+					if (fibers[t].pred)
+						wd.mask |= 1ull << (t - w0);
+					memcpy(wd.data[t - w0], fibers[t].payload, 16);
+					fibers[t].voting = false;
+					fibers[t].shared = &wd;
+				}
 				for (int t : voters) {
 					any = true;
 					g_tid = t;

@@ -19,6 +19,14 @@ unsigned int exchange(unsigned int value, int src);
 // this call before their next barrier (or their end) vote; a lane that goes to the barrier without voting is
 // a lane the branch had masked off.  Bit i = lane i's predicate.
 unsigned long long ballot(bool pred);
+// the same meeting with a payload (at most 16 bytes): what every voting lane of the wave handed in, for the
+// cross-lane instructions (DPP moves, the matrix instructions' operands)
+struct WaveData {
+	unsigned long long voters;   // lanes that took part
+	unsigned long long mask;     // their predicates
+	unsigned char data[64][16];
+};
+const WaveData &wave_share(const void *payload, int bytes, bool pred);
 // the block's dynamic LDS (set by whoever runs the block; convsep_stream's LDS-DMA addresses are offsets into it)
 void set_lds_base(unsigned char *base);
 unsigned char *lds_base();

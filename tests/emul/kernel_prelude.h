@@ -10,10 +10,15 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
-// ---- csrc/gcn.h, last section
+// ---- csrc/kernel_stmt.h (its guard is taken here: the product's meanings never reach a host build)
+#define VH_KERNEL_STMT_H
+#define VH_VECTOR1(a) ((void) (a))
+#define VH_USE2(a, b) ((void) (a), (void) (b))
 #define VH_SCALAR(x) ((void) (x))
 #define VH_SCALAR2(x, y) ((void) (x), (void) (y))
 #define VH_VECTOR2(a, b) ((void) (a), (void) (b))
@@ -77,6 +82,53 @@ static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __A
 #define __builtin_amdgcn_ballot_w64(p) emul::ballot(p)
 #define __all(p) (emul::ballot(!(p)) == 0)
 #define __any(p) (emul::ballot(p) != 0)
+// packed-integer instructions: the meanings of this directory's gcn.h
+template <typename V2>
+static inline int emul_sdot2(V2 a, V2 b, int acc)
+{
+	return vh::dot2(__builtin_bit_cast(unsigned int, a), __builtin_bit_cast(unsigned int, b), acc);
+}
+#define __builtin_amdgcn_sdot2(a, b, acc, clamp) emul_sdot2(a, b, acc)
+#define __builtin_amdgcn_udot4(a, b, acc, clamp) vh::udot4(a, b, acc)
+#define __builtin_amdgcn_sdot4(a, b, acc, clamp) vh::dot4((unsigned int) (a), (unsigned int) (b), acc)
+#define __builtin_amdgcn_perm(hi, lo, sel) vh::perm(hi, lo, sel)
+#define __builtin_amdgcn_cvt_pk_u8_f32(v, byte, old) vh::cvt_pk_u8(v, byte, old)
+#define __builtin_amdgcn_s_memrealtime() emul::clock_ticks()
+// v_mov_b32 with a DPP quad_perm control: lane l of a quad reads lane (ctrl >> 2 (l & 3)) & 3 of it
+static inline int emul_mov_dpp(int v, int ctrl)
+{
+	const emul::WaveData &wd = emul::wave_share(&v, 4, true);
+	const int lane = emul::current_tid() & 63;
+	if (ctrl >= 0x100) {
+		fprintf(stderr, "emul: DPP control %#x is not emulated\n", ctrl);
+		abort();
+	}
+	const int src = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+	int r;
+	memcpy(&r, wd.data[src], 4);
+	return r;
+}
+#define __builtin_amdgcn_mov_dpp(v, ctrl, row_mask, bank_mask, bound_ctrl) emul_mov_dpp((int) (v), ctrl)
+// v_mfma_f32_4x4x4_16b_f16: 16 blocks of 4 lanes; in a block lane i holds row i of A (4 halves), lane j column j
+// of B (4 halves) and gets column j of D = C + A B (4 floats)
+template <typename H4, typename F4>
+static inline F4 emul_mfma_4x4x4f16(H4 a, H4 b, F4 c)
+{
+	static_assert(sizeof(H4) == 8 && sizeof(F4) == 16, "operand sizes");
+	const emul::WaveData &wd = emul::wave_share(&a, 8, true);
+	const int base = (emul::current_tid() & 63) & ~3;
+	F4 d = c;
+	for (int i = 0; i < 4; i++) {
+		H4 ai;
+		memcpy(&ai, wd.data[base + i], 8);
+		float sum = c[i];
+		for (int k = 0; k < 4; k++)
+			sum += (float) ai[k] * (float) b[k];
+		d[i] = sum;
+	}
+	return d;
+}
+#define __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, cbsz, abid, blgp) emul_mfma_4x4x4f16(a, b, c)
 // v_div_fixup_f64: IEEE division's special cases around a computed quotient
 static inline double emul_div_fixup(double q, double den, double num)
 {
@@ -113,7 +165,7 @@ static inline int emul_float2int_rz(float v)
 #define __umulhi(a, b) ((unsigned int) (((unsigned long long) (unsigned int) (a) * (unsigned int) (b)) >> 32))
 
 // ---- the launch: the grid's blocks over the host's threads, each with its own dynamic LDS; the kernarg
-// segment is the first argument (what the kernels that read it read)
+// segment is rebuilt for the kernels that read their arguments where they lie
 #include <tuple>
 namespace emul {
 template <typename F>
@@ -147,10 +199,25 @@ static void launch(dim3 grid, dim3 block, size_t lds_bytes, const void *kernarg,
 		t.join();
 }
 } // namespace emul
+namespace emul {
+// the kernarg segment: the arguments one after the other, each at its own alignment
+template <typename... A>
+static std::vector<unsigned long long> pack_kernarg(const A &...args)
+{
+	size_t size = 0;
+	((size = (size + alignof(A) - 1) / alignof(A) * alignof(A) + sizeof(A)), ...);
+	std::vector<unsigned long long> buf(size / 8 + 4);
+	unsigned char *p = reinterpret_cast<unsigned char *>(buf.data());
+	size_t off = 0;
+	((off = (off + alignof(A) - 1) / alignof(A) * alignof(A), memcpy(p + off, &args, sizeof(A)), off += sizeof(A)), ...);
+	return buf;
+}
+} // namespace emul
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernel, grid, block, lds, strm, ...) \
 	do { \
 		(void) hipStreamSynchronize(strm); \
 		auto emul_args = std::make_tuple(__VA_ARGS__); \
-		emul::launch(dim3(grid), dim3(block), (size_t) (lds), &std::get<0>(emul_args), [&]() { std::apply(kernel, emul_args); }); \
+		const auto emul_kernarg = std::apply([](const auto &...a) { return emul::pack_kernarg(a...); }, emul_args); \
+		emul::launch(dim3(grid), dim3(block), (size_t) (lds), emul_kernarg.data(), [&]() { std::apply(kernel, emul_args); }); \
 	} while (0)
