@@ -25,6 +25,12 @@
 					 : "v"(voff), "s"(src), "s"(lds_dst) \
 					 : "memory"); \
 	} while (0)
+// instructions the compiler does not select by itself
+#define VH_SAT_PK_U8_I16(r, both) asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(both)) // {0, 0, sat_u8(hi16), sat_u8(lo16)}
+#define VH_DOT2_SCALAR_COEF(dst, pk, coef, acc) asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(dst) : "v"(pk), "s"(coef), "v"(acc))
+#define VH_STORE_BYTE(p, v) asm volatile("global_store_byte %0, %1, off" : : "v"(p), "v"(v) : "memory")
+// a marker that keeps two otherwise identical arms of a switch apart (merged, their register index is dynamic)
+#define VH_ASM_MARK(text) asm volatile("; " text)
 // the block's dynamic LDS, and the LDS byte address of a pointer into LDS
 #define VH_DYNAMIC_LDS(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
 #define VH_LDS_ADDR(p) ((unsigned int) (size_t) (p))

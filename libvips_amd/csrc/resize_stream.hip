@@ -33,6 +33,7 @@
 // compiled reference and with the unfused kernels).
 #include "resample.h"
 #include "reduce_u8.h"
+#include "kernel_stmt.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -82,7 +83,7 @@ static __device__ __forceinline__ int rs_dot2(unsigned int pix, unsigned int coe
 static __device__ __forceinline__ unsigned int rs_fin(int s)
 {
 	s = (s + (INTERPOLATE_SCALE >> 1)) >> INTERPOLATE_SHIFT;
-	asm volatile("" : "+v"(s));
+	VH_VECTOR1(s);
 	return (unsigned int) min(max(s, 0), 255);
 }
 
@@ -92,7 +93,7 @@ static __device__ __forceinline__ unsigned int rs_sat2(int lo, int hi)
 	// the low halves of the two sums side by side (|sum >> 12| < 2^15), then v_sat_pk_u8_i16
 	const unsigned int both = __builtin_amdgcn_perm((unsigned int) hi, (unsigned int) lo, 0x05040100u);
 	unsigned int r;
-	asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(both));
+	VH_SAT_PK_U8_I16(r, both);
 	return r;
 }
 
@@ -129,7 +130,7 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 {
 	constexpr int NT = RS_SPAN / (4 * DW);
 	constexpr int NB = 4 * DW; // byte columns per lane
-	extern __shared__ __attribute__((aligned(16))) unsigned int rs_lds[];
+	VH_DYNAMIC_LDS(unsigned int, rs_lds);
 	unsigned char *T = reinterpret_cast<unsigned char *>(rs_lds); // NP rows of RS_SPAN bytes
 	unsigned char *S = T + NP * RS_SPAN;                        // NP rows of s_pitch bytes
 	unsigned int *HM = reinterpret_cast<unsigned int *>(S + NP * a.s_pitch); // HF: byte masks [band][dword of a box]
@@ -232,7 +233,7 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 	// (sum + 2048) >> 12 (templates.h:152-157)
 	int acc[NP][NB];
 	int half = INTERPOLATE_SCALE >> 1;
-	asm volatile("" : "+v"(half)); // one register for all sums to start from
+	VH_VECTOR1(half); // one register for all sums to start from
 #pragma unroll
 	for (int s = 0; s < NP; s++)
 #pragma unroll
@@ -301,7 +302,7 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 				for (int q = 0; q < NP; q++) {
 					const int slot = (p - 1 - q + 2 * NP) % NP;
 					if (q == 0)
-						asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(acc[slot][b]) : "v"(pk), "s"(a.cv[0]), "v"(half));
+						VH_DOT2_SCALAR_COEF(acc[slot][b], pk, a.cv[0], half);
 					else
 						acc[slot][b] = rs_dot2(pk, a.cv[q], acc[slot][b]);
 				}
@@ -330,7 +331,7 @@ resize_stream_u8(StreamArgs a, StreamPtrs ptrs_by_value)
 		// (everything the horizontal pass derives from the thread index is made anew per slab:
 		// hoisted out of the row loop it would sit in ~30 registers through the vertical pass)
 		int th = t;
-		asm volatile("" : "+v"(th));
+		VH_VECTOR1(th);
 		if constexpr (!HF) {
 			// shrinkh: thread = one band element of the shrunk rows, all slab rows
 			{

@@ -28,6 +28,7 @@
 // geometries this kernel does not take.  Bit-exact with the separate operations.
 #include "resample.h"
 #include "reduce_u8.h"
+#include "kernel_stmt.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -80,14 +81,14 @@ static __device__ __forceinline__ unsigned int rg_sat2(int lo, int hi)
 {
 	const unsigned int both = __builtin_amdgcn_perm((unsigned int) hi, (unsigned int) lo, 0x05040100u);
 	unsigned int r;
-	asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(both));
+	VH_SAT_PK_U8_I16(r, both);
 	return r;
 }
 
 static __device__ __forceinline__ unsigned int rg_fin(int s)
 {
 	s = (s + (INTERPOLATE_SCALE >> 1)) >> INTERPOLATE_SHIFT;
-	asm volatile("" : "+v"(s));
+	VH_VECTOR1(s);
 	return (unsigned int) min(max(s, 0), 255);
 }
 
@@ -98,7 +99,7 @@ template <int NS, int GS>
 __global__ void __launch_bounds__(RG_NT)
 resize_streamg_u8(GenArgs a, GenPtrs ptrs_by_value)
 {
-	extern __shared__ __attribute__((aligned(16))) unsigned int rg_lds[];
+	VH_DYNAMIC_LDS(unsigned int, rg_lds);
 	unsigned char *T = reinterpret_cast<unsigned char *>(rg_lds); // RG_K rows of RG_SPAN bytes
 	unsigned char *S = T + RG_K * RG_SPAN;                        // RG_K rows of s_pitch bytes
 	short *ch = reinterpret_cast<short *>(T + a.off_ch);          // [x][n_h] horizontal taps of the strip
@@ -163,7 +164,7 @@ resize_streamg_u8(GenArgs a, GenPtrs ptrs_by_value)
 	auto hphase = [&](int ybase, int nr) __attribute__((always_inline)) {
 		__syncthreads();
 		int th = t;
-		asm volatile("" : "+v"(th)); // (see resize_stream.hip: nothing of this phase is held through the row loop)
+		VH_VECTOR1(th); // (see resize_stream.hip: nothing of this phase is held through the row loop)
 		// shrinkh: thread = one band element of the shrunk rows, all slab rows
 		{
 			const int per_row = ncol * B;
@@ -219,7 +220,7 @@ resize_streamg_u8(GenArgs a, GenPtrs ptrs_by_value)
 				if (r < nr) {
 					const unsigned int v = rg_fin(sum[r]);
 					const GlobalOut p = dst + (long long) r * a.out_stride;
-					asm volatile("global_store_byte %0, %1, off" : : "v"(p), "v"(v) : "memory");
+					VH_STORE_BYTE(p, v);
 				}
 		}
 	};
@@ -277,7 +278,7 @@ resize_streamg_u8(GenArgs a, GenPtrs ptrs_by_value)
 			// dynamic register index, i.e. the accumulators would live in scratch memory)
 #define RG_ARM(SL) \
 	case SL: \
-		asm volatile("; retire slot " #SL); \
+		VH_ASM_MARK("retire slot " #SL); \
 		packed = rg_sat2((acc[SL][0] + 2048) >> INTERPOLATE_SHIFT, (acc[SL][1] + 2048) >> INTERPOLATE_SHIFT) | \
 			(rg_sat2((acc[SL][2] + 2048) >> INTERPOLATE_SHIFT, (acc[SL][3] + 2048) >> INTERPOLATE_SHIFT) << 16); \
 		acc[SL][0] = acc[SL][1] = acc[SL][2] = acc[SL][3] = 0; \
@@ -292,7 +293,7 @@ resize_streamg_u8(GenArgs a, GenPtrs ptrs_by_value)
 				RG_ARM(6)
 			default:
 				if constexpr (NS == 8) {
-					asm volatile("; retire slot 7");
+					VH_ASM_MARK("retire slot 7");
 					packed = rg_sat2((acc[7][0] + 2048) >> INTERPOLATE_SHIFT, (acc[7][1] + 2048) >> INTERPOLATE_SHIFT) |
 						(rg_sat2((acc[7][2] + 2048) >> INTERPOLATE_SHIFT, (acc[7][3] + 2048) >> INTERPOLATE_SHIFT) << 16);
 					acc[7][0] = acc[7][1] = acc[7][2] = acc[7][3] = 0;
@@ -304,7 +305,7 @@ resize_streamg_u8(GenArgs a, GenPtrs ptrs_by_value)
 						RG_ARM(9)
 						RG_ARM(10)
 					default:
-						asm volatile("; retire slot 11");
+						VH_ASM_MARK("retire slot 11");
 						packed = rg_sat2((acc[NS - 1][0] + 2048) >> INTERPOLATE_SHIFT, (acc[NS - 1][1] + 2048) >> INTERPOLATE_SHIFT) |
 							(rg_sat2((acc[NS - 1][2] + 2048) >> INTERPOLATE_SHIFT, (acc[NS - 1][3] + 2048) >> INTERPOLATE_SHIFT) << 16);
 						acc[NS - 1][0] = acc[NS - 1][1] = acc[NS - 1][2] = acc[NS - 1][3] = 0;

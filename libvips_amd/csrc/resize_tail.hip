@@ -21,6 +21,7 @@
 // from HBM once per XCD.
 #include "resample.h"
 #include "reduce_u8.h"
+#include "kernel_stmt.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -63,11 +64,7 @@ constexpr int TAIL_NT = 256;
 static __device__ __forceinline__ void tail_dma_dword(const unsigned char *src, unsigned int voff,
 	unsigned int lds_dst)
 {
-	unsigned int keep;
-	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-				 : "=&s"(keep)
-				 : "v"(voff), "s"(src), "s"(lds_dst)
-				 : "memory");
+	VH_LDS_DMA_DWORD(src, voff, lds_dst);
 }
 
 // (sum + 2048) >> 12, clip (templates.h:152-157).  The shifted value is made opaque before the
@@ -77,7 +74,7 @@ static __device__ __forceinline__ void tail_dma_dword(const unsigned char *src, 
 static __device__ __forceinline__ unsigned int tail_fin(int s)
 {
 	s = (s + (INTERPOLATE_SCALE >> 1)) >> INTERPOLATE_SHIFT;
-	asm volatile("" : "+v"(s));
+	VH_VECTOR1(s);
 	return (unsigned int) min(max(s, 0), 255);
 }
 
@@ -161,7 +158,7 @@ __global__ void __launch_bounds__(TAIL_NT)
 resize_tail_u8(TailPtrs ptrs_by_value, TailArgs a, const ReducePos *__restrict__ posv, const short *__restrict__ tabv,
 	const ReducePos *__restrict__ posh, const short *__restrict__ tabh)
 {
-	extern __shared__ __attribute__((aligned(16))) unsigned int tail_lds[];
+	VH_DYNAMIC_LDS(unsigned int, tail_lds);
 	(void) ptrs_by_value;
 	typedef const unsigned long long __attribute__((address_space(4))) *KernargPtrs;
 	const KernargPtrs kp = (KernargPtrs) __builtin_amdgcn_kernarg_segment_ptr();
@@ -253,7 +250,7 @@ resize_tail_u8(TailPtrs ptrs_by_value, TailArgs a, const ReducePos *__restrict__
 			first[t] = posv[y0 + t].first - r_lo;
 		for (int i = t; i < nx; i += TAIL_NT)
 			first[a.th + i] = posh[x0 + i].first;
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		VH_WAIT_VMCNT(0);
 	}
 	__syncthreads();
 

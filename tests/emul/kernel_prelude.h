@@ -17,6 +17,10 @@
 
 // ---- csrc/kernel_stmt.h (its guard is taken here: the product's meanings never reach a host build)
 #define VH_KERNEL_STMT_H
+#define VH_SAT_PK_U8_I16(r, both) ((r) = vh::sat_pk_u8_i16(both))
+#define VH_DOT2_SCALAR_COEF(dst, pk, coef, acc) ((dst) = vh::dot2(pk, coef, acc))
+#define VH_STORE_BYTE(p, v) (*(unsigned char *) (p) = (unsigned char) (v))
+#define VH_ASM_MARK(text) ((void) 0)
 #define VH_VECTOR1(a) ((void) (a))
 #define VH_USE2(a, b) ((void) (a), (void) (b))
 #define VH_SCALAR(x) ((void) (x))

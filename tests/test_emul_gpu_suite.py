@@ -40,3 +40,11 @@ def test_conv_colour_file_on_the_cpu():
     colourspace kernel, every colour route, cast, premultiply, sharpen, the approximate convolutions --
     all but the cases that go through vips_resize."""
     _run(["tests/test_conv_colour_gpu.py"], ["thumbnail", "c4_pipeline"], 580)
+
+
+def test_resample_file_on_the_cpu():
+    """tests/test_resample_gpu.py: reduce / shrink in every format (the general kernels), the goldens, the
+    fused RGBA reduce on the matrix instruction and its VALU sibling, upsizing -- without the cases that go
+    through the one-kernel resize chains, the device-sized ones and the slow sweeps of the matrix-core
+    kernel's variants (a minute each on fibers: every v_mfma is a meeting of 64 fibers)."""
+    _run(["tests/test_resample_gpu.py"], ["resize", "thumbnail", "c2_full", "c2_quarter", "mfma_variants", "region_windows", "any_bands"], 160)
