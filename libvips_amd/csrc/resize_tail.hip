@@ -205,7 +205,7 @@ resize_tail_u8(TailPtrs ptrs_by_value, TailArgs a, const ReducePos *__restrict__
 		}
 		else if (a.aligned) {
 			// a row is ceil(ndw / 64) LDS-DMA loads
-			const unsigned int lds_tile = (unsigned int) (size_t) tile;
+			const unsigned int lds_tile = VH_LDS_ADDR(tile);
 			for (int r = wv; r < nrows; r += TAIL_NT / 64) {
 				const int row = min(max(r_lo + r, 0), a.height - 1);
 				const unsigned char *src = in + (long long) row * a.in_stride + start_al;

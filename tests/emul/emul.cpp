@@ -8,9 +8,42 @@
 #include <cstring>
 #include <vector>
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 namespace emul {
 
 namespace {
+
+// $EMUL_BACKTRACE=1: the native frames of a crash inside a fiber (addresses + /proc/self/maps for addr2line)
+void crash_handler(int sig)
+{
+	void *frames[48];
+	const int n = backtrace(frames, 48);
+	backtrace_symbols_fd(frames, n, 2);
+	signal(sig, SIG_DFL);
+	raise(sig);
+}
+struct CrashHook {
+	CrashHook()
+	{
+		if (getenv("EMUL_BACKTRACE")) {
+			static char altstack[1 << 16];
+			stack_t ss;
+			ss.ss_sp = altstack;
+			ss.ss_size = sizeof(altstack);
+			ss.ss_flags = 0;
+			sigaltstack(&ss, nullptr);
+			struct sigaction sa;
+			sa.sa_handler = crash_handler;
+			sigemptyset(&sa.sa_mask);
+			sa.sa_flags = SA_ONSTACK;
+			sigaction(SIGSEGV, &sa, nullptr);
+		}
+	}
+} g_crash_hook;
+
 
 struct Fiber {
 	ucontext_t ctx;
@@ -29,6 +62,7 @@ thread_local const std::function<void()> *g_fn = nullptr;
 thread_local unsigned long long g_ticks = 0;
 thread_local std::vector<unsigned int> *g_exchange = nullptr;
 thread_local unsigned char *g_lds = nullptr;
+thread_local size_t g_lds_bytes = 0;
 // fiber stacks are kept by the OS thread from block to block (a grid of one-thread-per-pixel kernels
 // runs tens of thousands of blocks)
 struct StackPool {
@@ -73,7 +107,12 @@ const WaveData &wave_share(const void *payload, int bytes, bool pred)
 
 unsigned long long ballot(bool pred) { return wave_share(nullptr, 0, pred).mask; }
 
-void set_lds_base(unsigned char *base) { g_lds = base; }
+void set_lds_base(unsigned char *base, size_t bytes)
+{
+	g_lds = base;
+	g_lds_bytes = bytes;
+}
+size_t lds_bytes() { return g_lds_bytes; }
 unsigned char *lds_base() { return g_lds; }
 
 unsigned int exchange(unsigned int value, int src)

@@ -6,6 +6,7 @@
 #ifndef VH_EMUL_H
 #define VH_EMUL_H
 
+#include <cstddef>
 #include <functional>
 
 namespace emul {
@@ -28,7 +29,8 @@ struct WaveData {
 };
 const WaveData &wave_share(const void *payload, int bytes, bool pred);
 // the block's dynamic LDS (set by whoever runs the block; convsep_stream's LDS-DMA addresses are offsets into it)
-void set_lds_base(unsigned char *base);
+void set_lds_base(unsigned char *base, size_t bytes = 0);
+size_t lds_bytes();
 unsigned char *lds_base();
 // run `fn` as `threads` fibers (one block); fn reads current_tid()
 void run_block(int threads, const std::function<void()> &fn);

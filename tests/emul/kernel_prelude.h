@@ -29,8 +29,16 @@
 #define VH_VECTOR5(a, b, c, d, e) ((void) (a), (void) (b), (void) (c), (void) (d), (void) (e))
 #define VH_WAIT_VMCNT(n) ((void) 0) // (the emulated LDS-DMA lands at once)
 // lane i's dword to LDS offset lds_dst + 4 i
-#define VH_LDS_DMA_DWORD(src, voff, lds_dst) \
-	memcpy(emul::lds_base() + (lds_dst) + 4u * (unsigned int) (emul::current_tid() & 63), (const char *) (src) + (voff), 4)
+static inline void emul_lds_dma_dword(const void *src, unsigned int voff, unsigned int lds_dst)
+{
+	const size_t at = (size_t) lds_dst + 4u * (unsigned int) (emul::current_tid() & 63);
+	if (at + 4 > emul::lds_bytes()) {
+		fprintf(stderr, "emul: LDS-DMA to byte %zu of %zu\n", at, emul::lds_bytes());
+		abort();
+	}
+	memcpy(emul::lds_base() + at, (const char *) src + voff, 4);
+}
+#define VH_LDS_DMA_DWORD(src, voff, lds_dst) emul_lds_dma_dword(src, voff, lds_dst)
 #define VH_DYNAMIC_LDS(T, name) T *name = reinterpret_cast<T *>(emul::lds_base())
 #define VH_LDS_ADDR(p) ((unsigned int) (reinterpret_cast<unsigned char *>(p) - emul::lds_base()))
 
@@ -190,7 +198,7 @@ static void launch(dim3 grid, dim3 block, size_t lds_bytes, const void *kernarg,
 			g.block = block;
 			g.block_idx = dim3((unsigned int) (wg % grid.x), (unsigned int) (wg / grid.x % grid.y), (unsigned int) (wg / ((long long) grid.x * grid.y)));
 			g.kernarg = kernarg;
-			set_lds_base(base);
+			set_lds_base(base, lds_bytes);
 			run_block((int) (block.x * block.y * block.z), body);
 		}
 	};
