@@ -7,7 +7,7 @@
 #   usage: tools/emul_gpu_suite.sh [log]      (8 cores: about 8 minutes)
 log=${1:-/tmp/emul_gpu_suite.log}
 cd "$(dirname "$0")/.." || exit 1
-make -C tests/mock_hip > /dev/null 2>&1
+python -c "from tests.test_host_glue_mock import _build_mock; import sys; sys.exit(0 if _build_mock() else 1)" || exit 1
 make -C tests/emul > /dev/null || exit 1
 LD_PRELOAD=$PWD/tests/mock_hip/_build/libmockhip.so VIPS_HIP_LIBRARY=$PWD/tests/emul/_build/libvipship_emul.so \
   python -m pytest tests -m gpu -q -p no:cacheprovider --durations=25 \
