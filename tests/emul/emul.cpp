@@ -111,6 +111,10 @@ void set_lds_base(unsigned char *base, size_t bytes)
 {
 	g_lds = base;
 	g_lds_bytes = bytes;
+	// A block starts on zeroed LDS: kernels may read LDS nobody wrote (lanes whose result is thrown away)
+	// and turn it into a table index through a cast that saturates on the device and is undefined here.
+	if (base && bytes)
+		memset(base, 0, bytes);
 }
 size_t lds_bytes() { return g_lds_bytes; }
 unsigned char *lds_base() { return g_lds; }

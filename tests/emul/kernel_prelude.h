@@ -186,9 +186,20 @@ static void launch(dim3 grid, dim3 block, size_t lds_bytes, const void *kernarg,
 	const long long blocks = (long long) grid.x * grid.y * grid.z;
 	std::atomic<long long> next(0);
 	auto worker = [&]() {
+		// (EMUL_EXACT_LDS, the sanitizer build: exactly the bytes the launch asked for, so that a step past
+		// the block's dynamic LDS is a heap overflow the sanitizer sees)
+#ifdef EMUL_EXACT_LDS
+		const size_t lds_alloc = (lds_bytes + 15) / 16 * 16;
+		unsigned char *base = static_cast<unsigned char *>(aligned_alloc(16, lds_alloc ? lds_alloc : 16));
+		struct Free {
+			unsigned char *p;
+			~Free() { free(p); }
+		} lds_free{base};
+#else
 		std::vector<unsigned char> lds(lds_bytes + 64);
 		unsigned char *base = lds.data();
 		base += (16 - ((uintptr_t) base & 15)) & 15;
+#endif
 		for (;;) {
 			const long long wg = next.fetch_add(1);
 			if (wg >= blocks)
