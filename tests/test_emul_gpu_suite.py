@@ -1,12 +1,11 @@
 """CPU: the GPU parity files themselves, run against libvipship_emul.so under the mock HIP runtime.
 
-tests/emul compiles the product's kernel FILES for host fibers (kernel_prelude.h: colour.hip, conv.hip,
-convsep_f32.hip, convsep_stream.hip, resample.hip, approx.hip, upsize.hip -- the source the GPU runs, not a
-restatement -- beside the kernel bodies written against gcn.h), so a `-m gpu` test whose kernels are all in
-that set can run here, on the CPU, against the same oracle with the same assertions.  What stays GPU-only:
-the matrix-core reduce and the one-kernel resize chains (inline assembly), anything that feeds NaN or
-out-of-range values into a C cast (the device's conversions saturate, the host's are undefined), sizes
-chosen for the device.  The selection below is what passes for those reasons and no other."""
+tests/emul compiles the product's kernel FILES for host fibers (kernel_prelude.h: the .hip sources the GPU
+runs, not restatements -- beside the kernel bodies written against gcn.h), so a `-m gpu` test whose kernels are in
+that set -- by the end of round 4: all of them, the matrix-core reduce included (v_mfma as a meeting of a
+wave's fibers) -- can run here, on the CPU, against the same oracle with the same assertions.  What stays
+GPU-only: what needs torch CUDA tensors or the libvips plugin's own library, device-sized cases, the slow
+sweeps (a v_mfma is 64 fiber switches).  tools/emul_gpu_suite.sh runs everything that can run."""
 import os
 import re
 import subprocess
@@ -38,8 +37,14 @@ def _run(files, deselect, at_least):
 def test_conv_colour_file_on_the_cpu():
     """tests/test_conv_colour_gpu.py: convi / convf / convsep / gaussblur in every format, the fused blur +
     colourspace kernel, every colour route, cast, premultiply, sharpen, the approximate convolutions --
-    all but the cases that go through vips_resize."""
-    _run(["tests/test_conv_colour_gpu.py"], ["thumbnail", "c4_pipeline"], 580)
+    the thumbnail goldens and BASELINE config 4's per-image pipeline (the one-kernel resize chains)."""
+    _run(["tests/test_conv_colour_gpu.py"], [], 589)
+
+
+def test_c1_and_the_new_kernels_files_on_the_cpu():
+    """BASELINE config 1 (the vipsthumbnail command line against the device part of vips_thumbnail_image) and
+    the parity file of the integer horizontal pass of convsep_stream."""
+    _run(["tests/test_c1_vipsthumbnail.py", "tests/test_convsep_int_gpu.py"], [], 38)
 
 
 def test_resample_file_on_the_cpu():
