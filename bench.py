@@ -129,27 +129,75 @@ def file_sha(path):
         return None
 
 
-def span_sha(path, span=None):
-    """Hash of a kernel's own source: the text between `// [span NAME]` and `// [/span NAME]` in
-    `path` (the whole file without a span), so that edits to other kernels of the same file do not
-    make the committed counters look stale."""
+_BUNDLE_MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def kernel_isa_sha(symbol_part, lib_path=None):
+    """Hash of a kernel's MACHINE CODE as it sits in the built library: the bytes of the gfx950
+    function whose mangled name contains `symbol_part`, read from the code objects bundled in
+    libvipship.so (clang offload bundle -> ELF64 -> .symtab -> the function's bytes in .text).
+    Branches are PC-relative, so the hash moves only when the kernel's instructions do: comments,
+    renamed statements and edits to other kernels of the same file leave it alone (round 4 stamped
+    the counters with a hash of the source text and a rename made them look stale)."""
+    import struct
+
+    if lib_path is None:
+        lib_path = os.path.join(ROOT, "libvips_amd", "lib", "libvipship.so")
     try:
-        text = open(path, "rb").read()
+        data = open(lib_path, "rb").read()
     except IOError:
         return None
-    if span:
-        a = text.find(("// [span %s]" % span).encode())
-        b = text.find(("// [/span %s]" % span).encode())
-        if a < 0 or b < a:
-            return None
-        text = text[a:b]
-    return hashlib.sha256(text).hexdigest()[:16]
+    found = []
+    pos = 0
+    while True:
+        p = data.find(_BUNDLE_MAGIC, pos)
+        if p < 0:
+            break
+        pos = p + len(_BUNDLE_MAGIC)
+        (n,) = struct.unpack_from("<Q", data, p + 24)
+        q = p + 32
+        if n > 64:
+            continue
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", data, q)
+            q += 24
+            triple = data[q:q + tl]
+            q += tl
+            if b"gfx950" not in triple:
+                continue
+            elf = data[p + off:p + off + size]
+            if elf[:4] != b"\x7fELF":
+                continue
+            (shoff,) = struct.unpack_from("<Q", elf, 0x28)
+            shentsize, shnum, _ = struct.unpack_from("<HHH", elf, 0x3A)
+            secs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize) for i in range(shnum)]
+            for sec in secs:
+                if sec[1] != 2:  # SHT_SYMTAB
+                    continue
+                stroff = secs[sec[6]][4]
+                for j in range(sec[5] // 24):
+                    st_name, st_info, _, st_shndx, st_value, st_size = struct.unpack_from(
+                        "<IBBHQQ", elf, sec[4] + j * 24)
+                    if (st_info & 0xF) != 2 or st_shndx >= len(secs) or not st_size:
+                        continue
+                    e = elf.index(b"\0", stroff + st_name)
+                    if symbol_part.encode() in elf[stroff + st_name:e]:
+                        text = secs[st_shndx]
+                        fo = st_value - text[3] + text[4]
+                        found.append((elf[stroff + st_name:e], elf[fo:fo + st_size]))
+    if not found:
+        return None
+    h = hashlib.sha256()
+    for name, code in sorted(found):
+        h.update(name + b"\0" + code)
+    return h.hexdigest()[:16]
 
 
 def traffic_for(kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
     (profiles/traffic.json; PMC passes cannot run inside the timed bench).  An entry is only
-    used while the kernel source it was measured on is unchanged (its `source_sha` stamp)."""
+    used while the kernel it was measured on is unchanged: its `isa_sha` stamp is the hash of the
+    kernel's machine code in the built library (kernel_isa_sha), not of its source text."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except (IOError, ValueError):
@@ -158,9 +206,9 @@ def traffic_for(kernel_name):
     if not keys:
         return None
     entry = table[max(keys, key=len)]
-    src = entry.get("source")
-    if not src or entry.get("source_sha") != span_sha(os.path.join(ROOT, src), entry.get("span")):
-        return None  # stale: the kernel changed since the counters were collected
+    sym = entry.get("symbol")
+    if not sym or entry.get("isa_sha") != kernel_isa_sha(sym):
+        return None  # stale: the kernel's instructions changed since the counters were collected
     return entry.get("traffic_bytes")
 
 
@@ -636,6 +684,11 @@ def run_c3(ctx, steps, warmup, verify=True, cpu=True, size=32768):
         u8 = lcg_image_device(torch, n, n, 3, 12345, ctx.device)
         src = u8.float()
         del u8
+        # $VIPS_BENCH_C3_INPUT=float: the whole entry on the float image proper (for a profiler: the
+        # kernel has one name for both inputs); default: the integers 0..255, the float image beside it
+        float_only = os.environ.get("VIPS_BENCH_C3_INPUT") == "float"
+        if float_only:
+            src.add_(0.25)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     im = Image.new_from_tensor(src, interpretation="srgb")
@@ -702,7 +755,9 @@ def run_c3(ctx, steps, warmup, verify=True, cpu=True, size=32768):
     # packed bytes (convsep_int_body.h; the test is per wave, the bits do not depend on it).  The same
     # pipeline on a float image proper -- every pixel + 0.25, both passes in double -- beside it:
     entry["input"] = "float pixels holding the integers 0..255 (LCG bytes cast to float): integer horizontal pass"
-    if ctx.world == 1:
+    if float_only:
+        entry["input"] = "the LCG bytes + 0.25 as float (no window of integers): horizontal pass in double"
+    elif ctx.world == 1:
         try:
             with torch.cuda.stream(ctx.stream):
                 src.add_(0.25)
@@ -1231,6 +1286,47 @@ def entry_as_line(entry, ctx, steps, warmup, metric, scaling="weak"):
     }
 
 
+def compact_summary(line):
+    """The other BASELINE configs and the per-call table as SCALARS inside `roofline` (the driver's
+    stored record keeps the scalar fields of `roofline` and the tail of stdout, not `configs` / `ops`),
+    and once more as one small object at the very END of the line (the tail of stdout)."""
+    by = {e.get("name"): e for e in line.get("configs", []) if isinstance(e, dict)}
+    others = {}
+    c3, c4, c5, c5s, c1 = (by.get(k) for k in ("c3", "c4", "c5", "c5slab", "c1"))
+    if c3:
+        others.update({"c3_ms": c3["ms"], "c3_frac_fp64": c3["frac_fp64"], "c3_frac_hbm": c3["frac_hbm"]})
+        if isinstance(c3.get("float_input"), dict) and "ms" in c3["float_input"]:
+            others["c3_ms_float_input"] = c3["float_input"]["ms"]
+        if "frac_of_fp64_stream" in c3:
+            others["c3_frac_of_fp64_stream"] = c3["frac_of_fp64_stream"]
+    if c4:
+        others.update({"c4_ms": c4["ms"], "c4_frac": c4["frac"], "c4_ms_per_image": c4["ms_per_image"],
+                       "c4_images": c4["images_per_gpu"]})
+    if c5:
+        others.update({"c5_ms": c5["ms"], "c5_tflops": c5.get("tflops"), "c5_frac_fp64": c5.get("frac")})
+    if c5s:
+        others.update({"c5slab_ms": c5s["ms"], "c5slab_tflops": c5s.get("tflops")})
+    if c1:
+        others["c1_ms"] = c1["ms"]
+    e2e = by.get("module_e2e")
+    if e2e and "ms" in e2e:
+        others["module_e2e_ms"] = e2e["ms"]
+    ops = {e["name"]: e["frac"] for e in line.get("ops", []) if isinstance(e, dict) and "frac" in e}
+    roof = line.get("roofline")
+    if roof is not None:
+        roof.update(others)
+        for name, frac in ops.items():
+            roof["op_%s_frac" % name] = frac
+        roof["others"] = dict(others)
+    # last key of the line: json.dumps keeps insertion order
+    line["summary"] = {"c2_frac": roof.get("frac") if roof else None,
+                       "c2_frac_cold": roof.get("frac_cold") if roof else None,
+                       "c2_traffic": roof.get("traffic") if roof else None,
+                       "others": others, "ops_frac": ops,
+                       "parity": {e.get("name"): (e.get("parity") or {}).get("bit_exact")
+                                  for e in line.get("configs", []) + line.get("ops", []) if isinstance(e, dict)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1269,6 +1365,7 @@ def main():
                 e2e = run_module_e2e(ctx, line["roofline"]["kernel_ms"] if line.get("roofline") else None)
                 if e2e:
                     line["configs"].append(e2e)
+            compact_summary(line)
     elif args.config == "c3":
         e = run_c3(ctx, args.steps, args.warmup, verify, cpu, args.size or 32768)
         line = entry_as_line(e, ctx, args.steps, args.warmup,

@@ -361,9 +361,9 @@ colour_lab_lds_kernel(RouteArgs a, CbrtExact cx)
 			const float n0 = quant_div_finite<0>(__fmul_rn(100000.0f, v.a));
 			const float n1 = quant_div_finite<1>(__fmul_rn(100000.0f, v.b));
 			const float n2 = quant_div_finite<2>(__fmul_rn(100000.0f, v.c));
-			const int i0 = min(max(__float2int_rz(n0), 0), CBRT_N - 2);
-			const int i1 = min(max(__float2int_rz(n1), 0), CBRT_N - 2);
-			const int i2 = min(max(__float2int_rz(n2), 0), CBRT_N - 2);
+			const int i0 = min(max(vh::cvt_i32(n0), 0), CBRT_N - 2);
+			const int i1 = min(max(vh::cvt_i32(n1), 0), CBRT_N - 2);
+			const int i2 = min(max(vh::cvt_i32(n2), 0), CBRT_N - 2);
 			float t0, dt;
 			if constexpr (F32)
 				cbrt_pair32(lds, i0, &t0, &dt);
@@ -444,7 +444,7 @@ CAST_II_ALL(int)
 			double d = (double) v; \
 			d = (double) (HI) < d ? (double) (HI) : d; \
 			d = (double) (LO) > d ? (double) (LO) : d; \
-			return (TOUT) d; \
+			return vh::cvt_to<TOUT>(d); \
 		} \
 	};
 #define CAST_FI_ALL(TIN) \
@@ -989,7 +989,7 @@ static __device__ __forceinline__ void premul_pixel(const TIN (&p)[NB], float (&
 	clip = 0.0 > clip ? 0.0 : clip;
 	if (!INVERSE) {
 		// IN clip_alpha = CLIP(...); OUT nalpha = (OUT) clip_alpha / max_alpha
-		const TIN clip_alpha = (TIN) clip;
+		const TIN clip_alpha = vh::cvt_to<TIN>(clip);
 		const float nalpha = (float) __ddiv_rn((double) (float) clip_alpha, max_alpha);
 #pragma unroll
 		for (int i = 0; i < ab; i++)
@@ -1038,7 +1038,7 @@ premul_float_kernel(PremulArgs a)
 		clip = 0.0 > clip ? 0.0 : clip;
 		if (!INVERSE) {
 			// IN clip_alpha = CLIP(...); OUT nalpha = (OUT) clip_alpha / max_alpha
-			const TIN clip_alpha = (TIN) clip;
+			const TIN clip_alpha = vh::cvt_to<TIN>(clip);
 			const float nalpha = (float) __ddiv_rn((double) (float) clip_alpha, a.max_alpha);
 			for (int i = 0; i < ab; i++)
 				q[i] = __fmul_rn((float) p[i], nalpha);

@@ -5,6 +5,7 @@
 #pragma once
 
 #include "colour.h"
+#include "kernel_stmt.h"
 
 namespace vh {
 
@@ -98,7 +99,7 @@ static __device__ __forceinline__ float cbrt_lerp(const float *__restrict__ tabl
 	// "integer indefinite" INT_MIN, which the clip turns into 0
 	// (v_cvt_i32_f32 saturates and turns NaN into 0: after the clip only n >= 2^31 -- INT_MAX
 	// here, INT_MIN there -- needs telling apart)
-	int i = __float2int_rz(n);
+	int i = vh::cvt_i32(n);
 	if (!FINITE)
 		i = n >= 2147483648.0f ? 0 : i;
 	i = min(max(i, 0), 100000 - 2);
@@ -116,7 +117,7 @@ template <int WHICH>
 static __device__ __forceinline__ int cbrt_index_finite(float v, float &f)
 {
 	const float n = quant_div_finite<WHICH>(__fmul_rn(100000.0f, v));
-	int i = __float2int_rz(n);
+	int i = vh::cvt_i32(n);
 	i = min(max(i, 0), 100000 - 2);
 	f = __fsub_rn(n, (float) i);
 	return i;
@@ -226,11 +227,11 @@ static __device__ __forceinline__ int scRGB2sRGB_channel(const int *__restrict__
 		Yf = 0;
 	else if (Yf > maxval)
 		Yf = maxval;
-	const int Yi = (int) Yf;
+	const int Yi = vh::cvt_i32(Yf); // (0 <= Yf <= maxval, or NaN -> 0)
 	const int l0 = lut[Yi];
 	const float r =
 		__fadd_rn((float) l0, __fmul_rn((float) (lut[Yi + 1] - l0), __fsub_rn(Yf, (float) Yi)));
-	return (int) rintf(r);
+	return vh::cvt_i32(rintf(r));
 }
 
 // vips_Lab2LabS_line, Lab2LabS.c:59-73: double multiply, clip, truncate
@@ -239,7 +240,7 @@ static __device__ __forceinline__ short lab2labs(float v, double scale, double l
 	double d = __dmul_rn((double) v, scale);
 	d = d > 32767.0 ? 32767.0 : d; // VIPS_MIN(B, V)
 	d = lo > d ? lo : d;           // VIPS_MAX(A, ...)
-	return (short) d;
+	return (short) vh::cvt_i32(d); // (NaN falls through both selects: 0, as the low half of x86's INT_MIN)
 }
 
 // ------------------------------------------------------------- pixel IO
@@ -262,7 +263,7 @@ __device__ __forceinline__ int load_as_uchar_like<float>(float v, int maxv)
 	float d = v;
 	d = (float) maxv < d ? (float) maxv : d;
 	d = 0.0f > d ? 0.0f : d;
-	return (int) d;
+	return vh::cvt_i32(d);
 }
 template <>
 __device__ __forceinline__ int load_as_uchar_like<double>(double v, int maxv)
@@ -270,7 +271,7 @@ __device__ __forceinline__ int load_as_uchar_like<double>(double v, int maxv)
 	double d = v;
 	d = (double) maxv < d ? (double) maxv : d;
 	d = 0.0 > d ? 0.0 : d;
-	return (int) d;
+	return vh::cvt_i32(d);
 }
 
 template <typename T>
@@ -285,7 +286,7 @@ __device__ __forceinline__ int load_as_short<float>(float v)
 	double d = (double) v;
 	d = 32767.0 < d ? 32767.0 : d;
 	d = -32768.0 > d ? -32768.0 : d;
-	return (int) d;
+	return vh::cvt_i32(d);
 }
 template <>
 __device__ __forceinline__ int load_as_short<double>(double v)
@@ -293,7 +294,7 @@ __device__ __forceinline__ int load_as_short<double>(double v)
 	double d = v;
 	d = 32767.0 < d ? 32767.0 : d;
 	d = -32768.0 > d ? -32768.0 : d;
-	return (int) d;
+	return vh::cvt_i32(d);
 }
 
 struct RouteArgs {
@@ -317,21 +318,21 @@ __device__ __forceinline__ unsigned char cast_from_double<unsigned char>(double 
 {
 	d = 255.0 < d ? 255.0 : d;
 	d = 0.0 > d ? 0.0 : d;
-	return (unsigned char) d;
+	return (unsigned char) vh::cvt_i32(d);
 }
 template <>
 __device__ __forceinline__ unsigned short cast_from_double<unsigned short>(double d)
 {
 	d = 65535.0 < d ? 65535.0 : d;
 	d = 0.0 > d ? 0.0 : d;
-	return (unsigned short) d;
+	return (unsigned short) vh::cvt_i32(d);
 }
 template <>
 __device__ __forceinline__ short cast_from_double<short>(double d)
 {
 	d = 32767.0 < d ? 32767.0 : d;
 	d = -32768.0 > d ? -32768.0 : d;
-	return (short) d;
+	return (short) vh::cvt_i32(d);
 }
 template <>
 __device__ __forceinline__ float cast_from_double<float>(double d)
@@ -515,9 +516,9 @@ static __device__ __forceinline__ void route_pixel(const RouteArgs &a, const flo
 		o2 = (TOUT) lab2labs(v.c, 32768.0 / 128.0, -32768.0);
 	}
 	else {
-		o0 = (TOUT) v.a;
-		o1 = (TOUT) v.b;
-		o2 = (TOUT) v.c;
+		o0 = vh::cvt_to<TOUT>(v.a);
+		o1 = vh::cvt_to<TOUT>(v.b);
+		o2 = vh::cvt_to<TOUT>(v.c);
 	}
 }
 
@@ -529,7 +530,7 @@ static __device__ __forceinline__ void route_pixel(const RouteArgs &a, const flo
 static __device__ __forceinline__ short lab2labs_finite(float v, double scale, double lo)
 {
 	const double d = __dmul_rn((double) v, scale);
-	return (short) __builtin_fmax(lo, __builtin_fmin(d, 32767.0));
+	return (short) vh::cvt_i32(__builtin_fmax(lo, __builtin_fmin(d, 32767.0)));
 }
 
 // step_XYZ2scRGB for finite input

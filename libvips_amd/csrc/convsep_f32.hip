@@ -119,7 +119,7 @@ static __device__ __forceinline__ typename CsTraits<MODE>::lt cs_fin(typename Cs
 		// rounded double quotient truncates to the exact integer quotient
 		int q = s + a.rounding;
 		if (a.scale_i != 1)
-			q = (int) cs_div_scale((double) q, a);
+			q = vh::cvt_i32(cs_div_scale((double) q, a));
 		q += pass == 1 ? a.offset1_i : a.offset2_i;
 		return min(max(q, a.clip_lo), a.clip_hi);
 	}

@@ -52,6 +52,7 @@ struct ScopedStream {
 	explicit ScopedStream(hipStream_t s);
 	~ScopedStream();
 	hipStream_t saved;
+	int slot; // the device slot `saved` came from
 	bool saved_external, active;
 };
 

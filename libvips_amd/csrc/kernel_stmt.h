@@ -4,6 +4,7 @@
 // meanings (and defines this header's guard), the product gets the instructions.
 #ifndef VH_KERNEL_STMT_H
 #define VH_KERNEL_STMT_H
+#include <type_traits>
 
 // register-class hints: "hold this value in a scalar / vector register here" (stops a hoist or a merge)
 #define VH_SCALAR(x) asm volatile("" : "+s"(x))
@@ -35,5 +36,52 @@
 #define VH_DYNAMIC_LDS(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
 #define VH_LDS_ADDR(p) ((unsigned int) (size_t) (p))
 
+// ---- float -> integer conversions, spelled as the instruction that does them.
+// A C cast of a NaN or of an out-of-range value is undefined in the language; what these kernels need is what
+// the part's converters do, so every float -> int conversion of the device code is one of these (no C cast of
+// a float to an integer type is left in device code: `hipcc -S` with and without
+// -fno-strict-float-cast-overflow is the same text, tests/test_isa_guard.py).
+//   v_cvt_i32_f32 / v_cvt_i32_f64: round toward zero, saturate at INT_MIN / INT_MAX, NaN -> 0
+//   v_cvt_u32_f32 / v_cvt_u32_f64: round toward zero, saturate at 0 / UINT_MAX,      NaN -> 0
+// (the x86 reference gives INT_MIN -- "integer indefinite" -- for NaN and for anything out of range; where a
+// caller can see the difference it says what it does about it)
+namespace vh {
+static __device__ __forceinline__ int cvt_i32(float v)
+{
+	int r;
+	asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+	return r;
+}
+static __device__ __forceinline__ int cvt_i32(double v)
+{
+	int r;
+	asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(v));
+	return r;
+}
+static __device__ __forceinline__ unsigned int cvt_u32(float v)
+{
+	unsigned int r;
+	asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(v));
+	return r;
+}
+static __device__ __forceinline__ unsigned int cvt_u32(double v)
+{
+	unsigned int r;
+	asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(v));
+	return r;
+}
+// a real value to a pel format: integer formats through the converters above (narrowing an int to 8 / 16
+// bits is defined: modulo 2^n), float formats by the ordinary conversion
+template <typename TOUT, typename TIN>
+static __device__ __forceinline__ TOUT cvt_to(TIN v)
+{
+	if constexpr (std::is_floating_point<TOUT>::value)
+		return (TOUT) v;
+	else if constexpr (std::is_same<TOUT, unsigned int>::value)
+		return cvt_u32(v);
+	else
+		return (TOUT) cvt_i32(v);
+}
+} // namespace vh
 
 #endif // VH_KERNEL_STMT_H

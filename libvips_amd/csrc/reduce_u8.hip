@@ -351,7 +351,6 @@ reduce_fused_u8x4(FusedArgs a, FusedCoefs<S, D> k_by_value)
 // Output rows are staged in LDS for the whole tile and written in one burst at its end: on
 // this part a 1.5 % stream of writes trickling into a streaming read costs 13 % of the
 // read rate (tools/write_probe.hip: 0.175 -> 0.198 ms per GiB), a burst at the end 4 %.
-// [span reduce_fused_u8_mfma] (profiles/traffic.json is stamped with the hash of the text between these marks)
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
@@ -756,7 +755,6 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 	}
 }
 
-// [/span reduce_fused_u8_mfma]
 
 // ------------------------------------------------ vertical-only pass on the matrix cores
 //

@@ -170,7 +170,7 @@ VH_DEV int rsh_convi_fin(int sum, const RshArgs &a)
 VH_DEV int rsh_labs(float v, double scale, double lo)
 {
 	const double d = (double) v * scale;
-	return (int) __builtin_fmax(lo, __builtin_fmin(d, 32767.0));
+	return vh::cvt_i32(__builtin_fmax(lo, __builtin_fmin(d, 32767.0)));
 }
 
 // one channel of vips_col_scRGB2sRGB (LabQ2sRGB.c:290-360) for a finite value, into byte k of `old`
@@ -179,7 +179,7 @@ VH_DEV unsigned int rsh_channel(const RshPair *Y2v, float v, unsigned int k, uns
 	float Yf = v * 255.0f;
 	Yf = Yf < 0.0f ? 0.0f : Yf; // (NaN cannot happen: finite input)
 	Yf = Yf > 255.0f ? 255.0f : Yf;
-	const int Yi = (int) Yf;
+	const int Yi = vh::cvt_i32(Yf);
 	const RshPair e = Y2v[Yi];
 	const float r = e.x + e.y * fract(Yf);
 	return cvt_pk_u8(rne(r), k, old);
@@ -323,9 +323,9 @@ static __device__ __forceinline__ void resize_sharpen_body(const RshArgs &a, con
 		const float n0 = rsh_quant(100000.0f * X, 95.0470);
 		const float n1 = rsh_quant(100000.0f * Y, 100.0);
 		const float n2 = rsh_quant(100000.0f * Z, 108.8827);
-		const int i0 = min(max((int) n0, 0), CBRT_N - 2);
-		const int i1 = min(max((int) n1, 0), CBRT_N - 2);
-		const int i2 = min(max((int) n2, 0), CBRT_N - 2);
+		const int i0 = min(max(vh::cvt_i32(n0), 0), CBRT_N - 2);
+		const int i1 = min(max(vh::cvt_i32(n1), 0), CBRT_N - 2);
+		const int i2 = min(max(vh::cvt_i32(n2), 0), CBRT_N - 2);
 		const int slot = (NP * sf + r) & (RSH_RING - 1);
 		float t0, dt;
 		if (c32)

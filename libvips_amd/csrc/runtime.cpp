@@ -183,7 +183,8 @@ void release_thread_stream()
 }
 
 ScopedStream::ScopedStream(hipStream_t s)
-	: saved(tls_external), saved_external(tls_stream_external), active(s != nullptr)
+	: saved(tls_external), slot(tls_device < 0 ? 0 : tls_device), saved_external(tls_stream_external),
+	  active(s != nullptr)
 {
 	if (active) {
 		tls_external = s;
@@ -191,11 +192,12 @@ ScopedStream::ScopedStream(hipStream_t s)
 	}
 }
 
+// (restores into the slot it saved from: the thread may have been rebound to another device inside the scope)
 ScopedStream::~ScopedStream()
 {
 	if (active) {
-		tls_external = saved;
-		tls_stream_external = saved_external;
+		tls_external_dev[slot] = saved;
+		tls_stream_external_dev[slot] = saved_external;
 	}
 }
 
@@ -754,10 +756,13 @@ void vips_hip_stream_free(void *s)
 {
 	if (!s)
 		return;
-	if (tls_stream_external && tls_external == (hipStream_t) s) {
-		tls_external = nullptr;
-		tls_stream_external = false;
-	}
+	// the stream may be remembered in the slot of ANY device this thread has been bound to (bind_to() moves a
+	// thread to an image's device and does not move it back): forget it everywhere before it is destroyed
+	for (int d = 0; d < MAX_DEVICES; d++)
+		if (tls_external_dev[d] == (hipStream_t) s) {
+			tls_external_dev[d] = nullptr;
+			tls_stream_external_dev[d] = false;
+		}
 	(void) hipStreamSynchronize((hipStream_t) s);
 	(void) hipStreamDestroy((hipStream_t) s);
 }

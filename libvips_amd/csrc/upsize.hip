@@ -18,6 +18,7 @@
 // One thread per output pixel column position; all float arithmetic in the reference's
 // order with separately rounded operations (the library is built with -ffp-contract=off).
 #include "resample.h"
+#include "kernel_stmt.h"
 
 #include <climits>
 #include <cmath>
@@ -82,6 +83,8 @@ struct UpTraits; // INT_PATH: fixed-point bilinear / bicubic; LO / HI: clip of t
 		static constexpr bool is_signed = SIGNED_; \
 		static __device__ __forceinline__ double lo() { return (double) (LO_); } \
 		static __device__ __forceinline__ double hi() { return (double) (HI_); } \
+		static constexpr int ilo = (int) (LO_); \
+		static constexpr int ihi = (int) (HI_); \
 	};
 UP_TRAITS(unsigned char, true, false, 0, UCHAR_MAX)
 UP_TRAITS(signed char, true, true, SCHAR_MIN, SCHAR_MAX)
@@ -133,16 +136,16 @@ upsize_kernel(UpsizeArgs a)
 	const int wo = a.window_offset;
 	// affine.c:330-336: the clip rectangle, embedded coordinates
 	const int ile = wo, ito = wo, iri = wo + a.im_width, ibo = wo + a.im_height;
-	const int fx = (int) floor(x);
-	const int ix = (int) x;
+	const int fx = vh::cvt_i32(floor(x));
+	const int ix = vh::cvt_i32(x);
 
 	for (int yy = blockIdx.y; yy < a.out_height; yy += gridDim.y) {
 		// affine.c:343-365 with ib = ic = -0: y = id * oy, -= idy, += window_offset
 		double y = __dmul_rn(a.id, (double) (a.out_top + yy));
 		y = __dsub_rn(y, a.tidy);
 		y = __dadd_rn(y, (double) wo);
-		const int fy = (int) floor(y);
-		const int iy = (int) y;
+		const int fy = vh::cvt_i32(floor(y));
+		const int iy = vh::cvt_i32(y);
 		T *q = (T *) (a.out + (long long) yy * a.out_stride) + (long long) i * a.bands;
 
 		if (!(fx >= ile && fx <= iri && fy >= ito && fy <= ibo)) {
@@ -156,8 +159,8 @@ upsize_kernel(UpsizeArgs a)
 		}
 		else if (INTERP == 1) {
 			if (UpTraits<T>::fixed_bilinear) {
-				const int X = (int) __dmul_rn(__dsub_rn(x, (double) ix), (double) INTERPOLATE_SCALE);
-				const int Y = (int) __dmul_rn(__dsub_rn(y, (double) iy), (double) INTERPOLATE_SCALE);
+				const int X = vh::cvt_i32(__dmul_rn(__dsub_rn(x, (double) ix), (double) INTERPOLATE_SCALE));
+				const int Y = vh::cvt_i32(__dmul_rn(__dsub_rn(y, (double) iy), (double) INTERPOLATE_SCALE));
 				const int Yd = INTERPOLATE_SCALE - Y;
 				const int c4 = (Y * X) >> INTERPOLATE_SHIFT;
 				const int c2 = (Yd * X) >> INTERPOLATE_SHIFT;
@@ -178,14 +181,14 @@ upsize_kernel(UpsizeArgs a)
 				const double c3 = __dsub_rn(Y, c4);
 				const double c1 = __dsub_rn(Yd, c2);
 				for (int z = 0; z < a.bands; z++)
-					q[z] = (T) dot4(c1, (double) fetch<T>(a, ix, iy, z), c2, (double) fetch<T>(a, ix + 1, iy, z), c3,
-						(double) fetch<T>(a, ix, iy + 1, z), c4, (double) fetch<T>(a, ix + 1, iy + 1, z));
+					q[z] = vh::cvt_to<T>(dot4(c1, (double) fetch<T>(a, ix, iy, z), c2, (double) fetch<T>(a, ix + 1, iy, z), c3,
+						(double) fetch<T>(a, ix, iy + 1, z), c4, (double) fetch<T>(a, ix + 1, iy + 1, z)));
 			}
 		}
 		else {
 			// bicubic.cpp:488-502: table index with round to nearest
-			const int sx = (int) __dmul_rn(__dmul_rn(x, (double) TRANSFORM_SCALE), 2.0);
-			const int sy = (int) __dmul_rn(__dmul_rn(y, (double) TRANSFORM_SCALE), 2.0);
+			const int sx = vh::cvt_i32(__dmul_rn(__dmul_rn(x, (double) TRANSFORM_SCALE), 2.0));
+			const int sy = vh::cvt_i32(__dmul_rn(__dmul_rn(y, (double) TRANSFORM_SCALE), 2.0));
 			const int tx = ((sx & (TRANSFORM_SCALE * 2 - 1)) + 1) >> 1;
 			const int ty = ((sy & (TRANSFORM_SCALE * 2 - 1)) + 1) >> 1;
 			if (sizeof(T) == 1) {
@@ -203,7 +206,7 @@ upsize_kernel(UpsizeArgs a)
 					}
 					const int s = cy[0] * r[0] + cy[1] * r[1] + cy[2] * r[2] + cy[3] * r[3];
 					int v = UpTraits<T>::is_signed ? signed_fixed_round(s) : unsigned_fixed_round(s);
-					v = min(max(v, (int) UpTraits<T>::lo()), (int) UpTraits<T>::hi());
+					v = min(max(v, UpTraits<T>::ilo), UpTraits<T>::ihi);
 					q[z] = (T) v;
 				}
 			}
@@ -233,7 +236,7 @@ upsize_kernel(UpsizeArgs a)
 						// VIPS_CLIP(lo, v, hi), then the C conversion
 						v = v < UpTraits<T>::lo() ? UpTraits<T>::lo() : (v > UpTraits<T>::hi() ? UpTraits<T>::hi() : v);
 					}
-					q[z] = (T) v;
+					q[z] = vh::cvt_to<T>(v);
 				}
 			}
 		}

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 
 #include "emul.h"
 
@@ -130,6 +131,37 @@ VH_DEV unsigned int sat_pk_u8_i16(unsigned int both)
 {
 	const int lo = (short) (both & 0xffff), hi = (short) (both >> 16);
 	return (unsigned int) min(max(lo, 0), 255) | ((unsigned int) min(max(hi, 0), 255) << 8);
+}
+// csrc/kernel_stmt.h's converters (v_cvt_i32_f32 / _f64, v_cvt_u32_f32 / _f64): toward zero, saturating, NaN -> 0
+template <typename F>
+VH_DEV int cvt_i32(F v)
+{
+	if (v != v)
+		return 0;
+	if (v >= (F) 2147483648.0)
+		return 2147483647;
+	if (v <= (F) -2147483648.0)
+		return -2147483647 - 1;
+	return (int) v;
+}
+template <typename F>
+VH_DEV unsigned int cvt_u32(F v)
+{
+	if (v != v || v <= (F) 0)
+		return 0;
+	if (v >= (F) 4294967296.0)
+		return 0xffffffffu;
+	return (unsigned int) v;
+}
+template <typename TOUT, typename TIN>
+VH_DEV TOUT cvt_to(TIN v)
+{
+	if constexpr (std::is_floating_point<TOUT>::value)
+		return (TOUT) v;
+	else if constexpr (std::is_same<TOUT, unsigned int>::value)
+		return cvt_u32(v);
+	else
+		return (TOUT) cvt_i32(v);
 }
 VH_DEV unsigned int umulhi(unsigned int a, unsigned int b) { return (unsigned int) (((unsigned long long) a * b) >> 32); }
 VH_DEV float fract(float x) { return x - floorf(x); }

@@ -43,3 +43,38 @@ def test_no_packed_shift_clamp_in_device_code(tmp_path):
             bad[os.path.basename(obj)] = n
     assert kernels > 100, kernels
     assert not bad, "v_ashr_pk_u8_i32 selected (its upper half is not what the compiler assumes): %r" % bad
+
+
+CSRC = os.path.join(helpers.ROOT, "libvips_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _device_ir(src):
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O0", "-std=c++17", "-ffp-contract=off",
+                          "-I" + os.path.join(helpers.ROOT, "include"), "-I" + CSRC, "-x", "hip",
+                          "--cuda-device-only", "-emit-llvm", "-S", src, "-o", "-"],
+                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, check=True).stdout
+    return src, out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_no_c_cast_of_a_float_to_an_integer_in_device_code():
+    """A C cast of NaN or of an out-of-range float to an integer type is undefined; the kernels need what the
+    part's converters do (saturate, NaN -> 0), so every such conversion is spelled as the instruction
+    (kernel_stmt.h: vh::cvt_i32 / cvt_u32 / cvt_to).  The unoptimised device IR of every kernel file must hold
+    no fptosi / fptoui -- neither from our sources nor from a HIP header's helper (__float2int_rz is a C cast)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    assert len(srcs) >= 15, srcs
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as pool:
+        results = list(pool.map(_device_ir, srcs))
+    bad = {}
+    defined = 0
+    for src, ir in results:
+        defined += len(re.findall(r"^define ", ir, flags=re.M))
+        hits = re.findall(r"^.*\b(?:fptosi|fptoui)\b.*$", ir, flags=re.M)
+        if hits:
+            bad[os.path.basename(src)] = hits[:3]
+    assert defined > 300, defined
+    assert not bad, "C float -> int casts in device code: %r" % bad

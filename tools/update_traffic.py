@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Stamp profiles/traffic.json with HBM bytes per launch of the C2 kernel from a rocprofv3 PMC
-summary (profiles/rocprof_summary.py output) and the hash of the kernel's own source span.
+summary (profiles/rocprof_summary.py output) and the hash of the kernel's machine code in the
+built library (bench.kernel_isa_sha): comment / rename edits cannot make the counters look stale.
 
 usage: python tools/update_traffic.py profiles/r03_c2_pmc.txt
 Reads the FETCH_SIZE / WRITE_SIZE (KB) rows of the reduce_fused_u8x4_mfma kernel; traffic =
@@ -13,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import span_sha  # noqa: E402
+from bench import kernel_isa_sha  # noqa: E402
 
 
 def main():
@@ -32,21 +33,26 @@ def main():
     if fetch is None or write is None:
         raise SystemExit("no FETCH_SIZE / WRITE_SIZE rows for reduce_fused_u8x4_mfma in %s" % path)
     src = "libvips_amd/csrc/reduce_u8.hip"
-    span = "reduce_fused_u8_mfma"
+    # the instantiation C2 launches: reduce_fused_u8x4_mfma<6, 1, 4, true, 0, true, 256, 1>
+    symbol = "reduce_fused_u8x4_mfmaILi6ELi1ELi4ELb1ELi0ELb1ELi256ELi1EE"
+    sha = kernel_isa_sha(symbol)
+    if sha is None:
+        raise SystemExit("libvipship.so holds no gfx950 function named *%s*" % symbol)
     fetch_b = int(round(fetch * 2 * 1024))
     write_b = int(round(write * 1024))
     table = {
         "_comment": "HBM bytes per launch from rocprofv3 PMC passes: FETCH_SIZE x 2 (gfx950 correction, "
                     "MI355X_MICROARCH.md section HBM) + WRITE_SIZE.  bench.py reports an entry only while "
-                    "source_sha equals the hash of the kernel's own source span (bench.span_sha).",
+                    "isa_sha equals the hash of the kernel's machine code in libvipship.so "
+                    "(bench.kernel_isa_sha).",
         "reduce_fused_u8_mfma": {
             "traffic_bytes": fetch_b + write_b,
             "fetch_bytes_x2": fetch_b,
             "write_bytes": write_b,
             "algorithmic_bytes": 16384 * 16384 * 4 + 2048 * 2048 * 4,
             "source": src,
-            "span": span,
-            "source_sha": span_sha(os.path.join(ROOT, src), span),
+            "symbol": symbol,
+            "isa_sha": sha,
             "profile": os.path.relpath(os.path.abspath(path), ROOT),
         },
     }
