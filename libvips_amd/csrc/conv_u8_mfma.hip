@@ -1,0 +1,53 @@
+// vips_convsep / vips_gaussblur (precision integer) on uchar images, both passes on the matrix cores: the
+// __global__ wrapper and launch of conv_u8_mfma_body.h (see there); host side conv_u8_mfma_host.h (both
+// shared with tests/emul).
+#include "conv_u8_mfma_body.h"
+
+namespace vh {
+
+// blocks are dealt to the 8 XCDs round-robin by the hardware: give an XCD a contiguous range of items
+// (neighbouring strips of a segment share their halo columns in its L2)
+template <int B>
+__global__ void __launch_bounds__(256, 3) // (3 waves per SIMD: the 45 KB of LDS a block takes allow 3 blocks per CU)
+conv_u8_mfma_sep(CmArgs a, int items)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned int cm_lds[];
+	const int per = (items + 7) >> 3;
+	const int item = (int) (blockIdx.x & 7) * per + (int) (blockIdx.x >> 3);
+	if ((int) (blockIdx.x >> 3) < per && item < items)
+		conv_u8_mfma_item<B>(a, item, cm_lds);
+}
+
+} // namespace vh
+
+#include "conv_u8_mfma_host.h"
+
+namespace vh {
+
+template <typename K>
+static int cm_go(K kernel, const CmArgs &a, int items, size_t lds)
+{
+	if (lds > 64 * 1024)
+		VH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	const int grid = 8 * ((items + 7) >> 3);
+	hipLaunchKernelGGL(kernel, dim3(grid), dim3(CM_NT), lds, stream(), a, items);
+	VH_CHECK(hipGetLastError());
+	return 0;
+}
+
+static int cm_launch(int bands, const CmArgs &a, int grid, size_t lds)
+{
+	switch (bands) {
+	case 1:
+		return cm_go(conv_u8_mfma_sep<1>, a, grid, lds);
+	case 2:
+		return cm_go(conv_u8_mfma_sep<2>, a, grid, lds);
+	case 3:
+		return cm_go(conv_u8_mfma_sep<3>, a, grid, lds);
+	case 4:
+		return cm_go(conv_u8_mfma_sep<4>, a, grid, lds);
+	}
+	return 1;
+}
+
+} // namespace vh

@@ -176,4 +176,41 @@ VH_DEV unsigned int cvt_pk_u8(float v, unsigned int byte, unsigned int old) { re
 
 #include "kernel_stmt.h"
 
+namespace vh {
+
+// the wave's index in its block, as a scalar
+VH_DEV int wave_index() { return __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); }
+// every vector memory operation of this wave has completed
+VH_DEV void wait_vmem0() { VH_WAIT_VMCNT(0); }
+// One dword per lane from global memory straight into LDS (global_load_lds_dword): lane i's dword, read at
+// base + voff (base wave-uniform), lands at lds_dst + i (lds_dst wave-uniform, a pointer into the block's LDS).
+// No register, no wait: wait_vmem0() + barrier() before anybody reads it.
+VH_DEV void lds_dma_dword(gptr_in base, unsigned int voff, unsigned int *lds_dst)
+{
+	const unsigned int where = __builtin_amdgcn_readfirstlane((int) VH_LDS_ADDR(lds_dst));
+	VH_LDS_DMA_DWORD(base, voff, where);
+}
+// v_mfma_f32_32x32x16_f16: D[i][j] = C[i][j] + sum_k A[i][k] B[k][j], 32 x 32 x 16, one wave.
+//   a: lane l holds A[l & 31][k] for the 8 k-slots (l >> 5, 0..7) as 8 halves (dword q = slots 2 q, 2 q + 1);
+//   b: lane l holds B[k][l & 31] for the SAME 8 k-slots of its half;
+//   acc: lane l holds D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31] in register r.
+// (which k a slot is does not matter to a sum as long as both operands agree.)  f16 denormals are not flushed.
+VH_DEV void mfma_32x32x16_f16(const unsigned int (&a)[4], const unsigned int (&b)[4], float (&acc)[16])
+{
+	typedef _Float16 gcn_half8 __attribute__((ext_vector_type(8)));
+	typedef unsigned int gcn_uint4v __attribute__((ext_vector_type(4)));
+	typedef float gcn_float16 __attribute__((ext_vector_type(16)));
+	const gcn_uint4v ua = { a[0], a[1], a[2], a[3] }, ub = { b[0], b[1], b[2], b[3] };
+	gcn_float16 c;
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+		c[r] = acc[r];
+	c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gcn_half8, ua), __builtin_bit_cast(gcn_half8, ub), c, 0, 0, 0);
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+		acc[r] = c[r];
+}
+
+} // namespace vh
+
 #endif // VH_GCN_H

@@ -86,6 +86,51 @@ VH_DEV int next_item(int *counter, int *slot)
 	return *slot;
 }
 VH_DEV void barrier() { emul::barrier(); }
+VH_DEV int wave_index() { return emul::current_tid() >> 6; }
+VH_DEV void wait_vmem0() {}
+// global_load_lds_dword: lane i's dword to lds_dst + i (the copy lands at once)
+VH_DEV void lds_dma_dword(gptr_in base, unsigned int voff, unsigned int *lds_dst)
+{
+	memcpy(lds_dst + (emul::current_tid() & 63), base + voff, 4);
+}
+// an IEEE half (denormals included) as a float
+VH_DEV float half_bits_to_float(unsigned int h)
+{
+	const int sign = (h >> 15) & 1, e = (h >> 10) & 31, m = h & 1023;
+	float v;
+	if (e == 0)
+		v = ldexpf((float) m, -24);
+	else if (e == 31)
+		v = m ? NAN : INFINITY;
+	else
+		v = ldexpf((float) (m | 1024), e - 25);
+	return sign ? -v : v;
+}
+// v_mfma_f32_32x32x16_f16 (csrc/gcn.h): a meeting of the wave's fibers; the sum in the order of the k-slots
+VH_DEV void mfma_32x32x16_f16(const unsigned int (&a)[4], const unsigned int (&b)[4], float (&acc)[16])
+{
+	unsigned int A[64][4], Bm[64][4];
+	{
+		const emul::WaveData &wd = emul::wave_share(a, 16, true);
+		memcpy(A, wd.data, sizeof(A));
+	}
+	{
+		const emul::WaveData &wd = emul::wave_share(b, 16, true);
+		memcpy(Bm, wd.data, sizeof(Bm));
+	}
+	const int lane = emul::current_tid() & 63, j = lane & 31, hf = lane >> 5;
+	for (int r = 0; r < 16; r++) {
+		const int i = (r & 3) + 8 * (r >> 2) + 4 * hf;
+		float sum = acc[r];
+		for (int half_of_wave = 0; half_of_wave < 2; half_of_wave++)
+			for (int idx = 0; idx < 8; idx++) {
+				const unsigned int av = (A[i + 32 * half_of_wave][idx >> 1] >> (16 * (idx & 1))) & 0xffffu;
+				const unsigned int bv = (Bm[j + 32 * half_of_wave][idx >> 1] >> (16 * (idx & 1))) & 0xffffu;
+				sum += half_bits_to_float(av) * half_bits_to_float(bv);
+			}
+		acc[r] = sum;
+	}
+}
 VH_DEV unsigned long long realtime() { return emul::clock_ticks(); }
 VH_DEV void sched_fence() {}
 VH_DEV void opaque(int &) {}

@@ -1,6 +1,7 @@
-"""GPU: the packed-byte integer convolutions on uchar (conv_u8.hip) against the compiled reference
-(or the port), whole images, bit for bit -- the cases of tests/test_emul_conv_u8.py, where the same
-kernel bodies run on host fibers, plus BASELINE-sized images."""
+"""GPU: the integer convolutions on uchar -- the packed-byte kernels (conv_u8.hip) and the matrix-core
+separable one (conv_u8_mfma.hip), which takes the separable masks first -- against the compiled reference
+(or the port), whole images, bit for bit: the cases of tests/test_emul_conv_u8.py / test_emul_conv_u8_mfma.py,
+where the same kernel bodies run on host fibers, plus BASELINE-sized images."""
 import numpy as np
 import pytest
 
@@ -21,6 +22,9 @@ CASES = [
     ("conv", 640, 64, 3, (K3, 8), "flat"),
     ("blur", 4096, 4096, 3, 2.0), ("blur", 4096, 3001, 3, 8.0), ("conv", 4096, 4096, 3, (K3, 8)),
     ("conv", 8192, 1027, 4, (K5, 256)), ("blur", 8192, 2048, 1, 3.0),
+    ("blur", 8192, 8192, 3, 8.0), ("blur", 3000, 1000, 4, 8.0), ("blur", 300, 140, 3, 8.0), ("blur", 160, 230, 3, 8.0),
+    ("sep", 172, 70, 3, (list(range(1, 18)) + list(range(16, 0, -1)), 289)),
+    ("sep", 1200, 300, 3, ([-20, 40, 90, 140, 90, 40, -20], 360)),
 ]
 
 
@@ -41,14 +45,18 @@ def _reference(kind, src, arg):
 
 
 @pytest.mark.parametrize("case", range(len(CASES)))
-@pytest.mark.parametrize("env", [{}, {"VIPS_HIP_CONV_U8_SEG": "3"}])
+@pytest.mark.parametrize("env", [{}, {"VIPS_HIP_CONV_U8_SEG": "3", "VIPS_HIP_CONV_MFMA_SEG": "2"},
+                                 {"VIPS_HIP_CONV_U8_MFMA": "0"}, {"VIPS_HIP_CONV_U8_MFMA": "0", "VIPS_HIP_CONV_U8_SEG": "3"}])
 def test_conv_u8(case, env, monkeypatch):
     case = CASES[case]
     kind, w, h, bands, arg = case[:5]
-    if env and w * h > 2000 * 2000:
+    if len(env) > 1 and w * h > 2000 * 2000:
         pytest.skip("short segments on the small cases only")
+    if kind == "conv" and env.get("VIPS_HIP_CONV_U8_MFMA") == "0":
+        pytest.skip("2-D masks have one kernel")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    sep_gate = "conv_u8_sep" if env.get("VIPS_HIP_CONV_U8_MFMA") == "0" else "conv_u8_mfma_sep"
     src = helpers.lcg_image(w, h, bands, np.uint8, 7 + w)
     if len(case) > 5:
         src[: h // 2] = 255
@@ -67,7 +75,7 @@ def test_conv_u8(case, env, monkeypatch):
     finally:
         libvips_amd.lib.vips_hip_gate_enable(0)
         libvips_amd.lib.vips_hip_gate_reset()
-    assert list(report) == ["conv_u8_2d" if kind == "conv" else "conv_u8_sep"], report
+    assert list(report) == ["conv_u8_2d" if kind == "conv" else sep_gate], report
     want = _reference(kind, src, arg)
     assert got.shape == want.shape and got.dtype == want.dtype
     bad = np.argwhere(got != want)

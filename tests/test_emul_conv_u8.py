@@ -64,7 +64,9 @@ def _run(cases, tmp_path, extra_env=None):
     script = os.path.join(str(tmp_path), "child.py")
     with open(script, "w") as f:
         f.write(CHILD % {"root": helpers.ROOT, "cases": cases})
-    env = dict(os.environ, LD_PRELOAD=MOCK_SO, VIPS_HIP_LIBRARY=EMUL_SO)
+    # (this file is about the packed-byte kernels: the matrix-core one, which takes these masks first, is
+    # tests/test_emul_conv_u8_mfma.py's)
+    env = dict(os.environ, LD_PRELOAD=MOCK_SO, VIPS_HIP_LIBRARY=EMUL_SO, VIPS_HIP_CONV_U8_MFMA="0")
     env.update(extra_env or {})
     proc = subprocess.run([sys.executable, script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                           env=env, timeout=1800)
