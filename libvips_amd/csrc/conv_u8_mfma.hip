@@ -3,11 +3,13 @@
 // shared with tests/emul).
 #include "conv_u8_mfma_body.h"
 
+#include <cstdio>
+
 namespace vh {
 
 // blocks are dealt to the 8 XCDs round-robin by the hardware: give an XCD a contiguous range of items
 // (neighbouring strips of a segment share their halo columns in its L2)
-template <int B>
+template <int B, bool WIDE>
 __global__ void __launch_bounds__(256, 3) // (3 waves per SIMD: the 45 KB of LDS a block takes allow 3 blocks per CU)
 conv_u8_mfma_sep(CmArgs a, int items)
 {
@@ -15,7 +17,7 @@ conv_u8_mfma_sep(CmArgs a, int items)
 	const int per = (items + 7) >> 3;
 	const int item = (int) (blockIdx.x & 7) * per + (int) (blockIdx.x >> 3);
 	if ((int) (blockIdx.x >> 3) < per && item < items)
-		conv_u8_mfma_item<B>(a, item, cm_lds);
+		conv_u8_mfma_item<B, WIDE>(a, item, cm_lds);
 }
 
 } // namespace vh
@@ -29,24 +31,29 @@ static int cm_go(K kernel, const CmArgs &a, int items, size_t lds)
 {
 	if (lds > 64 * 1024)
 		VH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	if (getenv("VIPS_HIP_CONV_MFMA_DEBUG")) {
+		int nb = -1;
+		(void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, CM_NT, lds);
+		fprintf(stderr, "conv_u8_mfma: %d items, %zu bytes of LDS, %d blocks per CU\n", items, lds, nb);
+	}
 	const int grid = 8 * ((items + 7) >> 3);
 	hipLaunchKernelGGL(kernel, dim3(grid), dim3(CM_NT), lds, stream(), a, items);
 	VH_CHECK(hipGetLastError());
 	return 0;
 }
 
-static int cm_launch(int bands, const CmArgs &a, int grid, size_t lds)
+static int cm_launch(int bands, bool wide, const CmArgs &a, int grid, size_t lds)
 {
+#define CM_CASE(B) \
+	case B: \
+		return wide ? cm_go(conv_u8_mfma_sep<B, true>, a, grid, lds) : cm_go(conv_u8_mfma_sep<B, false>, a, grid, lds);
 	switch (bands) {
-	case 1:
-		return cm_go(conv_u8_mfma_sep<1>, a, grid, lds);
-	case 2:
-		return cm_go(conv_u8_mfma_sep<2>, a, grid, lds);
-	case 3:
-		return cm_go(conv_u8_mfma_sep<3>, a, grid, lds);
-	case 4:
-		return cm_go(conv_u8_mfma_sep<4>, a, grid, lds);
+		CM_CASE(1)
+		CM_CASE(2)
+		CM_CASE(3)
+		CM_CASE(4)
 	}
+#undef CM_CASE
 	return 1;
 }
 

@@ -7,16 +7,17 @@
 //
 // Exact integers in f32, as in reduce_u8.hip: a pixel byte p is the f16 DENORMAL 0x00pp = p 2^-24 (no
 // conversion: a v_perm puts a zero byte above it), a coefficient |c| < 2048 is an exact half, every product
-// and every partial sum is an integer below 2^24 times 2^-24.  The accumulators start at (scale / 2) 2^-24, so
-// acc 2^24 = sum + scale / 2 and the rounding of conv_u8_body.h -- RN(x RN(1 / scale) - 0.5 + 1 / (2 scale)) =
-// floor(x / scale) for 0 <= x < 2^24, scale <= 8000, a negative numerator clips to 0 -- is one v_fma_f32
-// (by 2^24 RN(1 / scale): the same real product) and one v_cvt_pk_u8_f32.
+// and every partial sum is an integer below 2^24 times 2^-24.  Rounding as in conv_u8_body.h: clip(floor((S +
+// scale / 2) / scale)) = RNE(S RN(1 / scale) + bias) saturated to 0 .. 255, bias = -0.5 + 1 / (2 scale) + (scale / 2)
+// RN(1 / scale) -- one v_fma_f32 (by 2^24 RN(1 / scale): the same real product) and one v_cvt_pk_u8_f32; the host
+// walks every sum that does not saturate (S + scale / 2 < 257 scale) before it enables the kernel for a scale.
 //
 // A block of 4 waves owns 128 output columns and streams down a segment of rows in chunks of 32:
 //   stage    the chunk's 32 input rows x (128 + 2 hp) columns (hp = half rounded up to 4: row starts are
 //            dwords) go from global memory straight into LDS (global_load_lds_dword: no register, no wait
 //            until the chunk is needed; the next chunk travels while this one is computed), rows and
-//            columns outside the image clamped to its edge (vips_embed COPY);
+//            rows outside the image clamped to its edge (vips_embed COPY); columns outside it are not made at
+//            all: their taps are folded into the edge column's coefficient (Th below);
 //   pass 1   wave w makes mid[y][x] for its 32 columns: C1[y][x] = sum_u A1[y][u] T[u][x] over the 64 window
 //            columns u.  A1: lane (y = lane & 31, hf = lane >> 5) reads two groups of 4 pixels x B bands of ITS
 //            row from LDS per 16 columns, v_perm makes them halves per band; T[u][x] = c[u - x - (hp - half)],
@@ -28,8 +29,10 @@
 //            (chunks start at row Ya - hp, and pass 1 takes its pixels in the slot order the accumulators
 //            come out in, so ONE Toeplitz operand serves both passes); output rows Ya + 32 (c - 1) .. + 32
 //            after chunk c.  The result has lane & 31 = the ROW and 4
-//            neighbouring columns per register quad: bytes, bands interleaved, 4 B bytes to LDS;
-//   store    the block copies the 32 x 128 output pixels out of LDS in whole rows of dwords.
+//            neighbouring columns per register quad: bytes, bands interleaved, 4 B bytes to the wave's own
+//            32 x 32-pixel tile in LDS;
+//   store    the wave copies its tile out, 8 bytes per lane, whole tile rows per instruction (no barrier: one
+//            barrier per chunk, for the staged rows, is all the block shares).
 // Written against gcn.h (product) / tests/emul/gcn.h (host fibers, CPU suite).
 #pragma once
 
@@ -49,13 +52,13 @@ struct CmArgs {
 	int half, hp;        // taps / 2; rounded up to a multiple of 4
 	int strips, segs;    // blocks across; segments down
 	int seg_rows;        // output rows per segment: a multiple of 32
-	int in_dw;           // dwords of a staged row that hold pixels: (128 + 2 hp) B / 4
-	int in_pitch;        // ... and its pitch in LDS (in_pitch / 2 odd: a wave's 8-byte reads meet no bank twice)
-	int in_buf;          // dwords per staging buffer: 32 in_pitch rounded up to a whole number of 256
-	int out_pitch;       // dwords per output row in LDS: 32 B + 2
-	float acc0;          // (scale / 2) 2^-24
-	float k1, bias;      // 2^24 RN(1 / scale), -0.5 + 1 / (2 scale)
-	const unsigned int *tz;      // the Toeplitz operand: [4 k-steps][64 lanes][4 dwords]
+	int e_dw;            // dwords between the staged row's first byte (a multiple of the staging unit) and column X0 - hp
+	int in_dw;           // dwords of a staged row that hold pixels: e_dw + (128 + 2 hp) B / 4, in whole units
+	int in_pitch;        // ... and its pitch in LDS (a whole number of units; an odd number of them, or of dword pairs)
+	int in_buf;          // dwords per staging buffer: 32 in_pitch, + the last instruction's overrun
+	float k1, bias;      // 2^24 RN(1 / scale); -0.5 + 1 / (2 scale) + (scale / 2) RN(1 / scale): checked on the host
+	const unsigned int *tz;      // the Toeplitz operands: 4 tables of [4 k-steps][64 lanes][4 dwords]: the mask's, and
+	int edge_wave[3];            // pass 1's for the tiles 32 edge_wave[k] .. + 32 whose windows hang over an edge (-1: none)
 };
 
 // 4 pixels x B bands (B dwords as they lie in memory) -> band b as 4 halves 0x00pp: dword q = pixels 2 q, 2 q + 1
@@ -76,57 +79,107 @@ VH_DEV void cm_halves(const unsigned int (&raw)[B], int b, unsigned int &a0, uns
 }
 
 // one work item: strip x segment
-template <int B>
+template <int B, bool WIDE>
 VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 {
 	const int t = tid(), lane = t & 63, wv = wave_index(), n = lane & 31, hf = lane >> 5;
 	const int strip = item % a.strips, seg = item / a.strips;
 	const int X0 = strip * CM_BW;
-	const int Xs = X0 - a.hp; // first staged column
+	const int sb = (X0 - a.hp) * B - 4 * a.e_dw; // first staged byte of a row: a multiple of the staging unit
 	const int Ya = seg * a.seg_rows, Yb = min(Ya + a.seg_rows, a.height);
 	const int nchunks = (Yb - Ya + CM_ROWS - 1) / CM_ROWS + 1;
-	unsigned int *lds_out = lds + 2 * a.in_buf;
-	const bool interior = Xs >= 0 && Xs + CM_BW + 2 * a.hp <= a.width;
 	const gptr_in gin = gptr_in_of((unsigned long long) a.in);
+	const gptr_out gout = gptr_out_of((unsigned long long) a.out);
 
-	// the Toeplitz operand of both passes
-	unsigned int T[4][4];
+	// the Toeplitz operand of both passes, and pass 1's where the wave's window hangs over the left or right edge
+	// of the image: there every column outside is the edge column (vips_embed COPY), so its taps are ADDED to
+	// the edge column's and it gets zero -- no pixel is clamped, whatever the staging put there counts for nothing
+	unsigned int T[4][4], Th[4][4];
+	{
+		const int W = 4 * strip + wv; // the wave's tile across the image
+		int which = 0;
 #pragma unroll
-	for (int s = 0; s < 4; s++)
-		gload128(gptr_in_of((unsigned long long) a.tz), (unsigned int) ((s * 64 + lane) * 16), T[s]);
+		for (int k = 0; k < 3; k++)
+			which = a.edge_wave[k] == W ? k + 1 : which;
+#pragma unroll
+		for (int s = 0; s < 4; s++) {
+			gload128(gptr_in_of((unsigned long long) a.tz), (unsigned int) ((s * 64 + lane) * 16), T[s]);
+			gload128(gptr_in_of((unsigned long long) a.tz), (unsigned int) (((4 * which + s) * 64 + lane) * 16), Th[s]);
+		}
+	}
 
-	// chunk c: mid rows Ya - hp + 32 c .. + 32 = the same input rows, clamped
+	// the wave's own output tile in LDS (32 rows x 8 B dwords, pitch odd) and how its lanes copy it out:
+	// 4 B lanes x 8 bytes make a row of the tile, 64 / (4 B) rows per store instruction
+	constexpr int OP = 8 * B + 1, UNITS = 4 * B, RPI = 64 / UNITS;
+	unsigned int *otile = lds + 2 * a.in_buf + wv * (CM_ROWS * OP);
+	const int o_rsub = lane / UNITS, o_c2 = lane - o_rsub * UNITS;
+	const int o_xb = (X0 + 32 * wv) * B + 8 * o_c2; // byte of the output row
+	const int row_bytes = a.width * B;
+	const unsigned int o_voff = (unsigned int) (o_rsub * (int) a.out_stride + o_xb);
+
+	// chunk c: mid rows Ya - hp + 32 c .. + 32 = the same input rows, clamped.  The tile (32 rows x in_pitch
+	// dwords) is a line of units of U = 16 bytes (4 when base or stride are not multiples of 16): unit u =
+	// (row u / upr, column unit u % upr); a wave's instruction moves 64 consecutive units, lane by lane, so the
+	// LDS side is linear and the row / column of a lane's unit is two additions and a wrap per instruction
+	constexpr int U = WIDE ? 16 : 4;
+	const int upr = a.in_pitch / (U / 4), uvalid = a.in_dw / (U / 4);
+	const int row_units_last = ((a.width * B) / U - 1) * U; // byte of the last whole unit of an image row
+	// (a chunk whose 32 rows lie inside the image: a lane's offsets are the same for every such chunk)
+	constexpr int MAXI = 6; // instructions per wave and chunk the offsets are kept for
+	const int ninstr = (CM_ROWS * upr + 255) / 256;
+	unsigned int voff_in[MAXI];
+	{
+		int u = 64 * wv + lane;
+		int row = u / upr, cu = u - row * upr;
+		const int step_row = 256 / upr, step_cu = 256 - step_row * upr;
+#pragma unroll
+		for (int i = 0; i < MAXI; i++) {
+			const int rr = min(row, CM_ROWS - 1), cc = min(cu, uvalid - 1);
+			voff_in[i] = (unsigned int) (rr * (int) a.in_stride + min(max(sb + U * cc, 0), row_units_last));
+			cu += step_cu;
+			row += step_row;
+			if (cu >= upr) {
+				cu -= upr;
+				row++;
+			}
+		}
+	}
 	auto stage = [&](int c) {
 		unsigned int *dst = lds + (c & 1) * a.in_buf;
 		const int r0 = Ya - a.hp + CM_ROWS * c;
-		const int r0c = min(max(r0, 0), a.height - 1);
-		// (the uniform base carries the row and the strip: lane offsets stay below 32 strides)
-		const gptr_in base = gin + (long long) r0c * a.in_stride + (long long) Xs * B;
-		// dword d of the tile -> (row, col); a wave's instruction j covers d = 64 j .. 64 j + 63
-		int d = 64 * wv + lane;
-		int row = d / a.in_pitch, col = d - row * a.in_pitch;
-		const int step_row = 256 / a.in_pitch, step_col = 256 - step_row * a.in_pitch;
-		for (int j = wv; 64 * j < a.in_buf; j += 4) {
-			const int rr = min(row, CM_ROWS - 1), cc = min(col, a.in_dw - 1); // (padding, the tail: any valid dword)
-			const int rc = min(max(r0 + rr, 0), a.height - 1) - r0c;
-			if (interior)
-				lds_dma_dword(base, (unsigned int) (rc * (int) a.in_stride + 4 * cc), dst + 64 * j);
-			else {
-				// a strip over the left or right edge of the image: byte by byte, columns clamped
-				const gptr_in line = gin + (long long) (rc + r0c) * a.in_stride;
-				unsigned int w = 0;
+		if (r0 >= 0 && r0 + CM_ROWS <= a.height && ninstr <= MAXI) {
+			const gptr_in base = gin + (long long) r0 * a.in_stride;
 #pragma unroll
-				for (int k = 0; k < 4; k++) {
-					const int e = 4 * cc + k;
-					const int px = min(max(Xs + e / B, 0), a.width - 1);
-					w |= (unsigned int) gload8(line, (unsigned int) (px * B + e % B)) << (8 * k);
+			for (int i = 0; i < MAXI; i++)
+				if (i < ninstr && 64 * (wv + 4 * i) < CM_ROWS * upr) {
+					if constexpr (WIDE)
+						lds_dma_x4(base, voff_in[i], dst + 256 * (wv + 4 * i));
+					else
+						lds_dma_dword(base, voff_in[i], dst + 64 * (wv + 4 * i));
 				}
-				dst[64 * j + lane] = w;
-			}
-			col += step_col;
+			return;
+		}
+		const int r0c = min(max(r0, 0), a.height - 1);
+		// (the uniform base carries the row and the strip: lane offsets stay below 33 strides)
+		const gptr_in base = gin + (long long) r0c * a.in_stride;
+		int u = 64 * wv + lane;
+		int row = u / upr, cu = u - row * upr;
+		const int step_row = 256 / upr, step_cu = 256 - step_row * upr;
+		for (int j = wv; 64 * j < CM_ROWS * upr; j += 4) {
+			const int rr = min(row, CM_ROWS - 1), cc = min(cu, uvalid - 1); // (padding, the tail: any valid unit)
+			const int rc = min(max(r0 + rr, 0), a.height - 1);
+			// (a strip over the left or right edge of the image: the unit's address clamped into the row -- what
+			// lands in columns outside the image meets a zero coefficient, see Th)
+			const int ub = min(max(sb + U * cc, 0), row_units_last);
+			const unsigned int voff = (unsigned int) ((rc - r0c) * (int) a.in_stride + ub);
+			if constexpr (WIDE)
+				lds_dma_x4(base, voff, dst + 256 * j);
+			else
+				lds_dma_dword(base, voff, dst + 64 * j);
+			cu += step_cu;
 			row += step_row;
-			if (col >= a.in_pitch) {
-				col -= a.in_pitch;
+			if (cu >= upr) {
+				cu -= upr;
 				row++;
 			}
 		}
@@ -146,7 +199,7 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 		if (c + 1 < nchunks)
 			stage(c + 1);
 		// the lane's pixels of row n: per 16 window columns the groups 4 hf .. + 3 and 8 + 4 hf .. + 3
-		const unsigned int *src = lds + (c & 1) * a.in_buf + n * a.in_pitch + B * (8 * wv + hf);
+		const unsigned int *src = lds + (c & 1) * a.in_buf + n * a.in_pitch + a.e_dw + B * (8 * wv + hf);
 		unsigned int raw[4][2][B];
 #pragma unroll
 		for (int s = 0; s < 4; s++)
@@ -158,17 +211,17 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 		unsigned int P[B][4]; // [band][quad of columns 8 j + 4 hf .. + 3 of row n]
 #pragma unroll
 		for (int b = 0; b < B; b++) {
-			// ---- pass 1
+			// ---- pass 1 (the accumulators start at 0: the rounding constant is in a.bias)
 			float acc[16];
-#pragma unroll
-			for (int r = 0; r < 16; r++)
-				acc[r] = a.acc0;
 #pragma unroll
 			for (int s = 0; s < 4; s++) {
 				unsigned int A[4];
 				cm_halves<B>(raw[s][0], b, A[0], A[1]);
 				cm_halves<B>(raw[s][1], b, A[2], A[3]);
-				mfma_32x32x16_f16(A, T[s], acc);
+				if (s == 0)
+					mfma_32x32x16_f16_first(A, Th[s], acc);
+				else
+					mfma_32x32x16_f16(A, Th[s], acc);
 			}
 			// rows (r & 3) + 8 (r >> 2) + 4 hf of column n, rounded, as halves: pass 2's operand
 			unsigned int mid_cur[8];
@@ -179,16 +232,16 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 			}
 			// ---- pass 2: output rows Ya + 32 (c - 1) .. + 32
 			if (c >= 1) {
-#pragma unroll
-				for (int r = 0; r < 16; r++)
-					acc[r] = a.acc0;
 				unsigned int A[4];
 #pragma unroll
 				for (int s = 0; s < 2; s++) {
 #pragma unroll
 					for (int q = 0; q < 4; q++)
 						A[q] = mid_prev[b][4 * s + q];
-					mfma_32x32x16_f16(A, T[s], acc);
+					if (s == 0)
+						mfma_32x32x16_f16_first(A, T[s], acc);
+					else
+						mfma_32x32x16_f16(A, T[s], acc);
 				}
 #pragma unroll
 				for (int s = 0; s < 2; s++) {
@@ -209,10 +262,11 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 #pragma unroll
 			for (int q = 0; q < 8; q++)
 				mid_prev[b][q] = mid_cur[q];
-			sched_fence(); // (one band's accumulators at a time: interleaved, the bands do not fit 168 registers)
+			sched_fence(); // (one band's accumulators at a time)
 		}
 		if (c >= 1) {
-			unsigned int *orow = lds_out + n * a.out_pitch + B * (8 * wv + hf);
+			// row n, columns 8 j + 4 hf .. + 3 of the wave's tile: bands interleaved, B dwords
+			unsigned int *orow = otile + n * OP + B * hf;
 #pragma unroll
 			for (int j = 0; j < 4; j++) {
 				unsigned int Pj[B], w[B];
@@ -224,27 +278,40 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 				for (int b = 0; b < B; b++)
 					orow[2 * B * j + b] = w[b];
 			}
-			barrier();
-			// the block's 32 rows x 32 B dwords, whole rows of dwords
+			wave_lds_fence(); // (the tile is the wave's own: no barrier)
 			const int y0 = Ya + CM_ROWS * (c - 1);
-			const gptr_out gout = gptr_out_of((unsigned long long) a.out);
-			const int row_bytes = a.width * B;
-#pragma nounroll // (unrolled, the 4 B rows / columns / pointers are loop invariants that get spilled)
-			for (int i = 0; i < 4 * B; i++) {
-				const int idx = t + CM_NT * i;
-				const int row = idx / (32 * B), col = idx - row * (32 * B);
-				const int y = y0 + row;
-				const int xb = X0 * B + 4 * col; // byte of the row
-				if (y < Yb && xb < row_bytes) {
-					const unsigned int w = lds_out[row * a.out_pitch + col];
-					const gptr_out p = gout + (long long) y * a.out_stride + xb;
-					if (xb + 4 <= row_bytes)
-						gstore32(p, w);
-					else
-						for (int e = 0; e < row_bytes - xb; e++)
-							gstore8(p + e, (unsigned char) (w >> (8 * e)));
+			if (y0 + CM_ROWS <= Yb && (X0 + 32 * wv + 32) * B <= row_bytes) {
+				// the whole tile lies inside the image: no lane tests anything but its row of the last instruction
+				const gptr_out tile_out = gout + (long long) y0 * a.out_stride;
+#pragma unroll
+				for (int i = 0; i < (CM_ROWS + RPI - 1) / RPI; i++) {
+					const int row = RPI * i + o_rsub;
+					if (o_rsub < RPI && (RPI * (i + 1) <= CM_ROWS || row < CM_ROWS)) {
+						unsigned int w[2];
+						w[0] = otile[row * OP + 2 * o_c2];
+						w[1] = otile[row * OP + 2 * o_c2 + 1];
+						gstore_dwords<2>(tile_out + (unsigned int) (RPI * i * (int) a.out_stride) + o_voff, w);
+					}
 				}
 			}
+			else
+#pragma nounroll
+			for (int i = 0; i < (CM_ROWS + RPI - 1) / RPI; i++) {
+				const int row = RPI * i + o_rsub;
+				const int y = y0 + row;
+				if (o_rsub < RPI && row < CM_ROWS && y < Yb && o_xb < row_bytes) {
+					unsigned int w[2];
+					w[0] = otile[row * OP + 2 * o_c2];
+					w[1] = otile[row * OP + 2 * o_c2 + 1];
+					const gptr_out p = gout + (long long) y * a.out_stride + o_xb;
+					if (o_xb + 8 <= row_bytes)
+						gstore_dwords<2>(p, w);
+					else
+						for (int e = 0; e < row_bytes - o_xb; e++)
+							gstore8(p + e, (unsigned char) (w[e >> 2] >> (8 * (e & 3))));
+				}
+			}
+			wave_lds_fence(); // (the reads are done before the next chunk's rows overwrite the tile)
 		}
 	}
 	wait_vmem0();

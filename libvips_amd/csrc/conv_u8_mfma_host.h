@@ -16,7 +16,7 @@
 namespace vh {
 
 // defined by the including file; 0 on success
-static int cm_launch(int bands, const CmArgs &a, int grid, size_t lds);
+static int cm_launch(int bands, bool wide, const CmArgs &a, int grid, size_t lds);
 
 namespace {
 
@@ -36,10 +36,23 @@ unsigned int cm_half_bits(int v)
 
 // the Toeplitz operand of a mask, as conv_u8_mfma_body.h lays it out: [4][64][4] dwords.  Lane (m = l & 31, hf),
 // k-step s, slot idx <-> position w = 16 s + 8 (idx >> 2) + 4 hf + (idx & 3) of the 64-wide window (columns
-// in pass 1, mid rows in pass 2), tap w - m - (hp - half) of output m
-void cm_tables(const int *c, int n, int hp, unsigned int *tz)
+// in pass 1, mid rows in pass 2), tap w - m - (hp - half) of output m.  [lo, hi): the window positions inside
+// the image -- a tap on a position outside is added to position lo / hi - 1 (the embed copies the edge column
+// there).  false: a folded coefficient is not an exact half any more (|c| >= 2048)
+bool cm_tables(const int *c, int n, int hp, int lo, int hi, unsigned int *tz)
 {
 	const int half = n / 2;
+	std::vector<int> col(64 * 32, 0); // [w][m]
+	for (int m = 0; m < 32; m++)
+		for (int k = 0; k < n; k++) {
+			int w = m + (hp - half) + k;
+			w = w < lo ? lo : w >= hi ? hi - 1 : w;
+			if (w >= 0 && w < 64)
+				col[w * 32 + m] += c[k];
+		}
+	for (int v : col)
+		if (v <= -2048 || v >= 2048)
+			return false;
 	for (int s = 0; s < 4; s++)
 		for (int l = 0; l < 64; l++) {
 			const int m = l & 31, hf = l >> 5;
@@ -48,35 +61,97 @@ void cm_tables(const int *c, int n, int hp, unsigned int *tz)
 				for (int e = 0; e < 2; e++) {
 					const int idx = 2 * q + e;
 					const int w = 16 * s + 8 * (idx >> 2) + 4 * hf + (idx & 3);
-					const int k = w - m - (hp - half);
-					w1 |= cm_half_bits(k >= 0 && k < n ? c[k] : 0) << (16 * e);
+					w1 |= cm_half_bits(col[w * 32 + m]) << (16 * e);
 				}
 				tz[(s * 64 + l) * 4 + q] = w1;
 			}
 		}
+	return true;
 }
 
-// the operands live on the device for the life of the process, one pair per (device, mask)
+// clip(floor((S + h) / scale), 0, 255) as cvt_pk_u8(fma(S 2^-24, k1, bias)): the constants, and every S whose
+// quotient does not saturate walked once per scale (a negative S + h has a value below 0.5 and a quotient <= 0)
+bool cm_rounding(int scale, int h, float *k1, float *bias)
+{
+	static std::mutex mutex;
+	static std::map<std::pair<int, int>, std::pair<float, float>> good;
+	std::lock_guard<std::mutex> lock(mutex);
+	auto it = good.find(std::make_pair(scale, h));
+	if (it == good.end()) {
+		const float rs = 1.0f / (float) scale;
+		const float b = (float) (-0.5 + 1.0 / (2.0 * scale) + (double) h * (double) rs);
+		bool ok = true;
+		for (long long S = -h; S + h < 257LL * scale && ok; S++) {
+			const float v = fmaf((float) S, rs, b); // (the device multiplies S 2^-24 by 2^24 rs: the same product)
+			const float r = rintf(v);
+			const long long got = r <= 0.0f ? 0 : r >= 255.0f ? 255 : (long long) r;
+			long long want = (S + h) / scale;
+			want = want > 255 ? 255 : want;
+			ok = got == want;
+		}
+		// below -h the value only falls (rs > 0): one probe at the most negative sum a mask can make is enough
+		ok = ok && fmaf(-16777216.0f, rs, b) < 0.5f;
+		if (!ok)
+			return false;
+		it = good.emplace(std::make_pair(scale, h), std::make_pair(ldexpf(rs, 24), b)).first;
+	}
+	*k1 = it->second.first;
+	*bias = it->second.second;
+	return true;
+}
+
+// the operands live on the device for the life of the process, one set per (device, mask, edge geometry):
+// table 0 the mask's own, tables 1 .. 3 pass 1's for the tiles whose windows hang over an edge of the image
 struct CmTables {
 	unsigned int *tz;
+	int edge_wave[3];
 };
 std::mutex cm_mutex;
 std::map<std::vector<int>, CmTables> cm_cache;
 
-int cm_tables_device(const int *c, int n, int hp, CmTables *out)
+int cm_tables_device(const int *c, int n, int hp, int width, CmTables *out)
 {
+	// the tiles (32 columns each) whose 64-column window, which starts hp columns before the tile, leaves the image
+	int waves[3] = { -1, -1, -1 }, lo[3] = { 0, 0, 0 }, hi[3] = { 64, 64, 64 };
+	int count = 0;
+	const int last = (width - 1) / 32;
+	for (int W = 0; W <= last && count < 3; W++) {
+		const int first_col = 32 * W - hp; // image column of window position 0
+		const int l = first_col < 0 ? -first_col : 0, h = width - first_col < 64 ? width - first_col : 64;
+		if (l > 0 || h < 64) {
+			waves[count] = W;
+			lo[count] = l;
+			hi[count] = h;
+			count++;
+		}
+		if (W == 0 && last > 2)
+			W = last - 2; // (only tile 0 and the last two can: hp <= 16)
+	}
 	std::vector<int> key(c, c + n);
 	key.push_back(hp);
 	key.push_back(current_device());
+	for (int k = 0; k < 3; k++) {
+		key.push_back(waves[k]);
+		key.push_back(lo[k]);
+		key.push_back(hi[k]);
+	}
 	std::lock_guard<std::mutex> lock(cm_mutex);
 	auto it = cm_cache.find(key);
 	if (it == cm_cache.end()) {
-		std::vector<unsigned int> host(4 * 64 * 4);
-		cm_tables(c, n, hp, host.data());
+		const size_t one = 4 * 64 * 4;
+		std::vector<unsigned int> host(4 * one);
+		if (!cm_tables(c, n, hp, -1000, 1000, host.data()))
+			return 1;
+		for (int k = 0; k < 3; k++)
+			if (!cm_tables(c, n, hp, waves[k] < 0 ? -1000 : lo[k], waves[k] < 0 ? 1000 : hi[k], host.data() + (k + 1) * one))
+				return 1;
 		unsigned int *d = (unsigned int *) upload(host.data(), host.size() * sizeof(unsigned int));
 		if (!d)
 			return -1;
-		CmTables t = { d };
+		CmTables t;
+		t.tz = d;
+		for (int k = 0; k < 3; k++)
+			t.edge_wave[k] = waves[k];
 		it = cm_cache.emplace(key, t).first;
 	}
 	*out = it->second;
@@ -128,16 +203,31 @@ int conv_u8_mfma_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 	a.half = n / 2;
 	a.hp = (a.half + 3) & ~3;
 	a.strips = (a.width + CM_BW - 1) / CM_BW;
-	a.in_dw = (CM_BW + 2 * a.hp) * B / 4;
-	a.in_pitch = a.in_dw + (a.in_dw & 1);
-	if (!((a.in_pitch / 2) & 1))
-		a.in_pitch += 2;
-	a.in_buf = (CM_ROWS * a.in_pitch + 255) & ~255;
-	a.out_pitch = 32 * B + 2;
-	a.acc0 = ldexpf((float) c->rounding, -24);
-	a.k1 = ldexpf(1.0f / (float) c->scale_i, 24);
-	a.bias = (float) (-0.5 + 1.0 / (2.0 * c->scale_i));
-	const size_t lds = (size_t) (2 * a.in_buf + CM_ROWS * a.out_pitch) * sizeof(unsigned int);
+	// 16-byte staging units when every row start is a multiple of 16, else dwords
+	const bool wide = !(((uintptr_t) in->data | in->stride) & 15) && !getenv("VIPS_HIP_CONV_MFMA_NARROW");
+	const int U = wide ? 16 : 4;
+	const int lead = a.hp * B; // bytes in front of column X0 (X0 B is a multiple of 128 B: of 16)
+	a.e_dw = (((lead + U - 1) / U) * U - lead) / 4;
+	const int units = (4 * a.e_dw + (CM_BW + 2 * a.hp) * B + U - 1) / U;
+	a.in_dw = units * (U / 4);
+	{
+		// the pitch: a whole number of units; an odd number of 16-byte units (of dword pairs for dword units),
+		// and room for the 64 units of an instruction when the row is narrower
+		int pu = units;
+		if (wide)
+			pu += !(pu & 1);
+		else {
+			pu += pu & 1;
+			if (!((pu / 2) & 1))
+				pu += 2;
+		}
+		a.in_pitch = pu * (U / 4);
+	}
+	// (whole instructions of 64 units: the last one of a chunk may run past the 32 rows)
+	a.in_buf = ((CM_ROWS * (a.in_pitch / (U / 4)) + 63) / 64) * 64 * (U / 4);
+	if (!cm_rounding(c->scale_i, c->rounding, &a.k1, &a.bias))
+		return 1;
+	const size_t lds = (size_t) (2 * a.in_buf + (CM_NT / 64) * CM_ROWS * (8 * B + 1)) * sizeof(unsigned int);
 	// segments: one residency round of blocks (LDS allows 3 per CU), a segment re-makes one chunk of 32 rows
 	{
 		const int chunks = (a.height + CM_ROWS - 1) / CM_ROWS;
@@ -158,11 +248,16 @@ int conv_u8_mfma_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 		a.segs = (a.height + a.seg_rows - 1) / a.seg_rows;
 	}
 	CmTables tabs;
-	if (cm_tables_device(c->coeffi.data(), n, a.hp, &tabs))
-		return -1;
+	{
+		const int r = cm_tables_device(c->coeffi.data(), n, a.hp, a.width, &tabs);
+		if (r)
+			return r;
+	}
 	a.tz = tabs.tz;
+	for (int k = 0; k < 3; k++)
+		a.edge_wave[k] = tabs.edge_wave[k];
 	Gate gate("conv_u8_mfma_sep");
-	return cm_launch(B, a, a.strips * a.segs, lds);
+	return cm_launch(B, wide, a, a.strips * a.segs, lds);
 }
 
 } // namespace vh

@@ -190,6 +190,13 @@ VH_DEV void lds_dma_dword(gptr_in base, unsigned int voff, unsigned int *lds_dst
 	const unsigned int where = __builtin_amdgcn_readfirstlane((int) VH_LDS_ADDR(lds_dst));
 	VH_LDS_DMA_DWORD(base, voff, where);
 }
+// ... 16 bytes per lane (global_load_lds_dwordx4): lane i's 16 bytes land at lds_dst + 4 i dwords; base + voff and
+// lds_dst multiples of 16
+VH_DEV void lds_dma_x4(gptr_in base, unsigned int voff, unsigned int *lds_dst)
+{
+	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (base + voff),
+		(__attribute__((address_space(3))) void *) VH_LDS_ADDR(lds_dst), 16, 0, 0);
+}
 // v_mfma_f32_32x32x16_f16: D[i][j] = C[i][j] + sum_k A[i][k] B[k][j], 32 x 32 x 16, one wave.
 //   a: lane l holds A[l & 31][k] for the 8 k-slots (l >> 5, 0..7) as 8 halves (dword q = slots 2 q, 2 q + 1);
 //   b: lane l holds B[k][l & 31] for the SAME 8 k-slots of its half;
@@ -209,6 +216,27 @@ VH_DEV void mfma_32x32x16_f16(const unsigned int (&a)[4], const unsigned int (&b
 #pragma unroll
 	for (int r = 0; r < 16; r++)
 		acc[r] = c[r];
+}
+
+// ... with C = 0 (an inline constant: no register is cleared)
+VH_DEV void mfma_32x32x16_f16_first(const unsigned int (&a)[4], const unsigned int (&b)[4], float (&acc)[16])
+{
+	typedef _Float16 gcn_half8 __attribute__((ext_vector_type(8)));
+	typedef unsigned int gcn_uint4v __attribute__((ext_vector_type(4)));
+	typedef float gcn_float16 __attribute__((ext_vector_type(16)));
+	const gcn_uint4v ua = { a[0], a[1], a[2], a[3] }, ub = { b[0], b[1], b[2], b[3] };
+	gcn_float16 c = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gcn_half8, ua), __builtin_bit_cast(gcn_half8, ub), c, 0, 0, 0);
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+		acc[r] = c[r];
+}
+// LDS written by this wave is read back by this wave only: its LDS operations complete in order, the
+// compiler must not move them across this point
+VH_DEV void wave_lds_fence()
+{
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
 }
 
 } // namespace vh

@@ -11,7 +11,7 @@
 
 namespace vh {
 
-template <int B>
+template <int B, bool WIDE>
 static void cm_run(const CmArgs &a, int items, size_t lds)
 {
 	(void) hipStreamSynchronize(stream());
@@ -24,7 +24,7 @@ static void cm_run(const CmArgs &a, int items, size_t lds)
 				break;
 			for (size_t i = 0; i < buf.size(); i++)
 				buf[i] = 0xdeadbeefu + (unsigned int) i * 2654435761u;
-			emul::run_block(CM_NT, [&]() { conv_u8_mfma_item<B>(a, item, buf.data()); });
+			emul::run_block(CM_NT, [&]() { conv_u8_mfma_item<B, WIDE>(a, item, buf.data()); });
 		}
 	};
 	unsigned int nthreads = std::thread::hardware_concurrency();
@@ -36,22 +36,22 @@ static void cm_run(const CmArgs &a, int items, size_t lds)
 		t.join();
 }
 
-static int cm_launch(int bands, const CmArgs &a, int grid, size_t lds)
+static int cm_launch(int bands, bool wide, const CmArgs &a, int grid, size_t lds)
 {
+#define CM_CASE(B) \
+	case B: \
+		if (wide) \
+			cm_run<B, true>(a, grid, lds); \
+		else \
+			cm_run<B, false>(a, grid, lds); \
+		return 0;
 	switch (bands) {
-	case 1:
-		cm_run<1>(a, grid, lds);
-		return 0;
-	case 2:
-		cm_run<2>(a, grid, lds);
-		return 0;
-	case 3:
-		cm_run<3>(a, grid, lds);
-		return 0;
-	case 4:
-		cm_run<4>(a, grid, lds);
-		return 0;
+		CM_CASE(1)
+		CM_CASE(2)
+		CM_CASE(3)
+		CM_CASE(4)
 	}
+#undef CM_CASE
 	return 1;
 }
 

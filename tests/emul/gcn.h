@@ -93,6 +93,10 @@ VH_DEV void lds_dma_dword(gptr_in base, unsigned int voff, unsigned int *lds_dst
 {
 	memcpy(lds_dst + (emul::current_tid() & 63), base + voff, 4);
 }
+VH_DEV void lds_dma_x4(gptr_in base, unsigned int voff, unsigned int *lds_dst)
+{
+	memcpy(lds_dst + 4 * (emul::current_tid() & 63), base + voff, 16);
+}
 // an IEEE half (denormals included) as a float
 VH_DEV float half_bits_to_float(unsigned int h)
 {
@@ -131,6 +135,14 @@ VH_DEV void mfma_32x32x16_f16(const unsigned int (&a)[4], const unsigned int (&b
 		acc[r] = sum;
 	}
 }
+VH_DEV void mfma_32x32x16_f16_first(const unsigned int (&a)[4], const unsigned int (&b)[4], float (&acc)[16])
+{
+	for (int r = 0; r < 16; r++)
+		acc[r] = 0.0f;
+	mfma_32x32x16_f16(a, b, acc);
+}
+// the wave's own LDS traffic: its fibers meet (what one lane wrote, another reads)
+VH_DEV void wave_lds_fence() { (void) emul::wave_share(nullptr, 0, true); }
 VH_DEV unsigned long long realtime() { return emul::clock_ticks(); }
 VH_DEV void sched_fence() {}
 VH_DEV void opaque(int &) {}

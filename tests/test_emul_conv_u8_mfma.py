@@ -74,6 +74,15 @@ def test_gaussblur_and_convsep(tmp_path):
           ("sep", 172, 70, 3, (list(range(1, 18)) + list(range(16, 0, -1)), 289))], tmp_path)
 
 
+def test_rows_of_whole_16_byte_units(tmp_path):
+    # row starts that are multiples of 16 bytes: the staging moves 16 bytes per lane (global_load_lds_dwordx4)
+    _run([("blur", 320, 70, 3, 8.0), ("blur", 256, 64, 3, 2.0), ("blur", 272, 45, 4, 4.0), ("blur", 400, 40, 2, 6.0),
+          ("blur", 336, 100, 1, 3.0), ("sep", 176, 70, 3, (list(range(1, 18)) + list(range(16, 0, -1)), 289))], tmp_path)
+    _run([("blur", 320, 200, 3, 8.0)], tmp_path, {"VIPS_HIP_CONV_MFMA_SEG": "2"})
+    # ... and the same images through dword units
+    _run([("blur", 320, 70, 3, 8.0), ("blur", 336, 100, 1, 3.0)], tmp_path, {"VIPS_HIP_CONV_MFMA_NARROW": "1"})
+
+
 def test_short_segments(tmp_path):
     # two chunks per segment: every segment boundary inside the image, top and bottom rows clamped
     _run([("blur", 300, 200, 3, 2.0), ("blur", 160, 230, 3, 8.0)], tmp_path, {"VIPS_HIP_CONV_MFMA_SEG": "2"})

@@ -3,16 +3,16 @@
 # gaussblur entries of the ops table with the kernel on / off and for blocks per CU / segment lengths.
 tag=${1:-r05b}
 mkdir -p gpurun_out
-(timeout 900 python -m pytest tests/test_conv_u8_gpu.py tests/test_conv_colour_gpu.py -q -m gpu -x 2>&1 | tail -8) > gpurun_out/${tag}_tests.txt
+(timeout 900 python -m pytest tests/test_conv_u8_gpu.py -q -m gpu 2>&1 | tail -8) > gpurun_out/${tag}_tests.txt
 tail -4 gpurun_out/${tag}_tests.txt
-ops="python bench.py --config ops --ops gaussblur_s --steps 20 --warmup 3 --no-cpu-baseline"
+ops="python bench.py --config ops --ops gaussblur_s8_u8,gaussblur_s2_u8 --steps 20 --warmup 3 --no-cpu-baseline"
 show() { python -c "
 import json,sys
 l=json.loads(sys.stdin.read().strip().splitlines()[-1])
 for e in l['ops']: print('  %-22s %.4f ms frac %.3f %s %s' % (e['name'], e['ms'], e['frac'], e['kernel'], (e.get('parity') or {}).get('bit_exact')))
 "; }
 {
-for env in "VIPS_HIP_CONV_U8_MFMA=1" "VIPS_HIP_CONV_U8_MFMA=0" "VIPS_HIP_CONV_MFMA_PER_CU=2" "VIPS_HIP_CONV_MFMA_PER_CU=4" "VIPS_HIP_CONV_MFMA_PER_CU=6" "VIPS_HIP_CONV_MFMA_SEG=4" "VIPS_HIP_CONV_MFMA_SEG=8"; do
+for env in ${VARIANTS:-"VIPS_HIP_CONV_U8_MFMA=1" "VIPS_HIP_CONV_MFMA_PER_CU=4" "VIPS_HIP_CONV_MFMA_PER_CU=6" "VIPS_HIP_CONV_MFMA_SEG=3" "VIPS_HIP_CONV_MFMA_SEG=4" "VIPS_HIP_CONV_MFMA_SEG=6" "VIPS_HIP_CONV_MFMA_SEG=8" "VIPS_HIP_CONV_MFMA_SEG=12"}; do
   echo "# $env $ops"
   env $env $ops 2>/dev/null | show
 done
