@@ -1339,7 +1339,13 @@ int reducev_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsH
 			return done;
 	}
 	{
-		// a coefficient row per output row: stream down the rows once (resample16.hip)
+		// a coefficient row per output row: the banded matrix on the matrix cores (reduce_band.hip)
+		const int done = reducev_band_try(const_cast<_VipsHipReduce *>(r), in, out, tile);
+		if (done != 0)
+			return done;
+	}
+	{
+		// ... or stream down the rows once on the vector ALU (resample16.hip)
 		const int done = reducev8_stream_try(const_cast<_VipsHipReduce *>(r), in, out, tile);
 		if (done != 0)
 			return done;

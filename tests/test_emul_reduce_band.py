@@ -1,7 +1,7 @@
-"""CPU: the streaming vertical reduce on uchar with a coefficient row per output row
-(libvips_amd/csrc/resample16_body.h reducev8_body: the ushort kernel's walk and host-made schedule on
-bytes) run thread by thread on host fibers (tests/emul) under the mock HIP runtime and compared,
-whole image, bit for bit, with the compiled reference."""
+"""CPU: vips_reducev on uchar with a coefficient row per output row as a banded matrix product on the matrix
+cores (libvips_amd/csrc/reduce_band_body.h) run thread by thread on host fibers (tests/emul: the matrix
+instruction emulated as a wave meeting) under the mock HIP runtime and compared, whole image, bit for bit, with
+the compiled reference."""
 import os
 import subprocess
 import sys
@@ -37,21 +37,24 @@ for (w, h, bands, shrink, kernel, gate) in %(cases)r:
     lib.vips_hip_gate_enable(0)
     want = helpers.Ref.run_chain("reducev:vshrink=%%r,kernel=%%s" %% (shrink, kernel), src)
     assert list(report) == [gate], (w, h, bands, shrink, kernel, report)
-    if gate != "reducev_u8_stream":
-        continue  # (the older kernels are not emulated: under the mock runtime they make no pixels)
+    if gate != "reducev_u8_band":
+        continue
     assert got.shape == want.shape and got.dtype == want.dtype, (got.shape, want.shape)
     bad = np.argwhere(got != want)
     assert len(bad) == 0, (w, h, bands, shrink, kernel, len(bad), bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
 print("CHILD-OK")
 '''
 
-S = "reducev_u8_stream"
+S = "reducev_u8_band"
 # (width, height, bands, shrink, kernel, the kernel that must have run)
 CASES = [
-    (512, 733, 3, 7.3, "lanczos3", S), (304, 260, 1, 3.7, "linear", S), (300, 200, 4, 2.5, "cubic", S), (2104, 90, 4, 1.6, "lanczos3", S),
+    (512, 733, 3, 7.3, "lanczos3", S), (304, 260, 1, 3.7, "linear", S), (300, 200, 4, 2.5, "cubic", S),
     (1024, 333, 2, 5.1, "mitchell", S), (96, 415, 3, 11.7, "lanczos2", S),
-    # rows that are not whole 8-byte groups; a constant phase (the matrix-core kernel's case)
-    (516, 333, 3, 7.3, "lanczos3", "reducev_u8"), (512, 512, 4, 8.0, "lanczos3", "reducev_u8_mfma"),
+    # rows of whole dwords that are not whole 128-byte strips / 8-byte groups; a tall image (many blocks)
+    (516, 333, 3, 7.3, "lanczos3", S), (100, 1500, 1, 4.3, "lanczos3", S), (44, 90, 3, 2.2, "lanczos3", S),
+    # a shrink whose coefficients are not exact halves (>= 2048): the vector-ALU kernel; a constant phase: the
+    # matrix-core kernel of reduce_u8.hip
+    (2104, 90, 4, 1.6, "lanczos3", "reducev_u8_stream"), (512, 512, 4, 8.0, "lanczos3", "reducev_u8_mfma"),
 ]
 
 
@@ -59,18 +62,13 @@ def _run(cases, tmp_path, extra_env=None):
     script = os.path.join(str(tmp_path), "child.py")
     with open(script, "w") as f:
         f.write(CHILD % {"root": helpers.ROOT, "cases": cases})
-    # (this file is about the streaming kernel on the vector ALU: the matrix-core one, which takes these images
-    # first, is tests/test_emul_reduce_band.py's)
-    env = dict(os.environ, LD_PRELOAD=MOCK_SO, VIPS_HIP_LIBRARY=EMUL_SO, VIPS_HIP_REDUCE_BAND="0")
+    env = dict(os.environ, LD_PRELOAD=MOCK_SO, VIPS_HIP_LIBRARY=EMUL_SO)
+    env.pop("VIPS_HIP_REDUCE_BAND", None)
     env.update(extra_env or {})
     proc = subprocess.run([sys.executable, script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                           env=env, timeout=1800)
     assert proc.returncode == 0 and "CHILD-OK" in proc.stdout, proc.stdout[-3000:]
 
 
-def test_reducev8(tmp_path):
+def test_reducev_band(tmp_path):
     _run(CASES, tmp_path)
-
-
-def test_reducev8_short_segments(tmp_path):
-    _run([c for c in CASES if c[5] == S], tmp_path, {"VIPS_HIP_R16_SEG": "5"})

@@ -1,21 +1,22 @@
-"""GPU: the streaming vertical reduce on uchar with a coefficient row per output row
-(resample16.hip reducev8) against the compiled reference, whole image, bit for bit -- the cases of
-tests/test_emul_reducev8.py on the device, plus a large image and the two-axis fractional reduce."""
+"""GPU: vips_reducev on uchar with a coefficient row per output row as a banded matrix product on the matrix
+cores (reduce_band.hip) against the compiled reference, whole image, bit for bit -- the cases of
+tests/test_emul_reduce_band.py on the device, plus large images and the two-axis fractional reduce."""
 import numpy as np
 import pytest
 
 import libvips_amd
 from libvips_amd import Image
 from tests import helpers
-from tests.test_emul_reducev8 import CASES
+from tests.test_emul_reduce_band import CASES
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not helpers.have_ref(), reason="oracle/_ref missing")]
 
+BIG = [(8192, 2100, 3, 7.3, "lanczos3", "reducev_u8_band"), (8192, 8192, 3, 7.3, "lanczos3", "reducev_u8_band"),
+       (5000, 3000, 4, 2.9, "lanczos3", "reducev_u8_band"), (1000, 9000, 1, 16.5, "lanczos3", "reducev_u8_band")]
 
-@pytest.mark.parametrize("w,h,bands,shrink,kernel,gate", CASES + [(8192, 2100, 3, 7.3, "lanczos3", "reducev_u8_stream")])
-def test_reducev8_vs_reference(w, h, bands, shrink, kernel, gate, monkeypatch):
-    # (the vector-ALU kernel: the matrix-core one, tests/test_reduce_band_gpu.py, takes these images first)
-    monkeypatch.setenv("VIPS_HIP_REDUCE_BAND", "0")
+
+@pytest.mark.parametrize("w,h,bands,shrink,kernel,gate", CASES + BIG)
+def test_reducev_band_vs_reference(w, h, bands, shrink, kernel, gate):
     lib = libvips_amd.lib
     src = helpers.lcg_image(w, h, bands, np.uint8, 11 + w)
     src[: h // 3, : w // 2] = 255
@@ -34,6 +35,12 @@ def test_reducev8_vs_reference(w, h, bands, shrink, kernel, gate, monkeypatch):
 
 def test_reduce_fractional_both_axes():
     src = helpers.lcg_image(4096, 2048, 3, np.uint8, 3)
+    lib = libvips_amd.lib
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
     got = Image.new_from_array(src).reduce(7.3, 7.3).numpy()
+    report = libvips_amd.gate_report()
+    lib.vips_hip_gate_enable(0)
+    assert "reducev_u8_band" in report, report
     want = helpers.Ref.run_chain("reduce:hshrink=7.3,vshrink=7.3", src)
     assert np.array_equal(got, want)
