@@ -178,6 +178,14 @@ VH_DEV unsigned int cvt_pk_u8(float v, unsigned int byte, unsigned int old) { re
 
 namespace vh {
 
+// the next work item of a persistent WAVE: one atomic per wave, no barrier
+VH_DEV int wave_next_item(int *counter)
+{
+	int v = 0;
+	if ((threadIdx.x & 63) == 0)
+		v = atomicAdd(counter, 1);
+	return __builtin_amdgcn_readfirstlane(v);
+}
 // the wave's index in its block, as a scalar
 VH_DEV int wave_index() { return __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); }
 // every vector memory operation of this wave has completed
@@ -229,6 +237,33 @@ VH_DEV void mfma_32x32x16_f16_first(const unsigned int (&a)[4], const unsigned i
 	c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gcn_half8, ua), __builtin_bit_cast(gcn_half8, ub), c, 0, 0, 0);
 #pragma unroll
 	for (int r = 0; r < 16; r++)
+		acc[r] = c[r];
+}
+// v_mfma_f32_16x16x32_f16: D[i][j] = C[i][j] + sum_k A[i][k] B[k][j], 16 x 16 x 32, one wave.
+//   a: lane l holds A[l & 15][k] for the 8 k-slots (l >> 4, 0..7) as 8 halves; b: B[k][l & 15] for the SAME slots;
+//   acc: lane l holds D[4 (l >> 4) + r][l & 15] in register r.  (first: C = 0)
+VH_DEV void mfma_16x16x32_f16(const unsigned int (&a)[4], const unsigned int (&b)[4], float (&acc)[4])
+{
+	typedef _Float16 gcn_half8 __attribute__((ext_vector_type(8)));
+	typedef unsigned int gcn_uint4v __attribute__((ext_vector_type(4)));
+	typedef float gcn_float4 __attribute__((ext_vector_type(4)));
+	const gcn_uint4v ua = { a[0], a[1], a[2], a[3] }, ub = { b[0], b[1], b[2], b[3] };
+	gcn_float4 c = { acc[0], acc[1], acc[2], acc[3] };
+	c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(gcn_half8, ua), __builtin_bit_cast(gcn_half8, ub), c, 0, 0, 0);
+#pragma unroll
+	for (int r = 0; r < 4; r++)
+		acc[r] = c[r];
+}
+VH_DEV void mfma_16x16x32_f16_first(const unsigned int (&a)[4], const unsigned int (&b)[4], float (&acc)[4])
+{
+	typedef _Float16 gcn_half8 __attribute__((ext_vector_type(8)));
+	typedef unsigned int gcn_uint4v __attribute__((ext_vector_type(4)));
+	typedef float gcn_float4 __attribute__((ext_vector_type(4)));
+	const gcn_uint4v ua = { a[0], a[1], a[2], a[3] }, ub = { b[0], b[1], b[2], b[3] };
+	gcn_float4 c = { 0, 0, 0, 0 };
+	c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(gcn_half8, ua), __builtin_bit_cast(gcn_half8, ub), c, 0, 0, 0);
+#pragma unroll
+	for (int r = 0; r < 4; r++)
 		acc[r] = c[r];
 }
 // LDS written by this wave is read back by this wave only: its LDS operations complete in order, the

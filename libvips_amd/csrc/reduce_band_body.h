@@ -17,7 +17,7 @@
 // Written against gcn.h (product) / tests/emul/gcn.h (host fibers, CPU suite).
 #pragma once
 
-#include "gcn.h"
+#include "conv_u8_body.h" // (cu8_interleave)
 
 namespace vh {
 
@@ -105,6 +105,139 @@ VH_DEV void reducev_band_wave(const RbArgs &a, int strip, int g)
 			w = cvt_pk_u8(__builtin_fmaf(acc[c][r], 4096.0f, 0x1p-13f), (unsigned int) c, w);
 		if (live && y < a.out_height)
 			gstore32(gout + (long long) y * a.out_stride + xb, w);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// vips_reduceh with a coefficient row per output column (resample/reduceh.cpp:216-335), the same way: out^T =
+// A x in^T with A[x_out][x_in] the banded matrix of the coefficients.  Here the sum runs ALONG the rows, so a
+// lane holds 8 neighbouring pixels of ITS row (lane & 15 = the row: 16 rows per wave, v_mfma_f32_16x16x32_f16) --
+// 8 B contiguous bytes per lane and step, de-interleaved into one operand per band by v_perm.  The input of a
+// horizontal pass is small (the vertical pass ran first, reduce.c:98-121) and every line a lane touches is used
+// whole by its next steps, so there is no LDS staging either.  A wave makes 16 output columns of 16 rows; the
+// result comes out with 4 neighbouring columns per lane: 4 B bytes, one store.
+// Steps are aligned to 32 pixels of the image; a step that is not inside the image reads pixel by pixel, clamped
+// (vips_embed COPY, reduceh.cpp:515-520).
+
+struct RbhArgs {
+	const unsigned char *in;
+	unsigned char *out;
+	long long in_stride, out_stride;
+	int width;        // input pixels per row
+	int out_width;
+	int rows;         // rows of the pass
+	int xtiles;       // of 16 output columns
+	int ytiles;       // of 16 rows
+	int out_dwords;   // output rows start on dwords: a lane's 4 pixels leave as whole dwords
+	const RbBlock *blk; // per x tile: first 32-pixel step (may be negative), steps, first coefficient block
+	const unsigned int *tab;
+};
+
+// N dwords (up to 8) at a 4-byte aligned offset
+template <int N>
+VH_DEV void gload_dwords_n(gptr_in base, unsigned int off, unsigned int (&w)[N])
+{
+	if constexpr (N <= 4)
+		gload_dwords<N>(base, off, w);
+	else {
+		unsigned int lo[4], hi[N - 4];
+		gload_dwords<4>(base, off, lo);
+		gload_dwords<N - 4>(base, off + 16, hi);
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+			w[i] = lo[i];
+#pragma unroll
+		for (int i = 0; i < N - 4; i++)
+			w[4 + i] = hi[i];
+	}
+}
+
+// 4 pixels x B bands (B dwords as they lie in memory) -> band b as 4 halves 0x00pp
+template <int B>
+VH_DEV void rbh_halves(const unsigned int *raw, int b, unsigned int &a0, unsigned int &a1)
+{
+#pragma unroll
+	for (int q = 0; q < 2; q++) {
+		const int e0 = (2 * q) * B + b, e1 = (2 * q + 1) * B + b;
+		const unsigned int v =
+			perm(raw[e1 >> 2], raw[e0 >> 2], 0x0c000c00u | ((4u + (unsigned int) (e1 & 3)) << 16) | (unsigned int) (e0 & 3));
+		if (q == 0)
+			a0 = v;
+		else
+			a1 = v;
+	}
+}
+
+template <int B>
+VH_DEV void reduceh_band_wave(const RbhArgs &a, int xt, int yt)
+{
+	const int lane = tid() & 63, n = lane & 15, kg = lane >> 4;
+	const int y = 16 * yt + n, yc = min(y, a.rows - 1);
+	const RbBlock b = uniform_load(&a.blk[xt]);
+	const gptr_in line = gptr_in_of((unsigned long long) a.in) + (long long) yc * a.in_stride;
+	const gptr_in gtab = gptr_in_of((unsigned long long) a.tab);
+
+	// pixels 32 s + 8 kg .. + 7 of the lane's row as 2 B dwords
+	auto load = [&](int s, unsigned int (&d)[2 * B]) {
+		const int p0 = 32 * s;
+		if (p0 >= 0 && p0 + 32 <= a.width)
+			gload_dwords_n<2 * B>(line, (unsigned int) ((p0 + 8 * kg) * B), d);
+		else {
+#pragma unroll
+			for (int w = 0; w < 2 * B; w++) {
+				unsigned int v = 0;
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const int e = 4 * w + k;
+					const int px = min(max(p0 + 8 * kg + e / B, 0), a.width - 1);
+					v |= (unsigned int) gload8(line, (unsigned int) (px * B + e % B)) << (8 * k);
+				}
+				d[w] = v;
+			}
+		}
+	};
+
+	float acc[B][4];
+	unsigned int cur[2 * B], nxt[2 * B];
+	load(b.s0, cur);
+	for (int j = 0; j < b.ns; j++) {
+		if (j + 1 < b.ns)
+			load(b.s0 + j + 1, nxt);
+		unsigned int A[4];
+		gload128(gtab, (unsigned int) (((b.tab + j) * 64 + lane) * 16), A);
+#pragma unroll
+		for (int bb = 0; bb < B; bb++) {
+			unsigned int D[4];
+			rbh_halves<B>(cur, bb, D[0], D[1]);
+			rbh_halves<B>(cur + B, bb, D[2], D[3]);
+			if (j == 0)
+				mfma_16x16x32_f16_first(A, D, acc[bb]);
+			else
+				mfma_16x16x32_f16(A, D, acc[bb]);
+		}
+#pragma unroll
+		for (int i = 0; i < 2 * B; i++)
+			cur[i] = nxt[i];
+	}
+	// register r: output column 16 xt + 4 kg + r of row y
+	unsigned int P[B], w[B];
+#pragma unroll
+	for (int bb = 0; bb < B; bb++) {
+		unsigned int v = 0;
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+			v = cvt_pk_u8(__builtin_fmaf(acc[bb][r], 4096.0f, 0x1p-13f), (unsigned int) r, v);
+		P[bb] = v;
+	}
+	cu8_interleave<B>(P, w);
+	const int x0 = 16 * xt + 4 * kg;
+	if (y < a.rows && x0 < a.out_width) {
+		const gptr_out p = gptr_out_of((unsigned long long) a.out) + (long long) y * a.out_stride + (long long) x0 * B;
+		if (x0 + 4 <= a.out_width && a.out_dwords)
+			gstore_dwords<B>(p, w);
+		else
+			for (int e = 0; e < min(4, a.out_width - x0) * B; e++)
+				gstore8(p + e, (unsigned char) (w[e >> 2] >> (8 * (e & 3))));
 	}
 }
 

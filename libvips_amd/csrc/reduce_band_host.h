@@ -16,6 +16,7 @@ namespace vh {
 
 // defined by the including file; 0 on success
 static int rb_launch(const RbArgs &a, int grid);
+static int rbh_launch(int bands, const RbhArgs &a, int grid);
 
 namespace {
 
@@ -113,7 +114,129 @@ int rb_plan(_VipsHipReduce *r, int out_height, int tile, const unsigned char **b
 	return 0;
 }
 
+// the same for the horizontal pass: x tiles of 16 output columns, steps of 32 pixels, blocks for
+// v_mfma_f32_16x16x32_f16 -- lane (m = l & 15, kg = l >> 4), slot idx <-> pixel 32 (s0 + j) + 8 kg + idx, tap
+// pixel - first(x) of output column x = 16 X + m
+int rbh_plan(_VipsHipReduce *r, int out_width, int tile, const unsigned char **blob)
+{
+	std::lock_guard<std::mutex> lock(r->mutex);
+	const auto key = std::make_tuple(-(1 << 26), out_width, tile);
+	auto it = r->pos_cache.find(key);
+	if (it != r->pos_cache.end()) {
+		*blob = (const unsigned char *) it->second;
+		return 0;
+	}
+	*blob = nullptr;
+	const int n = r->n_point;
+	bool ok = true;
+	for (int ph = 0; ph <= 64 && ok; ph++) {
+		long long abs_sum = 0;
+		for (int k = 0; k < n; k++) {
+			const int c = r->matrixs[(size_t) ph * n + k];
+			ok = ok && c > -2048 && c < 2048;
+			abs_sum += c < 0 ? -c : c;
+		}
+		ok = ok && abs_sum * 255 + 2048 < (1LL << 24);
+	}
+	std::vector<unsigned char> bytes;
+	if (ok) {
+		std::vector<ReducePos> pos;
+		reduce_positions(r, 0, out_width, tile, pos);
+		const int xtiles = (out_width + 15) / 16;
+		std::vector<RbBlock> blk(xtiles);
+		std::vector<unsigned int> tab;
+		for (int X = 0; X < xtiles; X++) {
+			const int x0 = 16 * X, x1 = out_width < x0 + 16 ? out_width : x0 + 16;
+			int lo = pos[x0].first, hi = pos[x0].first + n - 1;
+			for (int x = x0; x < x1; x++) {
+				lo = pos[x].first < lo ? pos[x].first : lo;
+				hi = pos[x].first + n - 1 > hi ? pos[x].first + n - 1 : hi;
+			}
+			const int s0 = lo >= 0 ? lo / 32 : -((-lo + 31) / 32), s1 = hi >= 0 ? hi / 32 : -((-hi + 31) / 32);
+			blk[X].s0 = s0;
+			blk[X].ns = s1 - s0 + 1;
+			blk[X].tab = (int) (tab.size() / 256);
+			blk[X].pad = 0;
+			tab.resize(tab.size() + (size_t) blk[X].ns * 256, 0u);
+			unsigned int *t = tab.data() + (size_t) blk[X].tab * 256;
+			for (int j = 0; j < blk[X].ns; j++)
+				for (int l = 0; l < 64; l++) {
+					const int m = l & 15, kg = l >> 4, x = x0 + m;
+					for (int idx = 0; idx < 8; idx++) {
+						const int px = 32 * (s0 + j) + 8 * kg + idx;
+						int c = 0;
+						if (x < x1) {
+							const int k = px - pos[x].first;
+							if (k >= 0 && k < n)
+								c = r->matrixs[(size_t) pos[x].phase * n + k];
+						}
+						t[(j * 64 + l) * 4 + (idx >> 1)] |= rb_half_bits(c) << (16 * (idx & 1));
+					}
+				}
+		}
+		if (tab.size() * 4 > (64u << 20))
+			ok = false;
+		else {
+			bytes.resize(blk.size() * sizeof(RbBlock) + tab.size() * 4);
+			memcpy(bytes.data(), blk.data(), blk.size() * sizeof(RbBlock));
+			memcpy(bytes.data() + blk.size() * sizeof(RbBlock), tab.data(), tab.size() * 4);
+		}
+	}
+	void *d = nullptr;
+	if (ok) {
+		d = upload(bytes.data(), bytes.size());
+		if (!d)
+			return -1;
+	}
+	r->pos_cache[key] = (ReducePos *) d;
+	*blob = (const unsigned char *) d;
+	return 0;
+}
+
 } // namespace
+
+// vips_reduceh of whole rows of a uchar image with a coefficient row per output column; 1 = done, 0 = not this
+// kernel's case, -1 = error
+int reduceh_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out, int tile)
+{
+	const char *env = getenv("VIPS_HIP_REDUCE_BAND");
+	if (env && atoi(env) == 0)
+		return 0;
+	if (in->format != VIPS_HIP_FORMAT_UCHAR || out->format != VIPS_HIP_FORMAT_UCHAR || in->bands != out->bands ||
+		in->bands < 1 || in->bands > 4 || out->width < 1)
+		return 0;
+	// whole rows (any range of them)
+	if (in->left || out->left || in->width != in->im_width || out->width != out->im_width ||
+		out->top < in->top || out->top + out->height > in->top + in->height)
+		return 0;
+	if (((uintptr_t) in->data | (uintptr_t) in->stride) & 3)
+		return 0;
+	if ((long long) in->width * in->bands >= (1LL << 31) || in->width < 1)
+		return 0;
+	const unsigned char *blob;
+	if (rbh_plan(r, out->width, tile, &blob))
+		return -1;
+	if (!blob)
+		return 0;
+	RbhArgs a;
+	memset(&a, 0, sizeof(a));
+	a.in = (const unsigned char *) in->data + (long long) (out->top - in->top) * in->stride;
+	a.out = (unsigned char *) out->data;
+	a.in_stride = (long long) in->stride;
+	a.out_stride = (long long) out->stride;
+	a.width = in->width;
+	a.out_width = out->width;
+	a.rows = out->height;
+	a.xtiles = (out->width + 15) / 16;
+	a.ytiles = (out->height + 15) / 16;
+	a.out_dwords = !(((uintptr_t) out->data | (uintptr_t) out->stride) & 3);
+	a.blk = (const RbBlock *) blob;
+	a.tab = (const unsigned int *) (blob + (size_t) a.xtiles * sizeof(RbBlock));
+	const int groups = (a.xtiles + 3) / 4; // a block of 4 waves: 4 neighbouring x tiles of the same rows
+	Gate gate("reduceh_u8_band");
+	const int rc = rbh_launch(in->bands, a, groups * a.ytiles);
+	return rc ? -1 : 1;
+}
 
 // vips_reducev of a whole uchar image with a coefficient row per output row; 1 = done, 0 = not this
 // kernel's case, -1 = error
@@ -150,7 +273,7 @@ int reducev_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRe
 	a.nblocks = (out->height + 31) / 32;
 	a.blk = (const RbBlock *) blob;
 	a.tab = (const unsigned int *) (blob + (size_t) a.nblocks * sizeof(RbBlock));
-	const int groups = (a.strips + 3) / 4; // a block of 4 waves: 4 neighbouring strips
+	const int groups = (((a.strips + 3) / 4) + 7) & ~7; // blocks of 4 waves = 4 neighbouring strips; a multiple of 8
 	Gate gate("reducev_u8_band");
 	const int rc = rb_launch(a, groups * a.nblocks);
 	return rc ? -1 : 1;

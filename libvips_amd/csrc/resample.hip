@@ -582,6 +582,8 @@ static int reduce_gen(const char *domain, const VipsHipReduce *reduce, const Vip
 	if (fmt == VIPS_HIP_FORMAT_UCHAR) {
 		int done = vertical ? reducev_u8_try(r, in, out, pos, (const short *) table, tile) : reduceh_u8p_try(r, in, out, tile);
 		if (!done && !vertical)
+			done = reduceh_band_try(r, in, out, tile); // a coefficient row per column: the matrix cores (reduce_band.hip)
+		if (!done && !vertical)
 			done = reduceh_u8_lds_try(r, in, out, pos, (const short *) table);
 		if (done < 0)
 			return -1;

@@ -87,6 +87,16 @@ VH_DEV int next_item(int *counter, int *slot)
 }
 VH_DEV void barrier() { emul::barrier(); }
 VH_DEV int wave_index() { return emul::current_tid() >> 6; }
+VH_DEV int wave_next_item(int *counter)
+{
+	int v = 0;
+	if ((emul::current_tid() & 63) == 0)
+		v = __sync_fetch_and_add(counter, 1);
+	const emul::WaveData &wd = emul::wave_share(&v, 4, true);
+	int r;
+	memcpy(&r, wd.data[0], 4);
+	return r;
+}
 VH_DEV void wait_vmem0() {}
 // global_load_lds_dword: lane i's dword to lds_dst + i (the copy lands at once)
 VH_DEV void lds_dma_dword(gptr_in base, unsigned int voff, unsigned int *lds_dst)
@@ -140,6 +150,37 @@ VH_DEV void mfma_32x32x16_f16_first(const unsigned int (&a)[4], const unsigned i
 	for (int r = 0; r < 16; r++)
 		acc[r] = 0.0f;
 	mfma_32x32x16_f16(a, b, acc);
+}
+// v_mfma_f32_16x16x32_f16 (csrc/gcn.h)
+VH_DEV void mfma_16x16x32_f16(const unsigned int (&a)[4], const unsigned int (&b)[4], float (&acc)[4])
+{
+	unsigned int A[64][4], Bm[64][4];
+	{
+		const emul::WaveData &wd = emul::wave_share(a, 16, true);
+		memcpy(A, wd.data, sizeof(A));
+	}
+	{
+		const emul::WaveData &wd = emul::wave_share(b, 16, true);
+		memcpy(Bm, wd.data, sizeof(Bm));
+	}
+	const int lane = emul::current_tid() & 63, j = lane & 15, g = lane >> 4;
+	for (int r = 0; r < 4; r++) {
+		const int i = 4 * g + r;
+		float sum = acc[r];
+		for (int kg = 0; kg < 4; kg++)
+			for (int idx = 0; idx < 8; idx++) {
+				const unsigned int av = (A[i + 16 * kg][idx >> 1] >> (16 * (idx & 1))) & 0xffffu;
+				const unsigned int bv = (Bm[j + 16 * kg][idx >> 1] >> (16 * (idx & 1))) & 0xffffu;
+				sum += half_bits_to_float(av) * half_bits_to_float(bv);
+			}
+		acc[r] = sum;
+	}
+}
+VH_DEV void mfma_16x16x32_f16_first(const unsigned int (&a)[4], const unsigned int (&b)[4], float (&acc)[4])
+{
+	for (int r = 0; r < 4; r++)
+		acc[r] = 0.0f;
+	mfma_16x16x32_f16(a, b, acc);
 }
 // the wave's own LDS traffic: its fibers meet (what one lane wrote, another reads)
 VH_DEV void wave_lds_fence() { (void) emul::wave_share(nullptr, 0, true); }

@@ -32,12 +32,18 @@ for (w, h, bands, shrink, kernel, gate) in %(cases)r:
     im = Image.new_from_array(src)
     lib.vips_hip_gate_reset()
     lib.vips_hip_gate_enable(1)
-    got = im.reducev(shrink, kernel=kernel).numpy()
+    if gate.startswith("reduceh"):
+        got = im.reduceh(shrink, kernel=kernel).numpy()
+    else:
+        got = im.reducev(shrink, kernel=kernel).numpy()
     report = libvips_amd.gate_report()
     lib.vips_hip_gate_enable(0)
-    want = helpers.Ref.run_chain("reducev:vshrink=%%r,kernel=%%s" %% (shrink, kernel), src)
+    if gate.startswith("reduceh"):
+        want = helpers.Ref.run_chain("reduceh:hshrink=%%r,kernel=%%s" %% (shrink, kernel), src)
+    else:
+        want = helpers.Ref.run_chain("reducev:vshrink=%%r,kernel=%%s" %% (shrink, kernel), src)
     assert list(report) == [gate], (w, h, bands, shrink, kernel, report)
-    if gate != "reducev_u8_band":
+    if not gate.endswith("_band"):
         continue
     assert got.shape == want.shape and got.dtype == want.dtype, (got.shape, want.shape)
     bad = np.argwhere(got != want)
@@ -70,5 +76,20 @@ def _run(cases, tmp_path, extra_env=None):
     assert proc.returncode == 0 and "CHILD-OK" in proc.stdout, proc.stdout[-3000:]
 
 
+H = "reduceh_u8_band"
+HCASES = [
+    # (input rows of whole dwords; the output's need not be)
+    (732, 100, 3, 7.3, "lanczos3", H), (260, 64, 1, 3.7, "linear", H), (200, 37, 4, 2.5, "cubic", H),
+    (334, 50, 2, 5.1, "mitchell", H), (416, 33, 3, 11.7, "lanczos2", H), (1500, 20, 1, 4.3, "lanczos3", H),
+    (92, 44, 3, 2.2, "lanczos3", H), (1200, 18, 3, 16.5, "lanczos3", H), (744, 21, 3, 7.3, "lanczos3", H),
+    # coefficients that are not exact halves: the byte-at-a-time kernel; a constant phase: the packed-byte kernel
+    (300, 40, 4, 1.6, "lanczos3", "reduceh_u8_lds"), (512, 40, 4, 8.0, "lanczos3", "reduceh_u8_packed"),
+]
+
+
 def test_reducev_band(tmp_path):
     _run(CASES, tmp_path)
+
+
+def test_reduceh_band(tmp_path):
+    _run(HCASES, tmp_path)

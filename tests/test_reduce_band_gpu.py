@@ -7,7 +7,7 @@ import pytest
 import libvips_amd
 from libvips_amd import Image
 from tests import helpers
-from tests.test_emul_reduce_band import CASES
+from tests.test_emul_reduce_band import CASES, HCASES
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not helpers.have_ref(), reason="oracle/_ref missing")]
 
@@ -33,6 +33,28 @@ def test_reducev_band_vs_reference(w, h, bands, shrink, kernel, gate):
     assert np.array_equal(got, want)
 
 
+HBIG = [(8192, 1122, 3, 7.3, "lanczos3", "reduceh_u8_band"), (5000, 700, 4, 2.9, "lanczos3", "reduceh_u8_band"),
+        (9000, 300, 1, 16.5, "lanczos3", "reduceh_u8_band")]
+
+
+@pytest.mark.parametrize("w,h,bands,shrink,kernel,gate", HCASES + HBIG)
+def test_reduceh_band_vs_reference(w, h, bands, shrink, kernel, gate):
+    lib = libvips_amd.lib
+    src = helpers.lcg_image(w, h, bands, np.uint8, 11 + w)
+    src[: h // 3, : w // 2] = 255
+    src[h // 3: h // 2, w // 2:] = 0
+    im = Image.new_from_array(src)
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    got = im.reduceh(shrink, kernel=kernel).numpy()
+    report = libvips_amd.gate_report()
+    lib.vips_hip_gate_enable(0)
+    want = helpers.Ref.run_chain("reduceh:hshrink=%r,kernel=%s" % (shrink, kernel), src)
+    assert list(report) == [gate], report
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert np.array_equal(got, want)
+
+
 def test_reduce_fractional_both_axes():
     src = helpers.lcg_image(4096, 2048, 3, np.uint8, 3)
     lib = libvips_amd.lib
@@ -41,6 +63,6 @@ def test_reduce_fractional_both_axes():
     got = Image.new_from_array(src).reduce(7.3, 7.3).numpy()
     report = libvips_amd.gate_report()
     lib.vips_hip_gate_enable(0)
-    assert "reducev_u8_band" in report, report
+    assert sorted(report) == ["reduceh_u8_band", "reducev_u8_band"], report
     want = helpers.Ref.run_chain("reduce:hshrink=7.3,vshrink=7.3", src)
     assert np.array_equal(got, want)

@@ -14,7 +14,8 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not helpers.have_ref(), reason
 
 @pytest.mark.parametrize("w,h,bands,shrink,kernel,gate", CASES + [(8192, 300, 3, 8.0, "lanczos3", "reduceh_u8_packed"),
                                                                   (16384, 70, 4, 4.0, "lanczos3", "reduceh_u8_packed")])
-def test_reduceh_u8_vs_reference(w, h, bands, shrink, kernel, gate):
+def test_reduceh_u8_vs_reference(w, h, bands, shrink, kernel, gate, monkeypatch):
+    monkeypatch.setenv("VIPS_HIP_REDUCE_BAND", "0")  # (this kernel's fall-backs; the banded one: test_reduce_band_gpu.py)
     lib = libvips_amd.lib
     src = helpers.lcg_image(w, h, bands, np.uint8, 11 + w)
     src[: h // 3, : w // 2] = 255

@@ -3,7 +3,7 @@
 # ops table with the kernel on / off, counters.
 tag=${1:-r05h}
 mkdir -p gpurun_out
-(timeout 900 python -m pytest tests/test_reduce_band_gpu.py tests/test_reducev8_gpu.py -q -m gpu 2>&1 | tail -8) > gpurun_out/${tag}_tests.txt
+(timeout 900 python -m pytest tests/test_reduce_band_gpu.py tests/test_reducev8_gpu.py tests/test_reduceh_u8_gpu.py -q -m gpu 2>&1 | tail -8) > gpurun_out/${tag}_tests.txt
 tail -4 gpurun_out/${tag}_tests.txt
 ops="python bench.py --config ops --ops reduce_rgb_7.3,reducev_8 --steps 20 --warmup 3 --no-cpu-baseline"
 show() { python -c "
