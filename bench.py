@@ -1125,6 +1125,10 @@ def ops_table():
     chain("reduceh_8", rgb8, lambda im: im.reduceh(8), "reduceh:hshrink=8,kernel=lanczos3")
     chain("reduce_rgb_8", rgb8, lambda im: im.reduce(8, 8), "reduce:hshrink=8,vshrink=8,kernel=lanczos3")
     chain("reduce_rgb_7.3", rgb8, lambda im: im.reduce(7.3, 7.3), "reduce:hshrink=7.3,vshrink=7.3,kernel=lanczos3")
+    # the reference's common case: a size that does not divide the image (thumbnail.c:413, resize.c:207-228) --
+    # the whole vips_resize chain (box shrinks, then fractional reduces) and vips_thumbnail_image
+    chain("resize_rgb_to_1000", rgb8, lambda im: im.resize(1000.0 / 8192.0), "resize:scale=%r" % (1000.0 / 8192.0))
+    chain("thumbnail_500", rgb8, lambda im: im.thumbnail_image(500), "thumbnail_image:width=500")
     chain("shrinkv_4", rgb8, lambda im: im.shrinkv(4), "shrinkv:vshrink=4")
     chain("shrinkh_4", rgb8, lambda im: im.shrinkh(4), "shrinkh:hshrink=4")
     masked("convi_3x3_u8", rgb8, lambda im: im.conv(k3, scale=8, precision="integer"), "conv", k3, 8.0, "precision=integer")

@@ -1,0 +1,7 @@
+ops="python bench.py --config ops --ops resize_rgb_to_1000,thumbnail_500 --steps 10 --warmup 3 --no-cpu-baseline"
+show() { python -c "
+import json,sys
+l=json.loads(sys.stdin.read().strip().splitlines()[-1])
+for e in l['ops']: print('  %-22s %.4f ms frac %.3f %s %s %s' % (e['name'], e['ms'], e['frac'], e['kernel'], (e.get('parity') or {}).get('bit_exact'), {k: v['mean_ms'] for k, v in e['kernels'].items()}))
+"; }
+for env in "A=1" "VIPS_HIP_REDUCE_BAND=0"; do echo "# $env"; env $env $ops 2>&1 | tail -1 | show; done
