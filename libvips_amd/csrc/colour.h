@@ -31,6 +31,8 @@ void colour_tables_host(std::vector<float> &v2Y_8, std::vector<int> &Y2v_8, std:
 // nullptr when this host's cbrtf does not fit the scheme
 struct CbrtExact;
 const CbrtExact *cbrt_exact_tables();
+struct CbrtQuad;
+const CbrtQuad *cbrt_quad_tables(); // (cbrt_quad.h)
 
 // vips_resize's downsizing chain then vips_sharpen on n 3-band uchar sRGB images of one geometry in
 // ONE streaming kernel (resize_sharpen.hip); arguments as resize_stream_u8_try + the blur mask as

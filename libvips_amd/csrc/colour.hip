@@ -16,6 +16,7 @@
 #include "colour_device.h"
 #define VH_CBRT_FN static __host__ __device__ __forceinline__
 #include "cbrt_exact.h"
+#include "cbrt_quad.h"
 
 #include <climits>
 #include <cstdlib>
@@ -211,6 +212,119 @@ const CbrtExact *cbrt_exact_tables()
 	return &t;
 }
 
+// The tables of cbrt_quad.h for the calling thread's device, made from the cube-root table this host's libm
+// produces: per block a least-squares quadratic through the exact cube roots, then the residuals and every pair
+// checked by running cbq_pair() itself.  nullptr: the scheme does not fit this host's cbrtf, or an upload failed.
+static const CbrtQuad *cbq_refused(int where)
+{
+	if (getenv("VIPS_HIP_DEBUG_CBRT"))
+		fprintf(stderr, "cbrt_quad_tables: this host's cbrtf does not fit the scheme (check %d)\n", where);
+	return nullptr;
+}
+
+const CbrtQuad *cbrt_quad_tables()
+{
+	static std::mutex mutex;
+	static CbrtQuad by_device[64];
+	static int state[64]; // 0 not tried, 1 ready, -1 unusable
+	std::lock_guard<std::mutex> lock(mutex);
+	const int dev = current_device() < 0 ? 0 : current_device() & 63;
+	if (state[dev])
+		return state[dev] > 0 ? &by_device[dev] : nullptr;
+	state[dev] = -1;
+	if (getenv("VIPS_HIP_NO_CBRT_QUAD"))
+		return cbq_refused(1);
+	std::vector<float> cb;
+	cbrt_table(cb);
+	std::vector<CbqBlock> blk(CBQ_BLOCKS);
+	std::vector<int> first(CBQ_BLOCKS, -1), count(CBQ_BLOCKS, 0);
+	for (int i = 0; i < CBQ_N; i++) {
+		const int k = cbq_key((float) (i + CBQ_SHIFT));
+		if (k < 0 || k >= CBQ_BLOCKS)
+			return cbq_refused(2);
+		if (first[k] < 0)
+			first[k] = i;
+		count[k]++;
+	}
+	for (int k = 0; k < CBQ_BLOCKS; k++) {
+		CbqBlock &q = blk[k];
+		q.c0 = q.c1 = q.c2 = q.next = 0.0f;
+		if (first[k] < 0)
+			continue; // (a key no integer has)
+		const int i0 = first[k], n = count[k];
+		q.c0 = cb[i0];
+		q.next = i0 + n < CBQ_N ? cb[i0 + n] : cb[CBQ_N - 1];
+		if (n >= 2) {
+			// least squares of T[i0 + j] - c0 = c1 j + c2 j^2 over the block (c2 = 0 for two entries)
+			double s11 = 0, s12 = 0, s22 = 0, r1 = 0, r2 = 0;
+			for (int j = 1; j < n; j++) {
+				const double y = (double) cb[i0 + j] - (double) q.c0, x = j, x2 = x * x;
+				s11 += x * x;
+				s12 += x * x2;
+				s22 += x2 * x2;
+				r1 += x * y;
+				r2 += x2 * y;
+			}
+			if (n == 2) {
+				q.c1 = (float) (r1 / s11);
+			}
+			else {
+				const double det = s11 * s22 - s12 * s12;
+				q.c1 = (float) ((r1 * s22 - r2 * s12) / det);
+				q.c2 = (float) ((r2 * s11 - r1 * s12) / det);
+			}
+		}
+	}
+	// residuals: a signed 2-bit field + the block's bias (the lowest bit of c2, which takes part in the
+	// prediction: set first, then measured)
+	std::vector<unsigned int> res(CBQ_RES_WORDS, 0u);
+	for (int k = 0; k < CBQ_BLOCKS; k++) {
+		if (first[k] < 0)
+			continue;
+		const int i0 = first[k], n = count[k];
+		bool done = false;
+		for (unsigned int bias = 0; bias < 2 && !done; bias++) {
+			CbqBlock q = blk[k];
+			q.c2 = cbq_float((cbq_bits(q.c2) & ~1u) | bias);
+			bool ok = true;
+			for (int j = 0; j < n && ok; j++) {
+				const long long r = (long long) cbq_bits(cb[i0 + j]) - (long long) cbq_bits(cbq_predict(q, (float) j)) - (long long) bias;
+				ok = r >= -2 && r <= 1 && (j > 0 || r + (long long) bias == 0);
+			}
+			if (!ok)
+				continue;
+			blk[k] = q;
+			for (int j = 0; j < n; j++) {
+				const int i = i0 + j;
+				const long long r = (long long) cbq_bits(cb[i]) - (long long) cbq_bits(cbq_predict(q, (float) j)) - (long long) bias;
+				res[i >> 4] |= ((unsigned int) r & 3u) << (2 * (i & 15));
+			}
+			done = true;
+		}
+		if (!done)
+			return cbq_refused(100 + k);
+	}
+	// every pair a kernel can ask for, against the table the reference would read
+	for (int i = 0; i + 1 < CBQ_N; i++) {
+		float t0, dt;
+		cbq_pair(blk.data(), res.data(), i, (float) i, &t0, &dt);
+		const float want_dt = cb[i + 1] - cb[i];
+		if (memcmp(&t0, &cb[i], 4) || memcmp(&dt, &want_dt, 4))
+			return cbq_refused(4);
+	}
+	if (getenv("VIPS_HIP_DEBUG_CBRT"))
+		fprintf(stderr, "cbrt_quad_tables: every pair checked\n");
+	CbrtQuad &t = by_device[dev];
+	t.blk = (const CbqBlock *) upload(blk.data(), blk.size() * sizeof(CbqBlock));
+	t.res = (const unsigned int *) upload(res.data(), res.size() * sizeof(unsigned int));
+	if (!t.blk || !t.res) {
+		vips_hip_error_clear();
+		return cbq_refused(5);
+	}
+	state[dev] = 1;
+	return &t;
+}
+
 static int ensure_tables()
 {
 	std::lock_guard<std::mutex> lock(g_tables_mutex);
@@ -383,6 +497,92 @@ colour_lab_lds_kernel(RouteArgs a, CbrtExact cx)
 			const float L = __fsub_rn(__fmul_rn(116.0F, cby), 16.0F);
 			const float A = __fmul_rn(500.0F, __fsub_rn(cbx, cby));
 			const float B = __fmul_rn(200.0F, __fsub_rn(cby, cbz));
+			if constexpr (LABS) {
+				out[3 * m] = lab2labs_finite(L, 32767.0 / 100.0, 0.0);
+				out[3 * m + 1] = lab2labs_finite(A, 32768.0 / 128.0, -32768.0);
+				out[3 * m + 2] = lab2labs_finite(B, 32768.0 / 128.0, -32768.0);
+			}
+			else {
+				out[3 * m] = L;
+				out[3 * m + 1] = A;
+				out[3 * m + 2] = B;
+			}
+		}
+		Vec4<TOUT> r0 = { { out[0], out[1], out[2], out[3] } }, r1 = { { out[4], out[5], out[6], out[7] } },
+				   r2 = { { out[8], out[9], out[10], out[11] } };
+		q[0] = r0;
+		q[1] = r1;
+		q[2] = r2;
+	}
+}
+
+// ... with the table in cbrt_quad.h's form: 27 vector instructions and two LDS reads per channel instead of ~45
+// and seven (one 16-byte block record, the pair's residual bits), 57 KB of LDS: two blocks per CU
+// (1024 threads: ONE block's tables serve a CU's 16 waves -- 256-thread blocks, two per CU by their LDS, left two
+// waves per SIMD to hide the LDS reads behind and ran no faster than the older form)
+template <typename TIN, bool LABS>
+__global__ void __launch_bounds__(1024)
+colour_lab_quad_kernel(RouteArgs a, CbrtQuad cq)
+{
+	__shared__ float s_v2Y[256];
+	__shared__ unsigned int s_res[CBQ_RES_WORDS];
+	__shared__ __attribute__((aligned(16))) CbqBlock s_blk[CBQ_BLOCKS];
+	const int t = threadIdx.x;
+	if (t < 256)
+		s_v2Y[t] = a.tables.v2Y_8[t];
+	for (int i = t; i < CBQ_RES_WORDS; i += 1024)
+		s_res[i] = cq.res[i];
+	for (int i = t; i < CBQ_BLOCKS; i += 1024)
+		s_blk[i] = cq.blk[i];
+	__syncthreads();
+	const int x4 = blockIdx.x * blockDim.x + t;
+	if (x4 * 4 >= a.width)
+		return;
+	typedef typename std::conditional<LABS, short, float>::type TOUT;
+	// (the next row's pixels travel while this row's are converted: with 600 instructions between a load and its
+	// store a wave otherwise sits out the whole memory latency once per 4 pixels)
+	Vec4<TIN> n0, n1, n2;
+	{
+		const Vec4<TIN> *p = (const Vec4<TIN> *) (a.in + (long long) blockIdx.y * a.in_stride) + (long long) x4 * 3;
+		n0 = p[0];
+		n1 = p[1];
+		n2 = p[2];
+	}
+	for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
+		Vec4<TOUT> *q = (Vec4<TOUT> *) (a.out + (long long) y * a.out_stride) + (long long) x4 * 3;
+		const Vec4<TIN> v0 = n0, v1 = n1, v2 = n2;
+		if (y + (int) gridDim.y < a.height) {
+			const Vec4<TIN> *p = (const Vec4<TIN> *) (a.in + (long long) (y + (int) gridDim.y) * a.in_stride) + (long long) x4 * 3;
+			n0 = p[0];
+			n1 = p[1];
+			n2 = p[2];
+		}
+		const TIN in[12] = { v0.v[0], v0.v[1], v0.v[2], v0.v[3], v1.v[0], v1.v[1], v1.v[2], v1.v[3], v2.v[0], v2.v[1], v2.v[2],
+			v2.v[3] };
+		TOUT out[12];
+#pragma unroll
+		for (int m = 0; m < 4; m++) {
+			// sRGB2scRGB.c:72-90 (vips_colour_code_build casts to uchar), scRGB2XYZ.c:58-82
+			Px v;
+			v.a = s_v2Y[load_as_uchar_like<TIN>(in[3 * m], 255)];
+			v.b = s_v2Y[load_as_uchar_like<TIN>(in[3 * m + 1], 255)];
+			v.c = s_v2Y[load_as_uchar_like<TIN>(in[3 * m + 2], 255)];
+			v = step_scRGB2XYZ(v);
+			// XYZ2Lab.c:109-138 on small finite values
+			const float n[3] = { quant_div_finite<0>(__fmul_rn(100000.0f, v.a)), quant_div_finite<1>(__fmul_rn(100000.0f, v.b)),
+				quant_div_finite<2>(__fmul_rn(100000.0f, v.c)) };
+			float cb[3];
+#pragma unroll
+			for (int c = 0; c < 3; c++) {
+				const int i = min(max(vh::cvt_i32(n[c]), 0), CBRT_N - 2);
+				const float fi = (float) i;
+				float t0, dt;
+				cbq_pair(s_blk, s_res, i, fi, &t0, &dt);
+				cb[c] = __fadd_rn(t0, __fmul_rn(__fsub_rn(n[c], fi), dt));
+			}
+			const float L = __fsub_rn(__fmul_rn(116.0F, cb[1]), 16.0F);
+			const float A = __fmul_rn(500.0F, __fsub_rn(cb[0], cb[1]));
+			const float B = __fmul_rn(200.0F, __fsub_rn(cb[1], cb[2]));
 			if constexpr (LABS) {
 				out[3 * m] = lab2labs_finite(L, 32767.0 / 100.0, 0.0);
 				out[3 * m + 1] = lab2labs_finite(A, 32768.0 / 128.0, -32768.0);
@@ -1248,8 +1448,27 @@ int colour_route(const int *steps, int n_steps, double alpha_scale, const VipsHi
 	// sRGB -> Lab / LabS from uchar or float: the cube-root table from LDS (colour_lab_lds_kernel)
 	if ((route_id == 1 || route_id == 2) && !getenv("VIPS_HIP_NO_LAB_LDS") &&
 		(in->format == VIPS_HIP_FORMAT_UCHAR || in->format == VIPS_HIP_FORMAT_FLOAT)) {
-		const CbrtExact *cx = cbrt_exact_tables();
-		if (cx) {
+		const CbrtQuad *cq = cbrt_quad_tables();
+		const CbrtExact *cx = cq ? nullptr : cbrt_exact_tables();
+		if (cq) {
+			const int gx = (a.width / 4 + 1023) / 1024;
+			int gy = (256 + gx - 1) / gx; // one block of 1024 per CU, each walking its share of the rows
+			const char *e = getenv("VIPS_HIP_LAB_QUAD_GRID");
+			if (e && atoi(e) > 0)
+				gy = (atoi(e) + gx - 1) / gx;
+			gy = gy > a.height ? a.height : gy;
+			const dim3 gridp(gx, gy, 1), blockq(1024, 1, 1);
+			if (route_id == 1 && in->format == VIPS_HIP_FORMAT_UCHAR)
+				hipLaunchKernelGGL((colour_lab_quad_kernel<unsigned char, false>), gridp, blockq, 0, stream(), a, *cq);
+			else if (route_id == 1)
+				hipLaunchKernelGGL((colour_lab_quad_kernel<float, false>), gridp, blockq, 0, stream(), a, *cq);
+			else if (in->format == VIPS_HIP_FORMAT_UCHAR)
+				hipLaunchKernelGGL((colour_lab_quad_kernel<unsigned char, true>), gridp, blockq, 0, stream(), a, *cq);
+			else
+				hipLaunchKernelGGL((colour_lab_quad_kernel<float, true>), gridp, blockq, 0, stream(), a, *cq);
+			launched = true;
+		}
+		else if (cx) {
 			const int gx = (a.width / 4 + 255) / 256;
 			int gy = (256 * 4 + gx - 1) / gx; // four 34 KB blocks per CU, each walking its share of the rows
 			gy = gy > a.height ? a.height : gy;
