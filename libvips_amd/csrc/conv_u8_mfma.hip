@@ -9,7 +9,7 @@ namespace vh {
 
 // blocks are dealt to the 8 XCDs round-robin by the hardware: give an XCD a contiguous range of items
 // (neighbouring strips of a segment share their halo columns in its L2)
-template <int B, bool WIDE>
+template <int B, bool WIDE, int MODE>
 __global__ void __launch_bounds__(256, 3) // (3 waves per SIMD: the 45 KB of LDS a block takes allow 3 blocks per CU)
 conv_u8_mfma_sep(CmArgs a, int items)
 {
@@ -17,7 +17,7 @@ conv_u8_mfma_sep(CmArgs a, int items)
 	const int per = (items + 7) >> 3;
 	const int item = (int) (blockIdx.x & 7) * per + (int) (blockIdx.x >> 3);
 	if ((int) (blockIdx.x >> 3) < per && item < items)
-		conv_u8_mfma_item<B, WIDE>(a, item, cm_lds);
+		conv_u8_mfma_item<B, WIDE, MODE>(a, item, cm_lds);
 }
 
 } // namespace vh
@@ -42,11 +42,18 @@ static int cm_go(K kernel, const CmArgs &a, int items, size_t lds)
 	return 0;
 }
 
-static int cm_launch(int bands, bool wide, const CmArgs &a, int grid, size_t lds)
+static int cm_launch(int bands, bool wide, bool twod, const CmArgs &a, int grid, size_t lds)
 {
+#define CM_MODE(B, M) (wide ? cm_go(conv_u8_mfma_sep<B, true, M>, a, grid, lds) : cm_go(conv_u8_mfma_sep<B, false, M>, a, grid, lds))
 #define CM_CASE(B) \
 	case B: \
-		return wide ? cm_go(conv_u8_mfma_sep<B, true>, a, grid, lds) : cm_go(conv_u8_mfma_sep<B, false>, a, grid, lds);
+		if (twod && a.ksteps == 3 && a.mh == 3) \
+			return CM_MODE(B, 3); \
+		if (twod && a.ksteps == 3 && a.mh == 5) \
+			return CM_MODE(B, 5); \
+		if (twod) \
+			return CM_MODE(B, -1); \
+		return CM_MODE(B, 0);
 	switch (bands) {
 		CM_CASE(1)
 		CM_CASE(2)
@@ -54,6 +61,7 @@ static int cm_launch(int bands, bool wide, const CmArgs &a, int grid, size_t lds
 		CM_CASE(4)
 	}
 #undef CM_CASE
+#undef CM_MODE
 	return 1;
 }
 

@@ -52,6 +52,10 @@ struct CmArgs {
 	int half, hp;        // taps / 2; rounded up to a multiple of 4
 	int strips, segs;    // blocks across; segments down
 	int seg_rows;        // output rows per segment: a multiple of 32
+	int mh;              // 0: separable (both passes); else the rows of a two-dimensional mask (one pass)
+	int ksteps;          // 16-column steps of the window that hold a tap: 3 or 4
+	int stage_rows;      // rows staged per chunk: 32, + mh - 1 for a two-dimensional mask
+	int row_lead;        // rows between a chunk's first staged row and its first output row: hp, or mh / 2
 	int e_dw;            // dwords between the staged row's first byte (a multiple of the staging unit) and column X0 - hp
 	int in_dw;           // dwords of a staged row that hold pixels: e_dw + (128 + 2 hp) B / 4, in whole units
 	int in_pitch;        // ... and its pitch in LDS (a whole number of units; an odd number of them, or of dword pairs)
@@ -79,15 +83,19 @@ VH_DEV void cm_halves(const unsigned int (&raw)[B], int b, unsigned int &a0, uns
 }
 
 // one work item: strip x segment
-template <int B, bool WIDE>
+// MODE: 0 separable; 3 / 5: a two-dimensional mask of that many rows whose window takes 3 steps, its operands in
+// registers for the whole item; -1: any other two-dimensional mask (operands fetched as they are used)
+template <int B, bool WIDE, int MODE>
 VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 {
+	constexpr bool TWOD = MODE != 0;
 	const int t = tid(), lane = t & 63, wv = wave_index(), n = lane & 31, hf = lane >> 5;
 	const int strip = item % a.strips, seg = item / a.strips;
 	const int X0 = strip * CM_BW;
 	const int sb = (X0 - a.hp) * B - 4 * a.e_dw; // first staged byte of a row: a multiple of the staging unit
 	const int Ya = seg * a.seg_rows, Yb = min(Ya + a.seg_rows, a.height);
-	const int nchunks = (Yb - Ya + CM_ROWS - 1) / CM_ROWS + 1;
+	const int nchunks = (Yb - Ya + CM_ROWS - 1) / CM_ROWS + (TWOD ? 0 : 1);
+	const int SR = a.stage_rows;
 	const gptr_in gin = gptr_in_of((unsigned long long) a.in);
 	const gptr_out gout = gptr_out_of((unsigned long long) a.out);
 
@@ -95,16 +103,18 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 	// of the image: there every column outside is the edge column (vips_embed COPY), so its taps are ADDED to
 	// the edge column's and it gets zero -- no pixel is clamped, whatever the staging put there counts for nothing
 	unsigned int T[4][4], Th[4][4];
+	int which = 0; // which of the 4 operand sets the wave's tile across the image takes
 	{
-		const int W = 4 * strip + wv; // the wave's tile across the image
-		int which = 0;
+		const int W = 4 * strip + wv;
 #pragma unroll
 		for (int k = 0; k < 3; k++)
 			which = a.edge_wave[k] == W ? k + 1 : which;
+		if constexpr (!TWOD) {
 #pragma unroll
-		for (int s = 0; s < 4; s++) {
-			gload128(gptr_in_of((unsigned long long) a.tz), (unsigned int) ((s * 64 + lane) * 16), T[s]);
-			gload128(gptr_in_of((unsigned long long) a.tz), (unsigned int) (((4 * which + s) * 64 + lane) * 16), Th[s]);
+			for (int s = 0; s < 4; s++) {
+				gload128(gptr_in_of((unsigned long long) a.tz), (unsigned int) ((s * 64 + lane) * 16), T[s]);
+				gload128(gptr_in_of((unsigned long long) a.tz), (unsigned int) (((4 * which + s) * 64 + lane) * 16), Th[s]);
+			}
 		}
 	}
 
@@ -126,7 +136,7 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 	const int row_units_last = ((a.width * B) / U - 1) * U; // byte of the last whole unit of an image row
 	// (a chunk whose 32 rows lie inside the image: a lane's offsets are the same for every such chunk)
 	constexpr int MAXI = 6; // instructions per wave and chunk the offsets are kept for
-	const int ninstr = (CM_ROWS * upr + 255) / 256;
+	const int ninstr = (SR * upr + 255) / 256;
 	unsigned int voff_in[MAXI];
 	{
 		int u = 64 * wv + lane;
@@ -134,7 +144,7 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 		const int step_row = 256 / upr, step_cu = 256 - step_row * upr;
 #pragma unroll
 		for (int i = 0; i < MAXI; i++) {
-			const int rr = min(row, CM_ROWS - 1), cc = min(cu, uvalid - 1);
+			const int rr = min(row, SR - 1), cc = min(cu, uvalid - 1);
 			voff_in[i] = (unsigned int) (rr * (int) a.in_stride + min(max(sb + U * cc, 0), row_units_last));
 			cu += step_cu;
 			row += step_row;
@@ -146,12 +156,12 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 	}
 	auto stage = [&](int c) {
 		unsigned int *dst = lds + (c & 1) * a.in_buf;
-		const int r0 = Ya - a.hp + CM_ROWS * c;
-		if (r0 >= 0 && r0 + CM_ROWS <= a.height && ninstr <= MAXI) {
+		const int r0 = Ya - a.row_lead + CM_ROWS * c;
+		if (r0 >= 0 && r0 + SR <= a.height && ninstr <= MAXI) {
 			const gptr_in base = gin + (long long) r0 * a.in_stride;
 #pragma unroll
 			for (int i = 0; i < MAXI; i++)
-				if (i < ninstr && 64 * (wv + 4 * i) < CM_ROWS * upr) {
+				if (i < ninstr && 64 * (wv + 4 * i) < SR * upr) {
 					if constexpr (WIDE)
 						lds_dma_x4(base, voff_in[i], dst + 256 * (wv + 4 * i));
 					else
@@ -165,8 +175,8 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 		int u = 64 * wv + lane;
 		int row = u / upr, cu = u - row * upr;
 		const int step_row = 256 / upr, step_cu = 256 - step_row * upr;
-		for (int j = wv; 64 * j < CM_ROWS * upr; j += 4) {
-			const int rr = min(row, CM_ROWS - 1), cc = min(cu, uvalid - 1); // (padding, the tail: any valid unit)
+		for (int j = wv; 64 * j < SR * upr; j += 4) {
+			const int rr = min(row, SR - 1), cc = min(cu, uvalid - 1); // (padding, the tail: any valid unit)
 			const int rc = min(max(r0 + rr, 0), a.height - 1);
 			// (a strip over the left or right edge of the image: the unit's address clamped into the row -- what
 			// lands in columns outside the image meets a zero coefficient, see Th)
@@ -185,6 +195,16 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 		}
 	};
 
+	// a small two-dimensional mask: its operands for the whole item
+	unsigned int T2[MODE > 0 ? MODE : 1][3][4];
+	if constexpr (MODE > 0) {
+#pragma unroll
+		for (int i = 0; i < MODE; i++)
+#pragma unroll
+			for (int s = 0; s < 3; s++)
+				gload128(gptr_in_of((unsigned long long) a.tz), (unsigned int) ((((which * MODE + i) * 4 + s) * 64 + lane) * 16), T2[i][s]);
+	}
+
 	unsigned int mid_prev[B][8];
 #pragma unroll
 	for (int b = 0; b < B; b++)
@@ -198,6 +218,73 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 		barrier();    // ... everybody's; and every wave is past the reads of the buffer chunk c + 1 goes to
 		if (c + 1 < nchunks)
 			stage(c + 1);
+		unsigned int P[B][4]; // [band][quad of columns 8 j + 4 hf .. + 3 of row n]
+		if constexpr (TWOD) {
+			// ---- a two-dimensional mask: one product per mask row i, rows n + i of the staged chunk, all into
+			// the same accumulators; the operand roles of pass 2 (lane & 31 = the output ROW)
+			float acc[B][16];
+#pragma unroll
+			for (int b = 0; b < B; b++)
+#pragma unroll
+				for (int r = 0; r < 16; r++)
+					acc[b][r] = 0.0f;
+			auto step = [&](const unsigned int *src, int s, const unsigned int (&Ti)[4]) {
+				unsigned int raw[2][B];
+#pragma unroll
+				for (int g = 0; g < 2; g++)
+#pragma unroll
+					for (int k = 0; k < B; k++)
+						raw[g][k] = src[B * (4 * s + 2 * g) + k];
+#pragma unroll
+				for (int b = 0; b < B; b++) {
+					unsigned int A[4];
+					cm_halves<B>(raw[0], b, A[0], A[1]);
+					cm_halves<B>(raw[1], b, A[2], A[3]);
+					mfma_32x32x16_f16(Ti, A, acc[b]);
+				}
+			};
+			if constexpr (MODE > 0) {
+#pragma unroll
+				for (int i = 0; i < MODE; i++) {
+					const unsigned int *src = lds + (c & 1) * a.in_buf + (n + i) * a.in_pitch + a.e_dw + B * (8 * wv + hf);
+#pragma unroll
+					for (int s = 0; s < 3; s++)
+						step(src, s, T2[i][s]);
+				}
+			}
+			else {
+				// (the next step's operand travels while this step's products are made)
+				unsigned int Tn[4];
+				gload128(gptr_in_of((unsigned long long) a.tz), (unsigned int) ((((which * a.mh) * 4) * 64 + lane) * 16), Tn);
+				for (int i = 0; i < a.mh; i++) {
+					const unsigned int *src = lds + (c & 1) * a.in_buf + (n + i) * a.in_pitch + a.e_dw + B * (8 * wv + hf);
+					for (int s = 0; s < a.ksteps; s++) {
+						unsigned int Ti[4];
+#pragma unroll
+						for (int k = 0; k < 4; k++)
+							Ti[k] = Tn[k];
+						int in = i, sn = s + 1;
+						if (sn == a.ksteps) {
+							sn = 0;
+							in = i + 1 < a.mh ? i + 1 : i;
+						}
+						gload128(gptr_in_of((unsigned long long) a.tz), (unsigned int) ((((which * a.mh + in) * 4 + sn) * 64 + lane) * 16), Tn);
+						step(src, s, Ti);
+					}
+				}
+			}
+#pragma unroll
+			for (int b = 0; b < B; b++)
+#pragma unroll
+				for (int j = 0; j < 4; j++) {
+					unsigned int w = 0;
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+						w = cvt_pk_u8(__builtin_fmaf(acc[b][4 * j + k], a.k1, a.bias), (unsigned int) k, w);
+					P[b][j] = w;
+				}
+		}
+		else {
 		// the lane's pixels of row n: per 16 window columns the groups 4 hf .. + 3 and 8 + 4 hf .. + 3
 		const unsigned int *src = lds + (c & 1) * a.in_buf + n * a.in_pitch + a.e_dw + B * (8 * wv + hf);
 		unsigned int raw[4][2][B];
@@ -208,7 +295,6 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 #pragma unroll
 				for (int i = 0; i < B; i++)
 					raw[s][g][i] = src[B * (4 * s + 2 * g) + i];
-		unsigned int P[B][4]; // [band][quad of columns 8 j + 4 hf .. + 3 of row n]
 #pragma unroll
 		for (int b = 0; b < B; b++) {
 			// ---- pass 1 (the accumulators start at 0: the rounding constant is in a.bias)
@@ -264,7 +350,8 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 				mid_prev[b][q] = mid_cur[q];
 			sched_fence(); // (one band's accumulators at a time)
 		}
-		if (c >= 1) {
+		}
+		if (TWOD || c >= 1) {
 			// row n, columns 8 j + 4 hf .. + 3 of the wave's tile: bands interleaved, B dwords
 			unsigned int *orow = otile + n * OP + B * hf;
 #pragma unroll
@@ -279,7 +366,7 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 					orow[2 * B * j + b] = w[b];
 			}
 			wave_lds_fence(); // (the tile is the wave's own: no barrier)
-			const int y0 = Ya + CM_ROWS * (c - 1);
+			const int y0 = Ya + CM_ROWS * (TWOD ? c : c - 1);
 			if (y0 + CM_ROWS <= Yb && (X0 + 32 * wv + 32) * B <= row_bytes) {
 				// the whole tile lies inside the image: no lane tests anything but its row of the last instruction
 				const gptr_out tile_out = gout + (long long) y0 * a.out_stride;

@@ -16,7 +16,7 @@
 namespace vh {
 
 // defined by the including file; 0 on success
-static int cm_launch(int bands, bool wide, const CmArgs &a, int grid, size_t lds);
+static int cm_launch(int bands, bool wide, bool twod, const CmArgs &a, int grid, size_t lds);
 
 namespace {
 
@@ -109,7 +109,8 @@ struct CmTables {
 std::mutex cm_mutex;
 std::map<std::vector<int>, CmTables> cm_cache;
 
-int cm_tables_device(const int *c, int n, int hp, int width, CmTables *out)
+// c: rows x n taps (rows = 1: the separable mask); the set for variant v, mask row i starts at table (v rows + i)
+int cm_tables_device(const int *c, int n, int rows, int hp, int width, CmTables *out)
 {
 	// the tiles (32 columns each) whose 64-column window, which starts hp columns before the tile, leaves the image
 	int waves[3] = { -1, -1, -1 }, lo[3] = { 0, 0, 0 }, hi[3] = { 64, 64, 64 };
@@ -127,7 +128,8 @@ int cm_tables_device(const int *c, int n, int hp, int width, CmTables *out)
 		if (W == 0 && last > 2)
 			W = last - 2; // (only tile 0 and the last two can: hp <= 16)
 	}
-	std::vector<int> key(c, c + n);
+	std::vector<int> key(c, c + (size_t) n * rows);
+	key.push_back(rows);
 	key.push_back(hp);
 	key.push_back(current_device());
 	for (int k = 0; k < 3; k++) {
@@ -139,12 +141,15 @@ int cm_tables_device(const int *c, int n, int hp, int width, CmTables *out)
 	auto it = cm_cache.find(key);
 	if (it == cm_cache.end()) {
 		const size_t one = 4 * 64 * 4;
-		std::vector<unsigned int> host(4 * one);
-		if (!cm_tables(c, n, hp, -1000, 1000, host.data()))
-			return 1;
-		for (int k = 0; k < 3; k++)
-			if (!cm_tables(c, n, hp, waves[k] < 0 ? -1000 : lo[k], waves[k] < 0 ? 1000 : hi[k], host.data() + (k + 1) * one))
+		std::vector<unsigned int> host(4 * rows * one);
+		for (int i = 0; i < rows; i++) {
+			if (!cm_tables(c + (size_t) i * n, n, hp, -1000, 1000, host.data() + i * one))
 				return 1;
+			for (int k = 0; k < 3; k++)
+				if (!cm_tables(c + (size_t) i * n, n, hp, waves[k] < 0 ? -1000 : lo[k], waves[k] < 0 ? 1000 : hi[k],
+						host.data() + ((k + 1) * rows + i) * one))
+					return 1;
+		}
 		unsigned int *d = (unsigned int *) upload(host.data(), host.size() * sizeof(unsigned int));
 		if (!d)
 			return -1;
@@ -158,41 +163,12 @@ int cm_tables_device(const int *c, int n, int hp, int width, CmTables *out)
 	return 0;
 }
 
-} // namespace
-
-// Both passes of vips_convsep / vips_gaussblur (precision integer) on a uchar image, on the matrix cores.
-// 1 = not this kernel's case (nothing launched), 0 = done, -1 = error.
-int conv_u8_mfma_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConv *c, double offset2)
+// what both kernels need of the images: the staging geometry, the rounding, the segments; false: not their case
+bool cm_geometry(const _VipsHipImage *in, const _VipsHipImage *out, const _VipsHipConv *c, int half, int mh, CmArgs *pa,
+	size_t *plds, bool *pwide)
 {
-	const char *env = getenv("VIPS_HIP_CONV_U8_MFMA");
-	if ((env && atoi(env) == 0) || getenv("VIPS_HIP_NO_CONV_U8"))
-		return 1;
-	if (c->mask_height != 1 || c->nnz != c->mask_width || !(c->mask_width & 1) || c->mask_width > 33 || c->mask_width < 3)
-		return 1;
-	if (c->precision != VIPS_HIP_PRECISION_INTEGER || in->format != VIPS_HIP_FORMAT_UCHAR || out->format != VIPS_HIP_FORMAT_UCHAR)
-		return 1;
-	if (in->bands != out->bands || in->width != out->width || in->height != out->height)
-		return 1;
-	if (in->bands < 1 || in->bands > 4)
-		return 1;
-	if (((uintptr_t) in->data | (uintptr_t) out->data | in->stride | out->stride) & 3)
-		return 1;
-	// (the staging's lane offsets are 32-bit: 33 rows of the image; tiny images stay with the packed-byte kernel)
-	if ((long long) in->stride * 34 >= (1LL << 31) || in->width < 32 || in->height < 8)
-		return 1;
-	// the rounding of conv_u8_body.h: offset 0, 1 <= scale <= 8000, numerators below 2^24
-	if (c->offset_i != 0 || (int) rint(offset2) != 0 || c->scale_i < 1 || c->scale_i > 8000 || c->rounding != c->scale_i / 2)
-		return 1;
-	long long abs_sum = 0;
-	for (int k = 0; k < c->nnz; k++) {
-		if (c->coeffi[k] <= -2048 || c->coeffi[k] >= 2048) // an exact half
-			return 1;
-		abs_sum += c->coeffi[k] < 0 ? -c->coeffi[k] : c->coeffi[k];
-	}
-	if (abs_sum * 255 + c->rounding >= (1LL << 24))
-		return 1;
-	const int B = in->bands, n = c->mask_width;
-	CmArgs a;
+	const int B = in->bands;
+	CmArgs &a = *pa;
 	memset(&a, 0, sizeof(a));
 	a.in = (const unsigned char *) in->data;
 	a.out = (unsigned char *) out->data;
@@ -200,8 +176,15 @@ int conv_u8_mfma_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 	a.out_stride = (long long) out->stride;
 	a.width = in->width;
 	a.height = in->height;
-	a.half = n / 2;
+	a.half = half;
 	a.hp = (a.half + 3) & ~3;
+	if (a.hp < 4)
+		a.hp = 4;
+	a.mh = mh;
+	a.stage_rows = CM_ROWS + (mh ? mh - 1 : 0);
+	a.row_lead = mh ? mh / 2 : a.hp;
+	// the 16-column steps of the 64-column window that hold a tap of some output: columns up to 31 + hp + half
+	a.ksteps = (31 + a.hp + a.half) / 16 + 1;
 	a.strips = (a.width + CM_BW - 1) / CM_BW;
 	// 16-byte staging units when every row start is a multiple of 16, else dwords
 	const bool wide = !(((uintptr_t) in->data | in->stride) & 15) && !getenv("VIPS_HIP_CONV_MFMA_NARROW");
@@ -211,8 +194,7 @@ int conv_u8_mfma_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 	const int units = (4 * a.e_dw + (CM_BW + 2 * a.hp) * B + U - 1) / U;
 	a.in_dw = units * (U / 4);
 	{
-		// the pitch: a whole number of units; an odd number of 16-byte units (of dword pairs for dword units),
-		// and room for the 64 units of an instruction when the row is narrower
+		// the pitch: a whole number of units; an odd number of 16-byte units (of dword pairs for dword units)
 		int pu = units;
 		if (wide)
 			pu += !(pu & 1);
@@ -223,12 +205,14 @@ int conv_u8_mfma_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 		}
 		a.in_pitch = pu * (U / 4);
 	}
-	// (whole instructions of 64 units: the last one of a chunk may run past the 32 rows)
-	a.in_buf = ((CM_ROWS * (a.in_pitch / (U / 4)) + 63) / 64) * 64 * (U / 4);
+	// (whole instructions of 64 units: the last one of a chunk may run past the staged rows)
+	a.in_buf = ((a.stage_rows * (a.in_pitch / (U / 4)) + 63) / 64) * 64 * (U / 4);
 	if (!cm_rounding(c->scale_i, c->rounding, &a.k1, &a.bias))
-		return 1;
+		return false;
 	const size_t lds = (size_t) (2 * a.in_buf + (CM_NT / 64) * CM_ROWS * (8 * B + 1)) * sizeof(unsigned int);
-	// segments: one residency round of blocks (LDS allows 3 per CU), a segment re-makes one chunk of 32 rows
+	if (lds > 160 * 1024)
+		return false;
+	// segments: one residency round of blocks (LDS allows 3 per CU); a separable segment re-makes one chunk of 32 rows
 	{
 		const int chunks = (a.height + CM_ROWS - 1) / CM_ROWS;
 		int per_cu = (int) ((160 * 1024) / lds);
@@ -242,14 +226,64 @@ int conv_u8_mfma_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 		e = getenv("VIPS_HIP_CONV_MFMA_SEG");
 		if (e && atoi(e) > 0)
 			seg_chunks = atoi(e);
-		if (seg_chunks < 2 && chunks >= 2)
+		if (!mh && seg_chunks < 2 && chunks >= 2)
 			seg_chunks = 2;
 		a.seg_rows = CM_ROWS * seg_chunks;
 		a.segs = (a.height + a.seg_rows - 1) / a.seg_rows;
 	}
+	*plds = lds;
+	*pwide = wide;
+	return true;
+}
+
+// what both kernels ask of the images and the plan's rounding
+bool cm_common(const _VipsHipImage *in, const _VipsHipImage *out, const _VipsHipConv *c, double offset2)
+{
+	const char *env = getenv("VIPS_HIP_CONV_U8_MFMA");
+	if ((env && atoi(env) == 0) || getenv("VIPS_HIP_NO_CONV_U8"))
+		return false;
+	if (c->precision != VIPS_HIP_PRECISION_INTEGER || in->format != VIPS_HIP_FORMAT_UCHAR || out->format != VIPS_HIP_FORMAT_UCHAR)
+		return false;
+	if (in->bands != out->bands || in->width != out->width || in->height != out->height)
+		return false;
+	if (in->bands < 1 || in->bands > 4)
+		return false;
+	if (((uintptr_t) in->data | (uintptr_t) out->data | in->stride | out->stride) & 3)
+		return false;
+	// (the staging's lane offsets are 32-bit: 40 rows of the image; tiny images stay with the packed-byte kernels)
+	if ((long long) in->stride * 42 >= (1LL << 31) || in->width < 32 || in->height < 8)
+		return false;
+	// the rounding of conv_u8_body.h: offset 0, 1 <= scale <= 8000, numerators below 2^24
+	if (c->offset_i != 0 || (int) rint(offset2) != 0 || c->scale_i < 1 || c->scale_i > 8000 || c->rounding != c->scale_i / 2)
+		return false;
+	long long abs_sum = 0;
+	for (int k = 0; k < c->nnz; k++) {
+		if (c->coeffi[k] <= -2048 || c->coeffi[k] >= 2048) // an exact half
+			return false;
+		abs_sum += c->coeffi[k] < 0 ? -c->coeffi[k] : c->coeffi[k];
+	}
+	return abs_sum * 255 + c->rounding < (1LL << 24);
+}
+
+} // namespace
+
+// Both passes of vips_convsep / vips_gaussblur (precision integer) on a uchar image, on the matrix cores.
+// 1 = not this kernel's case (nothing launched), 0 = done, -1 = error.
+int conv_u8_mfma_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConv *c, double offset2)
+{
+	if (c->mask_height != 1 || c->nnz != c->mask_width || !(c->mask_width & 1) || c->mask_width > 33 || c->mask_width < 3)
+		return 1;
+	if (!cm_common(in, out, c, offset2))
+		return 1;
+	const int B = in->bands, n = c->mask_width;
+	CmArgs a;
+	size_t lds;
+	bool wide;
+	if (!cm_geometry(in, out, c, n / 2, 0, &a, &lds, &wide))
+		return 1;
 	CmTables tabs;
 	{
-		const int r = cm_tables_device(c->coeffi.data(), n, a.hp, a.width, &tabs);
+		const int r = cm_tables_device(c->coeffi.data(), n, 1, a.hp, a.width, &tabs);
 		if (r)
 			return r;
 	}
@@ -257,7 +291,39 @@ int conv_u8_mfma_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 	for (int k = 0; k < 3; k++)
 		a.edge_wave[k] = tabs.edge_wave[k];
 	Gate gate("conv_u8_mfma_sep");
-	return cm_launch(B, wide, a, a.strips * a.segs, lds);
+	return cm_launch(B, wide, false, a, a.strips * a.segs, lds);
+}
+
+// vips_conv (precision integer) with a two-dimensional mask of up to 9 rows and 33 columns on a uchar image: one
+// Toeplitz product per mask row.  1 = not this kernel's case, 0 = done, -1 = error.
+int conv_u8_mfma_2d_try(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConv *c)
+{
+	const int mw = c->mask_width, mh = c->mask_height;
+	if (!(mw & 1) || !(mh & 1) || mw > 33 || mh > 9 || mh < 3 || mw < 1)
+		return 1;
+	if (!cm_common(in, out, c, 0.0))
+		return 1;
+	const int B = in->bands;
+	CmArgs a;
+	size_t lds;
+	bool wide;
+	if (!cm_geometry(in, out, c, mw / 2, mh, &a, &lds, &wide))
+		return 1;
+	// the dense mask, row by row (zero taps were squeezed out of the plan)
+	std::vector<int> dense((size_t) mw * mh, 0);
+	for (int k = 0; k < c->nnz; k++)
+		dense[c->pos[k]] = c->coeffi[k];
+	CmTables tabs;
+	{
+		const int r = cm_tables_device(dense.data(), mw, mh, a.hp, a.width, &tabs);
+		if (r)
+			return r;
+	}
+	a.tz = tabs.tz;
+	for (int k = 0; k < 3; k++)
+		a.edge_wave[k] = tabs.edge_wave[k];
+	Gate gate("conv_u8_mfma_2d");
+	return cm_launch(B, wide, true, a, a.strips * a.segs, lds);
 }
 
 } // namespace vh

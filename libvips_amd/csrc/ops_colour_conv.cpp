@@ -203,7 +203,9 @@ int conv_image(VipsHipImage *in, VipsHipImage **out, const double *mask, int mw,
 	// (not with the Highway variant of convi selected: that one has its own arithmetic)
 	if (in->format == VIPS_HIP_FORMAT_UCHAR && precision == VIPS_HIP_PRECISION_INTEGER && !vips_hip_vector_isenabled() &&
 		mh > 1 && mw > 1) {
-		const int r = vh::conv_u8_2d_try(in, o.im, c.get());
+		int r = vh::conv_u8_mfma_2d_try(in, o.im, c.get()); // the matrix cores first (conv_u8_mfma.hip)
+		if (r == 1)
+			r = vh::conv_u8_2d_try(in, o.im, c.get());
 		if (r < 0)
 			return -1;
 		if (r == 0) {

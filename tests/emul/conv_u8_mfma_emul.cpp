@@ -11,7 +11,7 @@
 
 namespace vh {
 
-template <int B, bool WIDE>
+template <int B, bool WIDE, int MODE>
 static void cm_run(const CmArgs &a, int items, size_t lds)
 {
 	(void) hipStreamSynchronize(stream());
@@ -24,7 +24,7 @@ static void cm_run(const CmArgs &a, int items, size_t lds)
 				break;
 			for (size_t i = 0; i < buf.size(); i++)
 				buf[i] = 0xdeadbeefu + (unsigned int) i * 2654435761u;
-			emul::run_block(CM_NT, [&]() { conv_u8_mfma_item<B, WIDE>(a, item, buf.data()); });
+			emul::run_block(CM_NT, [&]() { conv_u8_mfma_item<B, WIDE, MODE>(a, item, buf.data()); });
 		}
 	};
 	unsigned int nthreads = std::thread::hardware_concurrency();
@@ -36,14 +36,25 @@ static void cm_run(const CmArgs &a, int items, size_t lds)
 		t.join();
 }
 
-static int cm_launch(int bands, bool wide, const CmArgs &a, int grid, size_t lds)
+static int cm_launch(int bands, bool wide, bool twod, const CmArgs &a, int grid, size_t lds)
 {
+#define CM_MODE(B, M) \
+	do { \
+		if (wide) \
+			cm_run<B, true, M>(a, grid, lds); \
+		else \
+			cm_run<B, false, M>(a, grid, lds); \
+	} while (0)
 #define CM_CASE(B) \
 	case B: \
-		if (wide) \
-			cm_run<B, true>(a, grid, lds); \
+		if (twod && a.ksteps == 3 && a.mh == 3) \
+			CM_MODE(B, 3); \
+		else if (twod && a.ksteps == 3 && a.mh == 5) \
+			CM_MODE(B, 5); \
+		else if (twod) \
+			CM_MODE(B, -1); \
 		else \
-			cm_run<B, false>(a, grid, lds); \
+			CM_MODE(B, 0); \
 		return 0;
 	switch (bands) {
 		CM_CASE(1)
@@ -52,6 +63,7 @@ static int cm_launch(int bands, bool wide, const CmArgs &a, int grid, size_t lds
 		CM_CASE(4)
 	}
 #undef CM_CASE
+#undef CM_MODE
 	return 1;
 }
 

@@ -52,8 +52,6 @@ def test_conv_u8(case, env, monkeypatch):
     kind, w, h, bands, arg = case[:5]
     if len(env) > 1 and w * h > 2000 * 2000:
         pytest.skip("short segments on the small cases only")
-    if kind == "conv" and env.get("VIPS_HIP_CONV_U8_MFMA") == "0":
-        pytest.skip("2-D masks have one kernel")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     sep_gate = "conv_u8_sep" if env.get("VIPS_HIP_CONV_U8_MFMA") == "0" else "conv_u8_mfma_sep"
@@ -77,7 +75,8 @@ def test_conv_u8(case, env, monkeypatch):
     finally:
         libvips_amd.lib.vips_hip_gate_enable(0)
         libvips_amd.lib.vips_hip_gate_reset()
-    assert list(report) == ["conv_u8_2d" if kind == "conv" else sep_gate], report
+    conv_gate = "conv_u8_2d" if env.get("VIPS_HIP_CONV_U8_MFMA") == "0" else "conv_u8_mfma_2d"
+    assert list(report) == [conv_gate if kind == "conv" else sep_gate], report
     want = _reference(kind, src, arg)
     assert got.shape == want.shape and got.dtype == want.dtype
     bad = np.argwhere(got != want)

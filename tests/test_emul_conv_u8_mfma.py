@@ -34,17 +34,24 @@ for case in %(cases)r:
     im = Image.new_from_array(src)
     lib.vips_hip_gate_reset()
     lib.vips_hip_gate_enable(1)
+    gate = "conv_u8_mfma_sep"
     if kind == "blur":
         sigma = case[4]
         got = im.gaussblur(sigma).numpy()
         want = helpers.Ref.run_chain("gaussblur:sigma=%%r" %% sigma, src)
+    elif kind == "conv":
+        mask, scale = case[4]
+        m = np.asarray(mask, dtype=np.float64)
+        got = im.conv(m, scale=scale, precision="integer").numpy()
+        want = helpers.Ref.run_mask("conv", src, m, scale, 0.0, "precision=integer")
+        gate = "conv_u8_mfma_2d"
     else:
         mask, scale = case[4]
         got = im.convsep(mask, scale=scale, precision="integer").numpy()
         want = helpers.Ref.run_mask("convsep", src, np.asarray(mask, dtype=np.float64)[None, :], scale, 0.0, "precision=integer")
     report = libvips_amd.gate_report()
     lib.vips_hip_gate_enable(0)
-    assert list(report) == ["conv_u8_mfma_sep"], (case, report)
+    assert list(report) == [gate], (case, report)
     assert got.shape == want.shape and got.dtype == want.dtype, (got.shape, want.shape)
     bad = np.argwhere(got != want)
     assert len(bad) == 0, (case[:4], len(bad), bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
@@ -81,6 +88,22 @@ def test_rows_of_whole_16_byte_units(tmp_path):
     _run([("blur", 320, 200, 3, 8.0)], tmp_path, {"VIPS_HIP_CONV_MFMA_SEG": "2"})
     # ... and the same images through dword units
     _run([("blur", 320, 70, 3, 8.0), ("blur", 336, 100, 1, 3.0)], tmp_path, {"VIPS_HIP_CONV_MFMA_NARROW": "1"})
+
+
+K3 = [[-1, -1, -1], [-1, 16, -1], [-1, -1, -1]]
+K5 = [[1, 4, 6, 4, 1], [4, 16, 24, 16, 4], [6, 24, 36, 24, 6], [4, 16, 24, 16, 4], [1, 4, 6, 4, 1]]
+K37 = [[1, 2, 3, 4, 3, 2, 1], [-2, -1, 0, 9, 0, -1, -2], [1, 2, 3, 4, 3, 2, 1]]
+K9x15 = [[(i * 7 + j * 3) % 11 - 2 for j in range(15)] for i in range(9)]
+
+
+def test_conv_2d(tmp_path):
+    # two-dimensional masks: 3 x 3, 5 x 5, 7 wide x 3, 15 wide x 9 (window steps 3 and 4), 1 .. 4 bands, narrow and
+    # ragged images, 16-byte and dword staging units, one chunk per segment
+    _run([("conv", 300, 70, 3, (K3, 8)), ("conv", 332, 41, 1, (K5, 256)), ("conv", 271, 37, 4, (K3, 8)),
+          ("conv", 260, 50, 3, (K5, 256)), ("conv", 200, 45, 2, (K37, 30)), ("conv", 96, 33, 3, (K3, 8)),
+          ("conv", 256, 64, 3, (K3, 8), "flat"), ("conv", 320, 100, 3, (K5, 256)),
+          ("conv", 176, 80, 3, (K9x15, sum(map(sum, K9x15))))], tmp_path)
+    _run([("conv", 300, 120, 3, (K5, 256))], tmp_path, {"VIPS_HIP_CONV_MFMA_SEG": "1"})
 
 
 def test_short_segments(tmp_path):
