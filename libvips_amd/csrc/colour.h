@@ -19,9 +19,15 @@ int colour_route(const int *steps, int n_steps, double alpha_scale, const VipsHi
 	const VipsHipRegion *out);
 
 // vips_sharpen on a whole 3-band uchar sRGB image in one kernel (colour.hip); 1 = not its case
+// (win: the part of the LUT that is not constant, as shorts on the device -- the kernel with every table in LDS;
+// nullptr: the kernel that reads the whole LUT through global memory)
+struct SharpenLutWindow {
+	int lo, n, below, above; // lut[i] = below for i < lo, above for i >= lo + n
+	const short *lut_win;    // device: n entries from index lo
+};
 int sharpen_fused_u8(const VipsHipRegion *const *in, const VipsHipRegion *const *out, int n_images,
 	const int *to_steps, int n_to, const int *from_steps, int n_from, const int *coef, int n, int scale,
-	const int *lut);
+	const int *lut, const SharpenLutWindow *win);
 
 // host copies of the 8-bit sRGB tables (256 floats, 257 ints) and the cube-root table (100000
 // floats), as the device tables are made (LabQ2sRGB.c:130-160, XYZ2Lab.c:92-106)

@@ -1031,10 +1031,212 @@ sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 	}
 }
 
+// ------------------------------------------------- ... with every table in LDS (round 5)
+//
+// sharpen_fused_u8 reads four tables per pixel through global memory (XYZ2Lab's 400 KB cube-root table three
+// times, sharpen's 256 KB LUT once) and a wave's gather from an L2-resident table takes ~146 cycles of its CU's
+// L1 fill path (tools/gather_probe.hip): 4 x 146 cycles per 64 pixels IS the kernel's 1.06 ms on 8192^2.  Here a
+// block of 1024 threads copies everything it looks up into LDS once and then walks tiles of 64 x 64 pixels:
+//   * the cube-root table in cbrt_quad.h's form (57 KB, ~27 instructions and two LDS reads per pair);
+//   * the part of sharpen's LUT that is not constant (sharpen.c:230-257 is flat outside a few thousand entries
+//     round the middle: the host finds the window; a LUT with a wider one takes the older kernel);
+//   * the two 8-bit sRGB tables.
+// Same steps, same roundings as the older kernel (colour_device.h); one block per CU (106 KB of LDS, 16 waves).
+constexpr int SQ_NT = 1024, SQ_T = 64, SQ_R = SQ_T + 2 * SF_MAXHALF;
+constexpr int SQ_MAXLUT = 6144; // entries of the LUT's window
+
+struct SharpenQuadArgs {
+	SharpenFusedArgs f;
+	CbrtQuad cq;
+	const short *lut_win; // lut_n entries from index lut_lo
+	int lut_lo, lut_n, lut_below, lut_above;
+	int tiles_x, tiles_y, n_images;
+};
+
+// XYZ2Lab.c:109-138 on a small finite value: the table pair from LDS
+static __device__ __forceinline__ float sq_cbrt(const CbqBlock *blk, const unsigned int *res, float n)
+{
+	const int i = min(max(vh::cvt_i32(n), 0), CBRT_N - 2);
+	const float fi = (float) i;
+	float t0, dt;
+	cbq_pair(blk, res, i, fi, &t0, &dt);
+	return __fadd_rn(t0, __fmul_rn(__fsub_rn(n, fi), dt));
+}
+
+template <bool WANT_AB>
+static __device__ __forceinline__ void sq_to_labs(const CbqBlock *blk, const unsigned int *res, const float *v2Y, int r, int g,
+	int b, short &L, short &A, short &B)
+{
+	Px v;
+	v.a = v2Y[r];
+	v.b = v2Y[g];
+	v.c = v2Y[b];
+	v = step_scRGB2XYZ(v);
+	const float cby = sq_cbrt(blk, res, quant_div_finite<1>(__fmul_rn(100000.0f, v.b)));
+	L = lab2labs_finite(__fsub_rn(__fmul_rn(116.0F, cby), 16.0F), 32767.0 / 100.0, 0.0);
+	if (WANT_AB) {
+		const float cbx = sq_cbrt(blk, res, quant_div_finite<0>(__fmul_rn(100000.0f, v.a)));
+		const float cbz = sq_cbrt(blk, res, quant_div_finite<2>(__fmul_rn(100000.0f, v.c)));
+		A = lab2labs_finite(__fmul_rn(500.0F, __fsub_rn(cbx, cby)), 32768.0 / 128.0, -32768.0);
+		B = lab2labs_finite(__fmul_rn(200.0F, __fsub_rn(cby, cbz)), 32768.0 / 128.0, -32768.0);
+	}
+}
+
+__global__ void __launch_bounds__(SQ_NT)
+sharpen_quad_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenQuadArgs q)
+{
+	VH_DYNAMIC_LDS(unsigned int, sq_lds);
+	(void) ptrs_by_value;
+	const SharpenFusedArgs &a = q.f;
+	CbqBlock *const s_blk = reinterpret_cast<CbqBlock *>(sq_lds);
+	unsigned int *const s_res = sq_lds + CBQ_BLOCKS * 4;
+	float *const s_v2Y = reinterpret_cast<float *>(s_res + CBQ_RES_WORDS);
+	int *const s_Y2v = reinterpret_cast<int *>(s_v2Y + 256);
+	short *const s_lut = reinterpret_cast<short *>(s_Y2v + 260);
+	short *const s_L = s_lut + SQ_MAXLUT + 8;                                   // [SQ_R][SQ_R]
+	unsigned int *const s_ab = reinterpret_cast<unsigned int *>(s_L + SQ_R * SQ_R); // [SQ_T][SQ_T]: a | b << 16
+	short *const s_h = reinterpret_cast<short *>(s_ab + SQ_T * SQ_T);            // [SQ_R][SQ_T]
+	const int t = threadIdx.x;
+	for (int i = t; i < CBQ_BLOCKS; i += SQ_NT)
+		s_blk[i] = q.cq.blk[i];
+	for (int i = t; i < CBQ_RES_WORDS; i += SQ_NT)
+		s_res[i] = q.cq.res[i];
+	if (t < 256)
+		s_v2Y[t] = a.tables.v2Y_8[t];
+	if (t < 257)
+		s_Y2v[t] = a.tables.Y2v_8[t];
+	for (int i = t; i < q.lut_n; i += SQ_NT)
+		s_lut[i] = q.lut_win[i];
+	typedef const unsigned long long __attribute__((address_space(4))) *KernargPtrs;
+	const KernargPtrs kp = (KernargPtrs) __builtin_amdgcn_kernarg_segment_ptr();
+	typedef const unsigned char __attribute__((address_space(1))) *GlobalIn;
+	typedef unsigned char __attribute__((address_space(1))) *GlobalOut;
+	const int h = a.half;
+	const int rw = SQ_T + 2 * h;
+	const int tiles = q.tiles_x * q.tiles_y * q.n_images;
+	const int row = t >> 4, quad = t & 15;
+	for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+		const int img = tile / (q.tiles_x * q.tiles_y), tt = tile - img * (q.tiles_x * q.tiles_y);
+		const int ty = tt / q.tiles_x, tx = tt - ty * q.tiles_x;
+		const GlobalIn in = (GlobalIn) kp[img];
+		const GlobalOut out = (GlobalOut) kp[SF_MAXB + img];
+		const int x0 = tx * SQ_T, y0 = ty * SQ_T;
+		__syncthreads(); // (the tables are there; the last tile's readers are done)
+		// 1a. the tile: 4 pixels per thread -> LabS
+		{
+			const int y = min(y0 + row, a.height - 1);
+			const int x = x0 + 4 * quad;
+			const GlobalIn line = in + (long long) y * a.in_stride;
+			unsigned char px[12];
+			if (x + 4 <= a.width && !((((unsigned long long) in) | (unsigned long long) a.in_stride) & 3)) {
+				const unsigned int __attribute__((address_space(1))) *p4 =
+					(const unsigned int __attribute__((address_space(1))) *) (line + 3LL * x);
+#pragma unroll
+				for (int w = 0; w < 3; w++) {
+					const unsigned int v = p4[w];
+					px[4 * w] = (unsigned char) v;
+					px[4 * w + 1] = (unsigned char) (v >> 8);
+					px[4 * w + 2] = (unsigned char) (v >> 16);
+					px[4 * w + 3] = (unsigned char) (v >> 24);
+				}
+			}
+			else {
+#pragma unroll
+				for (int m = 0; m < 4; m++) {
+					const GlobalIn p = line + 3LL * min(x + m, a.width - 1);
+					px[3 * m] = p[0];
+					px[3 * m + 1] = p[1];
+					px[3 * m + 2] = p[2];
+				}
+			}
+#pragma unroll
+			for (int m = 0; m < 4; m++) {
+				short L, A, B;
+				sq_to_labs<true>(s_blk, s_res, s_v2Y, px[3 * m], px[3 * m + 1], px[3 * m + 2], L, A, B);
+				s_L[(row + h) * SQ_R + 4 * quad + m + h] = L;
+				s_ab[row * SQ_T + 4 * quad + m] = ((unsigned int) A & 0xffffu) | ((unsigned int) B << 16);
+			}
+		}
+		// 1b. the ring of h pixels round it (image edges clamped): L only
+		{
+			const int ring = rw * rw - SQ_T * SQ_T;
+			if (t < ring) {
+				int ry, rx;
+				if (t < 2 * rw * h) {
+					const int r = t / rw;
+					rx = t - r * rw;
+					ry = r < h ? r : SQ_T + r;
+				}
+				else {
+					const int k = t - 2 * rw * h;
+					const int r = k / (2 * h), c = k - r * 2 * h;
+					ry = h + r;
+					rx = c < h ? c : SQ_T + c;
+				}
+				const int x = min(max(x0 + rx - h, 0), a.width - 1);
+				const int y = min(max(y0 + ry - h, 0), a.height - 1);
+				const GlobalIn p = in + (long long) y * a.in_stride + 3LL * x;
+				short L, A = 0, B = 0;
+				sq_to_labs<false>(s_blk, s_res, s_v2Y, p[0], p[1], p[2], L, A, B);
+				s_L[ry * SQ_R + rx] = L;
+			}
+		}
+		__syncthreads();
+		// 2. horizontal pass on L (all rows of the region, the tile's columns)
+		for (int idx = t; idx < rw * SQ_T; idx += SQ_NT) {
+			const int ry = idx >> 6, cx = idx & 63;
+			int sum = 0;
+#pragma unroll
+			for (int k = 0; k < 2 * SF_MAXHALF + 1; k++)
+				sum += a.coef[k] * (int) s_L[ry * SQ_R + cx + k];
+			s_h[ry * SQ_T + cx] = (short) sf_convi_fin(sum, a);
+		}
+		__syncthreads();
+		// 3. vertical pass, the LUT, back to sRGB: 4 pixels per thread, three dword stores
+		{
+			const int y = y0 + row;
+			if (y < a.height) {
+				unsigned char o[12];
+#pragma unroll
+				for (int m = 0; m < 4; m++) {
+					const int cx = 4 * quad + m;
+					int sum = 0;
+#pragma unroll
+					for (int k = 0; k < 2 * SF_MAXHALF + 1; k++)
+						sum += a.coef[k] * (int) s_h[(row + k) * SQ_T + cx];
+					const int blur = sf_convi_fin(sum, a);
+					const int v1 = s_L[(row + h) * SQ_R + cx + h];
+					// sharpen.c:116-168: index (v1 & 0x7fff) - (blur & 0x7fff) + 32768 of the LUT
+					const int d = (v1 & 0x7fff) - (blur & 0x7fff) + 32768 - q.lut_lo;
+					int lv = d < 0 ? q.lut_below : q.lut_above;
+					if ((unsigned int) d < (unsigned int) q.lut_n)
+						lv = s_lut[d];
+					const int sharp = min(max(v1 + lv, 0), 32767);
+					const unsigned int ab = s_ab[row * SQ_T + cx];
+					labs_to_srgb8(s_Y2v, sharp, (int) (short) (ab & 0xffffu), (int) ab >> 16, o[3 * m], o[3 * m + 1], o[3 * m + 2]);
+				}
+				const int x = x0 + 4 * quad;
+				const GlobalOut dst = out + (long long) y * a.out_stride + 3LL * x;
+				if (x + 4 <= a.width && !(((uintptr_t) dst) & 3)) {
+					unsigned int __attribute__((address_space(1))) *d4 = (unsigned int __attribute__((address_space(1))) *) dst;
+#pragma unroll
+					for (int w = 0; w < 3; w++)
+						d4[w] = (unsigned) o[4 * w] | ((unsigned) o[4 * w + 1] << 8) | ((unsigned) o[4 * w + 2] << 16) |
+							((unsigned) o[4 * w + 3] << 24);
+				}
+				else {
+					for (int m = 0; m < 12 && x + m / 3 < a.width; m++)
+						dst[m] = o[m];
+				}
+			}
+		}
+	}
+}
+
 // n images of one geometry (one launch per SF_MAXB of them).  0 done, 1 not this kernel's case, -1 error
 int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const *outs, int n_images,
 	const int *to_steps, int n_to, const int *from_steps, int n_from, const int *coef, int n, int scale,
-	const int *lut)
+	const int *lut, const SharpenLutWindow *win)
 {
 	if (getenv("VIPS_HIP_NO_FUSED_SHARPEN") || n_images < 1)
 		return 1;
@@ -1091,6 +1293,54 @@ int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const
 		a.shift = l - 1;
 	}
 	a.lut = lut;
+	// every table in LDS (sharpen_quad_u8_kernel) when the LUT's window and this host's cbrtf allow it -- for large
+	// images.  Measured (profiles/r05p_sharpen_quad.txt): 8192^2 of noise 1.08 -> 0.83 ms, but a batch of 1024^2
+	// thumbnails on its 64-CU partition 0.033 -> 0.049 ms per image: a thumbnail's values are few and near each
+	// other, the older kernel's table gathers hit its L1, and 106 KB of LDS per block leave that partition one block
+	// of 16 waves per CU to hide behind.  $VIPS_HIP_SHARPEN_QUAD=0 / 1 forces one or the other.
+	const char *quad_env = getenv("VIPS_HIP_SHARPEN_QUAD");
+	const bool want_quad = quad_env ? atoi(quad_env) != 0 : (long long) a.width * a.height >= 2048LL * 2048;
+	if (win && win->lut_win && win->n <= SQ_MAXLUT && want_quad && !getenv("VIPS_HIP_NO_SHARPEN_QUAD")) {
+		const CbrtQuad *cq = cbrt_quad_tables();
+		if (cq) {
+			SharpenQuadArgs q;
+			q.f = a;
+			q.cq = *cq;
+			q.lut_win = win->lut_win;
+			q.lut_lo = win->lo;
+			q.lut_n = win->n;
+			q.lut_below = win->below;
+			q.lut_above = win->above;
+			q.tiles_x = (a.width + SQ_T - 1) / SQ_T;
+			q.tiles_y = (a.height + SQ_T - 1) / SQ_T;
+			const size_t lds = (size_t) (CBQ_BLOCKS * 4 + CBQ_RES_WORDS + 256 + 260) * 4 + (size_t) (SQ_MAXLUT + 8) * 2 +
+				(size_t) SQ_R * SQ_R * 2 + (size_t) SQ_T * SQ_T * 4 + (size_t) SQ_R * SQ_T * 2;
+			static std::once_flag once;
+			std::call_once(once, [] {
+				(void) hipFuncSetAttribute(reinterpret_cast<const void *>(sharpen_quad_u8_kernel),
+					hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			});
+			Gate gate("sharpen_quad_u8");
+			for (int base = 0; base < n_images; base += SF_MAXB) {
+				const int count = n_images - base < SF_MAXB ? n_images - base : SF_MAXB;
+				SharpenFusedPtrs p;
+				memset(&p, 0, sizeof(p));
+				for (int i = 0; i < count; i++) {
+					p.in[i] = (const unsigned char *) ins[base + i]->data;
+					p.out[i] = (unsigned char *) outs[base + i]->data;
+				}
+				q.n_images = count;
+				const int tiles = q.tiles_x * q.tiles_y * count;
+				const char *e = getenv("VIPS_HIP_SHARPEN_QUAD_GRID");
+				int grid = e && atoi(e) > 0 ? atoi(e) : 256;
+				grid = grid > tiles ? tiles : grid;
+				hipLaunchKernelGGL(sharpen_quad_u8_kernel, dim3(grid), dim3(SQ_NT), lds, stream(), p, q);
+				VH_CHECK(hipGetLastError());
+			}
+			return 0;
+		}
+		vips_hip_error_clear();
+	}
 	Gate gate("sharpen_fused_u8");
 	for (int base = 0; base < n_images; base += SF_MAXB) {
 		const int count = n_images - base < SF_MAXB ? n_images - base : SF_MAXB;

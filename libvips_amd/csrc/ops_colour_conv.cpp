@@ -189,6 +189,56 @@ LutPtr sharpen_lut_cached(double x1, double y2, double y3, double m1, double m2)
 	return l;
 }
 
+// the window of sharpen's LUT that is not constant (sharpen.c:230-257 is flat outside the bends), on the device
+// as shorts: what colour.hip's all-in-LDS sharpen kernel copies into LDS.  A window of n = 0 with lut_win =
+// nullptr: this LUT does not fit (the callers take the kernel that reads the LUT through global memory)
+std::shared_ptr<vh::SharpenLutWindow> sharpen_lut_window_cached(double x1, double y2, double y3, double m1, double m2)
+{
+	// (leaked on purpose, like g_lut_cache: the deleter frees device memory, which must not happen from a static
+	// destructor after the runtime's own have run)
+	static std::mutex &mutex = *new std::mutex;
+	static std::list<std::pair<LutKey, std::shared_ptr<vh::SharpenLutWindow>>> &cache =
+		*new std::list<std::pair<LutKey, std::shared_ptr<vh::SharpenLutWindow>>>;
+	LutKey key = { current_device(), { x1, y2, y3, m1, m2 } };
+	std::lock_guard<std::mutex> lock(mutex);
+	for (auto it = cache.begin(); it != cache.end(); ++it)
+		if (it->first == key) {
+			cache.splice(cache.begin(), cache, it);
+			return cache.front().second;
+		}
+	std::vector<int> lut;
+	sharpen_lut_host(x1, y2, y3, m1, m2, lut);
+	int lo = 0, hi = 65535;
+	while (lo < 65536 && lut[lo] == lut[0])
+		lo++;
+	while (hi >= 0 && lut[hi] == lut[65535])
+		hi--;
+	std::shared_ptr<vh::SharpenLutWindow> w(new vh::SharpenLutWindow, [](vh::SharpenLutWindow *p) {
+		vips_hip_free(const_cast<short *>(p->lut_win));
+		delete p;
+	});
+	w->below = lut[0];
+	w->above = lut[65535];
+	w->lo = lo < 65536 ? lo : 0;
+	w->n = lo < 65536 && hi >= lo ? hi - lo + 1 : 0;
+	w->lut_win = nullptr;
+	bool ok = w->n <= 6144;
+	std::vector<short> sv((size_t) w->n + 1, 0);
+	for (int k = 0; k < w->n && ok; k++) {
+		ok = lut[w->lo + k] >= -32768 && lut[w->lo + k] <= 32767;
+		sv[k] = (short) lut[w->lo + k];
+	}
+	if (ok) {
+		w->lut_win = (const short *) upload(sv.data(), sv.size() * sizeof(short));
+		if (!w->lut_win)
+			vips_hip_error_clear();
+	}
+	cache.emplace_front(key, w);
+	while (cache.size() > 16)
+		cache.pop_back();
+	return w;
+}
+
 int conv_image(VipsHipImage *in, VipsHipImage **out, const double *mask, int mw, int mh,
 	double scale, double offset, int precision)
 {
@@ -1439,8 +1489,9 @@ static int sharpen_fused_images(VipsHipImage *const *in, int n_images, VipsHipIm
 		pi[i] = &ri[i];
 		po[i] = &ro[i];
 	}
+	std::shared_ptr<vh::SharpenLutWindow> win = sharpen_lut_window_cached(x1, y2, y3, m1, m2);
 	const int r = vh::sharpen_fused_u8(pi.data(), po.data(), n_images, to->steps, to->n, from->steps, from->n,
-		coef.data(), n, (int) rint(scale), lut.get());
+		coef.data(), n, (int) rint(scale), lut.get(), win.get());
 	if (r)
 		return r;
 	for (int i = 0; i < n_images; i++)

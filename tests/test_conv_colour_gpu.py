@@ -228,12 +228,18 @@ def test_gaussblur_colourspace_fallbacks():
 
 @pytest.mark.parametrize("size", [(1024, 768), (67, 19), (64, 16), (130, 33), (5, 3), (1000, 1)])
 @pytest.mark.parametrize("params", [dict(), dict(sigma=1.0), dict(sigma=0.3), dict(sigma=2.0),
-                                    dict(sigma=0.8, x1=1.0, y2=20.0, y3=30.0, m1=0.5, m2=2.0)])
-def test_sharpen_fused_uchar_srgb(size, params):
+                                    dict(sigma=0.8, x1=1.0, y2=20.0, y3=30.0, m1=0.5, m2=2.0),
+                                    dict(x1=0.5, y2=80.0, y3=90.0, m2=1.0)])
+@pytest.mark.parametrize("quad", [True, False])
+def test_sharpen_fused_uchar_srgb(size, params, quad, monkeypatch):
     """vips_sharpen on 3-band uchar sRGB in one kernel (colour.hip sharpen_fused_u8: the LabS round
     trip, the integer blur of L in LDS and the LUT step): tiles with partial edges, images smaller
     than a tile, 1..5-tap masks in the kernel and longer ones on the operation chain; against the
     port / the compiled reference and against the chain of six kernels."""
+    # quad: every table in LDS (sharpen_quad_u8, cbrt_quad.h) -- the default when the LUT's bending part is short
+    # enough (the last parameter set's is not); else the kernel that reads its tables through global memory
+    # (by default only images of 4 Mpixels and more take it: forced here)
+    monkeypatch.setenv("VIPS_HIP_SHARPEN_QUAD", "1" if quad else "0")
     w, h = size
     src = helpers.lcg_image(w, h, 3, np.uint8, 72)
     lib = _ffi.lib
@@ -258,7 +264,9 @@ def test_sharpen_fused_uchar_srgb(size, params):
         want = PortCC.sharpen(src, "srgb", **params)
     assert np.array_equal(got, want)
     if params.get("sigma", 0.5) <= 1.0:
-        assert list(report) == ["sharpen_fused_u8"], report
+        # (a LUT whose bending part is longer than 6144 entries -- the last two parameter sets -- does not fit LDS)
+        wide_lut = "y3" in params
+        assert list(report) == ["sharpen_quad_u8" if quad and not wide_lut else "sharpen_fused_u8"], report
 
 
 def ulp_distance(a, b):
