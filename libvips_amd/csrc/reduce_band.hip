@@ -9,6 +9,7 @@ namespace vh {
 // the rows two neighbouring blocks share are in its L2.  (Persistent waves dealt (strip, block) items from an
 // atomic counter ran 3 x slower -- 0.146 against 0.048 ms on 8192^2 x 3 by 7.3, profiles/r05j_reduce_band_ops.txt --
 // and 3 waves per SIMD instead of 4 5 % slower.)
+template <bool U16>
 __global__ void __launch_bounds__(256, 4)
 reducev_u8_band(RbArgs a, int groups)
 {
@@ -17,7 +18,7 @@ reducev_u8_band(RbArgs a, int groups)
 	const int g = id / groups, grp = id - g * groups;
 	const int strip = 4 * grp + wv;
 	if (strip < a.strips)
-		reducev_band_wave(a, strip, g);
+		reducev_band_wave<U16>(a, strip, g);
 }
 
 template <int B>
@@ -32,22 +33,57 @@ reduceh_u8_band(RbhArgs a, int groups)
 		reduceh_band_wave<B>(a, xt, yt);
 }
 
+template <int B>
+__global__ void __launch_bounds__(256)
+reduceh_u16_band(RbhArgs a, int groups)
+{
+	const int wv = wave_index();
+	const int id = (int) blockIdx.x;
+	const int yt = id / groups, grp = id - yt * groups;
+	const int xt = 4 * grp + wv;
+	if (xt < a.xtiles)
+		reduceh16_band_wave<B>(a, xt, yt);
+}
+
 } // namespace vh
 
 #include "reduce_band_host.h"
 
 namespace vh {
 
-static int rb_launch(const RbArgs &a, int grid)
+static int rb_launch(const RbArgs &a, int grid, bool u16)
 {
-	hipLaunchKernelGGL(reducev_u8_band, dim3(grid), dim3(RB_NT), 0, stream(), a, grid / a.nblocks);
+	if (u16)
+		hipLaunchKernelGGL(reducev_u8_band<true>, dim3(grid), dim3(RB_NT), 0, stream(), a, grid / a.nblocks);
+	else
+		hipLaunchKernelGGL(reducev_u8_band<false>, dim3(grid), dim3(RB_NT), 0, stream(), a, grid / a.nblocks);
 	VH_CHECK(hipGetLastError());
 	return 0;
 }
 
-static int rbh_launch(int bands, const RbhArgs &a, int grid)
+static int rbh_launch(int bands, const RbhArgs &a, int grid, bool u16)
 {
 	const int groups = (a.xtiles + 3) / 4;
+	if (u16) {
+		switch (bands) {
+		case 1:
+			hipLaunchKernelGGL(reduceh_u16_band<1>, dim3(grid), dim3(RB_NT), 0, stream(), a, groups);
+			break;
+		case 2:
+			hipLaunchKernelGGL(reduceh_u16_band<2>, dim3(grid), dim3(RB_NT), 0, stream(), a, groups);
+			break;
+		case 3:
+			hipLaunchKernelGGL(reduceh_u16_band<3>, dim3(grid), dim3(RB_NT), 0, stream(), a, groups);
+			break;
+		case 4:
+			hipLaunchKernelGGL(reduceh_u16_band<4>, dim3(grid), dim3(RB_NT), 0, stream(), a, groups);
+			break;
+		default:
+			return 1;
+		}
+		VH_CHECK(hipGetLastError());
+		return 0;
+	}
 	switch (bands) {
 	case 1:
 		hipLaunchKernelGGL(reduceh_u8_band<1>, dim3(grid), dim3(RB_NT), 0, stream(), a, groups);

@@ -41,7 +41,18 @@ struct RbArgs {
 	const unsigned int *tab; // [coefficient block][64 lanes][4 dwords]
 };
 
-// one wave: strip x block
+// S 2^-24 (two exact sums: of the low bytes and of the high bytes of ushort samples) -> clip((256 S_hi + S_lo +
+// 2048) >> 12, 0, 65535) (templates.h:152-157 for unsigned short): exact 32-bit integers (the sums are below 2^24)
+VH_DEV unsigned int rb_fin16(float lo, float hi)
+{
+	const int s = (vh::cvt_i32(hi * 16777216.0f) << 8) + vh::cvt_i32(lo * 16777216.0f);
+	return (unsigned int) min(max((s + 2048) >> 12, 0), 65535);
+}
+
+// one wave: strip x block.  U16: ushort samples -- the strip's 128 byte columns are 64 samples, byte column 2 c of
+// a lane's dword the low bytes of its sample c, 2 c + 1 the high bytes: the same four products, then both sums of
+// a sample are put together as integers
+template <bool U16>
 VH_DEV void reducev_band_wave(const RbArgs &a, int strip, int g)
 {
 	const int lane = tid() & 63, n = lane & 31, hf = lane >> 5;
@@ -100,9 +111,13 @@ VH_DEV void reducev_band_wave(const RbArgs &a, int strip, int g)
 	for (int r = 0; r < 16; r++) {
 		const int y = 32 * g + (r & 3) + 8 * (r >> 2) + 4 * hf;
 		unsigned int w = 0;
+		if constexpr (U16)
+			w = rb_fin16(acc[0][r], acc[1][r]) | (rb_fin16(acc[2][r], acc[3][r]) << 16);
+		else {
 #pragma unroll
-		for (int c = 0; c < 4; c++)
-			w = cvt_pk_u8(__builtin_fmaf(acc[c][r], 4096.0f, 0x1p-13f), (unsigned int) c, w);
+			for (int c = 0; c < 4; c++)
+				w = cvt_pk_u8(__builtin_fmaf(acc[c][r], 4096.0f, 0x1p-13f), (unsigned int) c, w);
+		}
 		if (live && y < a.out_height)
 			gstore32(gout + (long long) y * a.out_stride + xb, w);
 	}
@@ -165,6 +180,124 @@ VH_DEV void rbh_halves(const unsigned int *raw, int b, unsigned int &a0, unsigne
 			a0 = v;
 		else
 			a1 = v;
+	}
+}
+
+// N dwords (up to 16) at a 4-byte aligned offset / address
+template <int N>
+VH_DEV void gload_dwords_long(gptr_in base, unsigned int off, unsigned int (&w)[N])
+{
+#pragma unroll
+	for (int k = 0; k < N; k += 4) {
+		constexpr int dummy = 0;
+		(void) dummy;
+		if (N - k >= 4) {
+			unsigned int t[4];
+			gload_dwords<4>(base, off + 4 * k, t);
+#pragma unroll
+			for (int i = 0; i < 4; i++)
+				w[k + i] = t[i];
+		}
+		else {
+			unsigned int t[2];
+			gload_dwords<2>(base, off + 4 * k, t);
+			w[k] = t[0];
+			if (k + 1 < N)
+				w[k + 1] = t[1];
+		}
+	}
+}
+
+// ushort: 4 pixels x B bands (2 B dwords) -> the low (part 0) or high (part 1) bytes of band b as 4 halves 0x00pp
+template <int B>
+VH_DEV void rbh_halves16(const unsigned int *raw, int b, int part, unsigned int &a0, unsigned int &a1)
+{
+#pragma unroll
+	for (int q = 0; q < 2; q++) {
+		const int e0 = 2 * ((2 * q) * B + b) + part, e1 = 2 * ((2 * q + 1) * B + b) + part;
+		const unsigned int v =
+			perm(raw[e1 >> 2], raw[e0 >> 2], 0x0c000c00u | ((4u + (unsigned int) (e1 & 3)) << 16) | (unsigned int) (e0 & 3));
+		if (q == 0)
+			a0 = v;
+		else
+			a1 = v;
+	}
+}
+
+// the same for ushort images (rows, widths and strides in SAMPLES of 2 bytes where the uchar form has bytes): two
+// products per band and step -- the low bytes' and the high bytes' -- put together as integers at the end
+template <int B>
+VH_DEV void reduceh16_band_wave(const RbhArgs &a, int xt, int yt)
+{
+	static_assert(B % 2 == 0 || B == 1 || B == 3, "bands");
+	const int lane = tid() & 63, n = lane & 15, kg = lane >> 4;
+	const int y = 16 * yt + n, yc = min(y, a.rows - 1);
+	const RbBlock b = uniform_load(&a.blk[xt]);
+	const gptr_in line = gptr_in_of((unsigned long long) a.in) + (long long) yc * a.in_stride;
+	const gptr_in gtab = gptr_in_of((unsigned long long) a.tab);
+	constexpr int ND = 4 * B; // dwords of 8 pixels
+
+	auto load = [&](int s, unsigned int (&d)[ND]) {
+		const int p0 = 32 * s;
+		if (p0 >= 0 && p0 + 32 <= a.width)
+			gload_dwords_long<ND>(line, (unsigned int) ((p0 + 8 * kg) * B * 2), d);
+		else {
+#pragma unroll
+			for (int w = 0; w < ND; w++) {
+				unsigned int v = 0;
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					const int e = 2 * w + k; // sample of the group
+					const int px = min(max(p0 + 8 * kg + e / B, 0), a.width - 1);
+					v |= gload16(line, (unsigned int) ((px * B + e % B) * 2)) << (16 * k);
+				}
+				d[w] = v;
+			}
+		}
+	};
+
+	float acc[B][2][4];
+	unsigned int cur[ND], nxt[ND];
+	load(b.s0, cur);
+	for (int j = 0; j < b.ns; j++) {
+		if (j + 1 < b.ns)
+			load(b.s0 + j + 1, nxt);
+		unsigned int A[4];
+		gload128(gtab, (unsigned int) (((b.tab + j) * 64 + lane) * 16), A);
+#pragma unroll
+		for (int bb = 0; bb < B; bb++)
+#pragma unroll
+			for (int part = 0; part < 2; part++) {
+				unsigned int D[4];
+				rbh_halves16<B>(cur, bb, part, D[0], D[1]);
+				rbh_halves16<B>(cur + 2 * B, bb, part, D[2], D[3]);
+				if (j == 0)
+					mfma_16x16x32_f16_first(A, D, acc[bb][part]);
+				else
+					mfma_16x16x32_f16(A, D, acc[bb][part]);
+			}
+#pragma unroll
+		for (int i = 0; i < ND; i++)
+			cur[i] = nxt[i];
+	}
+	// register r: output column 16 xt + 4 kg + r of row y; the lane's 4 pixels x B samples in memory order
+	unsigned int w[2 * B];
+#pragma unroll
+	for (int d = 0; d < 2 * B; d++) {
+		const int e0 = 2 * d, e1 = 2 * d + 1; // samples (pixel e / B, band e % B)
+		w[d] = rb_fin16(acc[e0 % B][0][e0 / B], acc[e0 % B][1][e0 / B]) | (rb_fin16(acc[e1 % B][0][e1 / B], acc[e1 % B][1][e1 / B]) << 16);
+	}
+	const int x0 = 16 * xt + 4 * kg;
+	if (y < a.rows && x0 < a.out_width) {
+		const gptr_out p = gptr_out_of((unsigned long long) a.out) + (long long) y * a.out_stride + (long long) x0 * B * 2;
+		if (x0 + 4 <= a.out_width && a.out_dwords) {
+#pragma unroll
+			for (int d = 0; d < 2 * B; d++)
+				gstore32(p + 4 * d, w[d]);
+		}
+		else
+			for (int e = 0; e < min(4, a.out_width - x0) * B; e++)
+				gstore16(p + 2 * e, (unsigned short) (w[e >> 1] >> (16 * (e & 1))));
 	}
 }
 

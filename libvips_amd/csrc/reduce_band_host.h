@@ -15,8 +15,8 @@
 namespace vh {
 
 // defined by the including file; 0 on success
-static int rb_launch(const RbArgs &a, int grid);
-static int rbh_launch(int bands, const RbhArgs &a, int grid);
+static int rb_launch(const RbArgs &a, int grid, bool u16);
+static int rbh_launch(int bands, const RbhArgs &a, int grid, bool u16);
 
 namespace {
 
@@ -202,7 +202,8 @@ int reduceh_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRe
 	const char *env = getenv("VIPS_HIP_REDUCE_BAND");
 	if (env && atoi(env) == 0)
 		return 0;
-	if (in->format != VIPS_HIP_FORMAT_UCHAR || out->format != VIPS_HIP_FORMAT_UCHAR || in->bands != out->bands ||
+	const bool u16 = in->format == VIPS_HIP_FORMAT_USHORT;
+	if ((in->format != VIPS_HIP_FORMAT_UCHAR && !u16) || out->format != in->format || in->bands != out->bands ||
 		in->bands < 1 || in->bands > 4 || out->width < 1)
 		return 0;
 	// whole rows (any range of them)
@@ -211,7 +212,10 @@ int reduceh_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRe
 		return 0;
 	if (((uintptr_t) in->data | (uintptr_t) in->stride) & 3)
 		return 0;
-	if ((long long) in->width * in->bands >= (1LL << 31) || in->width < 1)
+	if ((long long) in->width * in->bands * (u16 ? 2 : 1) >= (1LL << 31) || in->width < 1)
+		return 0;
+	// (a ushort row of whole dwords: an even number of samples, or the clamped edge loads would split one)
+	if (u16 && (((uintptr_t) out->data | (uintptr_t) out->stride) & 1))
 		return 0;
 	const unsigned char *blob;
 	if (rbh_plan(r, out->width, tile, &blob))
@@ -233,8 +237,8 @@ int reduceh_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRe
 	a.blk = (const RbBlock *) blob;
 	a.tab = (const unsigned int *) (blob + (size_t) a.xtiles * sizeof(RbBlock));
 	const int groups = (a.xtiles + 3) / 4; // a block of 4 waves: 4 neighbouring x tiles of the same rows
-	Gate gate("reduceh_u8_band");
-	const int rc = rbh_launch(in->bands, a, groups * a.ytiles);
+	Gate gate(u16 ? "reduceh_u16_band" : "reduceh_u8_band");
+	const int rc = rbh_launch(in->bands, a, groups * a.ytiles, u16);
 	return rc ? -1 : 1;
 }
 
@@ -245,12 +249,14 @@ int reducev_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRe
 	const char *env = getenv("VIPS_HIP_REDUCE_BAND");
 	if (env && atoi(env) == 0)
 		return 0;
-	if (in->format != VIPS_HIP_FORMAT_UCHAR || out->format != VIPS_HIP_FORMAT_UCHAR || in->bands != out->bands)
+	const bool u16 = in->format == VIPS_HIP_FORMAT_USHORT;
+	if ((in->format != VIPS_HIP_FORMAT_UCHAR && !u16) || out->format != in->format || in->bands != out->bands)
 		return 0;
 	if (in->left || in->top || out->left || out->top || in->width != in->im_width || in->height != in->im_height ||
 		out->width != out->im_width || out->height != out->im_height || in->width != out->width)
 		return 0;
-	if ((((uintptr_t) in->data | in->stride | (uintptr_t) out->data | out->stride) & 3) || (in->width * in->bands) % 4)
+	if ((((uintptr_t) in->data | in->stride | (uintptr_t) out->data | out->stride) & 3) ||
+		(in->width * in->bands * (u16 ? 2 : 1)) % 4)
 		return 0;
 	// (lane offsets are 32-bit: 16 rows of the image)
 	if ((long long) in->stride * 17 >= (1LL << 31) || out->height < 1 || in->height < 1)
@@ -266,7 +272,7 @@ int reducev_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRe
 	a.out = (unsigned char *) out->data;
 	a.in_stride = (long long) in->stride;
 	a.out_stride = (long long) out->stride;
-	a.row_bytes = in->width * in->bands;
+	a.row_bytes = in->width * in->bands * (u16 ? 2 : 1);
 	a.height = in->height;
 	a.out_height = out->height;
 	a.strips = (a.row_bytes + 127) / 128;
@@ -274,8 +280,8 @@ int reducev_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRe
 	a.blk = (const RbBlock *) blob;
 	a.tab = (const unsigned int *) (blob + (size_t) a.nblocks * sizeof(RbBlock));
 	const int groups = (((a.strips + 3) / 4) + 7) & ~7; // blocks of 4 waves = 4 neighbouring strips; a multiple of 8
-	Gate gate("reducev_u8_band");
-	const int rc = rb_launch(a, groups * a.nblocks);
+	Gate gate(u16 ? "reducev_u16_band" : "reducev_u8_band");
+	const int rc = rb_launch(a, groups * a.nblocks, u16);
 	return rc ? -1 : 1;
 }
 

@@ -592,7 +592,10 @@ static int reduce_gen(const char *domain, const VipsHipReduce *reduce, const Vip
 	}
 
 	if (fmt == VIPS_HIP_FORMAT_USHORT && !format_iscomplex(out->format)) {
-		int done = vertical ? reducev16_stream_try(r, in, out, tile) : reduceh16_stream_try(r, in, out, pos, (const short *) table);
+		// the matrix cores first (reduce_band.hip: the low and the high bytes as two products)
+		int done = vertical ? reducev_band_try(r, in, out, tile) : reduceh_band_try(r, in, out, tile);
+		if (!done)
+			done = vertical ? reducev16_stream_try(r, in, out, tile) : reduceh16_stream_try(r, in, out, pos, (const short *) table);
 		if (done < 0)
 			return -1;
 		if (done > 0)

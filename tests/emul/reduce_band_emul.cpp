@@ -11,7 +11,7 @@
 
 namespace vh {
 
-static int rb_launch(const RbArgs &a, int grid)
+static int rb_launch(const RbArgs &a, int grid, bool u16)
 {
 	(void) hipStreamSynchronize(stream());
 	const int groups = grid / a.nblocks;
@@ -24,8 +24,12 @@ static int rb_launch(const RbArgs &a, int grid)
 			emul::run_block(RB_NT, [&]() {
 				const int g = id / groups, grp = id - g * groups;
 				const int strip = 4 * grp + wave_index();
-				if (strip < a.strips)
-					reducev_band_wave(a, strip, g);
+				if (strip < a.strips) {
+					if (u16)
+						reducev_band_wave<true>(a, strip, g);
+					else
+						reducev_band_wave<false>(a, strip, g);
+				}
 			});
 		}
 	};
@@ -39,7 +43,7 @@ static int rb_launch(const RbArgs &a, int grid)
 	return 0;
 }
 
-template <int B>
+template <int B, bool U16>
 static void rbh_run(const RbhArgs &a, int grid)
 {
 	(void) hipStreamSynchronize(stream());
@@ -53,8 +57,12 @@ static void rbh_run(const RbhArgs &a, int grid)
 			const int yt = id / groups, grp = id - yt * groups;
 			emul::run_block(RB_NT, [&]() {
 				const int xt = 4 * grp + wave_index();
-				if (xt < a.xtiles)
-					reduceh_band_wave<B>(a, xt, yt);
+				if (xt < a.xtiles) {
+					if constexpr (U16)
+						reduceh16_band_wave<B>(a, xt, yt);
+					else
+						reduceh_band_wave<B>(a, xt, yt);
+				}
 			});
 		}
 	};
@@ -67,22 +75,22 @@ static void rbh_run(const RbhArgs &a, int grid)
 		t.join();
 }
 
-static int rbh_launch(int bands, const RbhArgs &a, int grid)
+static int rbh_launch(int bands, const RbhArgs &a, int grid, bool u16)
 {
+#define RBH_CASE(B) \
+	case B: \
+		if (u16) \
+			rbh_run<B, true>(a, grid); \
+		else \
+			rbh_run<B, false>(a, grid); \
+		return 0;
 	switch (bands) {
-	case 1:
-		rbh_run<1>(a, grid);
-		return 0;
-	case 2:
-		rbh_run<2>(a, grid);
-		return 0;
-	case 3:
-		rbh_run<3>(a, grid);
-		return 0;
-	case 4:
-		rbh_run<4>(a, grid);
-		return 0;
+		RBH_CASE(1)
+		RBH_CASE(2)
+		RBH_CASE(3)
+		RBH_CASE(4)
 	}
+#undef RBH_CASE
 	return 1;
 }
 

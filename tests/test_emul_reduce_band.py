@@ -26,8 +26,9 @@ from tests import helpers
 libvips_amd.init(0)
 lib = libvips_amd.lib
 for (w, h, bands, shrink, kernel, gate) in %(cases)r:
-    src = helpers.lcg_image(w, h, bands, np.uint8, 11 + w)
-    src[: h // 3, : w // 2] = 255
+    dt = np.uint16 if "u16" in gate else np.uint8
+    src = helpers.lcg_image(w, h, bands, dt, 11 + w)
+    src[: h // 3, : w // 2] = 65535 if dt == np.uint16 else 255
     src[h // 3: h // 2, w // 2:] = 0
     im = Image.new_from_array(src)
     lib.vips_hip_gate_reset()
@@ -87,8 +88,22 @@ HCASES = [
 ]
 
 
+V16, H16 = "reducev_u16_band", "reduceh_u16_band"
+CASES16 = [
+    (512, 733, 3, 7.3, "lanczos3", V16), (304, 260, 1, 3.7, "linear", V16), (300, 200, 4, 2.5, "cubic", V16),
+    (130, 415, 2, 11.7, "lanczos2", V16), (256, 300, 4, 8.0, "lanczos3", V16), (62, 90, 3, 2.2, "lanczos3", V16),
+    (732, 100, 3, 7.3, "lanczos3", H16), (260, 64, 2, 3.7, "linear", H16), (200, 37, 4, 2.5, "cubic", H16),
+    (416, 33, 3, 11.7, "lanczos2", H16), (1500, 20, 2, 4.3, "lanczos3", H16), (512, 24, 4, 8.0, "lanczos3", H16),
+    (92, 44, 3, 2.2, "lanczos3", H16),
+]
+
+
 def test_reducev_band(tmp_path):
     _run(CASES, tmp_path)
+
+
+def test_reduce_band_ushort(tmp_path):
+    _run(CASES16, tmp_path)
 
 
 def test_reduceh_band(tmp_path):

@@ -7,7 +7,7 @@ import pytest
 import libvips_amd
 from libvips_amd import Image
 from tests import helpers
-from tests.test_emul_reduce_band import CASES, HCASES
+from tests.test_emul_reduce_band import CASES, CASES16, HCASES
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not helpers.have_ref(), reason="oracle/_ref missing")]
 
@@ -15,11 +15,15 @@ BIG = [(8192, 2100, 3, 7.3, "lanczos3", "reducev_u8_band"), (8192, 8192, 3, 7.3,
        (5000, 3000, 4, 2.9, "lanczos3", "reducev_u8_band"), (1000, 9000, 1, 16.5, "lanczos3", "reducev_u8_band")]
 
 
-@pytest.mark.parametrize("w,h,bands,shrink,kernel,gate", CASES + BIG)
+BIG16 = [(4096, 3001, 3, 7.3, "lanczos3", "reducev_u16_band"), (16384, 2048, 4, 8.0, "lanczos3", "reducev_u16_band")]
+
+
+@pytest.mark.parametrize("w,h,bands,shrink,kernel,gate", CASES + BIG + [c for c in CASES16 if c[5].startswith("reducev")] + BIG16)
 def test_reducev_band_vs_reference(w, h, bands, shrink, kernel, gate):
     lib = libvips_amd.lib
-    src = helpers.lcg_image(w, h, bands, np.uint8, 11 + w)
-    src[: h // 3, : w // 2] = 255
+    dt = np.uint16 if "u16" in gate else np.uint8
+    src = helpers.lcg_image(w, h, bands, dt, 11 + w)
+    src[: h // 3, : w // 2] = 65535 if dt == np.uint16 else 255
     src[h // 3: h // 2, w // 2:] = 0
     im = Image.new_from_array(src)
     lib.vips_hip_gate_reset()
@@ -37,11 +41,15 @@ HBIG = [(8192, 1122, 3, 7.3, "lanczos3", "reduceh_u8_band"), (5000, 700, 4, 2.9,
         (9000, 300, 1, 16.5, "lanczos3", "reduceh_u8_band")]
 
 
-@pytest.mark.parametrize("w,h,bands,shrink,kernel,gate", HCASES + HBIG)
+HBIG16 = [(8192, 1122, 3, 7.3, "lanczos3", "reduceh_u16_band"), (16384, 512, 4, 8.0, "lanczos3", "reduceh_u16_band")]
+
+
+@pytest.mark.parametrize("w,h,bands,shrink,kernel,gate", HCASES + HBIG + [c for c in CASES16 if c[5].startswith("reduceh")] + HBIG16)
 def test_reduceh_band_vs_reference(w, h, bands, shrink, kernel, gate):
     lib = libvips_amd.lib
-    src = helpers.lcg_image(w, h, bands, np.uint8, 11 + w)
-    src[: h // 3, : w // 2] = 255
+    dt = np.uint16 if "u16" in gate else np.uint8
+    src = helpers.lcg_image(w, h, bands, dt, 11 + w)
+    src[: h // 3, : w // 2] = 65535 if dt == np.uint16 else 255
     src[h // 3: h // 2, w // 2:] = 0
     im = Image.new_from_array(src)
     lib.vips_hip_gate_reset()
