@@ -580,9 +580,21 @@ static int reduce_gen(const char *domain, const VipsHipReduce *reduce, const Vip
 		return -1;
 
 	if (fmt == VIPS_HIP_FORMAT_UCHAR) {
-		int done = vertical ? reducev_u8_try(r, in, out, pos, (const short *) table, tile) : reduceh_u8p_try(r, in, out, tile);
-		if (!done && !vertical)
-			done = reduceh_band_try(r, in, out, tile); // a coefficient row per column: the matrix cores (reduce_band.hip)
+		int done = 0;
+		if (vertical)
+			done = reducev_u8_try(r, in, out, pos, (const short *) table, tile);
+		else {
+			// the matrix cores (reduce_band.hip: any factor) or, for an integer factor of 4 / 8, packed bytes on the
+			// vector ALU (reduceh_u8.hip); $VIPS_HIP_REDUCEH_FIRST=packed for the other order
+			const char *first = getenv("VIPS_HIP_REDUCEH_FIRST");
+			const bool packed_first = first && !strcmp(first, "packed");
+			if (packed_first)
+				done = reduceh_u8p_try(r, in, out, tile);
+			if (!done)
+				done = reduceh_band_try(r, in, out, tile);
+			if (!done && !packed_first)
+				done = reduceh_u8p_try(r, in, out, tile);
+		}
 		if (!done && !vertical)
 			done = reduceh_u8_lds_try(r, in, out, pos, (const short *) table);
 		if (done < 0)
