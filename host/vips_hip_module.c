@@ -700,8 +700,14 @@ hip_producer(void *data)
 	setup = 1;
 
 setup_done:
-	if (setup < 0)
+	/* (a LATER run -- a request for an evicted strip -- that cannot set up again must fail: "not this form's
+	 * case" (2) would leave every waiting generate call restarting the producer for ever) */
+	if (setup < 0 || (setup != 1 && op->cache)) {
+		if (setup == 2)
+			vips_error(nick, "%s", "the strip producer could not be set up again");
+		setup = -1;
 		hip_producer_fail(op, nick);
+	}
 	g_mutex_lock(&op->lock);
 	if (setup == 1 && !op->cache) {
 		const guint64 stage_bytes = resident ? 0 : 2 * (guint64) max_in_rows * in_ls;

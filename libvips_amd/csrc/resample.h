@@ -48,6 +48,9 @@ struct _VipsHipReduce {
 	short *d_matrixs;
 	// device copies of position arrays keyed by (start, count, tile)
 	std::map<std::tuple<int, int, int>, vh::ReducePos *> pos_cache;
+	// what the host keeps about a pos_cache blob (a few integers: the streaming kernels' geometry), by blob;
+	// lives and dies with the plan (round 4 kept it in a function-static map that outlived freed plans)
+	std::map<const void *, std::vector<long long>> blob_info;
 	std::mutex mutex;
 	mutable std::atomic<int> device{ -1 }; // where the device tables live (vh::plan_device)
 };

@@ -584,10 +584,11 @@ static int reduce_gen(const char *domain, const VipsHipReduce *reduce, const Vip
 		if (vertical)
 			done = reducev_u8_try(r, in, out, pos, (const short *) table, tile);
 		else {
-			// the matrix cores (reduce_band.hip: any factor) or, for an integer factor of 4 / 8, packed bytes on the
-			// vector ALU (reduceh_u8.hip); $VIPS_HIP_REDUCEH_FIRST=packed for the other order
+			// for an integer factor of 4 / 8, packed bytes on the vector ALU (reduceh_u8.hip: coalesced staging -- on a
+			// 201 MB input 0.062 ms against 0.075 for the matrix-core kernel, whose lanes read a row each); any other
+			// factor: the matrix cores (reduce_band.hip).  $VIPS_HIP_REDUCEH_FIRST=band for the other order
 			const char *first = getenv("VIPS_HIP_REDUCEH_FIRST");
-			const bool packed_first = first && !strcmp(first, "packed");
+			const bool packed_first = !(first && !strcmp(first, "band"));
 			if (packed_first)
 				done = reduceh_u8p_try(r, in, out, tile);
 			if (!done)

@@ -62,17 +62,35 @@ int r16_counter(int **counter)
 // the schedule of a vertical reduce to `out_height` rows in segments of seg_rows: built once per plan
 // and segment height, kept with the plan's other device tables (pos_cache, freed with the plan)
 // (bias: what a sample is stored less -- 32768 for the ushort kernel's signed 16-bit lanes, 0 for bytes)
-const R16Sched *r16_schedule(_VipsHipReduce *r, int out_height, int tile, int seg_rows, unsigned int bias = 32768u)
+// (returns the schedule BY VALUE: what the host keeps of it sits in the plan, r->blob_info, under the plan's
+// lock -- no pointer into a shared map outlives the lock; false + an error message on failure)
+static R16Sched r16_from_info(const void *blob, const std::vector<long long> &v)
 {
-	static std::mutex mutex;
-	static std::map<const void *, R16Sched> host; // by device blob
-	std::lock_guard<std::mutex> lock(mutex);
+	R16Sched s;
+	s.r_base = (int) v[0];
+	s.seg_rows = (int) v[1];
+	s.segs = (int) v[2];
+	s.ok = v[3] != 0;
+	if (s.ok) {
+		s.d_seg_pairs = (const int *) blob;
+		s.d_sched = (const R16Pair *) ((const unsigned char *) blob + v[4]);
+	}
+	return s;
+}
+
+bool r16_schedule(_VipsHipReduce *r, int out_height, int tile, int seg_rows, R16Sched *out, unsigned int bias = 32768u)
+{
 	std::lock_guard<std::mutex> plan_lock(r->mutex);
 	const auto key = std::make_tuple((bias ? -16 : -(1 << 24)) - seg_rows, out_height, tile);
 	auto it = r->pos_cache.find(key);
 	if (it != r->pos_cache.end()) {
-		auto h = host.find(it->second);
-		return h != host.end() ? &h->second : nullptr;
+		auto h = r->blob_info.find(it->second);
+		if (h == r->blob_info.end()) {
+			error("reduce", "a streaming schedule lost its host side");
+			return false;
+		}
+		*out = r16_from_info(it->second, h->second);
+		return true;
 	}
 	std::vector<ReducePos> pos;
 	reduce_positions(r, 0, out_height, tile, pos);
@@ -123,14 +141,16 @@ const R16Sched *r16_schedule(_VipsHipReduce *r, int out_height, int tile, int se
 			seg_pairs[2 * seg] = ps;
 	}
 	void *blob = nullptr;
+	size_t head_bytes = 0;
 	if (s.ok) {
 		const size_t head = (seg_pairs.size() * sizeof(int) + 15) & ~(size_t) 15;
+		head_bytes = head;
 		std::vector<unsigned char> bytes(head + sched.size() * sizeof(R16Pair));
 		memcpy(bytes.data(), seg_pairs.data(), seg_pairs.size() * sizeof(int));
 		memcpy(bytes.data() + head, sched.data(), sched.size() * sizeof(R16Pair));
 		blob = upload(bytes.data(), bytes.size());
 		if (!blob)
-			return nullptr;
+			return false;
 		s.d_seg_pairs = (const int *) blob;
 		s.d_sched = (const R16Pair *) ((const unsigned char *) blob + head);
 	}
@@ -138,11 +158,12 @@ const R16Sched *r16_schedule(_VipsHipReduce *r, int out_height, int tile, int se
 		static const unsigned char placeholder[16] = { 0 };
 		blob = upload(placeholder, sizeof(placeholder)); // (a block so that the refusal is cached with the plan too)
 		if (!blob)
-			return nullptr;
+			return false;
 	}
 	r->pos_cache[key] = (ReducePos *) blob;
-	host[blob] = s;
-	return &host[blob];
+	r->blob_info[blob] = { (long long) s.r_base, (long long) s.seg_rows, (long long) s.segs, s.ok ? 1LL : 0LL, (long long) head_bytes };
+	*out = s;
+	return true;
 }
 
 void r16_v_geometry(R16VArgs *a, const VipsHipRegion *in, const VipsHipRegion *out, int seg_rows, int elem_bytes = 2)
@@ -186,9 +207,10 @@ int reducev16_stream_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsH
 	// a segment re-reads n_point - 1 rows: at least 4 times that many input rows per segment
 	int min_rows = (int) (4.0 * r->n_point / r->shrink) + 1;
 	const int seg_rows = r16_seg_rows(out->height, strips, min_rows);
-	const R16Sched *s = r16_schedule(r, out->height, tile, seg_rows);
-	if (!s)
+	R16Sched sched_v;
+	if (!r16_schedule(r, out->height, tile, seg_rows, &sched_v))
 		return -1;
+	const R16Sched *s = &sched_v;
 	if (!s->ok)
 		return 0;
 	R16VArgs a;
@@ -224,9 +246,10 @@ int reducev8_stream_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHi
 	// / 6 rows ran 0.111 / 0.092 / 0.116 / 0.105 / 0.118 ms (profiles/NOTES.md R4.8)
 	int min_rows = (int) (2.0 * r->n_point / r->shrink) + 1;
 	const int seg_rows = r16_seg_rows(out->height, strips, min_rows, 3);
-	const R16Sched *s = r16_schedule(r, out->height, tile, seg_rows, 0u);
-	if (!s)
+	R16Sched sched_v;
+	if (!r16_schedule(r, out->height, tile, seg_rows, &sched_v, 0u))
 		return -1;
+	const R16Sched *s = &sched_v;
 	if (!s->ok)
 		return 0;
 	R16VArgs a;

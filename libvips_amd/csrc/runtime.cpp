@@ -338,10 +338,17 @@ struct Pool {
 			live_bytes -= b;
 			cached_bytes += b;
 		}
-		// (also when the thread is bound to another device right now: it may have work of its own
-		// queued on this device from before it re-bound -- its stream there orders the reuse, as
-		// for any block it frees; the block leaves the thread only through trim / thread exit,
-		// which synchronise)
+		// (also when the thread is bound to another device right now, IF it has a stream of its own on this
+		// device: it may have work queued there from before it re-bound -- that stream orders the reuse, as for
+		// any block it frees.  A thread that never ran anything on this device -- a libvips worker disposing of an
+		// operation whose result lives elsewhere -- would strand the block in a list nobody allocates from: it
+		// goes to the global list, which this device's own threads and trim() reach; nothing of the freeing thread
+		// can be pending on it)
+		if (device != tls_device && !tls_own_stream[device] && !tls_stream_external_dev[device]) {
+			std::lock_guard<std::mutex> lock(mutex);
+			free_lists[b].push_back(p);
+			return;
+		}
 		Local &l = local();
 		l.pool = this;
 		l.lists[b].push_back(p);

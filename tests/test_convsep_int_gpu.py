@@ -42,12 +42,32 @@ def _integer_image(w, h, bands, seed):
     return helpers.lcg_image(w, h, bands, np.uint8, seed).astype(np.float32)
 
 
+def _default(fn):
+    """fn() with $VIPS_HIP_STREAM_INT unset: the product's own choice of path."""
+    old = os.environ.pop("VIPS_HIP_STREAM_INT", None)
+    try:
+        return fn()
+    finally:
+        if old is not None:
+            os.environ["VIPS_HIP_STREAM_INT"] = old
+
+
+def _want_blur(src, sigma):
+    """The compiled reference itself when it is there (the port is pinned against it, but this file is the
+    integer pass's only direct comparison), else the port."""
+    if helpers.have_ref():
+        return helpers.Ref.run_chain("gaussblur:sigma=%r,precision=integer" % sigma, src)
+    return PortCC.gaussblur(src, sigma, precision="integer")
+
+
 @pytest.mark.parametrize("shape", [(700, 300, 3), (2300, 140, 3), (37, 411, 3), (5, 3, 3), (1030, 77, 3), (1500, 90, 1), (260, 200, 4)])
 @pytest.mark.parametrize("sigma", [8.0, 2.0, 0.6])
 def test_integer_image_blur(shape, sigma):
     w, h, b = shape
     src = _integer_image(w, h, b, 91)
-    want = PortCC.gaussblur(src, sigma, precision="integer")
+    want = _want_blur(src, sigma)
+    got = _default(lambda: Image.new_from_array(src).gaussblur(sigma, precision="integer").numpy())
+    assert np.array_equal(_bits(got), _bits(want)), ("default", shape, sigma)
     for mode in (0, 1, 2):
         got = _with_int(mode, lambda: Image.new_from_array(src).gaussblur(sigma, precision="integer").numpy())
         assert got.dtype == np.float32 and got.shape == want.shape
@@ -99,10 +119,12 @@ def test_almost_integer_image(sigma):
         if nonfinite:
             src[60, 900, 0] = np.inf
             src[61, 901, 1] = np.nan
-        want = PortCC.gaussblur(src, sigma, precision="integer")
+        want = _want_blur(src, sigma)
         a = _with_int(1, lambda: Image.new_from_array(src).gaussblur(sigma, precision="integer").numpy())
         b = _with_int(0, lambda: Image.new_from_array(src).gaussblur(sigma, precision="integer").numpy())
+        d = _default(lambda: Image.new_from_array(src).gaussblur(sigma, precision="integer").numpy())
         assert np.array_equal(_bits(a), _bits(b)), (sigma, nonfinite)
+        assert np.array_equal(_bits(a), _bits(d)), (sigma, nonfinite)  # (mixed windows under the product's default)
         assert np.array_equal(a, want, equal_nan=True), (sigma, nonfinite)
         if not nonfinite:
             assert np.array_equal(_bits(a), _bits(want)), sigma
