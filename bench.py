@@ -861,8 +861,10 @@ def run_c4(ctx, steps, warmup, images, verify=True, cpu=True, size=8192):
         if verify:
             checked = []
             exact = True
-            # first, a pair either side of a 64-image launch boundary, middle, last
-            for k in sorted(set(k for k in (0, 63, 64, len(ims) // 2, len(ims) - 1) if 0 <= k < len(ims))):
+            # first, a pair either side of a 64-image launch boundary, then one thumbnail of every 64-image launch
+            # (16 more at 1 024 images), middle, last
+            picks = {0, 63, 64, len(ims) // 2, len(ims) - 1} | {64 * j + (7 * j) % 64 for j in range(len(ims) // 64)}
+            for k in sorted(k for k in picks if 0 <= k < len(ims)):
                 host = store[k].cpu().numpy()
                 want = helpers.Ref.run_chain(chain, host, interp)
                 got = outs[k].numpy()

@@ -301,6 +301,9 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 			float acc[16];
 #pragma unroll
 			for (int s = 0; s < 4; s++) {
+				// (a short mask's window ends before the last 16-column step: its operand is all zeros)
+				if (s == 3 && a.ksteps < 4)
+					continue;
 				unsigned int A[4];
 				cm_halves<B>(raw[s][0], b, A[0], A[1]);
 				cm_halves<B>(raw[s][1], b, A[2], A[3]);
@@ -331,6 +334,8 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 				}
 #pragma unroll
 				for (int s = 0; s < 2; s++) {
+					if (s == 1 && a.ksteps < 4)
+						continue; // (the same for the rows: nothing of this chunk's second half is a tap yet)
 #pragma unroll
 					for (int q = 0; q < 4; q++)
 						A[q] = mid_cur[4 * s + q];
