@@ -41,6 +41,9 @@ for input in int float; do
   $sum $(db /tmp/pa_c3kt_$input) | grep -v "^$" | head -12
 done
 } > $repo/gpurun_out/${tag}_c3_rocprofv3.txt 2>&1
+ops="python $repo/bench.py --config ops --steps 10 --warmup 3 --no-cpu-baseline --no-verify"
+rocprofv3 --kernel-trace --stats -d /tmp/pa_ops -o kt -- $ops > /dev/null 2>&1
+{ echo "# rocprofv3 --kernel-trace --stats -- $ops"; $sum $(db /tmp/pa_ops) | grep -v "^$" | head -70; } > $repo/gpurun_out/${tag}_ops_rocprofv3.txt 2>&1
 cd $repo
 cut -c1-170 gpurun_out/${tag}_c2_pmc.txt
 cut -c1-170 gpurun_out/${tag}_c3_pmc.txt
