@@ -53,3 +53,9 @@ def test_resample_file_on_the_cpu():
     through the one-kernel resize chains, the device-sized ones and the slow sweeps of the matrix-core
     kernel's variants (a minute each on fibers: every v_mfma is a meeting of 64 fibers)."""
     _run(["tests/test_resample_gpu.py"], ["resize", "thumbnail", "c2_full", "c2_quarter", "mfma_variants", "region_windows", "any_bands"], 160)
+
+
+def test_dispatch_fuzz_file_on_the_cpu():
+    """tests/test_fuzz_dispatch_gpu.py: the seeded sweep over the dispatch guards of the streaming and matrix-core
+    kernels (round 5's conv_u8_mfma / reduce_band included: v_mfma_f32_32x32x16_f16 / 16x16x32 as wave meetings)."""
+    _run(["tests/test_fuzz_dispatch_gpu.py"], [], 5)
