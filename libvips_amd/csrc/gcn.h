@@ -136,6 +136,7 @@ VH_DEV unsigned long long realtime() { return __builtin_amdgcn_s_memrealtime(); 
 VH_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 VH_DEV void opaque(int &v) { asm volatile("" : "+v"(v)); }
 VH_DEV void opaque(unsigned int &v) { asm volatile("" : "+v"(v)); }
+VH_DEV void opaque_uniform(int &v) { asm volatile("" : "+s"(v)); } // (a wave-uniform value: stays in a scalar register)
 
 // v_perm_b32: byte k of the result is byte sel[k] of {hi, lo} (0-3 lo, 4-7 hi, 0x0c zero)
 VH_DEV unsigned int perm(unsigned int hi, unsigned int lo, unsigned int sel) { return __builtin_amdgcn_perm(hi, lo, sel); }

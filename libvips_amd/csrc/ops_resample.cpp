@@ -276,6 +276,48 @@ int resize_down_u8_stream(VipsHipImage *const *in, int n, VipsHipImage **out, co
 	if (pv.residual == 2.0 && ph.residual == 2.0)
 		done = resize_stream_u8_try(rv.get(), pv.int_shrink, rh.get(), ph.int_shrink, shrunk_height, shrunk_width,
 			pi.data(), po.data(), n, g_fatstrip_height);
+	// any other residual (a size that does not divide the image): shrinkv + reducev as one matrix-core kernel, then
+	// shrinkh, then reduceh on the matrix cores (reduce_band.hip) -- three launches that beat the one-kernel chain
+	// of resize_streamg.hip (8192^2 x 3 to 1000^2: 0.062 against 0.079 ms; profiles/NOTES.md R5.5)
+	// (three launches per image: where the image is large enough for a launch not to matter -- a batch of small
+	// ones stays with the one-kernel chain, 64 images a launch; VIPS_HIP_RESIZE_BAND_MIN = that size in bytes)
+	const long long band_min = getenv("VIPS_HIP_RESIZE_BAND_MIN") ? atoll(getenv("VIPS_HIP_RESIZE_BAND_MIN")) : 8LL << 20;
+	if (done == 0 && !getenv("VIPS_HIP_NO_RESIZE_BAND") && !getenv("VIPS_HIP_STREAMG_ALWAYS") &&
+		(long long) in[0]->width * in[0]->height * in[0]->bands >= band_min) {
+		done = 1;
+		for (int i = 0; i < n && done == 1; i++) {
+			ImageRef t1(like(in[i], in[i]->width, pv.size));
+			if (!t1.im)
+				return -1;
+			VipsHipRegion r1;
+			vips_hip_image_region(t1.im, &r1);
+			const int d = shrinkv_reducev_band_try(rv.get(), pv.int_shrink, shrunk_height, pi[i], &r1, g_fatstrip_height);
+			if (d < 0)
+				return -1;
+			if (d == 0) {
+				if (i != 0) {
+					error("resize", "the banded vertical kernel refused image %d of a batch it had started", i);
+					return -1;
+				}
+				done = 0; // (not its case: nothing has been written anywhere)
+				break;
+			}
+			ImageRef t2;
+			VipsHipRegion r2 = r1;
+			if (ph.int_shrink > 1) {
+				// (rows padded to whole dwords: the kernels either side read and write them as dwords)
+				t2.im = like(in[i], (shrunk_width + 3) & ~3, pv.size);
+				if (!t2.im)
+					return -1;
+				vips_hip_image_region(t2.im, &r2);
+				r2.width = r2.im_width = shrunk_width;
+				if (vips_hip_shrinkh_gen(ph.int_shrink, &r1, &r2))
+					return -1;
+			}
+			if (vips_hip_reduceh_gen(rh.get(), &r2, po[i]))
+				return -1;
+		}
+	}
 	if (done == 0)
 		done = resize_streamg_u8_try(rv.get(), pv.int_shrink, rh.get(), ph.int_shrink, shrunk_height, shrunk_width,
 			pi.data(), po.data(), n, g_fatstrip_height);

@@ -21,6 +21,18 @@ reducev_u8_band(RbArgs a, int groups)
 		reducev_band_wave<U16>(a, strip, g);
 }
 
+template <int VS>
+__global__ void __launch_bounds__(256, 3)
+shrinkv_reducev_u8_band(RbArgs a, int groups)
+{
+	const int wv = wave_index();
+	const int id = (int) blockIdx.x;
+	const int g = id / groups, grp = id - g * groups;
+	const int strip = 4 * grp + wv;
+	if (strip < a.strips)
+		reducev_box_band_wave<VS>(a, strip, g);
+}
+
 template <int B>
 __global__ void __launch_bounds__(256)
 reduceh_u8_band(RbhArgs a, int groups)
@@ -53,7 +65,20 @@ namespace vh {
 
 static int rb_launch(const RbArgs &a, int grid, bool u16)
 {
-	if (u16)
+	if (a.vs > 1) {
+		switch (a.vs) {
+#define RB_BOX(VS) \
+	case VS: \
+		hipLaunchKernelGGL(shrinkv_reducev_u8_band<VS>, dim3(grid), dim3(RB_NT), 0, stream(), a, grid / a.nblocks); \
+		break;
+			RB_BOX(2) RB_BOX(3) RB_BOX(4) RB_BOX(5) RB_BOX(6) RB_BOX(7) RB_BOX(8) RB_BOX(9) RB_BOX(10) RB_BOX(11) RB_BOX(12)
+			RB_BOX(13) RB_BOX(14) RB_BOX(15) RB_BOX(16)
+#undef RB_BOX
+		default:
+			return 1;
+		}
+	}
+	else if (u16)
 		hipLaunchKernelGGL(reducev_u8_band<true>, dim3(grid), dim3(RB_NT), 0, stream(), a, grid / a.nblocks);
 	else
 		hipLaunchKernelGGL(reducev_u8_band<false>, dim3(grid), dim3(RB_NT), 0, stream(), a, grid / a.nblocks);

@@ -35,6 +35,9 @@ struct RbArgs {
 	long long in_stride, out_stride;
 	int row_bytes;    // bytes per row: a multiple of 4
 	int height, out_height;
+	int vs;           // > 1: a vips_shrinkv(vs) in front (resize.c:207-228): the rows the products read are box sums
+	int mid_height;   // ... of vs image rows each, rounded as shrinkv.c:158-165 does; the height after it
+	unsigned int mult; // 2^32 / (256 vs)
 	int strips;       // of 128 bytes
 	int nblocks;      // of 32 output rows
 	const RbBlock *blk;
@@ -52,6 +55,141 @@ VH_DEV unsigned int rb_fin16(float lo, float hi)
 // one wave: strip x block.  U16: ushort samples -- the strip's 128 byte columns are 64 samples, byte column 2 c of
 // a lane's dword the low bytes of its sample c, 2 c + 1 the high bytes: the same four products, then both sums of
 // a sample are put together as integers
+// shrinkv's rounding on two 16-bit sums in one dword (bytes 0 and 2 of a dword column, or 1 and 3):
+// ((sum + vs / 2) * (2^32 / (256 vs))) >> 24, shrinkv.c:158-165; the result again as two 16-bit lanes
+template <int VS>
+VH_DEV unsigned int rb_box2(unsigned int sums, unsigned int mult)
+{
+	if constexpr ((VS & (VS - 1)) == 0) {
+		constexpr int SH = VS == 2 ? 1 : VS == 4 ? 2 : VS == 8 ? 3 : 4;
+		constexpr unsigned int RND = (unsigned int) (VS / 2) * 0x00010001u;
+		return ((sums + RND) >> SH) & 0x00ff00ffu;
+	}
+	else {
+		const unsigned int lo = (((sums & 0xffffu) + VS / 2) * mult) >> 24;
+		const unsigned int hi = (((sums >> 16) + VS / 2) * mult) >> 24;
+		return lo | (hi << 16);
+	}
+}
+
+// the same wave with a vips_shrinkv(VS) in front -- vips_resize's vertical half for a size that does not divide the
+// image (resize.c:207-228: shrinkv, then reducev): a row the products read is the box sum of VS image rows, made
+// from the loaded dwords as two 16-bit lanes per dword (even and odd byte columns) and rounded as shrinkv does; the
+// 1 / VS-size intermediate image never exists.  Rows past the image are the last row (shrinkv's own embed, ceil).
+template <int VS>
+VH_DEV void reducev_box_band_wave(const RbArgs &a, int strip, int g)
+{
+	const int lane = tid() & 63, n = lane & 31, hf = lane >> 5;
+	const int xb = min(strip * 128 + 4 * n, a.row_bytes - 4);
+	const bool live = strip * 128 + 4 * n < a.row_bytes;
+	const RbBlock b = uniform_load(&a.blk[g]);
+	const gptr_in gin = gptr_in_of((unsigned long long) a.in);
+	const gptr_in gtab = gptr_in_of((unsigned long long) a.tab);
+	const unsigned int lane_off = (unsigned int) (8 * hf * VS * (int) a.in_stride + xb);
+
+	// the image rows under shrunk rows 16 s + 8 hf + i, i = 0 .. 7, CH rows of each box at a time (rows k0 .. k0 +
+	// CH - 1 of the VS; past VS: row VS - 1 again, masked out of the sum): a chunk of 8 CH dwords is in flight while
+	// the products of the step before run -- all 8 VS rows at once do not fit the registers of three blocks a CU
+	// past VS = 4.  One loop over (step, chunk) pairs, not unrolled: the same registers for every chunk.
+	constexpr int CH = VS <= 4 ? VS : 4, NC = (VS + CH - 1) / CH;
+	auto load = [&](int s, int k0, unsigned int (&raw)[8 * CH]) {
+		const int m0 = 16 * s;
+		// (opaque: or the row offsets, the same at every step, are kept in registers across the loop and spill)
+		int st = (int) a.in_stride;
+		opaque_uniform(st);
+		if (m0 >= 0 && (m0 + 16) * VS <= a.height) {
+			const gptr_in base = gin + (long long) m0 * VS * st;
+#pragma unroll
+			for (int i = 0; i < 8; i++)
+#pragma unroll
+				for (int k = 0; k < CH; k++)
+					raw[i * CH + k] = gload32(base + (long long) (i * VS + min(k0 + k, VS - 1)) * st, lane_off);
+		}
+		else {
+			// (32-bit offsets from the first row the step can read: the host checked 16 VS rows fit)
+			const int r0 = min(min(max(m0, 0), a.mid_height - 1) * VS, a.height - 1);
+			const gptr_in base = gin + (long long) r0 * st;
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				const int m = min(max(m0 + 8 * hf + i, 0), a.mid_height - 1);
+#pragma unroll
+				for (int k = 0; k < CH; k++) {
+					const int r = min(m * VS + min(k0 + k, VS - 1), a.height - 1);
+					raw[i * CH + k] = gload32(base, (unsigned int) ((r - r0) * st + xb));
+				}
+				sched_fence(); // (a lane offset per load: not all 8 CH of them at once)
+			}
+		}
+	};
+
+	float acc[4][16];
+#pragma unroll
+	for (int c = 0; c < 4; c++)
+#pragma unroll
+		for (int r = 0; r < 16; r++)
+			acc[c][r] = 0.0f;
+	unsigned int raw[8 * CH], ev[8], od[8], A[4];
+#pragma unroll
+	for (int i = 0; i < 8; i++)
+		ev[i] = od[i] = 0;
+	load(b.s0, 0, raw);
+	int j = 0, c = 0;
+#pragma nounroll
+	for (int t = 0; t < b.ns * NC; t++) {
+		if (c == 0)
+			gload128(gtab, (unsigned int) (((b.tab + j) * 64 + lane) * 16), A);
+#pragma unroll
+		for (int k = 0; k < CH; k++) {
+			const unsigned int keep = NC * CH == VS || c * CH + k < VS ? 0x00ff00ffu : 0u;
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				ev[i] += raw[i * CH + k] & keep;
+				od[i] += (raw[i * CH + k] >> 8) & keep;
+			}
+		}
+		int c1 = c + 1, j1 = j;
+		if (c1 == NC) {
+			c1 = 0;
+			j1++;
+		}
+		// (past the last chunk: the last one again -- every path through the loop writes raw[], which keeps it
+		// in one set of registers)
+		if (NC > 1)
+			load(b.s0 + min(j1, b.ns - 1), (j1 < b.ns ? c1 : NC - 1) * CH, raw);
+		else if (j1 < b.ns)
+			load(b.s0 + j1, 0, raw);
+		if (c == NC - 1) {
+			unsigned int cur[8];
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				cur[i] = rb_box2<VS>(ev[i], a.mult) | (rb_box2<VS>(od[i], a.mult) << 8);
+				ev[i] = od[i] = 0;
+			}
+#pragma unroll
+			for (int q4 = 0; q4 < 4; q4++) {
+				unsigned int Bop[4];
+#pragma unroll
+				for (int q = 0; q < 4; q++)
+					Bop[q] = perm(cur[2 * q + 1], cur[2 * q], 0x0c000c00u | ((4u + (unsigned int) q4) << 16) | (unsigned int) q4);
+				mfma_32x32x16_f16(A, Bop, acc[q4]);
+			}
+		}
+		c = c1;
+		j = j1;
+	}
+	const gptr_out gout = gptr_out_of((unsigned long long) a.out);
+#pragma unroll
+	for (int r = 0; r < 16; r++) {
+		const int y = 32 * g + (r & 3) + 8 * (r >> 2) + 4 * hf;
+		unsigned int w = 0;
+#pragma unroll
+		for (int c = 0; c < 4; c++)
+			w = cvt_pk_u8(__builtin_fmaf(acc[c][r], 4096.0f, 0x1p-13f), (unsigned int) c, w);
+		if (live && y < a.out_height)
+			gstore32(gout + (long long) y * a.out_stride + xb, w);
+	}
+}
+
 template <bool U16>
 VH_DEV void reducev_band_wave(const RbArgs &a, int strip, int g)
 {

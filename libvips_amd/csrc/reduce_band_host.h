@@ -242,9 +242,18 @@ int reduceh_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRe
 	return rc ? -1 : 1;
 }
 
+int shrinkv_reducev_band_try(_VipsHipReduce *r, int vs, int mid_height, const VipsHipRegion *in, const VipsHipRegion *out, int tile);
+
 // vips_reducev of a whole uchar image with a coefficient row per output row; 1 = done, 0 = not this
 // kernel's case, -1 = error
 int reducev_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out, int tile)
+{
+	return shrinkv_reducev_band_try(r, 1, 0, in, out, tile);
+}
+
+// ... with a vips_shrinkv(vs, ceil) in front, the two as one kernel: `in` is the image BEFORE the shrink, `r` the
+// plan of the reduce on the image after it (mid_height rows); vs = 1: the reduce alone
+int shrinkv_reducev_band_try(_VipsHipReduce *r, int vs, int mid_height, const VipsHipRegion *in, const VipsHipRegion *out, int tile)
 {
 	const char *env = getenv("VIPS_HIP_REDUCE_BAND");
 	if (env && atoi(env) == 0)
@@ -258,8 +267,10 @@ int reducev_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRe
 	if ((((uintptr_t) in->data | in->stride | (uintptr_t) out->data | out->stride) & 3) ||
 		(in->width * in->bands * (u16 ? 2 : 1)) % 4)
 		return 0;
-	// (lane offsets are 32-bit: 16 rows of the image)
-	if ((long long) in->stride * 17 >= (1LL << 31) || out->height < 1 || in->height < 1)
+	if (vs != 1 && (u16 || vs < 2 || vs > 16 || mid_height < 1))
+		return 0;
+	// (lane offsets are 32-bit: 16 rows of the image, 16 vs with a shrink in front)
+	if ((long long) in->stride * (16 * vs + 1) >= (1LL << 31) || out->height < 1 || in->height < 1)
 		return 0;
 	const unsigned char *blob;
 	if (rb_plan(r, out->height, tile, &blob))
@@ -275,12 +286,15 @@ int reducev_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRe
 	a.row_bytes = in->width * in->bands * (u16 ? 2 : 1);
 	a.height = in->height;
 	a.out_height = out->height;
+	a.vs = vs;
+	a.mid_height = vs > 1 ? mid_height : in->height;
+	a.mult = (unsigned int) ((1LL << 32) / ((1 << 8) * (long long) vs));
 	a.strips = (a.row_bytes + 127) / 128;
 	a.nblocks = (out->height + 31) / 32;
 	a.blk = (const RbBlock *) blob;
 	a.tab = (const unsigned int *) (blob + (size_t) a.nblocks * sizeof(RbBlock));
 	const int groups = (((a.strips + 3) / 4) + 7) & ~7; // blocks of 4 waves = 4 neighbouring strips; a multiple of 8
-	Gate gate(u16 ? "reducev_u16_band" : "reducev_u8_band");
+	Gate gate(vs > 1 ? "shrinkv_reducev_u8_band" : u16 ? "reducev_u16_band" : "reducev_u8_band");
 	const int rc = rb_launch(a, groups * a.nblocks, u16);
 	return rc ? -1 : 1;
 }

@@ -188,6 +188,7 @@ VH_DEV unsigned long long realtime() { return emul::clock_ticks(); }
 VH_DEV void sched_fence() {}
 VH_DEV void opaque(int &) {}
 VH_DEV void opaque(unsigned int &) {}
+VH_DEV void opaque_uniform(int &) {}
 
 VH_DEV unsigned int perm(unsigned int hi, unsigned int lo, unsigned int sel)
 {

@@ -25,7 +25,18 @@ static int rb_launch(const RbArgs &a, int grid, bool u16)
 				const int g = id / groups, grp = id - g * groups;
 				const int strip = 4 * grp + wave_index();
 				if (strip < a.strips) {
-					if (u16)
+					if (a.vs > 1) {
+						switch (a.vs) {
+#define RB_BOX(VS) \
+	case VS: \
+		reducev_box_band_wave<VS>(a, strip, g); \
+		break;
+							RB_BOX(2) RB_BOX(3) RB_BOX(4) RB_BOX(5) RB_BOX(6) RB_BOX(7) RB_BOX(8) RB_BOX(9) RB_BOX(10) RB_BOX(11)
+							RB_BOX(12) RB_BOX(13) RB_BOX(14) RB_BOX(15) RB_BOX(16)
+#undef RB_BOX
+						}
+					}
+					else if (u16)
 						reducev_band_wave<true>(a, strip, g);
 					else
 						reducev_band_wave<false>(a, strip, g);

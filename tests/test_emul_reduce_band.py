@@ -108,3 +108,64 @@ def test_reduce_band_ushort(tmp_path):
 
 def test_reduceh_band(tmp_path):
     _run(HCASES, tmp_path)
+
+
+RESIZE_CHILD = r'''
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import libvips_amd
+from libvips_amd import Image
+from tests import helpers
+
+libvips_amd.init(0)
+lib = libvips_amd.lib
+for (w, h, bands, scale, vscale, gates) in %(cases)r:
+    src = helpers.lcg_image(w, h, bands, np.uint8, 5 + w)
+    src[: h // 3, : w // 2] = 255
+    src[h // 3: h // 2, w // 2:] = 0
+    im = Image.new_from_array(src)
+    kw = {} if vscale is None else {"vscale": vscale}
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    got = im.resize(scale, **kw).numpy()
+    report = libvips_amd.gate_report()
+    lib.vips_hip_gate_enable(0)
+    chain = "resize:scale=%%r" %% scale + ("" if vscale is None else ",vscale=%%r" %% vscale)
+    want = helpers.Ref.run_chain(chain, src)
+    assert sorted(report) == sorted(gates), (w, h, bands, scale, vscale, report)
+    assert got.shape == want.shape and got.dtype == want.dtype, (got.shape, want.shape)
+    bad = np.argwhere(got != want)
+    assert len(bad) == 0, (w, h, bands, scale, vscale, len(bad), bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
+print("CHILD-OK")
+'''
+
+BV, BH, SH = "shrinkv_reducev_u8_band", "reduceh_u8_band", "shrinkh_u8_stream"
+# (width, height, bands, scale, vscale, the kernels that must have run): box shrinks 2 .. 16 in front of the
+# banded reduce, heights that are not multiples of the shrink (the last box row is clipped), and beside them a box
+# shrink the fused kernel does not have (25: the one-kernel chain)
+RESIZE_CASES = [
+    (512, 733, 3, 0.23, None, [BV, SH, BH]), (304, 1260, 1, 0.07, None, [BV, SH, BH]),
+    (300, 611, 4, 0.15, None, [BV, SH, BH]), (1024, 333, 2, 0.3, 0.11, [BV, BH]),
+    (96, 815, 3, 0.4, 0.07, [BV, BH]), (516, 1003, 3, 1.0 / 7.3, None, [BV, SH, BH]),
+    (640, 480, 4, 0.45, 0.26, [S, BH]), (600, 401, 1, 0.09, 0.19, [BV, SH, BH]),
+    (256, 1100, 3, 0.3, 1.0 / 12.5, [BV, BH]), (128, 1531, 4, 0.4, 0.061, [BV, BH]),
+    (200, 900, 3, 0.3, 0.09, [BV, BH]), (512, 1290, 3, 0.04, None, [BV, SH, BH]),
+    (128, 1800, 3, 0.3, 1 / 18.5, [BV, BH]), (64, 2100, 4, 0.3, 1 / 22.1, [BV, BH]), (64, 2500, 3, 0.3, 1 / 26.3, [BV, BH]),
+    (64, 2900, 2, 0.4, 1 / 30.9, [BV, BH]), (60, 3100, 1, 0.4, 1 / 33.0, [BV, BH]), (128, 1900, 3, 0.3, 1 / 28.9, [BV, BH]),
+    (512, 1290, 3, 0.0199, None, ["resize_streamg_u8"]),
+]
+
+
+def test_resize_band_chain(tmp_path):
+    """vips_resize at a scale that leaves a fractional reduce on both axes: shrinkv + reducev as one banded
+    matrix-core kernel, shrinkh, reduceh (ops_resample.cpp), whole image against the compiled reference."""
+    script = os.path.join(str(tmp_path), "child.py")
+    with open(script, "w") as f:
+        f.write(RESIZE_CHILD % {"root": helpers.ROOT, "cases": RESIZE_CASES})
+    env = dict(os.environ, LD_PRELOAD=MOCK_SO, VIPS_HIP_LIBRARY=EMUL_SO, VIPS_HIP_RESIZE_BAND_MIN="0")
+    for k in ("VIPS_HIP_REDUCE_BAND", "VIPS_HIP_NO_RESIZE_BAND", "VIPS_HIP_STREAMG_ALWAYS"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                          env=env, timeout=1800)
+    assert proc.returncode == 0 and "CHILD-OK" in proc.stdout, proc.stdout[-3000:]

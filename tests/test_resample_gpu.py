@@ -441,6 +441,7 @@ def test_resize_tail_fused(bands, size, scale, vscale, monkeypatch):
     kw = {} if vscale is None else {"vscale": vscale}
     im = Image.new_from_array(src)
     monkeypatch.setenv("VIPS_HIP_NO_RESIZE_STREAM", "1")  # the whole-chain kernel takes 1 / (2 k) scales first
+    monkeypatch.setenv("VIPS_HIP_NO_RESIZE_BAND", "1")  # ... and the matrix-core chain the images of 8 MB and more
     libvips_amd.lib.vips_hip_gate_reset()
     libvips_amd.lib.vips_hip_gate_enable(1)
     try:
