@@ -1353,10 +1353,24 @@ int vips_hip_thumbnail_image_crop(VipsHipImage *in, VipsHipImage **out, int widt
 		cur = in;
 	}
 	else {
-		if (vips_hip_colourspace(in, &space.im,
-				linear ? VIPS_HIP_INTERPRETATION_scRGB : VIPS_HIP_INTERPRETATION_sRGB))
-			return -1;
-		cur = space.im;
+		// already there (the usual sRGB uchar photograph): vips_colourspace is a pointer copy then, and this
+		// function only reads the result -- caller-owned device memory, which vips_hip_colourspace would have
+		// to copy to own, is read where it is
+		const int target = linear ? VIPS_HIP_INTERPRETATION_scRGB : VIPS_HIP_INTERPRETATION_sRGB;
+		const int have = guess_interpretation(in);
+		const Route *route = nullptr;
+		for (const Route &r : routes)
+			if (r.from == have && r.to == target) {
+				route = &r;
+				break;
+			}
+		if (route && route->n == 0 && route->cast_format == in->format)
+			cur = in;
+		else {
+			if (vips_hip_colourspace(in, &space.im, target))
+				return -1;
+			cur = space.im;
+		}
 	}
 
 	// vips_thumbnail_calculate_shrink, thumbnail.c:413-467 (crop NONE, no rotate)
