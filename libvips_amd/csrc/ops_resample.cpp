@@ -302,14 +302,6 @@ int resize_down_u8_stream(VipsHipImage *const *in, int n, VipsHipImage **out, co
 				done = 0; // (not its case: nothing has been written anywhere)
 				break;
 			}
-			// shrinkh + reduceh as one kernel too (box shrinks up to 8), or the two one after the other
-			if (ph.int_shrink > 1) {
-				const int dh = shrinkh_reduceh_band_try(rh.get(), ph.int_shrink, shrunk_width, &r1, po[i], g_fatstrip_height);
-				if (dh < 0)
-					return -1;
-				if (dh == 1)
-					continue;
-			}
 			ImageRef t2;
 			VipsHipRegion r2 = r1;
 			if (ph.int_shrink > 1) {

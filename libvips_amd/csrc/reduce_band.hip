@@ -57,18 +57,6 @@ reduceh_u16_band(RbhArgs a, int groups)
 		reduceh16_band_wave<B>(a, xt, yt);
 }
 
-template <int B, int HS>
-__global__ void __launch_bounds__(256)
-shrinkh_reduceh_u8_band(RbhArgs a, int groups)
-{
-	const int wv = wave_index();
-	const int id = (int) blockIdx.x;
-	const int yt = id / groups, grp = id - yt * groups;
-	const int xt = 4 * grp + wv;
-	if (xt < a.xtiles)
-		reduceh_box_band_wave<B, HS>(a, xt, yt);
-}
-
 } // namespace vh
 
 #include "reduce_band_host.h"
@@ -98,40 +86,9 @@ static int rb_launch(const RbArgs &a, int grid, bool u16)
 	return 0;
 }
 
-template <int B>
-static int rbh_box_launch(const RbhArgs &a, int grid, int groups)
-{
-	switch (a.hs) {
-#define RBH_BOX(HS) \
-	case HS: \
-		hipLaunchKernelGGL((shrinkh_reduceh_u8_band<B, HS>), dim3(grid), dim3(RB_NT), 0, stream(), a, groups); \
-		break;
-		RBH_BOX(2) RBH_BOX(3) RBH_BOX(4) RBH_BOX(5) RBH_BOX(6) RBH_BOX(7) RBH_BOX(8)
-#undef RBH_BOX
-	default:
-		return 1;
-	}
-	VH_CHECK(hipGetLastError());
-	return 0;
-}
-
 static int rbh_launch(int bands, const RbhArgs &a, int grid, bool u16)
 {
 	const int groups = (a.xtiles + 3) / 4;
-	if (a.hs > 1) {
-		switch (bands) {
-		case 1:
-			return rbh_box_launch<1>(a, grid, groups);
-		case 2:
-			return rbh_box_launch<2>(a, grid, groups);
-		case 3:
-			return rbh_box_launch<3>(a, grid, groups);
-		case 4:
-			return rbh_box_launch<4>(a, grid, groups);
-		default:
-			return 1;
-		}
-	}
 	if (u16) {
 		switch (bands) {
 		case 1:

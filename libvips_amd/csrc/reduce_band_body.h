@@ -285,9 +285,6 @@ struct RbhArgs {
 	int xtiles;       // of 16 output columns
 	int ytiles;       // of 16 rows
 	int out_dwords;   // output rows start on dwords: a lane's 4 pixels leave as whole dwords
-	int hs;           // > 1: a vips_shrinkh(hs, ceil) in front -- `width` is the width after it, in_width before
-	int in_width;
-	unsigned int mult; // (1 << 32) / (256 hs)
 	const RbBlock *blk; // per x tile: first 32-pixel step (may be negative), steps, first coefficient block
 	const unsigned int *tab;
 };
@@ -495,118 +492,6 @@ VH_DEV void reduceh_band_wave(const RbhArgs &a, int xt, int yt)
 #pragma unroll
 		for (int i = 0; i < 2 * B; i++)
 			cur[i] = nxt[i];
-	}
-	// register r: output column 16 xt + 4 kg + r of row y
-	unsigned int P[B], w[B];
-#pragma unroll
-	for (int bb = 0; bb < B; bb++) {
-		unsigned int v = 0;
-#pragma unroll
-		for (int r = 0; r < 4; r++)
-			v = cvt_pk_u8(__builtin_fmaf(acc[bb][r], 4096.0f, 0x1p-13f), (unsigned int) r, v);
-		P[bb] = v;
-	}
-	cu8_interleave<B>(P, w);
-	const int x0 = 16 * xt + 4 * kg;
-	if (y < a.rows && x0 < a.out_width) {
-		const gptr_out p = gptr_out_of((unsigned long long) a.out) + (long long) y * a.out_stride + (long long) x0 * B;
-		if (x0 + 4 <= a.out_width && a.out_dwords)
-			gstore_dwords<B>(p, w);
-		else
-			for (int e = 0; e < min(4, a.out_width - x0) * B; e++)
-				gstore8(p + e, (unsigned char) (w[e >> 2] >> (8 * (e & 3))));
-	}
-}
-
-// the same wave with a vips_shrinkh(HS) in front -- vips_resize's horizontal half for a size that does not divide
-// the image (resize.c:230-252: shrinkh, then reduceh): the lane's 8 pixels of a step are box sums of 8 HS image
-// pixels, read as 2 HS groups of 4 pixels (B dwords each), every group made planar (cu8_planar) and summed with
-// v_dot4_u32_u8 against the byte mask of each box it touches (known at compile time), rounded as shrinkh does
-// (shrinkh.c:78-92: ((hs / 2 + sum) * ((1 << 32) / (256 hs))) >> 24) and handed to the product as halves 0x00pp
-// straight from the products' top bytes; the 1 / HS-wide intermediate image never exists.  Pixels past the row
-// are its last pixel (shrinkh's own embed).
-template <int B, int HS>
-VH_DEV void reduceh_box_band_wave(const RbhArgs &a, int xt, int yt)
-{
-	const int lane = tid() & 63, n = lane & 15, kg = lane >> 4;
-	const int y = 16 * yt + n, yc = min(y, a.rows - 1);
-	const RbBlock b = uniform_load(&a.blk[xt]);
-	const gptr_in line = gptr_in_of((unsigned long long) a.in) + (long long) yc * a.in_stride;
-	const gptr_in gtab = gptr_in_of((unsigned long long) a.tab);
-	constexpr int NG = 2 * HS; // groups of 4 image pixels under the lane's 8 shrunk pixels
-
-	// shrunk pixels 32 s + 8 kg .. + 7 of the lane's row: band bb of pixels 2 h, 2 h + 1 as D[bb][h]
-	auto load = [&](int s, unsigned int (&D)[B][4]) {
-		const int p0 = 32 * s;
-		unsigned int sum[8][B];
-#pragma unroll
-		for (int q = 0; q < 8; q++)
-#pragma unroll
-			for (int bb = 0; bb < B; bb++)
-				sum[q][bb] = HS / 2;
-		if (p0 >= 0 && (p0 + 32) * HS <= a.in_width) {
-			unsigned int raw[NG * B];
-			gload_dwords_long<NG * B>(line, (unsigned int) ((p0 + 8 * kg) * HS * B), raw);
-#pragma unroll
-			for (int g = 0; g < NG; g++) {
-				unsigned int w[B], P[B];
-#pragma unroll
-				for (int i = 0; i < B; i++)
-					w[i] = raw[g * B + i];
-				cu8_planar<B>(w, P);
-#pragma unroll
-				for (int q = (4 * g) / HS; q <= (4 * g + 3) / HS; q++) {
-					unsigned int mask = 0;
-#pragma unroll
-					for (int i = 0; i < 4; i++)
-						if ((4 * g + i) / HS == q)
-							mask |= 1u << (8 * i);
-#pragma unroll
-					for (int bb = 0; bb < B; bb++)
-						sum[q][bb] = udot4(P[bb], mask, sum[q][bb]);
-				}
-			}
-		}
-		else {
-#pragma unroll
-			for (int q = 0; q < 8; q++) {
-				const int pm = min(max(p0 + 8 * kg + q, 0), a.width - 1);
-#pragma nounroll
-				for (int t = 0; t < HS; t++) {
-					const int px = min(pm * HS + t, a.in_width - 1);
-#pragma unroll
-					for (int bb = 0; bb < B; bb++)
-						sum[q][bb] += (unsigned int) gload8(line, (unsigned int) (px * B + bb));
-				}
-			}
-		}
-#pragma unroll
-		for (int bb = 0; bb < B; bb++)
-#pragma unroll
-			for (int h = 0; h < 4; h++)
-				D[bb][h] = perm(sum[2 * h + 1][bb] * a.mult, sum[2 * h][bb] * a.mult, 0x0c070c03u);
-	};
-
-	float acc[B][4];
-	unsigned int cur[B][4], nxt[B][4];
-	load(b.s0, cur);
-	for (int j = 0; j < b.ns; j++) {
-		if (j + 1 < b.ns)
-			load(b.s0 + j + 1, nxt);
-		unsigned int A[4];
-		gload128(gtab, (unsigned int) (((b.tab + j) * 64 + lane) * 16), A);
-#pragma unroll
-		for (int bb = 0; bb < B; bb++) {
-			if (j == 0)
-				mfma_16x16x32_f16_first(A, cur[bb], acc[bb]);
-			else
-				mfma_16x16x32_f16(A, cur[bb], acc[bb]);
-		}
-#pragma unroll
-		for (int bb = 0; bb < B; bb++)
-#pragma unroll
-			for (int h = 0; h < 4; h++)
-				cur[bb][h] = nxt[bb][h];
 	}
 	// register r: output column 16 xt + 4 kg + r of row y
 	unsigned int P[B], w[B];

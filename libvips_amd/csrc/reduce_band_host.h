@@ -195,25 +195,14 @@ int rbh_plan(_VipsHipReduce *r, int out_width, int tile, const unsigned char **b
 
 } // namespace
 
-int shrinkh_reduceh_band_try(_VipsHipReduce *r, int hs, int mid_width, const VipsHipRegion *in, const VipsHipRegion *out, int tile);
-
 // vips_reduceh of whole rows of a uchar image with a coefficient row per output column; 1 = done, 0 = not this
 // kernel's case, -1 = error
 int reduceh_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out, int tile)
-{
-	return shrinkh_reduceh_band_try(r, 1, 0, in, out, tile);
-}
-
-// ... with a vips_shrinkh(hs, ceil) in front, the two as one kernel: `in` is the image BEFORE the shrink, `r` the
-// plan of the reduce on the image after it (mid_width pixels a row); hs = 1: the reduce alone
-int shrinkh_reduceh_band_try(_VipsHipReduce *r, int hs, int mid_width, const VipsHipRegion *in, const VipsHipRegion *out, int tile)
 {
 	const char *env = getenv("VIPS_HIP_REDUCE_BAND");
 	if (env && atoi(env) == 0)
 		return 0;
 	const bool u16 = in->format == VIPS_HIP_FORMAT_USHORT;
-	if (hs != 1 && (u16 || hs < 2 || hs > 8 || mid_width < 1 || getenv("VIPS_HIP_NO_SHRINKH_BAND")))
-		return 0;
 	if ((in->format != VIPS_HIP_FORMAT_UCHAR && !u16) || out->format != in->format || in->bands != out->bands ||
 		in->bands < 1 || in->bands > 4 || out->width < 1)
 		return 0;
@@ -239,10 +228,7 @@ int shrinkh_reduceh_band_try(_VipsHipReduce *r, int hs, int mid_width, const Vip
 	a.out = (unsigned char *) out->data;
 	a.in_stride = (long long) in->stride;
 	a.out_stride = (long long) out->stride;
-	a.width = hs > 1 ? mid_width : in->width;
-	a.in_width = in->width;
-	a.hs = hs;
-	a.mult = (unsigned int) ((1LL << 32) / ((1 << 8) * (long long) hs));
+	a.width = in->width;
 	a.out_width = out->width;
 	a.rows = out->height;
 	a.xtiles = (out->width + 15) / 16;
@@ -251,7 +237,7 @@ int shrinkh_reduceh_band_try(_VipsHipReduce *r, int hs, int mid_width, const Vip
 	a.blk = (const RbBlock *) blob;
 	a.tab = (const unsigned int *) (blob + (size_t) a.xtiles * sizeof(RbBlock));
 	const int groups = (a.xtiles + 3) / 4; // a block of 4 waves: 4 neighbouring x tiles of the same rows
-	Gate gate(hs > 1 ? "shrinkh_reduceh_u8_band" : u16 ? "reduceh_u16_band" : "reduceh_u8_band");
+	Gate gate(u16 ? "reduceh_u16_band" : "reduceh_u8_band");
 	const int rc = rbh_launch(in->bands, a, groups * a.ytiles, u16);
 	return rc ? -1 : 1;
 }

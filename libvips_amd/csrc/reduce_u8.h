@@ -51,7 +51,6 @@ int reducev8_stream_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHi
 int reducev_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out, int tile);
 int reduceh_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out, int tile);
 // vips_shrinkv(vs, ceil) + vips_reducev as one kernel (`in`: the image before the shrink; `r`: the reduce's plan)
-int shrinkh_reduceh_band_try(_VipsHipReduce *r, int hs, int mid_width, const VipsHipRegion *in, const VipsHipRegion *out, int tile);
 int shrinkv_reducev_band_try(_VipsHipReduce *r, int vs, int mid_height, const VipsHipRegion *in, const VipsHipRegion *out, int tile);
 int shrinkh16_stream_try(int hshrink, const VipsHipRegion *in, const VipsHipRegion *out);
 // reduceh_u8.hip: vips_reduceh on uchar with one coefficient row and first taps 4 or 8 pixels apart,

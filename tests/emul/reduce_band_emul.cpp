@@ -71,16 +71,6 @@ static void rbh_run(const RbhArgs &a, int grid)
 				if (xt < a.xtiles) {
 					if constexpr (U16)
 						reduceh16_band_wave<B>(a, xt, yt);
-					else if (a.hs > 1) {
-						switch (a.hs) {
-#define RBH_BOX(HS) \
-	case HS: \
-		reduceh_box_band_wave<B, HS>(a, xt, yt); \
-		break;
-							RBH_BOX(2) RBH_BOX(3) RBH_BOX(4) RBH_BOX(5) RBH_BOX(6) RBH_BOX(7) RBH_BOX(8)
-#undef RBH_BOX
-						}
-					}
 					else
 						reduceh_band_wave<B>(a, xt, yt);
 				}

@@ -140,19 +140,17 @@ for (w, h, bands, scale, vscale, gates) in %(cases)r:
 print("CHILD-OK")
 '''
 
-BV, BH, SH, SBH = "shrinkv_reducev_u8_band", "reduceh_u8_band", "shrinkh_u8_stream", "shrinkh_reduceh_u8_band"
+BV, BH, SH = "shrinkv_reducev_u8_band", "reduceh_u8_band", "shrinkh_u8_stream"
 # (width, height, bands, scale, vscale, the kernels that must have run): box shrinks 2 .. 16 in front of the
 # banded reduce, heights that are not multiples of the shrink (the last box row is clipped), and beside them a box
-# shrink the fused kernel does not have (25: the one-kernel chain); across, box shrinks 2 .. 8 inside the banded
-# reduceh (SBH), 12 as a kernel of its own
+# shrink the fused kernel does not have (25: the one-kernel chain)
 RESIZE_CASES = [
-    (512, 733, 3, 0.23, None, [BV, SBH]), (304, 1260, 1, 0.07, None, [BV, SBH]),
-    (300, 611, 4, 0.15, None, [BV, SBH]), (1024, 333, 2, 0.3, 0.11, [BV, BH]),
-    (96, 815, 3, 0.4, 0.07, [BV, BH]), (516, 1003, 3, 1.0 / 7.3, None, [BV, SBH]),
-    (640, 480, 4, 0.45, 0.26, [S, BH]), (600, 401, 1, 0.09, 0.19, [BV, SBH]),
+    (512, 733, 3, 0.23, None, [BV, SH, BH]), (304, 1260, 1, 0.07, None, [BV, SH, BH]),
+    (300, 611, 4, 0.15, None, [BV, SH, BH]), (1024, 333, 2, 0.3, 0.11, [BV, BH]),
+    (96, 815, 3, 0.4, 0.07, [BV, BH]), (516, 1003, 3, 1.0 / 7.3, None, [BV, SH, BH]),
+    (640, 480, 4, 0.45, 0.26, [S, BH]), (600, 401, 1, 0.09, 0.19, [BV, SH, BH]),
     (256, 1100, 3, 0.3, 1.0 / 12.5, [BV, BH]), (128, 1531, 4, 0.4, 0.061, [BV, BH]),
-    (200, 900, 3, 0.3, 0.09, [BV, BH]), (1000, 300, 2, 1 / 8.6, 0.2, [BV, SBH]), (1204, 300, 3, 1 / 12.9, 0.2, [BV, SBH]),
-    (2000, 200, 4, 1 / 16.9, 0.2, [BV, SBH]), (1996, 200, 1, 1 / 17.2, 0.2, [BV, SBH]), (1004, 200, 3, 1 / 10.3, 0.2, [BV, SBH]), (512, 1290, 3, 0.04, None, [BV, SH, BH]),
+    (200, 900, 3, 0.3, 0.09, [BV, BH]), (512, 1290, 3, 0.04, None, [BV, SH, BH]),
     (128, 1800, 3, 0.3, 1 / 18.5, [BV, BH]), (64, 2100, 4, 0.3, 1 / 22.1, [BV, BH]), (64, 2500, 3, 0.3, 1 / 26.3, [BV, BH]),
     (64, 2900, 2, 0.4, 1 / 30.9, [BV, BH]), (60, 3100, 1, 0.4, 1 / 33.0, [BV, BH]), (128, 1900, 3, 0.3, 1 / 28.9, [BV, BH]),
     (512, 1290, 3, 0.0199, None, ["resize_streamg_u8"]),

@@ -17,7 +17,7 @@ import libvips_amd  # noqa: E402
 from libvips_amd import Image  # noqa: E402
 from tests import helpers  # noqa: E402
 
-EMULATED = {"shrinkh_u8_stream", "shrinkv_reducev_u8_band", "shrinkh_reduceh_u8_band", "reduceh_u8_packed", "reducev_u8_stream", "reducev_u8_band", "reduceh_u8_band", "reducev_u16_band", "reduceh_u16_band", "conv_u16_2d", "conv_u8_2d", "conv_u8_sep", "conv_u8_mfma_sep", "conv_u8_mfma_2d",
+EMULATED = {"shrinkh_u8_stream", "shrinkv_reducev_u8_band", "reduceh_u8_packed", "reducev_u8_stream", "reducev_u8_band", "reduceh_u8_band", "reducev_u16_band", "reduceh_u16_band", "conv_u16_2d", "conv_u8_2d", "conv_u8_sep", "conv_u8_mfma_sep", "conv_u8_mfma_2d",
             "shrinkv_u16_stream", "shrinkh_u16_stream", "reducev_u16_stream", "reduceh_u16_lds"}
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
