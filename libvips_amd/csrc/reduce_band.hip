@@ -18,7 +18,7 @@ reducev_u8_band(RbArgs a, int groups)
 	const int g = id / groups, grp = id - g * groups;
 	const int strip = 4 * grp + wv;
 	if (strip < a.strips)
-		reducev_band_wave<U16>(a, strip, g);
+		reducev_band_wave<U16>(a, strip, g, rb_bottom_up(a, g));
 }
 
 template <int VS>
@@ -30,7 +30,7 @@ shrinkv_reducev_u8_band(RbArgs a, int groups)
 	const int g = id / groups, grp = id - g * groups;
 	const int strip = 4 * grp + wv;
 	if (strip < a.strips)
-		reducev_box_band_wave<VS>(a, strip, g);
+		reducev_box_band_wave<VS>(a, strip, g, rb_bottom_up(a, g));
 }
 
 template <int B>
@@ -63,13 +63,14 @@ reduceh_u16_band(RbhArgs a, int groups)
 
 namespace vh {
 
-static int rb_launch(const RbArgs &a, int grid, bool u16)
+static int rb_launch(const RbArgs &a, int groups, int wblocks, bool u16)
 {
+	const int grid = groups * wblocks;
 	if (a.vs > 1) {
 		switch (a.vs) {
 #define RB_BOX(VS) \
 	case VS: \
-		hipLaunchKernelGGL(shrinkv_reducev_u8_band<VS>, dim3(grid), dim3(RB_NT), 0, stream(), a, grid / a.nblocks); \
+		hipLaunchKernelGGL(shrinkv_reducev_u8_band<VS>, dim3(grid), dim3(RB_NT), 0, stream(), a, groups); \
 		break;
 			RB_BOX(2) RB_BOX(3) RB_BOX(4) RB_BOX(5) RB_BOX(6) RB_BOX(7) RB_BOX(8) RB_BOX(9) RB_BOX(10) RB_BOX(11) RB_BOX(12)
 			RB_BOX(13) RB_BOX(14) RB_BOX(15) RB_BOX(16)
@@ -79,9 +80,9 @@ static int rb_launch(const RbArgs &a, int grid, bool u16)
 		}
 	}
 	else if (u16)
-		hipLaunchKernelGGL(reducev_u8_band<true>, dim3(grid), dim3(RB_NT), 0, stream(), a, grid / a.nblocks);
+		hipLaunchKernelGGL(reducev_u8_band<true>, dim3(grid), dim3(RB_NT), 0, stream(), a, groups);
 	else
-		hipLaunchKernelGGL(reducev_u8_band<false>, dim3(grid), dim3(RB_NT), 0, stream(), a, grid / a.nblocks);
+		hipLaunchKernelGGL(reducev_u8_band<false>, dim3(grid), dim3(RB_NT), 0, stream(), a, groups);
 	VH_CHECK(hipGetLastError());
 	return 0;
 }

@@ -40,6 +40,7 @@ struct RbArgs {
 	unsigned int mult; // 2^32 / (256 vs)
 	int strips;       // of 128 bytes
 	int nblocks;      // of 32 output rows
+	int alternate;    // every other block of rows is walked from the bottom up
 	const RbBlock *blk;
 	const unsigned int *tab; // [coefficient block][64 lanes][4 dwords]
 };
@@ -77,7 +78,7 @@ VH_DEV unsigned int rb_box2(unsigned int sums, unsigned int mult)
 // from the loaded dwords as two 16-bit lanes per dword (even and odd byte columns) and rounded as shrinkv does; the
 // 1 / VS-size intermediate image never exists.  Rows past the image are the last row (shrinkv's own embed, ceil).
 template <int VS>
-VH_DEV void reducev_box_band_wave(const RbArgs &a, int strip, int g)
+VH_DEV void reducev_box_band_wave(const RbArgs &a, int strip, int g, bool rev)
 {
 	const int lane = tid() & 63, n = lane & 31, hf = lane >> 5;
 	const int xb = min(strip * 128 + 4 * n, a.row_bytes - 4);
@@ -132,12 +133,14 @@ VH_DEV void reducev_box_band_wave(const RbArgs &a, int strip, int g)
 #pragma unroll
 	for (int i = 0; i < 8; i++)
 		ev[i] = od[i] = 0;
-	load(b.s0, 0, raw);
+	// (rev: the steps from the last to the first -- sums of integers, exact in any order)
+	auto step_of = [&](int j) { return rev ? b.ns - 1 - j : j; };
+	load(b.s0 + step_of(0), 0, raw);
 	int j = 0, c = 0;
 #pragma nounroll
 	for (int t = 0; t < b.ns * NC; t++) {
 		if (c == 0)
-			gload128(gtab, (unsigned int) (((b.tab + j) * 64 + lane) * 16), A);
+			gload128(gtab, (unsigned int) (((b.tab + step_of(j)) * 64 + lane) * 16), A);
 #pragma unroll
 		for (int k = 0; k < CH; k++) {
 			const unsigned int keep = NC * CH == VS || c * CH + k < VS ? 0x00ff00ffu : 0u;
@@ -158,9 +161,9 @@ VH_DEV void reducev_box_band_wave(const RbArgs &a, int strip, int g)
 		// (past the last chunk: the last one again -- every path through the loop writes raw[], which keeps it
 		// in one set of registers)
 		if (NC > 1)
-			load(b.s0 + min(j1, b.ns - 1), (j1 < b.ns ? c1 : NC - 1) * CH, raw);
+			load(b.s0 + step_of(min(j1, b.ns - 1)), (j1 < b.ns ? c1 : NC - 1) * CH, raw);
 		else if (j1 < b.ns)
-			load(b.s0 + j1, 0, raw);
+			load(b.s0 + step_of(j1), 0, raw);
 		if (c == NC - 1) {
 			unsigned int cur[8];
 #pragma unroll
@@ -193,8 +196,16 @@ VH_DEV void reducev_box_band_wave(const RbArgs &a, int strip, int g)
 	}
 }
 
+// Every other block of rows is walked from the bottom up: two blocks that share rows (the taps of neighbouring
+// blocks overlap: 13 of 64 + 13 rows at a residual of 2) then read them at about the same time -- one at its end
+// as the other at its end, or both at their start -- and the second read is an L2 hit.  With every block walking
+// down, a block read the shared rows ~20 us after its neighbour had: 279 MB fetched for an image of 201, 209 MB now
+// (profiles/r05k_band_traffic.txt; 0.0472 -> 0.0396 ms).  Two or four blocks a wave one after the other instead
+// (the shared rows re-read by the same CU) were slower than either.
+VH_DEV bool rb_bottom_up(const RbArgs &a, int g) { return a.alternate && (g & 1); }
+
 template <bool U16>
-VH_DEV void reducev_band_wave(const RbArgs &a, int strip, int g)
+VH_DEV void reducev_band_wave(const RbArgs &a, int strip, int g, bool rev)
 {
 	const int lane = tid() & 63, n = lane & 31, hf = lane >> 5;
 	const int xb = min(strip * 128 + 4 * n, a.row_bytes - 4); // (lanes past the row: its last dword, not stored)
@@ -224,12 +235,14 @@ VH_DEV void reducev_band_wave(const RbArgs &a, int strip, int g)
 
 	float acc[4][16];
 	unsigned int cur[8], nxt[8];
-	load(b.s0, cur);
+	// (rev: the steps from the last to the first -- sums of integers, exact in any order)
+	auto step_of = [&](int j) { return rev ? b.ns - 1 - j : j; };
+	load(b.s0 + step_of(0), cur);
 	for (int j = 0; j < b.ns; j++) {
 		if (j + 1 < b.ns)
-			load(b.s0 + j + 1, nxt);
+			load(b.s0 + step_of(j + 1), nxt);
 		unsigned int A[4];
-		gload128(gtab, (unsigned int) (((b.tab + j) * 64 + lane) * 16), A);
+		gload128(gtab, (unsigned int) (((b.tab + step_of(j)) * 64 + lane) * 16), A);
 #pragma unroll
 		for (int c = 0; c < 4; c++) {
 			// byte column c of the 8 rows as halves: dword q = rows 2 q, 2 q + 1

@@ -15,7 +15,7 @@
 namespace vh {
 
 // defined by the including file; 0 on success
-static int rb_launch(const RbArgs &a, int grid, bool u16);
+static int rb_launch(const RbArgs &a, int groups, int wblocks, bool u16);
 static int rbh_launch(int bands, const RbhArgs &a, int grid, bool u16);
 
 namespace {
@@ -295,7 +295,8 @@ int shrinkv_reducev_band_try(_VipsHipReduce *r, int vs, int mid_height, const Vi
 	a.tab = (const unsigned int *) (blob + (size_t) a.nblocks * sizeof(RbBlock));
 	const int groups = (((a.strips + 3) / 4) + 7) & ~7; // blocks of 4 waves = 4 neighbouring strips; a multiple of 8
 	Gate gate(vs > 1 ? "shrinkv_reducev_u8_band" : u16 ? "reducev_u16_band" : "reducev_u8_band");
-	const int rc = rb_launch(a, groups * a.nblocks, u16);
+	a.alternate = !getenv("VIPS_HIP_BAND_NO_ALTERNATE");
+	const int rc = rb_launch(a, groups, a.nblocks, u16);
 	return rc ? -1 : 1;
 }
 

@@ -11,10 +11,10 @@
 
 namespace vh {
 
-static int rb_launch(const RbArgs &a, int grid, bool u16)
+static int rb_launch(const RbArgs &a, int groups, int wblocks, bool u16)
 {
 	(void) hipStreamSynchronize(stream());
-	const int groups = grid / a.nblocks;
+	const int grid = groups * wblocks;
 	std::atomic<int> next(0);
 	auto worker = [&]() {
 		for (;;) {
@@ -29,7 +29,7 @@ static int rb_launch(const RbArgs &a, int grid, bool u16)
 						switch (a.vs) {
 #define RB_BOX(VS) \
 	case VS: \
-		reducev_box_band_wave<VS>(a, strip, g); \
+		reducev_box_band_wave<VS>(a, strip, g, rb_bottom_up(a, g)); \
 		break;
 							RB_BOX(2) RB_BOX(3) RB_BOX(4) RB_BOX(5) RB_BOX(6) RB_BOX(7) RB_BOX(8) RB_BOX(9) RB_BOX(10) RB_BOX(11)
 							RB_BOX(12) RB_BOX(13) RB_BOX(14) RB_BOX(15) RB_BOX(16)
@@ -37,9 +37,9 @@ static int rb_launch(const RbArgs &a, int grid, bool u16)
 						}
 					}
 					else if (u16)
-						reducev_band_wave<true>(a, strip, g);
+						reducev_band_wave<true>(a, strip, g, rb_bottom_up(a, g));
 					else
-						reducev_band_wave<false>(a, strip, g);
+						reducev_band_wave<false>(a, strip, g, rb_bottom_up(a, g));
 				}
 			});
 		}
