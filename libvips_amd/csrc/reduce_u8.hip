@@ -773,6 +773,7 @@ struct VStreamArgs {
 	int fy0;                 // first tap (input row) of output row 0 of the rect
 	int row_u2;              // 8-byte columns per row
 	int oht, tiles_x, tiles; // tile = 256 columns x oht output rows
+	int alternate;           // every other row of tiles is walked bottom-up
 };
 
 template <int D>
@@ -781,20 +782,20 @@ struct VStreamStep {
 	static constexpr int S = 8;
 
 	template <int I0, int N>
-	static __device__ __forceinline__ void load_rows(const VStreamArgs &a, uint2 (&px)[S], int first_row,
+	static __device__ __forceinline__ void load_rows(const VStreamArgs &a, uint2 (&px)[S], int first_row, int dir,
 		unsigned int coff)
 	{
 		const unsigned int stride32 = (unsigned int) a.in_stride;
 #pragma unroll
 		for (int i = I0; i < I0 + N; i++) {
-			const int row = min(max(first_row + i, 0), a.im_height - 1) - a.in_top;
+			const int row = min(max(first_row + dir * i, 0), a.im_height - 1) - a.in_top;
 			px[i] = *reinterpret_cast<const uint2 *>(a.in + (size_t) ((unsigned int) row * stride32 + coff));
 		}
 	}
 
 	template <int ROT, int Q>
 	static __device__ __forceinline__ void quad(const VStreamArgs &a, uint2 (&px)[S], float4v (&acc)[8][2],
-		const half4v *lane_a, bool more, int next_row, unsigned int coff)
+		const half4v *lane_a, bool more, int next_row, int dir, unsigned int coff)
 	{
 		const half4v a0 = lane_a[((ROT * 2 + Q) * 2 + 0) * 4];
 		const half4v a1 = lane_a[((ROT * 2 + Q) * 2 + 1) * 4];
@@ -810,7 +811,7 @@ struct VStreamStep {
 			b[2] = Base::template make_b<2>(r0, r1, r2, r3);
 			b[3] = Base::template make_b<3>(r0, r1, r2, r3);
 			if (p == 1 && more)
-				load_rows<4 * Q, 4>(a, px, next_row, coff);
+				load_rows<4 * Q, 4>(a, px, next_row, dir, coff);
 #pragma unroll
 			for (int c = 0; c < 4; c++) {
 				acc[p * 4 + c][0] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, b[c], acc[p * 4 + c][0], 0, 0, 0);
@@ -839,20 +840,21 @@ struct VStreamStep {
 
 	template <int ROT>
 	static __device__ __forceinline__ void batch(const VStreamArgs &a, uint2 (&px)[S], int g0, int ngroups,
-		float4v (&acc)[8][2], const half4v *lane_a, int row0, unsigned int coff, unsigned char *out_col, int oh,
-		bool active)
+		float4v (&acc)[8][2], const half4v *lane_a, int row0, int dir, unsigned int coff, unsigned char *out_col,
+		int oh, bool active)
 	{
 		if constexpr (ROT < MFMA_SLOTS) {
 			const int g = g0 + ROT;
 			if (g < ngroups) {
 				const bool more = g + 1 < ngroups;
-				const int next_row = row0 + S * (g + 1);
-				quad<ROT, 0>(a, px, acc, lane_a, more, next_row, coff);
-				quad<ROT, 1>(a, px, acc, lane_a, more, next_row, coff);
-				const int j = g - (D - 1);
-				retire<ROT>(acc, out_col + (long long) j * a.out_stride, active && j >= 0 && j < oh);
+				const int next_row = row0 + dir * S * (g + 1);
+				quad<ROT, 0>(a, px, acc, lane_a, more, next_row, dir, coff);
+				quad<ROT, 1>(a, px, acc, lane_a, more, next_row, dir, coff);
+				const int j = g - (D - 1); // row of the (possibly flipped) tile
+				retire<ROT>(acc, out_col + (long long) (dir < 0 ? oh - 1 - j : j) * a.out_stride,
+					active && j >= 0 && j < oh);
 			}
-			batch<ROT + 1>(a, px, g0, ngroups, acc, lane_a, row0, coff, out_col, oh, active);
+			batch<ROT + 1>(a, px, g0, ngroups, acc, lane_a, row0, dir, coff, out_col, oh, active);
 		}
 	}
 };
@@ -878,10 +880,16 @@ reducev_u8_mfma(VStreamArgs a, const MfmaTables *__restrict__ tables)
 	const int col = bx * FUSED_THREADS + t;
 	const bool active = col < a.row_u2;
 	const unsigned int coff = 8u * (unsigned int) min(col, a.row_u2 - 1);
-	const int row0 = a.fy0 + S * y0;
+	// Every other row of tiles is walked bottom-up (the flipped problem: rows counted from the last one, taps
+	// reversed -- tables->a[1], as in the fused kernel above): a tile and the one below it share 8 (D - 1) input
+	// rows, which both now read at about the same time -- the second read is an L2 hit.  With every tile walking
+	// down they were read a whole kernel apart: 263 MB fetched for an image of 201 (profiles/r05l_ops_traffic.txt).
+	const bool flip = a.alternate && (by & 1);
+	const int dir = flip ? -1 : 1;
+	const int row0 = flip ? a.fy0 + S * (y0 + oh - 1) + S * D - 1 : a.fy0 + S * y0;
 
 	if (t < MFMA_TABLE_ENTRIES)
-		reinterpret_cast<uint2 *>(lds_a)[t] = reinterpret_cast<const uint2 *>(tables->a[0])[t];
+		reinterpret_cast<uint2 *>(lds_a)[t] = reinterpret_cast<const uint2 *>(tables->a[flip ? 1 : 0])[t];
 	const half4v *lane_a = lds_a + (t & 3);
 
 	float4v acc[8][2];
@@ -893,12 +901,12 @@ reducev_u8_mfma(VStreamArgs a, const MfmaTables *__restrict__ tables)
 
 	const int ngroups = oh + D - 1;
 	uint2 px[S];
-	Step::template load_rows<0, S>(a, px, row0, coff);
+	Step::template load_rows<0, S>(a, px, row0, dir, coff);
 	__syncthreads();
 
 	unsigned char *out_col = a.out + (long long) y0 * a.out_stride + coff;
 	for (int g0 = 0; g0 < ngroups; g0 += MFMA_SLOTS) {
-		Step::template batch<0>(a, px, g0, ngroups, acc, lane_a, row0, coff, out_col, oh, active);
+		Step::template batch<0>(a, px, g0, ngroups, acc, lane_a, row0, dir, coff, out_col, oh, active);
 	}
 }
 
@@ -1315,6 +1323,7 @@ static int reducev_stream_try(const _VipsHipReduce *rc, const VipsHipRegion *in,
 	if (oht < 16)
 		oht = 16;
 	a.oht = oht;
+	a.alternate = !getenv("VIPS_HIP_BAND_NO_ALTERNATE");
 	const int tiles_y = (out->height + oht - 1) / oht;
 	a.tiles = a.tiles_x * tiles_y;
 	const int grid = (a.tiles + 7) / 8 * 8;

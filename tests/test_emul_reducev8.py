@@ -37,7 +37,7 @@ for (w, h, bands, shrink, kernel, gate) in %(cases)r:
     lib.vips_hip_gate_enable(0)
     want = helpers.Ref.run_chain("reducev:vshrink=%%r,kernel=%%s" %% (shrink, kernel), src)
     assert list(report) == [gate], (w, h, bands, shrink, kernel, report)
-    if gate != "reducev_u8_stream":
+    if gate not in ("reducev_u8_stream", "reducev_u8_mfma"):
         continue  # (the older kernels are not emulated: under the mock runtime they make no pixels)
     assert got.shape == want.shape and got.dtype == want.dtype, (got.shape, want.shape)
     bad = np.argwhere(got != want)
@@ -74,3 +74,13 @@ def test_reducev8(tmp_path):
 
 def test_reducev8_short_segments(tmp_path):
     _run([c for c in CASES if c[5] == S], tmp_path, {"VIPS_HIP_R16_SEG": "5"})
+
+
+def test_reducev8_matrix_core_rows_of_tiles(tmp_path):
+    """reducev_u8_mfma (reduce_u8.hip) on images of several rows of tiles: every other row is walked bottom-up
+    (the flipped problem, taps reversed), and with VIPS_HIP_BAND_NO_ALTERNATE=1 all of them top-down."""
+    m = "reducev_u8_mfma"
+    cases = [(600, 1300, 3, 8.0, "lanczos3", m), (512, 523, 4, 8.0, "lanczos3", m), (1000, 2000, 1, 8.0, "lanczos3", m),
+             (344, 800, 2, 8.0, "lanczos3", m)]
+    _run(cases, tmp_path)
+    _run(cases[:2], tmp_path, {"VIPS_HIP_BAND_NO_ALTERNATE": "1"})
