@@ -279,11 +279,13 @@ int resize_down_u8_stream(VipsHipImage *const *in, int n, VipsHipImage **out, co
 	// any other residual (a size that does not divide the image): shrinkv + reducev as one matrix-core kernel, then
 	// shrinkh, then reduceh on the matrix cores (reduce_band.hip) -- three launches that beat the one-kernel chain
 	// of resize_streamg.hip (8192^2 x 3 to 1000^2: 0.062 against 0.079 ms; profiles/NOTES.md R5.5)
-	// (three launches per image: where the image is large enough for a launch not to matter -- a batch of small
-	// ones stays with the one-kernel chain, 64 images a launch; VIPS_HIP_RESIZE_BAND_MIN = that size in bytes)
+	// (three launches per image, every one of them spread over the whole image: a single image of any size -- the
+	// one-kernel chain walks a small image's rows with a handful of blocks, 50 us against 13 at 1024^2 x 3,
+	// tools/band_threshold.py -- and a batch of images of 8 MB and more; a batch of small ones stays with the
+	// one-kernel chain, 64 images a launch.  VIPS_HIP_RESIZE_BAND_MIN = that size in bytes)
 	const long long band_min = getenv("VIPS_HIP_RESIZE_BAND_MIN") ? atoll(getenv("VIPS_HIP_RESIZE_BAND_MIN")) : 8LL << 20;
 	if (done == 0 && !getenv("VIPS_HIP_NO_RESIZE_BAND") && !getenv("VIPS_HIP_STREAMG_ALWAYS") &&
-		(long long) in[0]->width * in[0]->height * in[0]->bands >= band_min) {
+		(n < 4 || (long long) in[0]->width * in[0]->height * in[0]->bands >= band_min)) {
 		done = 1;
 		for (int i = 0; i < n && done == 1; i++) {
 			ImageRef t1(like(in[i], in[i]->width, pv.size));

@@ -116,15 +116,34 @@ def test_resize_band_chain_vs_reference(w, h, bands, scale, vscale, gates, monke
     assert np.array_equal(got, im.resize(scale, **kw).numpy())
 
 
-def test_resize_band_chain_only_for_large_images():
-    """Without VIPS_HIP_RESIZE_BAND_MIN: an image under 8 MB stays with the one-kernel chain (a launch per step
-    would cost more than it saves), a larger one takes the three launches."""
+def test_resize_band_chain_where_it_pays():
+    """Without VIPS_HIP_RESIZE_BAND_MIN: a single image of any size takes the three launches (the one-kernel chain
+    walks a small image with a handful of blocks), a batch of small images stays with the one-kernel chain (64
+    images a launch), a batch of large ones takes the three launches per image."""
     lib = libvips_amd.lib
-    for (w, h, want) in ((2048, 1000, ["resize_streamg_u8"]), (4096, 3000, [BH, BV, SH])):
-        im = Image.new_from_array(helpers.lcg_image(w, h, 3, np.uint8, 9))
+
+    def gates(call):
         lib.vips_hip_gate_reset()
         lib.vips_hip_gate_enable(1)
-        im.resize(0.123).numpy()
-        report = libvips_amd.gate_report()
-        lib.vips_hip_gate_enable(0)
-        assert sorted(report) == sorted(want), report
+        try:
+            call()
+            return sorted(libvips_amd.gate_report())
+        finally:
+            lib.vips_hip_gate_enable(0)
+            lib.vips_hip_gate_reset()
+
+    band = sorted([BH, BV, SH])
+    for (w, h) in ((2048, 1000), (4096, 3000), (400, 300)):
+        im = Image.new_from_array(helpers.lcg_image(w, h, 3, np.uint8, 9))
+        assert gates(lambda: im.resize(0.123).numpy()) == band, (w, h)
+    small = [Image.new_from_array(helpers.lcg_image(1024, 768, 3, np.uint8, 20 + k), interpretation="srgb") for k in range(6)]
+    assert gates(lambda: libvips_amd.resize_sharpen_batch(small, 0.123, sharpen=False)) == ["resize_streamg_u8"]
+    large = [Image.new_from_array(helpers.lcg_image(4096, 1024, 3, np.uint8, 30 + k), interpretation="srgb") for k in range(5)]
+    outs = None
+
+    def run_large():
+        nonlocal outs
+        outs = libvips_amd.resize_sharpen_batch(large, 0.123, sharpen=False)
+    assert gates(run_large) == band
+    for k in (0, 4):
+        assert np.array_equal(outs[k].numpy(), large[k].resize(0.123).numpy())
