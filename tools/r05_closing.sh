@@ -47,6 +47,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/pa_ops -o kt -- $ops > /dev/null 2>&1
 cd $repo
 cut -c1-170 gpurun_out/${tag}_c2_pmc.txt
 cut -c1-170 gpurun_out/${tag}_c3_pmc.txt
+(timeout 100 python tools/fuzz_gpu.py 40 91 resize; timeout 100 python tools/fuzz_gpu.py 30 92 thumb) 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_fuzz.txt; cat gpurun_out/${tag}_fuzz.txt
 (timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo rc=$?
 python - <<PY
 import json
