@@ -1139,6 +1139,8 @@ def ops_table():
     masked("convi_5x5_u16", rgb16, lambda im: im.conv(k5, scale=256, precision="integer"), "conv", k5, 256.0, "precision=integer")
     chain("gaussblur_s2_u8", rgb8, lambda im: im.gaussblur(2.0), "gaussblur:sigma=2")
     chain("gaussblur_s8_u8", rgb8, lambda im: im.gaussblur(8.0), "gaussblur:sigma=8")
+    chain("gaussblur_s2_u16", rgb16, lambda im: im.gaussblur(2.0), "gaussblur:sigma=2")
+    chain("gaussblur_s8_u16", rgb16, lambda im: im.gaussblur(8.0), "gaussblur:sigma=8")
     chain("gaussblur_s2_f32", rgbf, lambda im: im.gaussblur(2.0, precision="float"), "gaussblur:sigma=2,precision=float",
           float_out=True)
     chain("colourspace_srgb_lab_u8", rgb8, lambda im: im.colourspace("lab"), "colourspace:space=lab", float_out=True)

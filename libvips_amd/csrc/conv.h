@@ -51,6 +51,8 @@ int convsep_stream_fused(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 int conv_u8_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConv *pass1, double offset2);
 // ... on the matrix cores (conv_u8_mfma.hip): masks of 3 .. 33 taps, 1 .. 4 bands
 int conv_u8_mfma_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConv *pass1, double offset2);
+// ... and of ushort images: their bytes as 2 x bands planes, two exact products per sample and pass
+int conv_u16_mfma_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConv *pass1, double offset2);
 int conv_u8_mfma_2d_try(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConv *c);
 int conv_u8_2d_try(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConv *c);
 // conv_u16.hip: the same for ushort images and masks up to 5 x 5 (1 = not its case, 0 = done, -1 = error)

@@ -20,6 +20,18 @@ conv_u8_mfma_sep(CmArgs a, int items)
 		conv_u8_mfma_item<B, WIDE, MODE>(a, item, cm_lds);
 }
 
+// ushort: B byte planes (2 x bands); 93 KB of LDS a block at 3 bands, one or two blocks a CU
+template <int B, bool WIDE>
+__global__ void __launch_bounds__(256, B <= 4 ? 2 : 1)
+conv_u16_mfma_sep(CmArgs a, int items)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned int cm_lds[];
+	const int per = (items + 7) >> 3;
+	const int item = (int) (blockIdx.x & 7) * per + (int) (blockIdx.x >> 3);
+	if ((int) (blockIdx.x >> 3) < per && item < items)
+		conv_u8_mfma_item<B, WIDE, 0, true>(a, item, cm_lds);
+}
+
 } // namespace vh
 
 #include "conv_u8_mfma_host.h"
@@ -40,6 +52,21 @@ static int cm_go(K kernel, const CmArgs &a, int items, size_t lds)
 	hipLaunchKernelGGL(kernel, dim3(grid), dim3(CM_NT), lds, stream(), a, items);
 	VH_CHECK(hipGetLastError());
 	return 0;
+}
+
+static int cm_launch16(int bands, bool wide, const CmArgs &a, int grid, size_t lds)
+{
+#define CM_CASE16(NB) \
+	case NB: \
+		return wide ? cm_go(conv_u16_mfma_sep<2 * NB, true>, a, grid, lds) : cm_go(conv_u16_mfma_sep<2 * NB, false>, a, grid, lds);
+	switch (bands) {
+		CM_CASE16(1)
+		CM_CASE16(2)
+		CM_CASE16(3)
+		CM_CASE16(4)
+	}
+#undef CM_CASE16
+	return 1;
 }
 
 static int cm_launch(int bands, bool wide, bool twod, const CmArgs &a, int grid, size_t lds)

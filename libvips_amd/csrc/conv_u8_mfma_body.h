@@ -61,6 +61,9 @@ struct CmArgs {
 	int in_pitch;        // ... and its pitch in LDS (a whole number of units; an odd number of them, or of dword pairs)
 	int in_buf;          // dwords per staging buffer: 32 in_pitch, + the last instruction's overrun
 	float k1, bias;      // 2^24 RN(1 / scale); -0.5 + 1 / (2 scale) + (scale / 2) RN(1 / scale): checked on the host
+	int rnd;             // ushort: (S + rnd) / scale as ((S + rnd) * div_m) >> (32 + div_s), S + rnd < 2^31 (div_m = 0: scale 1)
+	unsigned int div_m;
+	int div_s;
 	const unsigned int *tz;      // the Toeplitz operands: 4 tables of [4 k-steps][64 lanes][4 dwords]: the mask's, and
 	int edge_wave[3];            // pass 1's for the tiles 32 edge_wave[k] .. + 32 whose windows hang over an edge (-1: none)
 };
@@ -82,13 +85,49 @@ VH_DEV void cm_halves(const unsigned int (&raw)[B], int b, unsigned int &a0, uns
 	}
 }
 
+// ushort (conv_u8_mfma_item<B, .., U16 = true>: B = 2 x bands BYTE planes, plane 2 b the low bytes of band b): the two
+// exact sums of a sample -- of the low and of the high bytes, each n 2^-24 -- to clip((256 S_hi + S_lo + rnd) / scale,
+// 0, 65535) in 32-bit integers (convi.c:698-716 for unsigned short: int sums, C division -- a negative numerator
+// gives a quotient <= 0, clipped to 0 either way); the host keeps 256 S_hi + S_lo + rnd below 2^31
+VH_DEV unsigned int cm_fin16(float lo, float hi, const CmArgs &a)
+{
+	const int s = (vh::cvt_i32(hi * 16777216.0f) << 8) + vh::cvt_i32(lo * 16777216.0f) + a.rnd;
+	if (s <= 0)
+		return 0u;
+	const unsigned int q = a.div_m ? (unsigned int) (((unsigned long long) (unsigned int) s * a.div_m) >> 32) >> a.div_s : (unsigned int) s;
+	return min(q, 65535u);
+}
+
+// 4 pixels x NB bands of ushort samples given as byte planes (lo[b], hi[b]: the 4 pixels' low / high bytes of band
+// b) -> the 2 NB dwords as they lie in memory (sample (p, b) = halfword p NB + b)
+template <int NB>
+VH_DEV void cm_interleave16(const unsigned int (&lo)[NB], const unsigned int (&hi)[NB], unsigned int (&w)[2 * NB])
+{
+	// pl[b][h]: pixels 2 h, 2 h + 1 of band b as two ushorts
+	unsigned int pl[NB][2];
+#pragma unroll
+	for (int b = 0; b < NB; b++) {
+		pl[b][0] = perm(hi[b], lo[b], 0x05010400u);
+		pl[b][1] = perm(hi[b], lo[b], 0x07030602u);
+	}
+#pragma unroll
+	for (int d = 0; d < 2 * NB; d++) {
+		const int h0 = 2 * d, h1 = 2 * d + 1;
+		const int p0 = h0 / NB, b0 = h0 % NB, p1 = h1 / NB, b1 = h1 % NB;
+		w[d] = perm(pl[b1][p1 >> 1], pl[b0][p0 >> 1],
+			((4u + 2u * (unsigned int) (p1 & 1) + 1u) << 24) | ((4u + 2u * (unsigned int) (p1 & 1)) << 16) |
+				((2u * (unsigned int) (p0 & 1) + 1u) << 8) | (2u * (unsigned int) (p0 & 1)));
+	}
+}
+
 // one work item: strip x segment
 // MODE: 0 separable; 3 / 5: a two-dimensional mask of that many rows whose window takes 3 steps, its operands in
 // registers for the whole item; -1: any other two-dimensional mask (operands fetched as they are used)
-template <int B, bool WIDE, int MODE>
+template <int B, bool WIDE, int MODE, bool U16 = false>
 VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 {
 	constexpr bool TWOD = MODE != 0;
+	static_assert(!U16 || (MODE == 0 && B % 2 == 0), "ushort: the separable form, B byte planes");
 	const int t = tid(), lane = t & 63, wv = wave_index(), n = lane & 31, hf = lane >> 5;
 	const int strip = item % a.strips, seg = item / a.strips;
 	const int X0 = strip * CM_BW;
@@ -295,6 +334,80 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 #pragma unroll
 				for (int i = 0; i < B; i++)
 					raw[s][g][i] = src[B * (4 * s + 2 * g) + i];
+		if constexpr (U16) {
+#pragma unroll
+		for (int b = 0; b < B / 2; b++) {
+			// ---- pass 1: the low and the high bytes of band b, each its own exact product
+			float acc[2][16];
+#pragma unroll
+			for (int part = 0; part < 2; part++)
+#pragma unroll
+				for (int s = 0; s < 4; s++) {
+					if (s == 3 && a.ksteps < 4)
+						continue;
+					unsigned int A[4];
+					cm_halves<B>(raw[s][0], 2 * b + part, A[0], A[1]);
+					cm_halves<B>(raw[s][1], 2 * b + part, A[2], A[3]);
+					if (s == 0)
+						mfma_32x32x16_f16_first(A, Th[s], acc[part]);
+					else
+						mfma_32x32x16_f16(A, Th[s], acc[part]);
+				}
+			// rows (r & 3) + 8 (r >> 2) + 4 hf of column n as ushorts: their bytes are pass 2's two operands
+			unsigned int mid_cur[2][8];
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				const unsigned int v0 = cm_fin16(acc[0][2 * q], acc[1][2 * q], a), v1 = cm_fin16(acc[0][2 * q + 1], acc[1][2 * q + 1], a);
+				mid_cur[0][q] = (v0 & 255u) | ((v1 & 255u) << 16);
+				mid_cur[1][q] = (v0 >> 8) | ((v1 >> 8) << 16);
+			}
+			// ---- pass 2: output rows Ya + 32 (c - 1) .. + 32
+			if (c >= 1) {
+#pragma unroll
+				for (int part = 0; part < 2; part++) {
+					unsigned int A[4];
+#pragma unroll
+					for (int s = 0; s < 2; s++) {
+#pragma unroll
+						for (int q = 0; q < 4; q++)
+							A[q] = mid_prev[2 * b + part][4 * s + q];
+						if (s == 0)
+							mfma_32x32x16_f16_first(A, T[s], acc[part]);
+						else
+							mfma_32x32x16_f16(A, T[s], acc[part]);
+					}
+#pragma unroll
+					for (int s = 0; s < 2; s++) {
+						if (s == 1 && a.ksteps < 4)
+							continue;
+#pragma unroll
+						for (int q = 0; q < 4; q++)
+							A[q] = mid_cur[part][4 * s + q];
+						mfma_32x32x16_f16(A, T[2 + s], acc[part]);
+					}
+				}
+#pragma unroll
+				for (int j = 0; j < 4; j++) {
+					unsigned int wl = 0, wh = 0;
+#pragma unroll
+					for (int i = 0; i < 4; i++) {
+						const unsigned int v = cm_fin16(acc[0][4 * j + i], acc[1][4 * j + i], a);
+						wl |= (v & 255u) << (8 * i);
+						wh |= (v >> 8) << (8 * i);
+					}
+					P[2 * b][j] = wl;
+					P[2 * b + 1][j] = wh;
+				}
+			}
+#pragma unroll
+			for (int part = 0; part < 2; part++)
+#pragma unroll
+				for (int q = 0; q < 8; q++)
+					mid_prev[2 * b + part][q] = mid_cur[part][q];
+			sched_fence(); // (one band's accumulators at a time)
+		}
+		}
+		else {
 #pragma unroll
 		for (int b = 0; b < B; b++) {
 			// ---- pass 1 (the accumulators start at 0: the rounding constant is in a.bias)
@@ -356,6 +469,7 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 			sched_fence(); // (one band's accumulators at a time)
 		}
 		}
+		}
 		if (TWOD || c >= 1) {
 			// row n, columns 8 j + 4 hf .. + 3 of the wave's tile: bands interleaved, B dwords
 			unsigned int *orow = otile + n * OP + B * hf;
@@ -365,7 +479,17 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 #pragma unroll
 				for (int b = 0; b < B; b++)
 					Pj[b] = P[b][j];
-				cu8_interleave<B>(Pj, w);
+				if constexpr (U16) {
+					unsigned int lo[B / 2], hi[B / 2];
+#pragma unroll
+					for (int b = 0; b < B / 2; b++) {
+						lo[b] = Pj[2 * b];
+						hi[b] = Pj[2 * b + 1];
+					}
+					cm_interleave16<B / 2>(lo, hi, w);
+				}
+				else
+					cu8_interleave<B>(Pj, w);
 #pragma unroll
 				for (int b = 0; b < B; b++)
 					orow[2 * B * j + b] = w[b];

@@ -17,6 +17,8 @@ namespace vh {
 
 // defined by the including file; 0 on success
 static int cm_launch(int bands, bool wide, bool twod, const CmArgs &a, int grid, size_t lds);
+// ... the ushort form (separable masks): bands = samples per pixel
+static int cm_launch16(int bands, bool wide, const CmArgs &a, int grid, size_t lds);
 
 namespace {
 
@@ -167,7 +169,7 @@ int cm_tables_device(const int *c, int n, int rows, int hp, int width, CmTables 
 bool cm_geometry(const _VipsHipImage *in, const _VipsHipImage *out, const _VipsHipConv *c, int half, int mh, CmArgs *pa,
 	size_t *plds, bool *pwide)
 {
-	const int B = in->bands;
+	const int B = in->bands * (in->format == VIPS_HIP_FORMAT_USHORT ? 2 : 1); // bytes a pixel: the kernel's byte planes
 	CmArgs &a = *pa;
 	memset(&a, 0, sizeof(a));
 	a.in = (const unsigned char *) in->data;
@@ -207,7 +209,27 @@ bool cm_geometry(const _VipsHipImage *in, const _VipsHipImage *out, const _VipsH
 	}
 	// (whole instructions of 64 units: the last one of a chunk may run past the staged rows)
 	a.in_buf = ((a.stage_rows * (a.in_pitch / (U / 4)) + 63) / 64) * 64 * (U / 4);
-	if (!cm_rounding(c->scale_i, c->rounding, &a.k1, &a.bias))
+	if (in->format == VIPS_HIP_FORMAT_USHORT) {
+		// (S + rnd) / scale for 0 < S + rnd < 2^31 as a multiplication: m = ceil(2^(31 + l) / scale), l = ceil(log2
+		// scale); the error m scale - 2^(31 + l) is below scale <= 2^l, so (S + rnd) m / 2^(31 + l) and (S + rnd) /
+		// scale have the same floor (Granlund & Montgomery 1994, theorem 4.2 with N = 31)
+		a.rnd = c->rounding;
+		if (c->scale_i == 1) {
+			a.div_m = 0;
+			a.div_s = 0;
+		}
+		else {
+			int l = 0;
+			while ((1LL << l) < c->scale_i)
+				l++;
+			const unsigned long long m = ((1ULL << (31 + l)) + (unsigned long long) c->scale_i - 1) / (unsigned long long) c->scale_i;
+			if (m >= (1ULL << 32) || l < 1)
+				return false;
+			a.div_m = (unsigned int) m;
+			a.div_s = l - 1;
+		}
+	}
+	else if (!cm_rounding(c->scale_i, c->rounding, &a.k1, &a.bias))
 		return false;
 	const size_t lds = (size_t) (2 * a.in_buf + (CM_NT / 64) * CM_ROWS * (8 * B + 1)) * sizeof(unsigned int);
 	if (lds > 160 * 1024)
@@ -237,12 +259,13 @@ bool cm_geometry(const _VipsHipImage *in, const _VipsHipImage *out, const _VipsH
 }
 
 // what both kernels ask of the images and the plan's rounding
-bool cm_common(const _VipsHipImage *in, const _VipsHipImage *out, const _VipsHipConv *c, double offset2)
+bool cm_common(const _VipsHipImage *in, const _VipsHipImage *out, const _VipsHipConv *c, double offset2, bool u16 = false)
 {
 	const char *env = getenv("VIPS_HIP_CONV_U8_MFMA");
 	if ((env && atoi(env) == 0) || getenv("VIPS_HIP_NO_CONV_U8"))
 		return false;
-	if (c->precision != VIPS_HIP_PRECISION_INTEGER || in->format != VIPS_HIP_FORMAT_UCHAR || out->format != VIPS_HIP_FORMAT_UCHAR)
+	const int format = u16 ? VIPS_HIP_FORMAT_USHORT : VIPS_HIP_FORMAT_UCHAR;
+	if (c->precision != VIPS_HIP_PRECISION_INTEGER || in->format != format || out->format != format)
 		return false;
 	if (in->bands != out->bands || in->width != out->width || in->height != out->height)
 		return false;
@@ -262,6 +285,9 @@ bool cm_common(const _VipsHipImage *in, const _VipsHipImage *out, const _VipsHip
 			return false;
 		abs_sum += c->coeffi[k] < 0 ? -c->coeffi[k] : c->coeffi[k];
 	}
+	// (ushort: the two byte planes' sums each below 2^24, and 256 S_hi + S_lo + rounding in an int as in the reference)
+	if (u16 && abs_sum * 65535 + c->rounding >= (1LL << 31))
+		return false;
 	return abs_sum * 255 + c->rounding < (1LL << 24);
 }
 
@@ -292,6 +318,34 @@ int conv_u8_mfma_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _Vip
 		a.edge_wave[k] = tabs.edge_wave[k];
 	Gate gate("conv_u8_mfma_sep");
 	return cm_launch(B, wide, false, a, a.strips * a.segs, lds);
+}
+
+// The same on a ushort image: its bytes as 2 x bands planes of a uchar image through the same staging and the same
+// operands, two exact products per sample and pass (low and high bytes), put together as integers where a pass
+// rounds (conv_u8_mfma_body.h cm_fin16).  1 = not this kernel's case (nothing launched), 0 = done, -1 = error.
+int conv_u16_mfma_sep_try(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConv *c, double offset2)
+{
+	if (c->mask_height != 1 || c->nnz != c->mask_width || !(c->mask_width & 1) || c->mask_width > 33 || c->mask_width < 3)
+		return 1;
+	if (getenv("VIPS_HIP_NO_CONV_U16_MFMA") || !cm_common(in, out, c, offset2, true))
+		return 1;
+	const int n = c->mask_width;
+	CmArgs a;
+	size_t lds;
+	bool wide;
+	if (!cm_geometry(in, out, c, n / 2, 0, &a, &lds, &wide))
+		return 1;
+	CmTables tabs;
+	{
+		const int r = cm_tables_device(c->coeffi.data(), n, 1, a.hp, a.width, &tabs);
+		if (r)
+			return r;
+	}
+	a.tz = tabs.tz;
+	for (int k = 0; k < 3; k++)
+		a.edge_wave[k] = tabs.edge_wave[k];
+	Gate gate("conv_u16_mfma_sep");
+	return cm_launch16(in->bands, wide, a, a.strips * a.segs, lds);
 }
 
 // vips_conv (precision integer) with a two-dimensional mask of up to 9 rows and 33 columns on a uchar image: one

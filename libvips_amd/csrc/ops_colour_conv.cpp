@@ -633,6 +633,8 @@ int vips_hip_convsep(VipsHipImage *in, VipsHipImage **out, const double *mask, i
 		if (r == 1)
 			r = vh::conv_u8_mfma_sep_try(in, o.im, c.get(), 0.0);
 		if (r == 1)
+			r = vh::conv_u16_mfma_sep_try(in, o.im, c.get(), 0.0);
+		if (r == 1)
 			r = vh::conv_u8_sep_try(in, o.im, c.get(), 0.0);
 		if (r == 1)
 			r = vh::convsep_f32_fused(in, o.im, c.get(), 0.0);

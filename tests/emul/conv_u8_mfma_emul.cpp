@@ -11,7 +11,7 @@
 
 namespace vh {
 
-template <int B, bool WIDE, int MODE>
+template <int B, bool WIDE, int MODE, bool U16 = false>
 static void cm_run(const CmArgs &a, int items, size_t lds)
 {
 	(void) hipStreamSynchronize(stream());
@@ -24,7 +24,7 @@ static void cm_run(const CmArgs &a, int items, size_t lds)
 				break;
 			for (size_t i = 0; i < buf.size(); i++)
 				buf[i] = 0xdeadbeefu + (unsigned int) i * 2654435761u;
-			emul::run_block(CM_NT, [&]() { conv_u8_mfma_item<B, WIDE, MODE>(a, item, buf.data()); });
+			emul::run_block(CM_NT, [&]() { conv_u8_mfma_item<B, WIDE, MODE, U16>(a, item, buf.data()); });
 		}
 	};
 	unsigned int nthreads = std::thread::hardware_concurrency();
@@ -34,6 +34,25 @@ static void cm_run(const CmArgs &a, int items, size_t lds)
 		pool.emplace_back(worker);
 	for (std::thread &t : pool)
 		t.join();
+}
+
+static int cm_launch16(int bands, bool wide, const CmArgs &a, int grid, size_t lds)
+{
+#define CM_CASE16(NB) \
+	case NB: \
+		if (wide) \
+			cm_run<2 * NB, true, 0, true>(a, grid, lds); \
+		else \
+			cm_run<2 * NB, false, 0, true>(a, grid, lds); \
+		return 0;
+	switch (bands) {
+		CM_CASE16(1)
+		CM_CASE16(2)
+		CM_CASE16(3)
+		CM_CASE16(4)
+	}
+#undef CM_CASE16
+	return 1;
 }
 
 static int cm_launch(int bands, bool wide, bool twod, const CmArgs &a, int grid, size_t lds)

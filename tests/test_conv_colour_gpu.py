@@ -419,7 +419,7 @@ def test_fused_convsep_integer(shape, sigma, dtype):
         lib.vips_hip_gate_reset()
     if sigma >= 2.0:  # masks shorter than 7 taps stay on the two register-tiled passes
         # (uchar images whose rows are whole dwords: the packed-byte kernel of conv_u8.hip)
-        assert any(k.startswith("convsep_") or k in ("conv_u8_sep", "conv_u8_mfma_sep") for k in report), report
+        assert any(k.startswith("convsep_") or k in ("conv_u8_sep", "conv_u8_mfma_sep", "conv_u16_mfma_sep") for k in report), report
     want = PortCC.gaussblur(src, sigma)
     assert got.dtype == src.dtype and np.array_equal(got, want)
     os.environ["VIPS_HIP_NO_FUSED_CONVSEP"] = "1"

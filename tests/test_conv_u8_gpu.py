@@ -85,3 +85,53 @@ def test_conv_u8(case, env, monkeypatch):
     monkeypatch.setenv("VIPS_HIP_NO_CONV_U8", "1")
     if kind == "blur":
         assert np.array_equal(got, im.gaussblur(arg).numpy())
+
+
+CASES16 = [
+    ("blur", 1100, 70, 3, 2.0), ("blur", 332, 41, 1, 1.0), ("blur", 2071, 37, 4, 2.0), ("blur", 1028, 150, 3, 4.0),
+    ("blur", 600, 130, 2, 6.0), ("blur", 532, 140, 3, 8.0), ("blur", 96, 33, 3, 2.0), ("blur", 640, 64, 3, 2.0, "flat"),
+    ("blur", 1024, 90, 4, 8.0, "flat"),
+    ("sep", 700, 50, 3, ([1, -3, 9, -3, 1], 5)), ("sep", 260, 40, 1, ([5, 1, 5], 11)),
+    ("sep", 172, 70, 3, (list(range(1, 18)) + list(range(16, 0, -1)), 289)),
+    ("blur", 4096, 4096, 3, 2.0), ("blur", 4096, 3001, 4, 8.0), ("blur", 8192, 2048, 1, 3.0), ("blur", 8192, 4099, 3, 8.0),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES16)))
+@pytest.mark.parametrize("env", [{}, {"VIPS_HIP_CONV_MFMA_SEG": "2"}, {"VIPS_HIP_CONV_MFMA_NARROW": "1"}])
+def test_conv_u16_separable_on_the_matrix_cores(case, env, monkeypatch):
+    """vips_gaussblur / vips_convsep (precision integer) on ushort images: conv_u8_mfma_body.h with the image's bytes
+    as 2 x bands planes, two exact products per sample and pass -- against the compiled reference and against the
+    vector-ALU kernel it replaced."""
+    case = CASES16[case]
+    kind, w, h, bands, arg = case[:5]
+    if env and w * h > 2000 * 2000:
+        pytest.skip("the variants on the small cases only")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    src = helpers.lcg_image(w, h, bands, np.uint16, 7 + w)
+    if len(case) > 5:
+        src[: h // 2] = 65535
+        src[h // 2:, : w // 3] = 0
+    im = Image.new_from_array(src)
+
+    def run():
+        if kind == "blur":
+            return im.gaussblur(arg).numpy()
+        return im.convsep(arg[0], scale=arg[1], precision="integer").numpy()
+
+    libvips_amd.lib.vips_hip_gate_reset()
+    libvips_amd.lib.vips_hip_gate_enable(1)
+    try:
+        got = run()
+        report = libvips_amd.gate_report()
+    finally:
+        libvips_amd.lib.vips_hip_gate_enable(0)
+        libvips_amd.lib.vips_hip_gate_reset()
+    assert list(report) == ["conv_u16_mfma_sep"], report
+    want = _reference(kind, src, arg)
+    assert got.shape == want.shape and got.dtype == want.dtype
+    bad = np.argwhere(got != want)
+    assert len(bad) == 0, (len(bad), bad[:5])
+    monkeypatch.setenv("VIPS_HIP_NO_CONV_U16_MFMA", "1")
+    assert np.array_equal(got, run())

@@ -27,14 +27,16 @@ libvips_amd.init(0)
 lib = libvips_amd.lib
 for case in %(cases)r:
     kind, w, h, bands = case[:4]
-    src = helpers.lcg_image(w, h, bands, np.uint8, 7 + w)
+    u16 = kind.endswith("16")
+    kind = kind[:-2] if u16 else kind
+    src = helpers.lcg_image(w, h, bands, np.uint16 if u16 else np.uint8, 7 + w)
     if len(case) > 5 and case[5] == "flat":
-        src[: h // 2] = 255
+        src[: h // 2] = 65535 if u16 else 255
         src[h // 2:, : w // 3] = 0
     im = Image.new_from_array(src)
     lib.vips_hip_gate_reset()
     lib.vips_hip_gate_enable(1)
-    gate = "conv_u8_mfma_sep"
+    gate = "conv_u16_mfma_sep" if u16 else "conv_u8_mfma_sep"
     if kind == "blur":
         sigma = case[4]
         got = im.gaussblur(sigma).numpy()
@@ -109,3 +111,16 @@ def test_conv_2d(tmp_path):
 def test_short_segments(tmp_path):
     # two chunks per segment: every segment boundary inside the image, top and bottom rows clamped
     _run([("blur", 300, 200, 3, 2.0), ("blur", 160, 230, 3, 8.0)], tmp_path, {"VIPS_HIP_CONV_MFMA_SEG": "2"})
+
+
+def test_ushort_gaussblur_and_convsep(tmp_path):
+    # the same kernel on ushort images (2 x bands byte planes, two exact products per sample and pass, the rounding
+    # in integers): sigma 1 .. 8, 1 .. 4 bands, ragged strips, saturated and zero areas, a mask with negative taps,
+    # the widest window; 16-byte and dword staging units; segment boundaries inside the image
+    _run([("blur16", 300, 70, 3, 2.0), ("blur16", 332, 41, 1, 1.0), ("blur16", 271, 37, 4, 2.0),
+          ("blur16", 260, 100, 3, 4.0), ("blur16", 200, 80, 2, 6.0), ("blur16", 300, 140, 3, 8.0),
+          ("blur16", 96, 33, 3, 2.0), ("blur16", 256, 64, 3, 2.0, "flat"), ("blur16", 320, 70, 4, 8.0, "flat"),
+          ("sep16", 200, 50, 3, ([1, -3, 9, -3, 1], 5)), ("sep16", 260, 40, 1, ([5, 1, 5], 11)),
+          ("sep16", 172, 70, 3, (list(range(1, 18)) + list(range(16, 0, -1)), 289))], tmp_path)
+    _run([("blur16", 320, 70, 3, 8.0), ("blur16", 336, 100, 1, 3.0)], tmp_path, {"VIPS_HIP_CONV_MFMA_NARROW": "1"})
+    _run([("blur16", 300, 200, 3, 2.0), ("blur16", 160, 230, 2, 8.0)], tmp_path, {"VIPS_HIP_CONV_MFMA_SEG": "2"})
