@@ -20,9 +20,9 @@ conv_u8_mfma_sep(CmArgs a, int items)
 		conv_u8_mfma_item<B, WIDE, MODE>(a, item, cm_lds);
 }
 
-// ushort: B byte planes (2 x bands); 93 KB of LDS a block at 3 bands, one or two blocks a CU
+// ushort: B byte planes (2 x bands); 75 KB of LDS a block at 3 bands and 33 taps: two blocks a CU (one at 4 bands)
 template <int B, bool WIDE>
-__global__ void __launch_bounds__(256, B <= 4 ? 2 : 1)
+__global__ void __launch_bounds__(256, B <= 6 ? 2 : 1)
 conv_u16_mfma_sep(CmArgs a, int items)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned int cm_lds[];

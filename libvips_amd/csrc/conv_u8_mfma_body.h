@@ -159,8 +159,9 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 
 	// the wave's own output tile in LDS (32 rows x 8 B dwords, pitch odd) and how its lanes copy it out:
 	// 4 B lanes x 8 bytes make a row of the tile, 64 / (4 B) rows per store instruction
-	constexpr int OP = 8 * B + 1, UNITS = 4 * B, RPI = 64 / UNITS;
-	unsigned int *otile = lds + 2 * a.in_buf + wv * (CM_ROWS * OP);
+	// (ushort: the tile leaves in two halves of 16 rows -- half the LDS, and two blocks a CU at 3 bands)
+	constexpr int OP = 8 * B + 1, UNITS = 4 * B, RPI = 64 / UNITS, TR = U16 ? 16 : CM_ROWS;
+	unsigned int *otile = lds + 2 * a.in_buf + wv * (TR * OP);
 	const int o_rsub = lane / UNITS, o_c2 = lane - o_rsub * UNITS;
 	const int o_xb = (X0 + 32 * wv) * B + 8 * o_c2; // byte of the output row
 	const int row_bytes = a.width * B;
@@ -471,38 +472,42 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 		}
 		}
 		if (TWOD || c >= 1) {
+#pragma unroll
+			for (int th = 0; th < CM_ROWS / TR; th++) {
 			// row n, columns 8 j + 4 hf .. + 3 of the wave's tile: bands interleaved, B dwords
-			unsigned int *orow = otile + n * OP + B * hf;
+			if (TR == CM_ROWS || (n >> 4) == th) {
+				unsigned int *orow = otile + (n & (TR - 1)) * OP + B * hf;
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
-				unsigned int Pj[B], w[B];
+				for (int j = 0; j < 4; j++) {
+					unsigned int Pj[B], w[B];
 #pragma unroll
-				for (int b = 0; b < B; b++)
-					Pj[b] = P[b][j];
-				if constexpr (U16) {
-					unsigned int lo[B / 2], hi[B / 2];
+					for (int b = 0; b < B; b++)
+						Pj[b] = P[b][j];
+					if constexpr (U16) {
+						unsigned int lo[B / 2], hi[B / 2];
 #pragma unroll
-					for (int b = 0; b < B / 2; b++) {
-						lo[b] = Pj[2 * b];
-						hi[b] = Pj[2 * b + 1];
+						for (int b = 0; b < B / 2; b++) {
+							lo[b] = Pj[2 * b];
+							hi[b] = Pj[2 * b + 1];
+						}
+						cm_interleave16<B / 2>(lo, hi, w);
 					}
-					cm_interleave16<B / 2>(lo, hi, w);
-				}
-				else
-					cu8_interleave<B>(Pj, w);
+					else
+						cu8_interleave<B>(Pj, w);
 #pragma unroll
-				for (int b = 0; b < B; b++)
-					orow[2 * B * j + b] = w[b];
+					for (int b = 0; b < B; b++)
+						orow[2 * B * j + b] = w[b];
+				}
 			}
 			wave_lds_fence(); // (the tile is the wave's own: no barrier)
-			const int y0 = Ya + CM_ROWS * (TWOD ? c : c - 1);
-			if (y0 + CM_ROWS <= Yb && (X0 + 32 * wv + 32) * B <= row_bytes) {
+			const int y0 = Ya + CM_ROWS * (TWOD ? c : c - 1) + TR * th;
+			if (y0 + TR <= Yb && (X0 + 32 * wv + 32) * B <= row_bytes) {
 				// the whole tile lies inside the image: no lane tests anything but its row of the last instruction
 				const gptr_out tile_out = gout + (long long) y0 * a.out_stride;
 #pragma unroll
-				for (int i = 0; i < (CM_ROWS + RPI - 1) / RPI; i++) {
+				for (int i = 0; i < (TR + RPI - 1) / RPI; i++) {
 					const int row = RPI * i + o_rsub;
-					if (o_rsub < RPI && (RPI * (i + 1) <= CM_ROWS || row < CM_ROWS)) {
+					if (o_rsub < RPI && (RPI * (i + 1) <= TR || row < TR)) {
 						unsigned int w[2];
 						w[0] = otile[row * OP + 2 * o_c2];
 						w[1] = otile[row * OP + 2 * o_c2 + 1];
@@ -512,10 +517,10 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 			}
 			else
 #pragma nounroll
-			for (int i = 0; i < (CM_ROWS + RPI - 1) / RPI; i++) {
+			for (int i = 0; i < (TR + RPI - 1) / RPI; i++) {
 				const int row = RPI * i + o_rsub;
 				const int y = y0 + row;
-				if (o_rsub < RPI && row < CM_ROWS && y < Yb && o_xb < row_bytes) {
+				if (o_rsub < RPI && row < TR && y < Yb && o_xb < row_bytes) {
 					unsigned int w[2];
 					w[0] = otile[row * OP + 2 * o_c2];
 					w[1] = otile[row * OP + 2 * o_c2 + 1];
@@ -527,7 +532,8 @@ VH_DEV void conv_u8_mfma_item(const CmArgs &a, int item, unsigned int *lds)
 							gstore8(p + e, (unsigned char) (w[e >> 2] >> (8 * (e & 3))));
 				}
 			}
-			wave_lds_fence(); // (the reads are done before the next chunk's rows overwrite the tile)
+			wave_lds_fence(); // (the reads are done before the next rows overwrite the tile)
+			}
 		}
 	}
 	wait_vmem0();

@@ -231,7 +231,9 @@ bool cm_geometry(const _VipsHipImage *in, const _VipsHipImage *out, const _VipsH
 	}
 	else if (!cm_rounding(c->scale_i, c->rounding, &a.k1, &a.bias))
 		return false;
-	const size_t lds = (size_t) (2 * a.in_buf + (CM_NT / 64) * CM_ROWS * (8 * B + 1)) * sizeof(unsigned int);
+	// (the waves' output tiles: 32 rows, 16 on ushort images)
+	const int tile_rows = in->format == VIPS_HIP_FORMAT_USHORT ? 16 : CM_ROWS;
+	const size_t lds = (size_t) (2 * a.in_buf + (CM_NT / 64) * tile_rows * (8 * B + 1)) * sizeof(unsigned int);
 	if (lds > 160 * 1024)
 		return false;
 	// segments: one residency round of blocks (LDS allows 3 per CU); a separable segment re-makes one chunk of 32 rows
