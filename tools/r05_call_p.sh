@@ -1,5 +1,5 @@
 # the ushort separable convolution on the matrix cores: parity, time (default / the vector-ALU kernel)
-timeout 900 python -m pytest tests/test_conv_u8_gpu.py tests/test_conv_colour_gpu.py tests/test_conv_u16_gpu.py -x -q -m gpu 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_conv_u8_gpu.py -x -q -m gpu 2>&1 | tail -3
 show() { python -c "
 import json,sys
 l=json.loads(sys.stdin.read().strip().splitlines()[-1])
