@@ -5,7 +5,7 @@ gaussblur on uchar.  Whatever kernel the dispatcher picks must give the referenc
 emulated one; cases that land on a kernel the mock runtime cannot run (no pixels) are counted and skipped.
 
 usage:  LD_PRELOAD=tests/mock_hip/_build/libmockhip.so VIPS_HIP_LIBRARY=tests/emul/_build/libvipship_emul.so \
-        python tools/fuzz_emul.py [cases] [seed]
+        python tools/fuzz_emul.py [cases] [seed] [kind,kind,...]
 """
 import os
 import sys
@@ -17,21 +17,23 @@ import libvips_amd  # noqa: E402
 from libvips_amd import Image  # noqa: E402
 from tests import helpers  # noqa: E402
 
-EMULATED = {"shrinkh_u8_stream", "shrinkv_reducev_u8_band", "reduceh_u8_packed", "reducev_u8_stream", "reducev_u8_band", "reduceh_u8_band", "reducev_u16_band", "reduceh_u16_band", "conv_u16_2d", "conv_u8_2d", "conv_u8_sep", "conv_u8_mfma_sep", "conv_u8_mfma_2d",
+EMULATED = {"shrinkh_u8_stream", "shrinkv_reducev_u8_band", "reduceh_u8_packed", "reducev_u8_stream", "reducev_u8_band", "reduceh_u8_band", "reducev_u16_band", "reduceh_u16_band", "conv_u16_2d", "conv_u8_2d", "conv_u8_sep", "conv_u8_mfma_sep", "conv_u8_mfma_2d", "conv_u16_mfma_sep",
             "shrinkv_u16_stream", "shrinkh_u16_stream", "reducev_u16_stream", "reduceh_u16_lds"}
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+# (round 5: ushort gaussblur / convsep on the matrix cores, and vips_resize through the band chain)
+KINDS = sys.argv[3].split(",") if len(sys.argv) > 3 else ["shrinkh", "reduceh", "reducev", "conv16", "conv8", "blur8", "blur16", "sep16", "resize"]
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 libvips_amd.init(0)
 lib = libvips_amd.lib
 ran = {}
 skipped = 0
 for case in range(n_cases):
-    kind = rng.choice(["shrinkh", "reduceh", "reducev", "conv16", "conv8", "blur8"])
+    kind = rng.choice(KINDS)
     bands = int(rng.choice([1, 2, 3, 4]))
     # widths that make rows of whole dwords most of the time
     w = int(rng.integers(1, 160)) * 4 if rng.random() < 0.8 else int(rng.integers(2, 700))
     h = int(rng.integers(1, 90))
-    dt = np.uint16 if kind == "conv16" else np.uint8
+    dt = np.uint16 if kind in ("conv16", "blur16", "sep16") else np.uint8
     src = helpers.lcg_image(w, h, bands, dt, 1000 + case)
     if rng.random() < 0.3:
         src[: h // 2] = np.iinfo(dt).max
@@ -76,8 +78,27 @@ for case in range(n_cases):
             scale = int(max(1, abs(mask.sum()))) if rng.random() < 0.7 else int(rng.integers(1, 300))
             got = im.conv(mask, scale=scale, precision="integer").numpy()
             want = lambda: helpers.Ref.run_mask("conv", src, mask, scale, 0.0, "precision=integer")
+        elif kind == "sep16":
+            n = int(rng.choice([3, 5, 7, 9, 13, 21, 33]))
+            mask = rng.integers(-3, 30, size=n).astype(np.float64)
+            scale = int(max(1, abs(mask.sum()))) if rng.random() < 0.7 else int(rng.integers(1, 500))
+            got = im.convsep(list(mask), scale=scale, precision="integer").numpy()
+            want = lambda: helpers.Ref.run_mask("convsep", src, mask[None, :], scale, 0.0, "precision=integer")
+        elif kind == "resize":
+            hh = int(rng.integers(40, 900))
+            src = helpers.lcg_image(w, hh, bands, np.uint8, 4000 + case)
+            if rng.random() < 0.3:
+                src[: hh // 2] = 255
+            im = Image.new_from_array(src)
+            hscale = float(rng.choice([0.45, 0.3, 0.23, 0.17, 0.11, 0.07]))
+            vscale = 1.0 / float(rng.uniform(2.1, 34.0))
+            if w * hscale < 2 or hh * vscale < 2:
+                continue
+            got = im.resize(hscale, vscale=vscale).numpy()
+            chain = "resize:scale=%r,vscale=%r" % (hscale, vscale)
+            want = lambda: helpers.Ref.run_chain(chain, src)
         else:
-            if bands == 2:
+            if bands == 2 and kind == "blur8":
                 continue
             sigma = float(rng.choice([1.0, 2.0, 3.0, 5.0, 8.0]))
             got = im.gaussblur(sigma).numpy()
