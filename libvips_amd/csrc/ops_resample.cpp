@@ -278,7 +278,7 @@ int resize_down_u8_stream(VipsHipImage *const *in, int n, VipsHipImage **out, co
 			pi.data(), po.data(), n, g_fatstrip_height);
 	// any other residual (a size that does not divide the image): shrinkv + reducev as one matrix-core kernel, then
 	// shrinkh, then reduceh on the matrix cores (reduce_band.hip) -- three launches that beat the one-kernel chain
-	// of resize_streamg.hip (8192^2 x 3 to 1000^2: 0.062 against 0.079 ms; profiles/NOTES.md R5.5)
+	// of resize_streamg.hip (8192^2 x 3 to 1000^2: 0.0515 against 0.079 ms; profiles/NOTES.md R5.5, R5.6)
 	// (three launches per image, every one of them spread over the whole image: a single image of any size -- the
 	// one-kernel chain walks a small image's rows with a handful of blocks, 50 us against 13 at 1024^2 x 3,
 	// tools/band_threshold.py -- and a batch of images of 8 MB and more; a batch of small ones stays with the
