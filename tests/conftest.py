@@ -13,6 +13,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "ref: needs the compiled reference in oracle/_ref")
 
 
+# Test files whose cases are child processes of minutes each (see helpers.Background): each has a
+# prestart(selected test names) that launches the children of the selected cases.
+PRESTART = ("test_emul_gpu_suite", "test_module_stream")
+
+
+def pytest_collection_finish(session):
+    if hasattr(session.config, "workerinput") or session.config.option.collectonly:
+        return  # (pytest-xdist workers start theirs when the test itself runs)
+    selected = {}
+    for item in session.items:
+        mod = getattr(item, "module", None)
+        name = getattr(mod, "__name__", "").rsplit(".", 1)[-1]
+        if name in PRESTART and hasattr(mod, "prestart"):
+            selected.setdefault(mod, []).append(item.name)
+    for mod, names in selected.items():
+        mod.prestart(names)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    from tests import helpers
+
+    helpers.Background.reap_all()
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built():
     """Make sure the HIP library and the oracle port are built (no-op when fresh)."""

@@ -768,3 +768,50 @@ def read_v(path):
     dtype = np.dtype(FORMAT_DTYPES[fmt])
     n = w * h * b * dtype.itemsize
     return np.frombuffer(raw[64:64 + n], dtype=dtype).reshape(h, w, b).copy(), interp
+
+
+class Background(object):
+    """Child processes of the CPU suite that take minutes (a `-m gpu` file on host fibers, the module's strip
+    producer under the mock runtime): started early -- tests/conftest.py starts the selected ones when collection
+    ends -- and waited for by the test that asserts on them, so that they run beside the rest of the suite
+    instead of after it.  Test infrastructure only."""
+
+    jobs = {}
+
+    @classmethod
+    def start(cls, name, cmd, env=None, cwd=None):
+        import subprocess
+        import tempfile
+
+        if name in cls.jobs:
+            return
+        out = tempfile.TemporaryFile(mode="w+")
+        cls.jobs[name] = (subprocess.Popen(cmd, stdout=out, stderr=subprocess.STDOUT, text=True, env=env, cwd=cwd), out)
+
+    @classmethod
+    def wait(cls, name, timeout=3000):
+        """-> (returncode, everything the child printed); the job is forgotten."""
+        import subprocess
+
+        proc, out = cls.jobs.pop(name)
+        try:
+            proc.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            proc.wait()
+            out.close()
+            raise
+        out.seek(0)
+        text = out.read()
+        out.close()
+        return proc.returncode, text
+
+    @classmethod
+    def reap_all(cls):
+        """(runs nobody waited for: -x after a failure, a keyboard interrupt)"""
+        for proc, out in cls.jobs.values():
+            if proc.poll() is None:
+                proc.kill()
+                proc.wait()
+            out.close()
+        cls.jobs.clear()

@@ -26,7 +26,9 @@ EMUL_SO = os.path.join(EMUL_DIR, "_build", "libvipship_emul.so")
 def _build_emul():
     if not os.path.isdir(os.path.join(helpers.ROOT, "libvips_amd", "csrc", "_obj")):
         return False
-    proc = subprocess.run(["make", "-C", EMUL_DIR], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    # (a cold build is 26 translation units of whole kernel files: minutes one after another)
+    proc = subprocess.run(["make", "-j", str(os.cpu_count() or 4), "-C", EMUL_DIR], stdout=subprocess.PIPE,
+                          stderr=subprocess.STDOUT, text=True)
     return proc.returncode == 0 and os.path.exists(EMUL_SO)
 
 

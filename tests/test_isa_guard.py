@@ -33,10 +33,18 @@ def _disassemble(obj, tmp):
 def test_no_packed_shift_clamp_in_device_code(tmp_path):
     objs = sorted(glob.glob(os.path.join(OBJ, "*.hip.o")))
     assert len(objs) >= 15, objs
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(obj):
+        tmp = os.path.join(str(tmp_path), os.path.basename(obj) + ".d")
+        os.makedirs(tmp)
+        return _disassemble(obj, tmp)
+
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as pool:
+        texts = list(pool.map(one, objs))
     bad = {}
     kernels = 0
-    for obj in objs:
-        text = _disassemble(obj, str(tmp_path))
+    for obj, text in zip(objs, texts):
         kernels += len(re.findall(r"^[0-9a-f]+ <_Z\w+>:", text, flags=re.M))
         n = text.count("v_ashr_pk_u8_i32")
         if n:

@@ -10,7 +10,6 @@ producer / cache / generate machinery, bit for bit against the built-in gaussblu
 access pattern.  GPU: the same on the device, plus the resample family and a large float image with
 the process's resident set watched."""
 import os
-import subprocess
 import sys
 
 import numpy as np
@@ -97,22 +96,36 @@ print("CHILD-OK")
 '''
 
 
-@pytest.mark.skipif(_gpu_present() or not helpers.have_module() or not _build_mock() or not _build_emul(),
+RING_ENABLED = not (_gpu_present() or not helpers.have_module() or not _build_mock() or not _build_emul())
+RING_TEST = "test_strips_stream_through_a_bounded_host_ring"
+
+
+def prestart(names):
+    """The two ring runs are child processes of half a minute each: started when collection ends
+    (tests/conftest.py), waited for by their test (helpers.Background)."""
+    if not RING_ENABLED:
+        return
+    for name in names:
+        if not name.startswith(RING_TEST + "["):
+            continue
+        devices = int(name[len(RING_TEST) + 1:-1])
+        env = dict(os.environ, LD_PRELOAD=MOCK_SO + ":" + EMUL_SO)
+        if devices > 1:
+            env.update(MOCK_HIP_DEVICES=str(devices), VIPS_HIP_DEVICES=",".join(str(d) for d in range(devices)))
+        helpers.Background.start("module_stream:" + name, [sys.executable, "-c", CHILD % {"root": helpers.ROOT}], env=env)
+
+
+@pytest.mark.skipif(not RING_ENABLED,
                     reason="a real GPU is present, or the reference / module / mock runtime / emulation cannot be built")
 @pytest.mark.parametrize("devices", [1, 2])
-def test_strips_stream_through_a_bounded_host_ring(tmp_path, devices):
+def test_strips_stream_through_a_bounded_host_ring(devices):
     """devices = 2: two fake devices dealt round-robin over the threads that never bind themselves
     ($VIPS_HIP_DEVICES=0,1: libvips' workers AND the strip producers); a producer that is started
     again for an evicted strip goes back to its first run's device (the slot events live there)."""
-    script = os.path.join(str(tmp_path), "child.py")
-    with open(script, "w") as f:
-        f.write(CHILD % {"root": helpers.ROOT})
-    env = dict(os.environ, LD_PRELOAD=MOCK_SO + ":" + EMUL_SO)
-    if devices > 1:
-        env.update(MOCK_HIP_DEVICES=str(devices), VIPS_HIP_DEVICES=",".join(str(d) for d in range(devices)))
-    proc = subprocess.run([sys.executable, script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                          env=env, timeout=1800)
-    assert proc.returncode == 0 and "CHILD-OK" in proc.stdout, proc.stdout[-3000:]
+    name = "%s[%d]" % (RING_TEST, devices)
+    prestart([name])  # (no-op when conftest already did)
+    rc, text = helpers.Background.wait("module_stream:" + name, timeout=1800)
+    assert rc == 0 and "CHILD-OK" in text, text[-3000:]
 
 
 def _stats(module, reset=0):

@@ -156,15 +156,25 @@ def cli_thumbnail(tmp_path, src, size, extra=()):
 def test_find_jpegshrink_matches_what_the_reference_logs(tmp_path):
     from libvips_amd import _ffi
 
-    path = str(tmp_path / "t.jpg")
-    for (w, h, size, args, mode, linear, crop) in (
-            (2000, 1500, "200x200", (), 0, 0, 0), (1801, 1203, "100x100", (), 0, 0, 0),
-            (640, 480, "300x300", (), 0, 0, 0), (4000, 3000, "128x128", (), 0, 0, 0),
-            (1600, 1200, "100x100", ("--linear",), 0, 1, 0), (1600, 400, "100x100!", (), 3, 0, 0),
-            (1000, 800, "125x100", (), 0, 0, 0), (1600, 400, "100x100", ("--smartcrop", "centre"), 0, 0, 1),
-            (900, 2000, "50x100", ("--smartcrop", "high"), 0, 0, 5)):
+    from concurrent.futures import ThreadPoolExecutor
+
+    cases = ((2000, 1500, "200x200", (), 0, 0, 0), (1801, 1203, "100x100", (), 0, 0, 0),
+             (640, 480, "300x300", (), 0, 0, 0), (4000, 3000, "128x128", (), 0, 0, 0),
+             (1600, 1200, "100x100", ("--linear",), 0, 1, 0), (1600, 400, "100x100!", (), 3, 0, 0),
+             (1000, 800, "125x100", (), 0, 0, 0), (1600, 400, "100x100", ("--smartcrop", "centre"), 0, 0, 1),
+             (900, 2000, "50x100", ("--smartcrop", "high"), 0, 0, 5))
+
+    def logged(k):  # (two child processes of the reference's command line per case: side by side)
+        w, h, size, args = cases[k][:4]
+        tmp = tmp_path / ("case%d" % k)
+        tmp.mkdir()
+        path = str(tmp / "t.jpg")
         make_jpeg(path, w, h, quality=60)
-        _, factor = cli_thumbnail(tmp_path, path, size, args)
+        return cli_thumbnail(tmp, path, size, args)[1]
+
+    with ThreadPoolExecutor(max_workers=min(len(cases), os.cpu_count() or 2)) as pool:
+        factors = list(pool.map(logged, range(len(cases))))
+    for (w, h, size, args, mode, linear, crop), factor in zip(cases, factors):
         tw, th = [int(v) for v in size.rstrip("!").split("x")]
         assert _ffi.lib.vips_hip_thumbnail_find_jpegshrink(w, h, tw, th, mode, linear, crop) == factor, (w, h, size)
 

@@ -23,6 +23,8 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 # (round 5: ushort gaussblur / convsep on the matrix cores, and vips_resize through the band chain)
 KINDS = sys.argv[3].split(",") if len(sys.argv) > 3 else ["shrinkh", "reduceh", "reducev", "conv16", "conv8", "blur8", "blur16", "sep16", "resize"]
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+MAX_H = int(os.environ.get("FUZZ_MAX_H", "90"))
+MAX_W = int(os.environ.get("FUZZ_MAX_W", "640"))
 libvips_amd.init(0)
 lib = libvips_amd.lib
 ran = {}
@@ -31,8 +33,10 @@ for case in range(n_cases):
     kind = rng.choice(KINDS)
     bands = int(rng.choice([1, 2, 3, 4]))
     # widths that make rows of whole dwords most of the time
-    w = int(rng.integers(1, 160)) * 4 if rng.random() < 0.8 else int(rng.integers(2, 700))
-    h = int(rng.integers(1, 90))
+    # ($FUZZ_MAX_H / $FUZZ_MAX_W: taller / wider images -- several rows of tiles, the bottom-up walk of every other
+    # block of rows, more than one 16-row half of an output tile)
+    w = int(rng.integers(1, MAX_W // 4)) * 4 if rng.random() < 0.8 else int(rng.integers(2, MAX_W + 60))
+    h = int(rng.integers(1, MAX_H))
     dt = np.uint16 if kind in ("conv16", "blur16", "sep16") else np.uint8
     src = helpers.lcg_image(w, h, bands, dt, 1000 + case)
     if rng.random() < 0.3:
