@@ -86,3 +86,31 @@ def test_no_c_cast_of_a_float_to_an_integer_in_device_code():
             bad[os.path.basename(src)] = hits[:3]
     assert defined > 300, defined
     assert not bad, "C float -> int casts in device code: %r" % bad
+
+
+# Kernels that are ALLOWED a few bytes of scratch (their register budget is fixed by the launch bounds their LDS
+# layout needs; profiles/r05_kernel_resources.txt): anything else with a private segment, or any of these past
+# 64 bytes, is a spill nobody chose.
+SCRATCH_ALLOWED = ("vh::conv_u8_mfma_sep<4, false, 0>", "vh::conv_u8_mfma_sep<4, true, 0>",
+                   "vh::convsep_stream<1, 8, 1, 768, 0>", "vh::convsep_stream<1, 8, 2, 768, 0>",
+                   "vh::convsep_stream<1, 8, 2, 768, 1>", "vh::reduce_fused_u8x4<8, 7>", "vh::resize_sharpen_u8<8, 7>")
+
+
+@pytest.mark.skipif(not os.path.exists(LLVM + "/llvm-readelf"), reason="no llvm-readelf")
+def test_no_kernel_spills_to_scratch():
+    """The code objects' metadata (tools/kernel_resources.py): every kernel of the built library keeps its registers
+    -- no private segment -- but the seven listed, and BASELINE configs[1]'s kernel runs four waves a SIMD."""
+    import importlib.util
+
+    from libvips_amd import _ffi
+
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(helpers.ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    ks = kr.kernels_of(_ffi.LIB_PATH)
+    assert len(ks) > 500, len(ks)
+    bad = {k["demangled"]: k["private_segment_fixed_size"] for k in ks
+           if k["private_segment_fixed_size"] > (64 if k["demangled"] in SCRATCH_ALLOWED else 0)}
+    assert not bad, "kernels with scratch: %r" % bad
+    c2 = [k for k in ks if k["demangled"].startswith("vh::reduce_fused_u8x4_mfma<6, 1, 4, true, 0, true, 256,")]
+    assert c2 and all(kr.waves_per_simd(k) == 4 and k["vgpr_spill_count"] == 0 for k in c2), c2
