@@ -182,6 +182,7 @@ typedef struct _VipsHipOp {
 	 * strip by the producer thread below, and generate calls are served as their strips land. */
 	struct _HipCache *cache;
 	gboolean striped;       /* items are strips from the producer thread */
+	int first_row;          /* the top row of the generate call that started the evaluation */
 	GThread *producer;
 	gboolean producer_running;
 	gboolean producer_quit;
@@ -713,6 +714,10 @@ setup_done:
 		const guint64 stage_bytes = resident ? 0 : 2 * (guint64) max_in_rows * in_ls;
 
 		op->cache = hip_cache_new(out->Ysize, rows, ls, host_budget > stage_bytes ? host_budget - stage_bytes : 0, TRUE);
+		/* the walk starts at the strip the first consumer is waiting for (its call cannot say so itself: the
+		 * cache it would note its wish in is made here) -- a crop at the bottom does not pay for strip 0 */
+		if (op->cache && op->first_row > 0)
+			cursor = VIPS_MIN(op->first_row / rows, op->cache->n_items - 1);
 	}
 	if (!op->setup)
 		op->setup = setup;
@@ -1387,6 +1392,8 @@ vips_hip_op_gen(VipsRegion *out_region, void *seq, void *a, void *b, gboolean *s
 	/* First demand: evaluate.  A result that fits HBM is made here and now (then its bands come
 	 * down as they are asked for); an image over the budget only gets its producer started. */
 	g_mutex_lock(&op->lock);
+	if (!op->cache && !op->striped)
+		op->first_row = r->top; /* (where a strip producer started by this call begins its walk) */
 	hip_ensure_eval(op);
 	if (op->eval_error) {
 		vips_error(VIPS_OBJECT_GET_CLASS(op)->nickname, "%s", op->eval_error);

@@ -15,7 +15,9 @@ def pytest_configure(config):
 
 # Test files whose cases are child processes of minutes each (see helpers.Background): each has a
 # prestart(selected test names) that launches the children of the selected cases.
-PRESTART = ("test_emul_gpu_suite", "test_module_stream")
+# (NOT tests/test_module_stream.py's ring runs: they count the strips a producer thread makes before its consumer
+# goes away -- a race the producer loses on an idle machine and may win on a loaded one.)
+PRESTART = ("test_emul_gpu_suite",)
 
 
 def pytest_collection_finish(session):

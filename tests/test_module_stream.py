@@ -101,8 +101,8 @@ RING_TEST = "test_strips_stream_through_a_bounded_host_ring"
 
 
 def prestart(names):
-    """The two ring runs are child processes of half a minute each: started when collection ends
-    (tests/conftest.py), waited for by their test (helpers.Background)."""
+    """A ring run is a child process of half a minute, started by its own test and nothing else (see
+    tests/conftest.py: its strip counts need a machine that is not loaded)."""
     if not RING_ENABLED:
         return
     for name in names:
@@ -123,7 +123,7 @@ def test_strips_stream_through_a_bounded_host_ring(devices):
     ($VIPS_HIP_DEVICES=0,1: libvips' workers AND the strip producers); a producer that is started
     again for an evicted strip goes back to its first run's device (the slot events live there)."""
     name = "%s[%d]" % (RING_TEST, devices)
-    prestart([name])  # (no-op when conftest already did)
+    prestart([name])
     rc, text = helpers.Background.wait("module_stream:" + name, timeout=1800)
     assert rc == 0 and "CHILD-OK" in text, text[-3000:]
 
