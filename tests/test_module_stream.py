@@ -75,6 +75,15 @@ for tail in ["flip:direction=vertical", "rot:angle=d90", "extract_area:left=7,to
 before = module.vips_hip_module_strips_done()
 Ref.run_chain("gaussblur_hip:sigma=3;extract_area:left=7,top=600,width=50,height=10", src, 22)
 assert module.vips_hip_module_strips_done() - before <= 3
+# (the producer's walk starts at the strip of the call that started the evaluation, not at strip 0 -- also on an
+# image one tile wide, where libvips' workers ask for tiles of different tops at once)
+narrow = helpers.lcg_image(100, 600, 3, np.uint8, 83)
+for tail in ["extract_area:left=3,top=540,width=40,height=25", "extract_area:left=0,top=300,width=100,height=40"]:
+    before = module.vips_hip_module_strips_done()
+    g = Ref.run_chain("gaussblur_hip:sigma=2;" + tail, narrow, 22)
+    assert np.array_equal(g, Ref.run_chain("gaussblur:sigma=2;" + tail, narrow, 22)), tail
+    if tail.startswith("extract_area:left=3"):
+        assert module.vips_hip_module_strips_done() - before <= 3, tail
 
 # 5. a partial (pulled) input: the producer's prefetch, and a strip-mined result feeding a
 #    following *_hip operation
