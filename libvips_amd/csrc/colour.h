@@ -23,6 +23,7 @@ int colour_route(const int *steps, int n_steps, double alpha_scale, const VipsHi
 // nullptr: the kernel that reads the whole LUT through global memory)
 struct SharpenLutWindow {
 	int lo, n, below, above; // lut[i] = below for i < lo, above for i >= lo + n
+	int zero_lo, zero_hi;    // lut[d + 32768] == 0 for zero_lo <= d <= zero_hi, the run around d = 0 (empty: lo > hi)
 	const short *lut_win;    // device: n entries from index lo
 };
 int sharpen_fused_u8(const VipsHipRegion *const *in, const VipsHipRegion *const *out, int n_images,

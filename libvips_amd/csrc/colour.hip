@@ -867,6 +867,11 @@ struct SharpenFusedArgs {
 	unsigned int magic;   // n / scale = (t + ((n - t) >> 1)) >> shift with t = mulhi(magic, n), 0 <= n < 2^32
 	int shift;            // (Granlund & Montgomery's round-up multiplier; scale > 1)
 	const int *lut;       // 65536 ints (sharpen.c:230-257)
+	int zero_lo, zero_hi; // SKIP: lut[diff + 32768] == 0 for zero_lo <= diff <= zero_hi (empty: lo > hi)
+	// SKIP: n / scale == ((n << sh24) * m24) >> 32 for every n a blur sum can be, both factors below 2^24 (the
+	// full-rate v_mul_hi_u32_u24 instead of the quarter-rate v_mul_hi_u32; the host tried every n); sh24 < 0: no
+	unsigned int m24;
+	int sh24;
 	ColourTables tables;
 };
 
@@ -886,23 +891,52 @@ static __device__ __forceinline__ int sf_convi_fin(int sum, const SharpenFusedAr
 	return min(max(q, -32768), 32767);
 }
 
+// the same for a sum that is not negative (the SKIP kernel: L >= 0, coefficients >= 0): n = sum + rounding < 2^31
+static __device__ __forceinline__ unsigned int sf_div_nonneg(unsigned int n, const SharpenFusedArgs &a)
+{
+	// (the SKIP kernel is only launched with sh24 >= 0)
+	unsigned int m;
+	VH_MUL_HI_U24(m, n << a.sh24, a.m24);
+	return min(m, 32767u);
+}
+
 // SF_TH = rows of a tile: 16 rows per pass of the block's 256 threads (4 pixels each), SF_TH / 16
 // passes; the halo ring and the tables a block loads are shared by all of them
-template <int SF_TH>
+//
+// SKIP (round 6): the pixels sharpen leaves alone skip the way back.  With the default parameters (m1 = 0) the
+// LUT is 0 for |L - blur| < x1 = 2 L units (sharpen.c:230-257) -- every pixel of a smooth region: 95.7 % of the
+// pixels of BASELINE config 4's thumbnails, most of a photograph.  Such a pixel leaves vips_sharpen as
+// sRGB(LabS(pixel)) with L, a, b untouched, and sRGB -> LabS -> sRGB is the IDENTITY on all 2^24 colours: checked
+// with the compiled reference on the host (tests/test_oracle_conv_colour.py) and, for the device's own tables and
+// these very functions, exhaustively on the device before the first launch (sharpen_identity_kernel: the kernel is
+// only selected when the count of colours that do not come back is 0).  So: L alone (not a, b: a third of the
+// forward path's table reads) for the tile and its halo, the blur, the test of L - blur against the LUT's zero
+// window (no gather); the tile's INPUT bytes wait in LDS as its output; the few pixels whose LUT entry is not 0
+// are appended to a list (LDS atomic), taken through the full forward and backward path DENSELY (a wave of list
+// entries, not a wave of tile pixels 4 % of which are live) and patched into the staged bytes.
+// (NT = taps the SKIP kernel's blur passes compute: 3 or 5; the other kernel always runs five, zeros included)
+template <int SF_TH, bool SKIP, int NT = 2 * SF_MAXHALF + 1>
 __global__ void __launch_bounds__(256)
 sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 {
 	constexpr int SF_RH = SF_TH + 2 * SF_MAXHALF;
-	__shared__ short s_lab[SF_RH][SF_RW][3];
-	__shared__ short s_h[SF_RH][SF_TW];
+	constexpr int NCH = SKIP ? 1 : 3;
+	constexpr int OUT_DW = SF_TW * 3 / 4; // dwords per staged row
+	__shared__ __attribute__((aligned(16))) short s_lab[SF_RH][SF_RW][NCH];
+	__shared__ __attribute__((aligned(16))) short s_h[SF_RH][SF_TW];
 	// the two 8-bit colour tables in LDS: six of a pixel's table reads stay off the vector memory path
 	__shared__ float s_v2Y[256];
 	__shared__ int s_Y2v[260];
+	__shared__ unsigned int s_out[SKIP ? SF_TH * OUT_DW : 1];  // SKIP: the tile's bytes, input until patched
+	__shared__ unsigned int s_list[SKIP ? SF_TH * SF_TW : 1];  // SKIP: (LUT index << 11) | row << 6 | column
+	__shared__ int s_count;
 	(void) ptrs_by_value;
 	s_v2Y[threadIdx.x] = a.tables.v2Y_8[threadIdx.x];
 	s_Y2v[threadIdx.x] = a.tables.Y2v_8[threadIdx.x];
-	if (threadIdx.x == 0)
+	if (threadIdx.x == 0) {
 		s_Y2v[256] = a.tables.Y2v_8[256];
+		s_count = 0;
+	}
 	__syncthreads();
 	typedef const unsigned long long __attribute__((address_space(4))) *KernargPtrs;
 	const KernargPtrs kp = (KernargPtrs) __builtin_amdgcn_kernarg_segment_ptr();
@@ -916,6 +950,121 @@ sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 	const int h = a.half;
 	const int rw = SF_TW + 2 * h, rh = SF_TH + 2 * h;
 
+	// ring pixel idx -> its place in the region (the frame of h pixels around the tile)
+	auto ring_place = [&](int idx, int &ry, int &rx) {
+		if (idx < 2 * rw * h) {
+			// rows above and below (h <= 2: at most four rows, no division)
+			const int r = (idx >= rw) + (idx >= 2 * rw) + (idx >= 3 * rw);
+			rx = idx - r * rw;
+			ry = r < h ? r : SF_TH + r;
+		}
+		else {
+			// columns left and right of the tile's rows (2 h = 2 or 4 = 1 << h)
+			const int k = idx - 2 * rw * h;
+			const int r = k >> h, c = k & (2 * h - 1);
+			ry = h + r;
+			rx = c < h ? c : SF_TW + c;
+		}
+	};
+	if constexpr (SKIP) {
+		// 1 (SKIP). L of the tile and its ring, IN THREE SWEEPS over the thread's pixels (4 per 16 rows of the tile
+		// and up to two of the ring): every pixel load, then every table index and its gather, then the
+		// interpolations -- two memory latencies a block instead of two per pixel group (the block's life is those
+		// latencies: with the conversions one after the other the kernel ran no faster for 40 % fewer instructions)
+		constexpr int NPASS = SF_TH / 16, NRING = 2, NPX = 4 * NPASS + NRING;
+		const int ring = rw * rh - SF_TW * SF_TH;
+		const int quad = t & 15;
+		const bool words = !((((unsigned long long) in) | (unsigned long long) a.in_stride) & 3) && x0 + 4 * quad + 4 <= a.width;
+		unsigned int w[NPASS][3];
+		unsigned int rpx[NRING][3];
+		int rry[NRING], rrx[NRING];
+#pragma unroll
+		for (int pass = 0; pass < NPASS; pass++) {
+			const int row = (t >> 4) + 16 * pass;
+			const int y = min(y0 + row, a.height - 1);
+			const int x = x0 + 4 * quad;
+			unsigned int off;
+			VH_MAD_U24(off, (unsigned int) y, (unsigned int) a.in_stride, 0u);
+			const GlobalIn line = in + off;
+			if (words) {
+				const unsigned int __attribute__((address_space(1))) *p4 =
+					(const unsigned int __attribute__((address_space(1))) *) (line + 3 * x);
+#pragma unroll
+				for (int k = 0; k < 3; k++)
+					w[pass][k] = p4[k];
+			}
+			else {
+				unsigned char px[12];
+#pragma unroll
+				for (int m = 0; m < 4; m++) {
+					const GlobalIn p = line + 3 * min(x + m, a.width - 1);
+					px[3 * m] = p[0];
+					px[3 * m + 1] = p[1];
+					px[3 * m + 2] = p[2];
+				}
+#pragma unroll
+				for (int k = 0; k < 3; k++)
+					w[pass][k] = (unsigned) px[4 * k] | ((unsigned) px[4 * k + 1] << 8) | ((unsigned) px[4 * k + 2] << 16) |
+						((unsigned) px[4 * k + 3] << 24);
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < NRING; j++) {
+			const int idx = min(t + 256 * j, ring - 1); // (a lane beyond the ring repeats its last pixel: same value, same place)
+			ring_place(max(idx, 0), rry[j], rrx[j]);
+			const int x = min(max(x0 + rrx[j] - h, 0), a.width - 1);
+			const int y = min(max(y0 + rry[j] - h, 0), a.height - 1);
+			unsigned int off;
+			VH_MAD_U24(off, (unsigned int) y, (unsigned int) a.in_stride, (unsigned int) (3 * x));
+			const GlobalIn p = in + off;
+			rpx[j][0] = p[0];
+			rpx[j][1] = p[1];
+			rpx[j][2] = p[2];
+		}
+		// sweep 2: Y of every pixel, its table index and fraction, the gather
+		float fr[NPX];
+		float2 pair[NPX];
+		auto index_of = [&](int n, unsigned int r8, unsigned int g8, unsigned int b8) {
+			Px v;
+			v.a = s_v2Y[r8];
+			v.b = s_v2Y[g8];
+			v.c = s_v2Y[b8];
+			v = step_scRGB2XYZ(v);
+			const int i = cbrt_index_finite<1>(v.b, fr[n]);
+			__builtin_memcpy(&pair[n], a.tables.cbrt + i, sizeof(float2));
+		};
+#pragma unroll
+		for (int pass = 0; pass < NPASS; pass++)
+#pragma unroll
+			for (int m = 0; m < 4; m++) {
+				// byte 3 m + c of the 12: dword (3 m + c) / 4, byte (3 m + c) % 4
+				auto byte_of = [&](int c) -> unsigned int { return (w[pass][(3 * m + c) >> 2] >> (8 * ((3 * m + c) & 3))) & 0xffu; };
+				index_of(4 * pass + m, byte_of(0), byte_of(1), byte_of(2));
+			}
+#pragma unroll
+		for (int j = 0; j < NRING; j++)
+			index_of(4 * NPASS + j, rpx[j][0], rpx[j][1], rpx[j][2]);
+		// sweep 3: interpolate, L, LabS (the operations of srgb8_to_labs<false>, in its order)
+		auto finish = [&](int n) -> short {
+			const float cby = cbrt_finish(pair[n], fr[n]);
+			return lab2labs_finite(__fsub_rn(__fmul_rn(116.0F, cby), 16.0F), 32767.0 / 100.0, 0.0);
+		};
+#pragma unroll
+		for (int pass = 0; pass < NPASS; pass++) {
+			const int row = (t >> 4) + 16 * pass;
+#pragma unroll
+			for (int m = 0; m < 4; m++)
+				s_lab[row + h][4 * quad + m + h][0] = finish(4 * pass + m);
+#pragma unroll
+			for (int k = 0; k < 3; k++)
+				s_out[row * OUT_DW + 3 * quad + k] = w[pass][k];
+		}
+#pragma unroll
+		for (int j = 0; j < NRING; j++)
+			if (t + 256 * j < ring)
+				s_lab[rry[j]][rrx[j]][0] = finish(4 * NPASS + j);
+	}
+	else {
 	// 1. the tile and its halo: sRGB uchar -> LabS.
 	// 1a. the tile itself, 4 pixels per thread (the mapping of step 3): 12 bytes as three dwords
 	// when the row allows it, the four conversions side by side (their table reads overlap)
@@ -948,11 +1097,19 @@ sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 		}
 #pragma unroll
 		for (int m = 0; m < 4; m++) {
-			short L, A, B;
-			srgb8_to_labs<true>(a.tables, s_v2Y, px[3 * m], px[3 * m + 1], px[3 * m + 2], L, A, B);
+			short L, A = 0, B = 0;
+			srgb8_to_labs<!SKIP>(a.tables, s_v2Y, px[3 * m], px[3 * m + 1], px[3 * m + 2], L, A, B);
 			s_lab[row + h][4 * quad + m + h][0] = L;
-			s_lab[row + h][4 * quad + m + h][1] = A;
-			s_lab[row + h][4 * quad + m + h][2] = B;
+			if constexpr (!SKIP) {
+				s_lab[row + h][4 * quad + m + h][1] = A;
+				s_lab[row + h][4 * quad + m + h][2] = B;
+			}
+		}
+		if constexpr (SKIP) {
+#pragma unroll
+			for (int w = 0; w < 3; w++)
+				s_out[row * OUT_DW + 3 * quad + w] = (unsigned) px[4 * w] | ((unsigned) px[4 * w + 1] << 8) |
+					((unsigned) px[4 * w + 2] << 16) | ((unsigned) px[4 * w + 3] << 24);
 		}
 	}
 	// 1b. the ring of h pixels around it (image edges clamped): only L is blurred, so only L
@@ -960,43 +1117,101 @@ sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 		const int ring = rw * rh - SF_TW * SF_TH;
 		for (int idx = t; idx < ring; idx += 256) {
 			int ry, rx;
-			if (idx < 2 * rw * h) {
-				// rows above and below
-				const int r = idx / rw;
-				rx = idx - r * rw;
-				ry = r < h ? r : SF_TH + r;
-			}
-			else {
-				// columns left and right of the tile's rows
-				const int k = idx - 2 * rw * h;
-				const int r = k / (2 * h), c = k - r * 2 * h;
-				ry = h + r;
-				rx = c < h ? c : SF_TW + c;
-			}
+			ring_place(idx, ry, rx);
 			const int x = min(max(x0 + rx - h, 0), a.width - 1);
 			const int y = min(max(y0 + ry - h, 0), a.height - 1);
-			const GlobalIn p = in + (long long) y * a.in_stride + 3LL * x;
+			GlobalIn p;
+			if constexpr (SKIP) {
+				// (the host keeps height * stride below 2^31 and both factors below 2^24 for this kernel)
+				unsigned int off;
+				VH_MAD_U24(off, (unsigned int) y, (unsigned int) a.in_stride, (unsigned int) (3 * x));
+				p = in + off;
+			}
+			else
+				p = in + (long long) y * a.in_stride + 3LL * x;
 			short L, A = 0, B = 0;
 			srgb8_to_labs<false>(a.tables, s_v2Y, p[0], p[1], p[2], L, A, B);
 			s_lab[ry][rx][0] = L;
 		}
 	}
+		}
 	__syncthreads();
 	// 2. horizontal pass on L (all rows of the region, the tile's columns)
-	for (int idx = t; idx < rh * SF_TW; idx += 256) {
-		const int ry = idx / SF_TW, cx = idx - ry * SF_TW;
-		// always five taps (coefficients beyond the mask are zero, the reads stay inside the arrays)
-		int sum = 0;
+	if constexpr (SKIP) {
+		// four neighbouring outputs per thread from ONE read of their 8 shorts (rows are 8-byte aligned); L and the
+		// coefficients are not negative here (host), so a sum is not and its division is the multiply-high alone
+		for (int item = t; item < rh * (SF_TW / 4); item += 256) {
+			const int ry = item >> 4, q4 = (item & 15) * 4;
+			const uint2 w0 = *reinterpret_cast<const uint2 *>(&s_lab[ry][q4][0]);
+			const uint2 w1 = *reinterpret_cast<const uint2 *>(&s_lab[ry][q4 + 4][0]);
+			const int v[8] = { (int) (w0.x & 0xffffu), (int) (w0.x >> 16), (int) (w0.y & 0xffffu), (int) (w0.y >> 16),
+				(int) (w1.x & 0xffffu), (int) (w1.x >> 16), (int) (w1.y & 0xffffu), (int) (w1.y >> 16) };
+			unsigned int o[4];
 #pragma unroll
-		for (int k = 0; k < 2 * SF_MAXHALF + 1; k++)
-			sum += a.coef[k] * (int) s_lab[ry][cx + k][0];
-		s_h[ry][cx] = (short) sf_convi_fin(sum, a);
+			for (int m = 0; m < 4; m++) {
+				unsigned int sum = (unsigned int) a.rounding;
+#pragma unroll
+				for (int k = 0; k < NT; k++)
+					VH_MAD_U24(sum, (unsigned int) v[m + k], (unsigned int) a.coef[k], sum);
+				o[m] = sf_div_nonneg(sum, a);
+			}
+			*reinterpret_cast<uint2 *>(&s_h[ry][q4]) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+		}
+	}
+	else {
+		for (int idx = t; idx < rh * SF_TW; idx += 256) {
+			const int ry = idx / SF_TW, cx = idx - ry * SF_TW;
+			// always five taps (coefficients beyond the mask are zero, the reads stay inside the arrays)
+			int sum = 0;
+#pragma unroll
+			for (int k = 0; k < 2 * SF_MAXHALF + 1; k++)
+				sum += a.coef[k] * (int) s_lab[ry][cx + k][0];
+			s_h[ry][cx] = (short) sf_convi_fin(sum, a);
+		}
 	}
 	__syncthreads();
 	// 3. vertical pass, the LUT, back to sRGB: 4 pixels per thread, three dword stores
 	for (int pass = 0; pass < SF_TH / 16; pass++) {
 		const int row = (t >> 4) + 16 * pass, quad = t & 15;
 		const int y = y0 + row;
+		if constexpr (SKIP) {
+			if (y >= a.height)
+				continue;
+			// the thread's four columns of the 2 h + 1 rows above and below: one 8-byte read per row
+			unsigned int sum[4] = { (unsigned int) a.rounding, (unsigned int) a.rounding, (unsigned int) a.rounding,
+				(unsigned int) a.rounding };
+#pragma unroll
+			for (int k = 0; k < NT; k++) {
+				const uint2 w = *reinterpret_cast<const uint2 *>(&s_h[row + k][4 * quad]);
+				const unsigned int ck = (unsigned int) a.coef[k];
+				VH_MAD_U24(sum[0], w.x & 0xffffu, ck, sum[0]);
+				VH_MAD_U24(sum[1], w.x >> 16, ck, sum[1]);
+				VH_MAD_U24(sum[2], w.y & 0xffffu, ck, sum[2]);
+				VH_MAD_U24(sum[3], w.y >> 16, ck, sum[3]);
+			}
+			// inside the LUT's zero window: the staged input bytes are the result.  The others go on the list with
+			// their LUT index (the LUT itself is read in step 4: no memory latency here), one LDS atomic per thread
+			unsigned int entry[4];
+			int n_mine = 0;
+#pragma unroll
+			for (int m = 0; m < 4; m++) {
+				const int cx = 4 * quad + m;
+				const int blur = (int) sf_div_nonneg(sum[m], a);
+				const int v1 = s_lab[row + h][cx + h][0];
+				const int diff = (v1 & 0x7fff) - (blur & 0x7fff);
+				const bool live = (diff < a.zero_lo || diff > a.zero_hi) && x0 + cx < a.width;
+				entry[m] = live ? ((unsigned) (diff + 32768) << 11) | (unsigned) (row * SF_TW + cx) : 0xffffffffu;
+				n_mine += live ? 1 : 0;
+			}
+			if (n_mine > 0) {
+				int at = atomicAdd(&s_count, n_mine);
+#pragma unroll
+				for (int m = 0; m < 4; m++)
+					if (entry[m] != 0xffffffffu)
+						s_list[at++] = entry[m];
+			}
+			continue;
+		}
 		if (y < a.height) {
 			unsigned char o[12];
 #pragma unroll
@@ -1029,6 +1244,74 @@ sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 			}
 		}
 	}
+	if constexpr (SKIP) {
+		// 4. the listed pixels, densely: forward for a, b, back from (sharpened L, a, b), patched into the stage
+		__syncthreads();
+		const int count = s_count;
+		unsigned char *bytes = reinterpret_cast<unsigned char *>(s_out);
+		for (int i = t; i < count; i += 256) {
+			const unsigned int e = s_list[i];
+			const int pos = (int) (e & 2047u);
+			const int add = a.lut[e >> 11]; // sharpen.c:116-168: index (v1 & 0x7fff) - (blur & 0x7fff) + 32768
+			if (add == 0)
+				continue; // (a zero of the LUT outside the window around 0: the staged bytes stand)
+			const int row = pos / SF_TW, cx = pos - row * SF_TW;
+			const int sharp = min(max((int) s_lab[row + h][cx + h][0] + add, 0), 32767);
+			unsigned char *p = bytes + row * (OUT_DW * 4) + 3 * cx;
+			short L, A, B;
+			srgb8_to_labs<true>(a.tables, s_v2Y, p[0], p[1], p[2], L, A, B);
+			unsigned char r8, g8, b8;
+			labs_to_srgb8(s_Y2v, sharp, A, B, r8, g8, b8);
+			p[0] = r8;
+			p[1] = g8;
+			p[2] = b8;
+		}
+		__syncthreads();
+		// 5. the stage leaves: 4 pixels per thread, three dword stores
+		for (int pass = 0; pass < SF_TH / 16; pass++) {
+			const int row = (t >> 4) + 16 * pass, quad = t & 15;
+			const int y = y0 + row;
+			if (y >= a.height)
+				continue;
+			const int x = x0 + 4 * quad;
+			const GlobalOut dst = out + (long long) y * a.out_stride + 3LL * x;
+			const unsigned int *src = s_out + row * OUT_DW + 3 * quad;
+			if (x + 4 <= a.width && !(((uintptr_t) dst) & 3)) {
+				unsigned int __attribute__((address_space(1))) *d4 = (unsigned int __attribute__((address_space(1))) *) dst;
+#pragma unroll
+				for (int w = 0; w < 3; w++)
+					d4[w] = src[w];
+			}
+			else {
+				const unsigned char *sb = reinterpret_cast<const unsigned char *>(src);
+				for (int m = 0; m < 12 && x + m / 3 < a.width; m++)
+					dst[m] = sb[m];
+			}
+		}
+	}
+}
+
+// sRGB -> LabS -> sRGB with the functions above on every one of the 2^24 colours: the count of colours that do not
+// come back.  0 is what lets sharpen_fused_u8_kernel<*, true> hand a pixel whose LUT entry is 0 through untouched.
+__global__ void __launch_bounds__(256)
+sharpen_identity_kernel(ColourTables tables, unsigned int *bad)
+{
+	__shared__ float s_v2Y[256];
+	__shared__ int s_Y2v[260];
+	s_v2Y[threadIdx.x] = tables.v2Y_8[threadIdx.x];
+	s_Y2v[threadIdx.x] = tables.Y2v_8[threadIdx.x];
+	if (threadIdx.x == 0)
+		s_Y2v[256] = tables.Y2v_8[256];
+	__syncthreads();
+	const unsigned int c = blockIdx.x * 256u + threadIdx.x;
+	const int r = (int) (c >> 16), g = (int) ((c >> 8) & 255u), b = (int) (c & 255u);
+	short L, A, B;
+	srgb8_to_labs<true>(tables, s_v2Y, r, g, b, L, A, B);
+	unsigned char r8, g8, b8;
+	// (the kernel's clip of L + 0 to 0 .. 32767 is part of what is checked)
+	labs_to_srgb8(s_Y2v, min(max((int) L, 0), 32767), A, B, r8, g8, b8);
+	if (r8 != r || g8 != g || b8 != b)
+		atomicAdd(bad, 1u);
 }
 
 // ------------------------------------------------- ... with every table in LDS (round 5)
@@ -1234,6 +1517,55 @@ sharpen_quad_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenQuadArgs q)
 }
 
 // n images of one geometry (one launch per SF_MAXB of them).  0 done, 1 not this kernel's case, -1 error
+// Per device, once: does every colour come back from sRGB -> LabS -> sRGB (sharpen_identity_kernel)?  A failure
+// to run the check counts as "no": the kernel that takes every pixel the whole way needs no such proof.
+static bool sharpen_identity_proven(const ColourTables &tables)
+{
+	constexpr int MAXDEV = 64;
+	static std::mutex mutex;
+	static signed char state[MAXDEV]; // 0 unknown, 1 proven, -1 not
+	const int dev = current_device();
+	if (dev < 0 || dev >= MAXDEV)
+		return false;
+	std::lock_guard<std::mutex> lock(mutex);
+	if (state[dev] == 0) {
+		state[dev] = -1;
+		unsigned int zero = 0, bad = 1;
+		unsigned int *d_bad = (unsigned int *) upload(&zero, sizeof(zero));
+		if (d_bad) {
+			hipLaunchKernelGGL(sharpen_identity_kernel, dim3(65536), dim3(256), 0, stream(), tables, d_bad);
+			if (hipGetLastError() == hipSuccess &&
+				hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, stream()) == hipSuccess &&
+				hipStreamSynchronize(stream()) == hipSuccess && bad == 0)
+				state[dev] = 1;
+			vips_hip_free(d_bad);
+		}
+		else
+			vips_hip_error_clear();
+	}
+	return state[dev] == 1;
+}
+
+// sharpen_quad_u8_kernel's 106 KB of dynamic LDS need the opt-in, which is a per-device attribute of the function
+static bool sharpen_quad_lds_allowed()
+{
+	constexpr int MAXDEV = 64;
+	static std::mutex mutex;
+	static signed char state[MAXDEV];
+	const int dev = current_device();
+	if (dev < 0 || dev >= MAXDEV)
+		return false;
+	std::lock_guard<std::mutex> lock(mutex);
+	if (state[dev] == 0) {
+		const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sharpen_quad_u8_kernel),
+			hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		state[dev] = e == hipSuccess ? 1 : -1;
+		if (e != hipSuccess)
+			(void) hipGetLastError();
+	}
+	return state[dev] == 1;
+}
+
 int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const *outs, int n_images,
 	const int *to_steps, int n_to, const int *from_steps, int n_from, const int *coef, int n, int scale,
 	const int *lut, const SharpenLutWindow *win)
@@ -1293,6 +1625,27 @@ int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const
 		a.shift = l - 1;
 	}
 	a.lut = lut;
+	// the blur's division as a 24-bit multiply-high: tried on every sum the mask can make (under a million)
+	a.sh24 = -1;
+	a.m24 = 0;
+	{
+		const long long n_max = abs_sum * 32767 + a.rounding;
+		int sh = 0;
+		while (sh < 24 && (n_max << (sh + 1)) < (1LL << 24))
+			sh++;
+		const unsigned long long m = ((1ULL << (32 - sh)) + (unsigned long long) scale - 1) / (unsigned long long) scale;
+		if (n_max < (1LL << 24) && (n_max << sh) < (1LL << 24) && m < (1ULL << 24)) {
+			bool ok = true;
+			for (long long v = 0; v <= n_max && ok; v++)
+				ok = (((unsigned long long) (v << sh) * m) >> 32) == (unsigned long long) (v / scale);
+			if (ok) {
+				a.sh24 = sh;
+				a.m24 = (unsigned int) m;
+			}
+		}
+	}
+	a.zero_lo = win ? win->zero_lo : 1;
+	a.zero_hi = win ? win->zero_hi : 0;
 	// every table in LDS (sharpen_quad_u8_kernel) when the LUT's window and this host's cbrtf allow it -- for large
 	// images.  Measured (profiles/r05p_sharpen_quad.txt): 8192^2 of noise 1.08 -> 0.83 ms, but a batch of 1024^2
 	// thumbnails on its 64-CU partition 0.033 -> 0.049 ms per image: a thumbnail's values are few and near each
@@ -1300,7 +1653,10 @@ int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const
 	// of 16 waves per CU to hide behind.  $VIPS_HIP_SHARPEN_QUAD=0 / 1 forces one or the other.
 	const char *quad_env = getenv("VIPS_HIP_SHARPEN_QUAD");
 	const bool want_quad = quad_env ? atoi(quad_env) != 0 : (long long) a.width * a.height >= 2048LL * 2048;
-	if (win && win->lut_win && win->n <= SQ_MAXLUT && want_quad && !getenv("VIPS_HIP_NO_SHARPEN_QUAD")) {
+	// (the LDS opt-in is per DEVICE: asked for on every device this code reaches; a device that refuses it keeps
+	// the kernel that needs none)
+	if (win && win->lut_win && win->n <= SQ_MAXLUT && want_quad && !getenv("VIPS_HIP_NO_SHARPEN_QUAD") &&
+		sharpen_quad_lds_allowed()) {
 		const CbrtQuad *cq = cbrt_quad_tables();
 		if (cq) {
 			SharpenQuadArgs q;
@@ -1315,11 +1671,6 @@ int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const
 			q.tiles_y = (a.height + SQ_T - 1) / SQ_T;
 			const size_t lds = (size_t) (CBQ_BLOCKS * 4 + CBQ_RES_WORDS + 256 + 260) * 4 + (size_t) (SQ_MAXLUT + 8) * 2 +
 				(size_t) SQ_R * SQ_R * 2 + (size_t) SQ_T * SQ_T * 4 + (size_t) SQ_R * SQ_T * 2;
-			static std::once_flag once;
-			std::call_once(once, [] {
-				(void) hipFuncSetAttribute(reinterpret_cast<const void *>(sharpen_quad_u8_kernel),
-					hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-			});
 			Gate gate("sharpen_quad_u8");
 			for (int base = 0; base < n_images; base += SF_MAXB) {
 				const int count = n_images - base < SF_MAXB ? n_images - base : SF_MAXB;
@@ -1341,7 +1692,18 @@ int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const
 		}
 		vips_hip_error_clear();
 	}
-	Gate gate("sharpen_fused_u8");
+	// the pixels the LUT leaves alone skip the way back (sharpen_fused_u8_kernel<*, true>) when the LUT has a zero
+	// window at all and sRGB -> LabS -> sRGB is the identity with this device's tables.  $VIPS_HIP_SHARPEN_SKIP=0:
+	// every pixel the whole way.
+	const char *skip_env = getenv("VIPS_HIP_SHARPEN_SKIP");
+	bool nonneg = true; // (a gaussian's integer mask: what lets the skip kernel divide without a sign)
+	for (int k = 0; k < n; k++)
+		nonneg = nonneg && coef[k] >= 0;
+	const bool small = (long long) a.height * a.in_stride < (1LL << 31) && a.in_stride < (1LL << 24) && a.height < (1 << 24) &&
+		a.in_stride >= 0;
+	const bool skip = nonneg && small && a.sh24 >= 0 && a.zero_lo <= 0 && a.zero_hi >= 0 && !(skip_env && atoi(skip_env) == 0) &&
+		sharpen_identity_proven(a.tables);
+	Gate gate(skip ? "sharpen_skip_u8" : "sharpen_fused_u8");
 	for (int base = 0; base < n_images; base += SF_MAXB) {
 		const int count = n_images - base < SF_MAXB ? n_images - base : SF_MAXB;
 		SharpenFusedPtrs p;
@@ -1356,11 +1718,21 @@ int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const
 		const int th = getenv("VIPS_HIP_SHARPEN_TH") ? atoi(getenv("VIPS_HIP_SHARPEN_TH")) : 32;
 		if (th != 16 && a.height > 16) {
 			dim3 grid((a.width + SF_TW - 1) / SF_TW, (a.height + 31) / 32, count);
-			hipLaunchKernelGGL(sharpen_fused_u8_kernel<32>, grid, dim3(256, 1, 1), 0, stream(), p, a);
+			if (skip && a.n <= 3)
+				hipLaunchKernelGGL((sharpen_fused_u8_kernel<32, true, 3>), grid, dim3(256, 1, 1), 0, stream(), p, a);
+			else if (skip)
+				hipLaunchKernelGGL((sharpen_fused_u8_kernel<32, true, 5>), grid, dim3(256, 1, 1), 0, stream(), p, a);
+			else
+				hipLaunchKernelGGL((sharpen_fused_u8_kernel<32, false>), grid, dim3(256, 1, 1), 0, stream(), p, a);
 		}
 		else {
 			dim3 grid((a.width + SF_TW - 1) / SF_TW, (a.height + 15) / 16, count);
-			hipLaunchKernelGGL(sharpen_fused_u8_kernel<16>, grid, dim3(256, 1, 1), 0, stream(), p, a);
+			if (skip && a.n <= 3)
+				hipLaunchKernelGGL((sharpen_fused_u8_kernel<16, true, 3>), grid, dim3(256, 1, 1), 0, stream(), p, a);
+			else if (skip)
+				hipLaunchKernelGGL((sharpen_fused_u8_kernel<16, true, 5>), grid, dim3(256, 1, 1), 0, stream(), p, a);
+			else
+				hipLaunchKernelGGL((sharpen_fused_u8_kernel<16, false>), grid, dim3(256, 1, 1), 0, stream(), p, a);
 		}
 		VH_CHECK(hipGetLastError());
 	}

@@ -29,6 +29,9 @@
 // instructions the compiler does not select by itself
 #define VH_SAT_PK_U8_I16(r, both) asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(both)) // {0, 0, sat_u8(hi16), sat_u8(lo16)}
 #define VH_DOT2_SCALAR_COEF(dst, pk, coef, acc) asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(dst) : "v"(pk), "s"(coef), "v"(acc))
+// 24-bit multiplies (full rate; v_mul_lo_u32 / v_mul_hi_u32 issue at a quarter of it): both factors below 2^24
+#define VH_MAD_U24(dst, a, b, c) asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(dst) : "v"(a), "s"(b), "v"(c)) // a * b + c, b scalar
+#define VH_MUL_HI_U24(dst, a, b) asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(dst) : "v"(a), "v"(b))          // (a * b) >> 32
 #define VH_STORE_BYTE(p, v) asm volatile("global_store_byte %0, %1, off" : : "v"(p), "v"(v) : "memory")
 // a marker that keeps two otherwise identical arms of a switch apart (merged, their register index is dynamic)
 #define VH_ASM_MARK(text) asm volatile("; " text)

@@ -219,6 +219,18 @@ std::shared_ptr<vh::SharpenLutWindow> sharpen_lut_window_cached(double x1, doubl
 	});
 	w->below = lut[0];
 	w->above = lut[65535];
+	// the run of zeros around a difference of 0 (m1 = 0, the default: |difference| < x1): the pixels sharpen leaves alone
+	w->zero_lo = 1;
+	w->zero_hi = 0;
+	if (lut[32768] == 0) {
+		int zl = 32768, zh = 32768;
+		while (zl > 0 && lut[zl - 1] == 0)
+			zl--;
+		while (zh < 65535 && lut[zh + 1] == 0)
+			zh++;
+		w->zero_lo = zl - 32768;
+		w->zero_hi = zh - 32768;
+	}
 	w->lo = lo < 65536 ? lo : 0;
 	w->n = lo < 65536 && hi >= lo ? hi - lo + 1 : 0;
 	w->lut_win = nullptr;
@@ -942,6 +954,19 @@ static BatchStreams *batch_streams()
 		return nullptr;
 	const int cus = prop.multiProcessorCount;
 	const int share = getenv("VIPS_HIP_BATCH_SHARPEN_CUS") ? atoi(getenv("VIPS_HIP_BATCH_SHARPEN_CUS")) : cus / 4;
+	if (share == 0) {
+		// $VIPS_HIP_BATCH_SHARPEN_CUS=0: two plain streams, both kernels on every CU (the sharpen's at the lowest
+		// priority the device offers: it fills what the resize leaves)
+		int least = 0, greatest = 0;
+		(void) hipDeviceGetStreamPriorityRange(&least, &greatest);
+		if (hipStreamCreateWithPriority(&bs.resize, hipStreamNonBlocking, greatest) != hipSuccess ||
+			hipStreamCreateWithPriority(&bs.sharpen, hipStreamNonBlocking, least) != hipSuccess) {
+			bs.resize = bs.sharpen = nullptr;
+			(void) hipGetLastError();
+			return nullptr;
+		}
+		return &bs;
+	}
 	if (cus < 16 || cus > 1024 || share < 8 || share > cus - 8)
 		return nullptr;
 	std::vector<uint32_t> lo((cus + 31) / 32, 0u), hi((cus + 31) / 32, 0u);

@@ -19,6 +19,9 @@
 #define VH_KERNEL_STMT_H
 #define VH_SAT_PK_U8_I16(r, both) ((r) = vh::sat_pk_u8_i16(both))
 #define VH_DOT2_SCALAR_COEF(dst, pk, coef, acc) ((dst) = vh::dot2(pk, coef, acc))
+#define VH_MAD_U24(dst, a, b, c) ((dst) = ((unsigned int) (a) & 0xffffffu) * ((unsigned int) (b) & 0xffffffu) + (unsigned int) (c))
+#define VH_MUL_HI_U24(dst, a, b) \
+	((dst) = (unsigned int) (((unsigned long long) ((unsigned int) (a) & 0xffffffu) * ((unsigned int) (b) & 0xffffffu)) >> 32))
 #define VH_STORE_BYTE(p, v) (*(unsigned char *) (p) = (unsigned char) (v))
 #define VH_ASM_MARK(text) ((void) 0)
 #define VH_VECTOR1(a) ((void) (a))
@@ -87,6 +90,7 @@ struct ThreadIdx {
 #define __builtin_amdgcn_kernarg_segment_ptr() (emul::geometry().kernarg)
 #define __syncthreads() emul::barrier()
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned int atomicAdd(unsigned int *p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 
 // ---- amdgcn builtins (wave-uniform values are uniform by construction in the kernels emulated here)
 #define __builtin_amdgcn_readfirstlane(x) (x)
