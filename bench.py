@@ -1167,6 +1167,27 @@ def ops_table():
     chain("premultiply_u8", rgba8, lambda im: im.premultiply(), "premultiply:", float_out=True)
     chain("reduce_rgba16_8", rgba16, lambda im: im.reduce(8, 8), "reduce:hshrink=8,vshrink=8,kernel=lanczos3")
     chain("shrink_rgba16_4", rgba16, lambda im: im.shrink(4, 4), "shrink:hshrink=4,vshrink=4")
+    # ---- round 6 (VERDICT r5 "missing 4"): the rows north_star names that the table never timed
+    chain("shrinkv_rgba16_4", rgba16, lambda im: im.shrinkv(4), "shrinkv:vshrink=4")
+    chain("shrinkh_rgba16_4", rgba16, lambda im: im.shrinkh(4), "shrinkh:hshrink=4")
+    chain("reduce_f32_8", rgbf, lambda im: im.reduce(8, 8), "reduce:hshrink=8,vshrink=8,kernel=lanczos3", float_out=True)
+    chain("shrink_f32_4", rgbf, lambda im: im.shrink(4, 4), "shrink:hshrink=4,vshrink=4", float_out=True)
+    chain("unpremultiply_u8", rgba8, lambda im: im.unpremultiply(), "unpremultiply:", float_out=True)
+    # vips_thumbnail_image of an RGBA image: premultiply -> resize -> unpremultiply -> cast (thumbnail.c:848-904)
+    chain("thumbnail_rgba_500", rgba8, lambda im: im.thumbnail_image(500), "thumbnail_image:width=500")
+    # the upsizing half of vips_resize: vips_affine + bicubic (resize.c:230-300, bicubic.cpp:482-600)
+    chain("resize_bicubic_x2.5", (3276, 3, "u8", "srgb", "lcg"), lambda im: im.resize(2.5, kernel="cubic"),
+          "resize:scale=2.5,kernel=cubic")
+    chain("colourspace_lab_xyz_f32", (8192, 3, "f32", "lab", "lab"), lambda im: im.colourspace("xyz"),
+          "colourspace:space=xyz", float_out=True)
+    chain("colourspace_xyz_scrgb_f32", (8192, 3, "f32", "xyz", "xyz"), lambda im: im.colourspace("scrgb"),
+          "colourspace:space=scrgb", float_out=True)
+    masked("conva_5x5_u8", rgb8, lambda im: im.conv(k5, scale=256, precision="approximate"), "conv", k5, 256.0,
+           "precision=approximate")
+    # vips_sharpen on an image whose neighbouring pixels are near each other (a photograph's case; the LCG noise
+    # above is the other end: every pixel outside the LUT's flat centre): bilinear x 8 of 1024 x 1024 of noise
+    chain("sharpen_u8_smooth", (8192, 3, "u8", "srgb", "smooth"), lambda im: im.sharpen(), "sharpen:")
+    chain("sharpen_u8_smooth_2k", (2000, 3, "u8", "srgb", "smooth"), lambda im: im.sharpen(), "sharpen:")
     return ops
 
 
@@ -1195,11 +1216,17 @@ def run_ops(ctx, steps, warmup, verify=True, cpu=True, only=None):
                 if dt == "u16":
                     src = lcg_image_device(torch, edge, edge, 2 * bands, 12345, ctx.device).view(torch.uint16)
                     src = src.reshape(edge, edge, bands)
-                elif how == "lab":
+                elif how in ("lab", "xyz"):
                     u8 = lcg_image_device(torch, edge, edge, bands, 12345, ctx.device)
-                    lab = Image.new_from_tensor(u8, interpretation="srgb").colourspace("lab")
+                    lab = Image.new_from_tensor(u8, interpretation="srgb").colourspace(how)
                     src = torch.from_numpy(lab.numpy()).to(ctx.device)
                     del lab, u8
+                elif how == "smooth":
+                    small = lcg_image_device(torch, (edge + 7) // 8, (edge + 7) // 8, bands, 12345, ctx.device)
+                    up = torch.nn.functional.interpolate(small.permute(2, 0, 1)[None].float(), scale_factor=8,
+                                                         mode="bilinear", align_corners=False)
+                    src = up[0, :, :edge, :edge].permute(1, 2, 0).round().clamp(0, 255).to(torch.uint8).contiguous()
+                    del small, up
                 else:
                     src = lcg_image_device(torch, edge, edge, bands, 12345, ctx.device)
                     if dt == "f32":

@@ -715,14 +715,75 @@ cast_kernel(CastArgs a)
 	}
 }
 
+// A plain cast (every band, rows that start where a group of four elements does on both sides): a lane owns FOUR
+// neighbouring elements -- one load, one store of 4 x sizeof (16 bytes for a float: a wave writes 1 KiB of a line
+// in one instruction) -- and RU rows are in flight per lane.  vips_cast's arithmetic is CastOne's, element by
+// element (conversion/cast.c:120-330); round 5's one-element-per-lane form ran at 56 % of 8 TB/s on uchar -> float.
+template <typename T>
+struct alignas(4 * sizeof(T)) CastQuad {
+	T v[4];
+};
+
+template <typename TIN, typename TOUT>
+__global__ void __launch_bounds__(256)
+cast_quad_kernel(CastArgs a)
+{
+	const int g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= a.ne / 4)
+		return;
+	for (int y0 = blockIdx.y * RU; y0 < a.height; y0 += gridDim.y * RU) {
+		CastQuad<TIN> v[RU];
+#pragma unroll
+		for (int r = 0; r < RU; r++) {
+			const int y = min(y0 + r, a.height - 1);
+			v[r] = ((const CastQuad<TIN> *) (a.in + (long long) y * a.in_stride))[g];
+		}
+#pragma unroll
+		for (int r = 0; r < RU; r++)
+			if (y0 + r < a.height) {
+				CastQuad<TOUT> o;
+#pragma unroll
+				for (int i = 0; i < 4; i++)
+					o.v[i] = CastOne<TIN, TOUT>::run(v[r].v[i]);
+				((CastQuad<TOUT> *) (a.out + (long long) (y0 + r) * a.out_stride))[g] = o;
+			}
+	}
+}
+
+template <typename TIN, typename TOUT>
+static bool cast_quad_ok(const CastArgs &a)
+{
+	if (a.take != a.in_bands || a.take != a.out_bands || a.in_first != 0 || a.out_first != 0 || a.ne < 1024)
+		return false;
+	if (getenv("VIPS_HIP_NO_CAST_QUAD"))
+		return false;
+	return !(((uintptr_t) a.in | (uintptr_t) a.in_stride) % (4 * sizeof(TIN))) &&
+		!(((uintptr_t) a.out | (uintptr_t) a.out_stride) % (4 * sizeof(TOUT)));
+}
+
 template <typename TIN>
-static int launch_cast_out(const CastArgs &a, int out_format)
+static int launch_cast_out(const CastArgs &a_all, int out_format)
 {
 	dim3 block(256, 1, 1);
-	dim3 grid((a.ne + 255) / 256, rows_grid((a.ne + 255) / 256, a.height), 1);
+	CastArgs a = a_all;
 	Gate gate("cast");
 #define GO(TOUT) \
-	hipLaunchKernelGGL((cast_kernel<TIN, TOUT>), grid, block, 0, stream(), a); \
+	if (cast_quad_ok<TIN, TOUT>(a)) { \
+		const int groups = a.ne / 4; \
+		dim3 qgrid((groups + 255) / 256, rows_grid((groups + 255) / 256, a.height), 1); \
+		hipLaunchKernelGGL((cast_quad_kernel<TIN, TOUT>), qgrid, block, 0, stream(), a); \
+		/* the last ne % 4 elements of every row: the element kernel on what is left */ \
+		a.in += (size_t) groups * 4 * sizeof(TIN); \
+		a.out += (size_t) groups * 4 * sizeof(TOUT); \
+		a.ne -= groups * 4; \
+		/* (a.take stays: x = e / take, b = e % take address the same elements from the moved base \
+		   only when the split falls on a pixel boundary or take == bands == the whole row's period; \
+		   with every band taken ie == oe == e, so any split is right) */ \
+	} \
+	if (a.ne > 0) { \
+		dim3 grid((a.ne + 255) / 256, rows_grid((a.ne + 255) / 256, a.height), 1); \
+		hipLaunchKernelGGL((cast_kernel<TIN, TOUT>), grid, block, 0, stream(), a); \
+	} \
 	break;
 	switch (out_format) {
 	case VIPS_HIP_FORMAT_UCHAR: GO(unsigned char)
@@ -1831,6 +1892,51 @@ static __device__ __forceinline__ void premul_pixel(const TIN (&p)[NB], float (&
 	}
 }
 
+// RGBA with aligned rows: one vector load and one 16-byte store per pixel (a wave writes 1 KiB of a line per
+// instruction), RU rows in flight per lane.  8-bit alpha: what premul_pixel makes of an alpha value -- the factor
+// (a double division) and the alpha it writes -- is a 256-entry table the block fills with premul_pixel itself
+// (1.0f * factor == factor), so a pixel is three multiplies.  Round 5's form (a row per turn, the division per
+// pixel) ran at 62 % of 8 TB/s.
+template <typename TIN, bool INVERSE>
+__global__ void __launch_bounds__(256)
+premul_rgba_kernel(PremulArgs a)
+{
+	constexpr bool TABLE = sizeof(TIN) == 1;
+	__shared__ float2 s_tab[TABLE ? 256 : 1];
+	if constexpr (TABLE) {
+		const TIN one[4] = { (TIN) 1, (TIN) 1, (TIN) 1, (TIN) (unsigned char) threadIdx.x };
+		float q[4];
+		premul_pixel<TIN, INVERSE, 4>(one, q, a.max_alpha);
+		s_tab[threadIdx.x] = make_float2(q[0], q[3]);
+		__syncthreads();
+	}
+	const int x = blockIdx.x * blockDim.x + threadIdx.x;
+	if (x >= a.width)
+		return;
+	for (int y0 = blockIdx.y * RU; y0 < a.height; y0 += gridDim.y * RU) {
+		Vec4<TIN> pv[RU];
+#pragma unroll
+		for (int r = 0; r < RU; r++)
+			pv[r] = ((const Vec4<TIN> *) (a.in + (long long) min(y0 + r, a.height - 1) * a.in_stride))[x];
+#pragma unroll
+		for (int r = 0; r < RU; r++) {
+			if (y0 + r >= a.height)
+				break;
+			float qv[4];
+			if constexpr (TABLE) {
+				const float2 e = s_tab[(unsigned char) pv[r].v[3]];
+#pragma unroll
+				for (int i = 0; i < 3; i++)
+					qv[i] = INVERSE ? __fmul_rn(e.x, (float) pv[r].v[i]) : __fmul_rn((float) pv[r].v[i], e.x);
+				qv[3] = e.y;
+			}
+			else
+				premul_pixel<TIN, INVERSE, 4>(pv[r].v, qv, a.max_alpha);
+			((float4 *) (a.out + (long long) (y0 + r) * a.out_stride))[x] = make_float4(qv[0], qv[1], qv[2], qv[3]);
+		}
+	}
+}
+
 template <typename TIN, bool INVERSE>
 __global__ void __launch_bounds__(256)
 premul_float_kernel(PremulArgs a)
@@ -1838,17 +1944,6 @@ premul_float_kernel(PremulArgs a)
 	const int x = blockIdx.x * blockDim.x + threadIdx.x;
 	if (x >= a.width)
 		return;
-	// RGBA with aligned rows: one vector load and one 16-byte store per pixel
-	if (a.bands == 4 && !(((uintptr_t) a.in | (uintptr_t) a.in_stride) % (4 * sizeof(TIN))) &&
-		!(((uintptr_t) a.out | (uintptr_t) a.out_stride) & 15)) {
-		for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
-			const Vec4<TIN> pv = ((const Vec4<TIN> *) (a.in + (long long) y * a.in_stride))[x];
-			float qv[4];
-			premul_pixel<TIN, INVERSE, 4>(pv.v, qv, a.max_alpha);
-			((float4 *) (a.out + (long long) y * a.out_stride))[x] = make_float4(qv[0], qv[1], qv[2], qv[3]);
-		}
-		return;
-	}
 	const int ab = a.bands - 1;
 	for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
 		const TIN *p = (const TIN *) (a.in + (long long) y * a.in_stride) + (long long) x * a.bands;
@@ -1934,7 +2029,14 @@ int premultiply_region(const VipsHipRegion *in, const VipsHipRegion *out, double
 	}
 	else {
 #define GO(TIN) \
-	if (inverse) \
+	if (a.bands == 4 && !(((uintptr_t) a.in | (uintptr_t) a.in_stride) % (4 * sizeof(TIN))) && \
+		!(((uintptr_t) a.out | (uintptr_t) a.out_stride) & 15) && !getenv("VIPS_HIP_NO_PREMUL_RGBA")) { \
+		if (inverse) \
+			hipLaunchKernelGGL((premul_rgba_kernel<TIN, true>), grid, block, 0, stream(), a); \
+		else \
+			hipLaunchKernelGGL((premul_rgba_kernel<TIN, false>), grid, block, 0, stream(), a); \
+	} \
+	else if (inverse) \
 		hipLaunchKernelGGL((premul_float_kernel<TIN, true>), grid, block, 0, stream(), a); \
 	else \
 		hipLaunchKernelGGL((premul_float_kernel<TIN, false>), grid, block, 0, stream(), a); \

@@ -10,7 +10,10 @@ namespace vh {
 // blocks are dealt to the 8 XCDs round-robin by the hardware: give an XCD a contiguous range of items
 // (neighbouring strips of a segment share their halo columns in its L2)
 template <int B, bool WIDE, int MODE>
-__global__ void __launch_bounds__(256, 3) // (3 waves per SIMD: the 45 KB of LDS a block takes allow 3 blocks per CU)
+// (3 waves per SIMD: the 45 KB of LDS a block takes at up to 3 bands allow 3 blocks per CU; the separable kernel on
+// 4 bands takes 56-64 KB -- two blocks a CU whatever the registers -- and spilled 10 / 24 vector registers at 168:
+// two waves per SIMD there, profiles/r05_kernel_resources.txt)
+__global__ void __launch_bounds__(256, (B == 4 && MODE == 0) ? 2 : 3)
 conv_u8_mfma_sep(CmArgs a, int items)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned int cm_lds[];

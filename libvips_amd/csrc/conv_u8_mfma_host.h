@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <list>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -110,6 +111,12 @@ struct CmTables {
 };
 std::mutex cm_mutex;
 std::map<std::vector<int>, CmTables> cm_cache;
+// least recently used first.  The key holds the edge geometry, which changes with nearly every image width: a
+// process that blurs images of arbitrary widths would otherwise grow this (16 KB x rows of device memory an
+// entry) without bound.  An evicted table may still be read by a kernel some thread has queued, so
+// eviction -- rare: CM_CACHE_MAX distinct (mask, width) pairs later -- waits for the device before it frees.
+std::list<std::vector<int>> cm_order;
+constexpr size_t CM_CACHE_MAX = 128;
 
 // c: rows x n taps (rows = 1: the separable mask); the set for variant v, mask row i starts at table (v rows + i)
 int cm_tables_device(const int *c, int n, int rows, int hp, int width, CmTables *out)
@@ -160,6 +167,24 @@ int cm_tables_device(const int *c, int n, int rows, int hp, int width, CmTables 
 		for (int k = 0; k < 3; k++)
 			t.edge_wave[k] = waves[k];
 		it = cm_cache.emplace(key, t).first;
+		cm_order.push_back(key);
+		while (cm_cache.size() > CM_CACHE_MAX && !cm_order.empty()) {
+			auto old = cm_cache.find(cm_order.front());
+			cm_order.pop_front();
+			if (old == cm_cache.end() || old == it)
+				continue;
+			(void) hipDeviceSynchronize();
+			vips_hip_free(old->second.tz);
+			cm_cache.erase(old);
+		}
+	}
+	else {
+		// (touch: to the young end)
+		for (auto o = cm_order.begin(); o != cm_order.end(); ++o)
+			if (*o == key) {
+				cm_order.splice(cm_order.end(), cm_order, o);
+				break;
+			}
 	}
 	*out = it->second;
 	return 0;

@@ -424,10 +424,18 @@ const ReducePos *reduce_device_positions(_VipsHipReduce *r, int start, int count
 	if (!d)
 		return nullptr;
 	// Bound the cache: tiled callers walk many distinct rects.
+	// (only the position arrays -- keys with start >= 0 -- go: the map also holds the plan's long-lived blobs under
+	// negative tags (the matrix-core operand tables, reduce_band's coefficient blocks of up to 64 MB, the ushort
+	// schedules with their host records in blob_info), which other threads hold raw pointers to: ADVICE r5)
 	if (r->pos_cache.size() > 256) {
-		for (auto &kv : r->pos_cache)
-			vips_hip_free(kv.second);
-		r->pos_cache.clear();
+		for (auto it2 = r->pos_cache.begin(); it2 != r->pos_cache.end();) {
+			if (std::get<0>(it2->first) >= 0) {
+				vips_hip_free(it2->second);
+				it2 = r->pos_cache.erase(it2);
+			}
+			else
+				++it2;
+		}
 	}
 	r->pos_cache[key] = d;
 	return d;

@@ -41,7 +41,11 @@ def test_ops_table_has_the_calls_of_the_path():
     for want in ("reducev_8", "reduceh_8", "reduce_rgb_8", "reduce_rgb_7.3", "resize_rgb_to_1000", "thumbnail_500",
                  "shrinkv_4", "shrinkh_4", "convi_3x3_u8", "convi_5x5_u8", "convi_3x3_u16", "gaussblur_s2_u8",
                  "gaussblur_s8_u8", "gaussblur_s2_u16", "gaussblur_s8_u16", "gaussblur_s2_f32",
-                 "colourspace_srgb_lab_u8", "colourspace_srgb_labs_u8", "sharpen_u8", "reduce_rgba16_8"):
+                 "colourspace_srgb_lab_u8", "colourspace_srgb_labs_u8", "sharpen_u8", "reduce_rgba16_8",
+                 # round 6: the rows VERDICT r5 found untimed
+                 "reduce_f32_8", "shrink_f32_4", "shrinkv_rgba16_4", "shrinkh_rgba16_4", "unpremultiply_u8",
+                 "thumbnail_rgba_500", "resize_bicubic_x2.5", "colourspace_lab_xyz_f32", "colourspace_xyz_scrgb_f32",
+                 "conva_5x5_u8", "sharpen_u8_smooth"):
         assert want in names, want
     for op in bench.ops_table():
         assert ("chain" in op) != ("mask" in op), op["name"]  # every entry has exactly one reference recipe

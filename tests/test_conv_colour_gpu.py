@@ -574,3 +574,45 @@ def test_hip_approximate_regions(approx_path):
         finally:
             lib.vips_hip_conva_free(plan)
             lib.vips_hip_conva_free(sep)
+
+
+CAST_FORMATS = [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.float32, np.float64]
+
+
+@pytest.mark.parametrize("src_dtype", CAST_FORMATS, ids=lambda d: np.dtype(d).name)
+def test_cast_quad_rows(src_dtype, monkeypatch):
+    """Round 6: a plain vips_cast takes four elements per lane (cast_quad_kernel: one load, one 16-byte store for a
+    float) when rows start on a group of four on both sides, and the element kernel takes the last ne % 4 of every
+    row.  Every format pair on rows of 1 365 and 1 366 elements x 3 bands (the second leaves a tail of 2), against
+    the port (conversion/cast.c:120-330) and against the element kernel alone."""
+    for width in (455, 683):
+        src = helpers.lcg_image(width, 37, 3, src_dtype, 90 + width)
+        if np.issubdtype(src_dtype, np.floating):
+            src = (src.astype(np.float64) * 700.0 - 40000.0).astype(src_dtype)  # (beyond every integer range, both signs)
+        for dst in CAST_FORMATS:
+            want = PortCC.cast(src, np.dtype(dst))
+            got = Image.new_from_array(src).cast(helpers.DTYPE_FORMATS[np.dtype(dst)]).numpy()
+            monkeypatch.setenv("VIPS_HIP_NO_CAST_QUAD", "1")
+            old = Image.new_from_array(src).cast(helpers.DTYPE_FORMATS[np.dtype(dst)]).numpy()
+            monkeypatch.delenv("VIPS_HIP_NO_CAST_QUAD")
+            assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True), (src_dtype, dst, width)
+            assert np.array_equal(got, old, equal_nan=True)
+
+
+@pytest.mark.parametrize("src_dtype", [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.float32],
+                         ids=lambda d: np.dtype(d).name)
+@pytest.mark.parametrize("inverse", [False, True])
+def test_premultiply_rgba_rows(src_dtype, inverse, monkeypatch):
+    """Round 6: premultiply / unpremultiply of RGBA to float with RU rows in flight and, for 8-bit alpha, the factor
+    from a 256-entry table the block makes with the per-pixel code itself (premul_rgba_kernel): against the port
+    (conversion/premultiply.c:78-128, unpremultiply.c:85-186) and against the older kernel, every alpha value."""
+    src = helpers.lcg_image(300, 41, 4, src_dtype, 93)
+    src[0, :256, 3] = np.arange(256).astype(src_dtype)  # every 8-bit alpha (and small values of the wider formats)
+    interp = "srgb"
+    want = PortCC.premultiply(src, interp, uchar=False, inverse=inverse)
+    im = Image.new_from_array(src, interpretation=interp)
+    got = (im.unpremultiply() if inverse else im.premultiply()).numpy()
+    monkeypatch.setenv("VIPS_HIP_NO_PREMUL_RGBA", "1")
+    old = (im.unpremultiply() if inverse else im.premultiply()).numpy()
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.int32), want.view(np.int32))
+    assert np.array_equal(got.view(np.int32), old.view(np.int32))

@@ -135,3 +135,23 @@ def test_port_vs_ref_convsep_signed_zeros():
             want = Ref.run_mask("convsep", src, m, scale, offset, "precision=integer")
             got = PortCC.convsep(src, m, scale, offset, "integer")
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (scale, offset)
+
+
+@needs_ref
+def test_srgb_labs_srgb_is_the_identity_on_every_colour():
+    """What colour.hip's sharpen_skip_u8 rests on (round 6): with the compiled reference, sRGB -> LabS -> sRGB gives
+    back every one of the 2^24 uchar colours -- so a pixel vips_sharpen's LUT leaves alone (lut[L - blur] == 0: the
+    whole centre section for m1 = 0, sharpen.c:230-257) leaves the operation as it came in.  (The library repeats the
+    check on the device with its own tables and functions before it selects that kernel: sharpen_identity_kernel.)"""
+    v = np.arange(1 << 24, dtype=np.uint32)
+    img = np.stack([(v >> 16) & 255, (v >> 8) & 255, v & 255], axis=-1).astype(np.uint8).reshape(4096, 4096, 3)
+    back = Ref.run_chain("colourspace:space=labs;colourspace:space=srgb", img, cases.INTERP["srgb"])
+    assert back.dtype == np.uint8 and back.shape == img.shape
+    assert int((back != img).any(axis=-1).sum()) == 0
+    # and the LUT's zero run with the default parameters: |difference| <= 654 or so LabS units either side of 0
+    i = np.arange(65536)
+    d = (i - 32767) / 327.67
+    y = np.where(d < -2.0, (d + 2.0) * 3.0, np.where(d < 2.0, d * 0.0, (d - 2.0) * 3.0))
+    lut = np.rint(np.clip(y, -20.0, 10.0) * 327.67).astype(np.int64)
+    zeros = np.nonzero(lut == 0)[0] - 32768
+    assert zeros.min() <= -650 and zeros.max() >= 650 and np.all(np.diff(zeros) == 1)

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round 5, closing run (the same script as the first call): the evidence on the final tree with the explicit
-# float -> int converters (kernel_stmt.h vh::cvt_*) and -fno-strict-float-cast-overflow.
+# A round's closing run on one box (usage: gpurun -- 'bash tools/closing_run.sh <tag>'; outputs under
+# gpurun_out/<tag>_*, the ones worth keeping are copied into profiles/):
 #   1. the whole GPU suite (no -x)
 #   2. C2: the two PMC passes that stamp profiles/traffic.json (by the kernel's machine-code hash) + a kernel
 #      trace of the driver's command
 #   3. C3: counters + kernel trace of the shipped build, on both inputs (integers / float proper)
 #   4. the full default bench (roofline.traffic non-null, C3/C4/C5 scalars inside roofline, summary last)
-tag=${1:-r05z}
+tag=${1:-closing}
 mkdir -p gpurun_out
 (timeout 1500 python -m pytest tests -q -m gpu --durations=5 2>&1 | tail -14) > gpurun_out/${tag}_tests.txt
 tail -3 gpurun_out/${tag}_tests.txt
@@ -48,10 +48,10 @@ cd $repo
 cut -c1-170 gpurun_out/${tag}_c2_pmc.txt
 cut -c1-170 gpurun_out/${tag}_c3_pmc.txt
 (timeout 100 python tools/fuzz_gpu.py 40 91 resize; timeout 100 python tools/fuzz_gpu.py 30 92 thumb) 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_fuzz.txt; cat gpurun_out/${tag}_fuzz.txt
-(timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo rc=$?
+(timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 | tail -1) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo rc=$?; cp gpurun_out/bench_full.json gpurun_out/${tag}_bench_full.json
 python - <<PY
 import json
 l=json.load(open("gpurun_out/${tag}_bench.json"))
 print({k:l[k] for k in ("ms_per_step","value")}, l["roofline"]["frac"], l["roofline"]["traffic"])
-print(json.dumps(l["summary"]))
+print(json.dumps(l["roofline"]))
 PY
