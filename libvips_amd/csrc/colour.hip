@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <map>
 #include <mutex>
 #include <type_traits>
 
@@ -1687,23 +1688,34 @@ int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const
 	}
 	a.lut = lut;
 	// the blur's division as a 24-bit multiply-high: tried on every sum the mask can make (under a million)
+	// (once per (scale, largest sum): the answer is kept)
 	a.sh24 = -1;
 	a.m24 = 0;
 	{
 		const long long n_max = abs_sum * 32767 + a.rounding;
-		int sh = 0;
-		while (sh < 24 && (n_max << (sh + 1)) < (1LL << 24))
-			sh++;
-		const unsigned long long m = ((1ULL << (32 - sh)) + (unsigned long long) scale - 1) / (unsigned long long) scale;
-		if (n_max < (1LL << 24) && (n_max << sh) < (1LL << 24) && m < (1ULL << 24)) {
-			bool ok = true;
-			for (long long v = 0; v <= n_max && ok; v++)
-				ok = (((unsigned long long) (v << sh) * m) >> 32) == (unsigned long long) (v / scale);
-			if (ok) {
-				a.sh24 = sh;
-				a.m24 = (unsigned int) m;
+		static std::mutex mutex;
+		static std::map<std::pair<int, long long>, std::pair<int, unsigned int>> proven;
+		std::lock_guard<std::mutex> lock(mutex);
+		auto it = proven.find(std::make_pair(scale, n_max));
+		if (it == proven.end()) {
+			std::pair<int, unsigned int> answer(-1, 0u);
+			int sh = 0;
+			while (sh < 24 && (n_max << (sh + 1)) < (1LL << 24))
+				sh++;
+			const unsigned long long m = ((1ULL << (32 - sh)) + (unsigned long long) scale - 1) / (unsigned long long) scale;
+			if (n_max < (1LL << 24) && (n_max << sh) < (1LL << 24) && m < (1ULL << 24)) {
+				bool ok = true;
+				for (long long v = 0; v <= n_max && ok; v++)
+					ok = (((unsigned long long) (v << sh) * m) >> 32) == (unsigned long long) (v / scale);
+				if (ok)
+					answer = std::make_pair(sh, (unsigned int) m);
 			}
+			if (proven.size() > 64)
+				proven.clear();
+			it = proven.emplace(std::make_pair(scale, n_max), answer).first;
 		}
+		a.sh24 = it->second.first;
+		a.m24 = it->second.second;
 	}
 	a.zero_lo = win ? win->zero_lo : 1;
 	a.zero_hi = win ? win->zero_hi : 0;

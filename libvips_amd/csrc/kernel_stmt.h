@@ -32,6 +32,13 @@
 // 24-bit multiplies (full rate; v_mul_lo_u32 / v_mul_hi_u32 issue at a quarter of it): both factors below 2^24
 #define VH_MAD_U24(dst, a, b, c) asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(dst) : "v"(a), "s"(b), "v"(c)) // a * b + c, b scalar
 #define VH_MUL_HI_U24(dst, a, b) asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(dst) : "v"(a), "v"(b))          // (a * b) >> 32
+// hand-off between blocks of one launch without fences (MI355X_MICROARCH.md "valid forms": system-scope stores and
+// loads on both sides, an atomic for the flag): a 16-byte write-through store, a dword load that bypasses the caches
+#define VH_STORE4_SYS(p, v) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory")
+#define VH_LOAD_SYS(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#define VH_STORE_SYS(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+// which of the part's 8 XCDs (each with an L2 of its own) this wave runs on: HW_REG_XCC_ID, bits 3:0
+#define VH_XCC_ID() ((int) (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u))
 #define VH_STORE_BYTE(p, v) asm volatile("global_store_byte %0, %1, off" : : "v"(p), "v"(v) : "memory")
 // a marker that keeps two otherwise identical arms of a switch apart (merged, their register index is dynamic)
 #define VH_ASM_MARK(text) asm volatile("; " text)

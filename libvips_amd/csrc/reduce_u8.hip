@@ -28,7 +28,11 @@
 #include "reduce_u8.h"
 #include "kernel_stmt.h"
 
+#include <atomic>
+#include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <cstring>
 #include <vector>
 
@@ -385,10 +389,10 @@ struct MfmaGeo {
 	}
 };
 
-template <int D, bool NT = false, int PROF = 0, bool PAIRS = false, int NTH = FUSED_THREADS, int LATE = 0>
+template <int D, bool NT = false, int PROF = 0, bool PAIRS = false, int NTH = FUSED_THREADS, int LATE = 0, int XPLANE = 0>
 struct MfmaStep {
 	static constexpr int S = 8;
-	static constexpr int MFMA_PLANE = MfmaGeo<NTH>::PLANE;
+	static constexpr int MFMA_PLANE = XPLANE ? XPLANE : MfmaGeo<NTH>::PLANE; // (XPLANE: the exchange kernel's wider planes)
 
 	// Rows first_row + dir * i, I0 <= i < I0 + N.  The launcher only picks this kernel for
 	// windows < 2 GB, so every address is the uniform base (an SGPR pair) plus one 32-bit lane
@@ -579,6 +583,42 @@ struct MfmaStep {
 		}
 	}
 
+	// hwalk that also hands out the UNROUNDED sums of the segment's outputs 0, 1, 2 (raw[0..2]) and 5, 6, 7
+	// (raw[3..5]): the exchange kernel's partial sums of the outputs that straddle a tile boundary
+	template <int G>
+	static __device__ __forceinline__ void hwalk_x(float4v (&hacc)[2], const unsigned char *line, const half4v *lane_ah,
+		int hc, unsigned int (&pix)[2], float (&raw)[6])
+	{
+		constexpr int NG = HSEG_OUT + D - 1;
+		if constexpr (G < NG) {
+			constexpr int ROT = G % MFMA_SLOTS;
+			const half4v b0 = bytes_b(*reinterpret_cast<const unsigned int *>(line + 8 * G));
+			const half4v b1 = bytes_b(*reinterpret_cast<const unsigned int *>(line + 8 * G + 4));
+			hacc[0] = __builtin_amdgcn_mfma_f32_4x4x4f16(lane_ah[((ROT * 2 + 0) * 2 + 0) * 4], b0, hacc[0], 0, 0, 0);
+			hacc[1] = __builtin_amdgcn_mfma_f32_4x4x4f16(lane_ah[((ROT * 2 + 0) * 2 + 1) * 4], b0, hacc[1], 0, 0, 0);
+			hacc[0] = __builtin_amdgcn_mfma_f32_4x4x4f16(lane_ah[((ROT * 2 + 1) * 2 + 0) * 4], b1, hacc[0], 0, 0, 0);
+			hacc[1] = __builtin_amdgcn_mfma_f32_4x4x4f16(lane_ah[((ROT * 2 + 1) * 2 + 1) * 4], b1, hacc[1], 0, 0, 0);
+			constexpr int SLOT = (ROT - (D - 1) + 2 * MFMA_SLOTS) % MFMA_SLOTS;
+			constexpr int H = SLOT >> 2, I = SLOT & 3;
+			if constexpr (G >= D - 1) {
+				constexpr int O = G - (D - 1);
+				if constexpr (O < 3)
+					raw[O] = hacc[H][I];
+				if constexpr (O >= 5)
+					raw[O - 2] = hacc[H][I];
+				int v = (int) fin_pack(hacc[H][I], (unsigned int) hc, 0);
+				v |= __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
+				v |= __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
+				if (hc == O / 2)
+					pix[O & 1] = (unsigned int) v;
+			}
+			hacc[H][I] = 0.0f;
+			if constexpr ((G & 1) == 1)
+				__builtin_amdgcn_sched_barrier(0);
+			hwalk_x<G + 1>(hacc, line, lane_ah, hc, pix, raw);
+		}
+	}
+
 	// NB = prefetch depth: group g lives in ring buffer g mod NB (NB divides 8, so the index is
 	// static) and each of its quads is refilled with group g + NB as soon as it has been consumed.
 	template <int ROT, int NB>
@@ -755,6 +795,300 @@ reduce_fused_u8x4_mfma(FusedArgs a, const MfmaTables *__restrict__ tables)
 	}
 }
 
+
+// ------------------------------------------------ ... without the tiles' horizontal halo (round 6)
+//
+// reduce_fused_u8x4_mfma reads 512 input columns to make 56 outputs' worth (448): one eighth of its requests are
+// columns the tile on either side reads too, and on this part the requests a CU issues bound the stream
+// (profiles/NOTES.md 3.1: 2 KB strips without halos stream at 7.1 TB/s, the 59-pixel tiles at 5.8).  Here a tile
+// IS 512 aligned columns -- a wave's row segment is four whole 128-byte lines, no column is requested twice -- and
+// makes all 64 of its outputs; the six outputs whose 48 taps straddle a tile boundary (three either side) are made
+// as PARTIAL SUMS by both tiles, each over its own columns (the T planes carry 48 bytes of zeros either side; at
+// the image's edges the edge column, replicated: vips_embed COPY), and a second, tiny kernel adds the two halves
+// and rounds them (exact: both are integers below 2^23 in units of 2^-24).  Partial sums and output rows wait in
+// LDS and leave in one burst at the tile's end (a trickle of writes would cost the read stream a tenth of its
+// rate: tools/write_probe).  Two blocks a CU (78 KB of LDS each), NB row groups in flight per lane, tiles of 128
+// output rows: 32 x 16 tiles for BASELINE config 2 = one residency round; requests 1.04 x the image (the
+// vertical halo) against 1.22 x.
+constexpr int XH = 48;                 // halo bytes either side of a T plane row
+constexpr int XPLANE = XH + 512 + XH + 4; // 612 bytes = 153 dwords (odd: 32 planes in 32 banks)
+constexpr int XGUARD = 64;             // in front of the planes: segment -1 of plane 0 reads 40 bytes before its row
+constexpr int XPLANES_BYTES = XGUARD + MFMA_SLOTS * 4 * XPLANE;
+constexpr int XPART = 48;              // floats per row: [side 2][straddling output 6][channel 4]
+constexpr int XMAX_OHT = 128;
+static constexpr size_t xlds_bytes(int oht)
+{
+	return (size_t) XPLANES_BYTES + 2 * MFMA_TABLE_ENTRIES * 8 + (size_t) oht * 64 * 4 + (size_t) oht * XPART * 4;
+}
+
+template <int D, int NB, int OCC>
+__global__ void __launch_bounds__(FUSED_THREADS, OCC)
+reduce_fused_u8x4_mfma_x(FusedArgs a, const MfmaTables *__restrict__ tables, float *parts, int *arrivals, int plain,
+	int *misplaced)
+{
+	constexpr int S = 8;
+	typedef MfmaStep<D, true, 0, true, FUSED_THREADS, 1, XPLANE> Step;
+	VH_DYNAMIC_LDS(unsigned char, lds_raw);
+	unsigned char *planes = lds_raw + XGUARD + XH; // byte p of a plane row = the tile's own column p
+	half4v *lds_a = reinterpret_cast<half4v *>(lds_raw + XPLANES_BYTES);
+	half4v *lds_ah = lds_a + MFMA_TABLE_ENTRIES;
+	unsigned int *stage = reinterpret_cast<unsigned int *>(lds_ah + MFMA_TABLE_ENTRIES); // oht rows of 64 pixels
+	float *part = reinterpret_cast<float *>(stage + a.oht * 64);                           // oht rows of XPART floats
+
+	// XCD k (blocks b = k mod 8) takes WHOLE rows of tiles, a contiguous run of them: horizontal neighbours -- which
+	// hand partial sums to each other -- and most vertical ones share an L2
+	const int per_xcd = gridDim.x / 8; // = rows of tiles per XCD x tiles_x (host)
+	const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+	if (tile >= a.tiles)
+		return;
+	const int t = threadIdx.x;
+	const int by = tile / a.tiles_x;
+	const int bx = tile - by * a.tiles_x;
+	const int y0 = by * a.oht;
+	const int oh = min(a.oht, a.out_height - y0);
+	const int ca = 512 * bx + 2 * t - a.in_left;
+	const bool flip = (by & 1) != 0;
+	const int dir = flip ? -1 : 1;
+	const int row0 = flip ? a.fy0 + S * (y0 + oh - 1) + S * D - 1 : a.fy0 + S * y0;
+
+	// zeros in the planes (the halos stay zero: a group only ever writes its own 512 columns), the tables
+	for (int i = t; i < XPLANES_BYTES / 4; i += FUSED_THREADS)
+		reinterpret_cast<unsigned int *>(lds_raw)[i] = 0u;
+	if (t < MFMA_TABLE_ENTRIES) {
+		reinterpret_cast<uint2 *>(lds_a)[t] = reinterpret_cast<const uint2 *>(tables->a[flip ? 1 : 0])[t];
+		reinterpret_cast<uint2 *>(lds_ah)[t] = reinterpret_cast<const uint2 *>(tables->ah)[t];
+	}
+	const half4v *lane_a = lds_a + (t & 3);
+
+	float4v acc[8][2];
+#pragma unroll
+	for (int o = 0; o < 8; o++)
+#pragma unroll
+		for (int h = 0; h < 2; h++)
+			acc[o][h] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+
+	const int ngroups = oh + D - 1;
+	uint2 px[NB][S];
+#pragma unroll
+	for (int b = 0; b < NB; b++)
+		if (b < ngroups)
+			Step::template load_rows<0, S>(a, px[b], row0 + dir * S * b, dir, ca, 0, 1);
+	__syncthreads();
+
+	const bool left_edge = bx == 0, right_edge = bx == a.tiles_x - 1;
+	for (int g0 = 0; g0 < ngroups; g0 += MFMA_SLOTS) {
+		Step::template batch<0, NB>(a, px, g0, ngroups, acc, planes, lane_a, t, row0, dir, ca, 0, 1, oh);
+
+		// ---- horizontal pass over the rows this batch completed (T row r <-> group g0 + r)
+		const int jlo = max(g0 - (D - 1), 0);
+		const int jhi = min(g0 + MFMA_SLOTS - 1 - (D - 1), oh - 1); // inclusive
+		if (jhi < jlo)
+			continue;
+		__syncthreads();
+		if (left_edge || right_edge) {
+			// vips_embed(COPY): the columns beyond the image are its edge column, in every plane row
+			for (int i = t; i < MFMA_SLOTS * 4 * (XH / 4); i += FUSED_THREADS) {
+				const int rowc = i / (XH / 4), d = i - rowc * (XH / 4);
+				unsigned char *prow = planes + rowc * XPLANE;
+				if (left_edge)
+					*reinterpret_cast<unsigned int *>(prow - XH + 4 * d) = (unsigned int) prow[0] * 0x01010101u;
+				if (right_edge)
+					*reinterpret_cast<unsigned int *>(prow + 512 + 4 * d) = (unsigned int) prow[511] * 0x01010101u;
+			}
+			__syncthreads();
+		}
+		const int nrows = jhi - jlo + 1;
+		const int r_lo = jlo - (g0 - (D - 1));
+		// thread -> (T row, segment of HSEG_OUT outputs, channel); then the first wave again for the two
+		// segments outside the tile (outputs -8 .. -1 and 64 .. 71: the neighbours' straddling outputs)
+#pragma unroll 1
+		for (int round = 0; round < 2; round++) {
+			if (round == 1 && t >= 64)
+				break;
+			const int hc = t & 3, hr = (t >> 2) & 7;
+			const int hseg = round == 0 ? t >> 5 : ((t >> 5) & 1 ? 8 : -1);
+			const half4v *lane_ah = lds_ah + hc;
+			const bool row_ok = hr < nrows;
+			const int lrow = r_lo + (row_ok ? hr : 0);
+			const unsigned char *line = planes + (lrow * 4 + hc) * XPLANE + a.fx0 + 8 * HSEG_OUT * hseg;
+			float4v hacc[2];
+			hacc[0] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+			hacc[1] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+			unsigned int pix[2] = { 0, 0 };
+			float raw[6];
+			Step::template hwalk_x<0>(hacc, line, lane_ah, hc, pix, raw);
+			if (!row_ok)
+				continue;
+			const int jj = jlo + hr;
+			if (round == 0)
+				*reinterpret_cast<uint2 *>(stage + jj * 64 + HSEG_OUT * hseg + 2 * hc) = make_uint2(pix[0], pix[1]);
+			// straddling outputs, side 0: local outputs -3 .. 2, side 1: 61 .. 66
+			float *prow = part + jj * XPART + hc;
+			if (hseg == 0) {
+#pragma unroll
+				for (int o = 0; o < 3; o++)
+					prow[(3 + o) * 4] = raw[o];
+			}
+			else if (hseg == 7) {
+#pragma unroll
+				for (int o = 0; o < 3; o++)
+					prow[24 + o * 4] = raw[3 + o];
+			}
+			else if (hseg == -1) {
+#pragma unroll
+				for (int o = 0; o < 3; o++)
+					prow[o * 4] = raw[3 + o];
+			}
+			else if (hseg == 8) {
+#pragma unroll
+				for (int o = 0; o < 3; o++)
+					prow[24 + (3 + o) * 4] = raw[o];
+			}
+		}
+		__syncthreads();
+	}
+
+	// ---- the tile's end.  Its partial sums leave first (write-through); then it ARRIVES at its two boundaries (an
+	// atomic counter each: two arrivals a launch, so the parity of what the atomic returns says who is second, launch
+	// after launch without a reset).  The LATER tile of a boundary reads the earlier one's halves -- published before
+	// that tile arrived -- adds its own, rounds (MfmaStep::fin_pack: exact integers below 2^23 in units of 2^-24) and
+	// writes all six straddling pixels: its own three through the stage, the neighbour's three straight to the
+	// image.  The earlier tile leaves those three alone.  Nobody waits for anybody.  At the image's edges the tile
+	// holds the whole sums (the replicated edge column) and is "second" by itself.
+	if (a.debug & 32) {
+		// ($VIPS_HIP_FUSED_DEBUG=32: the two-kernel form -- partial sums by output row, reduce_fused_edges adds them)
+		const int part16 = t & 15;
+		for (int r = t >> 4; r < oh; r += 16) {
+			unsigned int *dst = reinterpret_cast<unsigned int *>(
+				a.out + (long long) (y0 + (flip ? oh - 1 - r : r)) * a.out_stride + (long long) (64 * bx) * 4);
+			typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+			*reinterpret_cast<u32x4 *>(dst + 4 * part16) = *reinterpret_cast<const u32x4 *>(stage + r * 64 + 4 * part16);
+		}
+		float *dstp = parts + (size_t) tile * a.oht * XPART;
+		for (int i = t; i < oh * (XPART / 4); i += FUSED_THREADS) {
+			const int r = i / (XPART / 4), q = i - r * (XPART / 4);
+			const int yrel = flip ? oh - 1 - r : r;
+			reinterpret_cast<float4 *>(dstp + (size_t) yrel * XPART)[q] = reinterpret_cast<const float4 *>(part + r * XPART)[q];
+		}
+		return;
+	}
+	{
+		typedef float f32x4 __attribute__((ext_vector_type(4)));
+		const bool placed = VH_XCC_ID() == (int) (blockIdx.x & 7u);
+		const bool use_plain = plain && placed;
+		if (plain && !placed && t == 0)
+			VH_STORE_SYS(misplaced, 1);
+		float *dstp = parts + (size_t) tile * a.oht * XPART; // (rows in WALK order: the tiles of a row of tiles share it)
+		for (int i = t; i < oh * (XPART / 4); i += FUSED_THREADS) {
+			f32x4 *dst = reinterpret_cast<f32x4 *>(dstp) + i;
+			const f32x4 v = reinterpret_cast<const f32x4 *>(part)[i];
+			// The two tiles of a boundary are neighbours in one row of tiles, and a row of tiles belongs to ONE XCD
+			// (the tile numbering above, with block b on XCD b % 8: what the part does, checked by a census launch
+			// before `plain` is ever set -- xcc_census_kernel -- and by every block for itself here): their hand-off
+			// can stay in that XCD's L2 -- plain stores, read by the other tile with loads that skip ITS L1 --
+			// instead of going through to memory (12.6 MB of write-through at the kernel's tail: 0.1914 against
+			// 0.1867 ms a launch).  A block that finds itself elsewhere writes through and says so (*misplaced, host
+			// memory: the host stops using the plain form and reports it -- never seen).
+			if (use_plain)
+				*dst = v;
+			else
+				VH_STORE4_SYS(dst, v);
+		}
+		VH_WAIT_VMCNT(0);
+		__syncthreads();
+		int *second = reinterpret_cast<int *>(lds_raw); // (the planes are done with)
+		if (t < 2) { // (two lanes: the two atomics travel together)
+			int *at = arrivals + by * (a.tiles_x + 1) + bx + t;
+			const bool edge = t == 0 ? left_edge : right_edge;
+			second[t] = edge ? 1 : (atomicAdd(at, 1) & 1);
+		}
+		__syncthreads();
+		const int sec[2] = { second[0], second[1] };
+#pragma unroll 1
+		for (int side = 0; side < 2; side++) {
+			if (!sec[side])
+				continue;
+			const bool at_edge = side == 0 ? left_edge : right_edge;
+			const float *theirs = parts + (size_t) (tile + (side ? 1 : -1)) * a.oht * XPART + (1 - side) * 24;
+			for (int i = t; i < oh * 6; i += FUSED_THREADS) {
+				const int r = i / 6, o = i - r * 6;
+				const float *mine = part + r * XPART + side * 24 + o * 4;
+				float v[4] = { mine[0], mine[1], mine[2], mine[3] };
+				if (!at_edge) {
+					const float *p = theirs + (size_t) r * XPART + o * 4;
+#pragma unroll
+					for (int c = 0; c < 4; c++)
+						v[c] += VH_LOAD_SYS(p + c);
+				}
+				unsigned int pxl = Step::fin_pack(v[0], 0, 0);
+				pxl = Step::fin_pack(v[1], 1, pxl);
+				pxl = Step::fin_pack(v[2], 2, pxl);
+				pxl = Step::fin_pack(v[3], 3, pxl);
+				const int xl = (side ? 61 : -3) + o; // local output
+				if (xl >= 0 && xl < 64)
+					stage[r * 64 + xl] = pxl;
+				else if (!at_edge)
+					*reinterpret_cast<unsigned int *>(a.out + (long long) (y0 + (flip ? oh - 1 - r : r)) * a.out_stride +
+						(long long) (64 * bx + xl) * 4) = pxl;
+			}
+		}
+		__syncthreads();
+		// the burst: 16 lanes a row, 4 pixels each; the first and the last lane's straddling pixels only if this tile
+		// made them
+		const int part16 = t & 15;
+		for (int r = t >> 4; r < oh; r += 16) {
+			unsigned int *dst = reinterpret_cast<unsigned int *>(
+				a.out + (long long) (y0 + (flip ? oh - 1 - r : r)) * a.out_stride + (long long) (64 * bx) * 4);
+			const unsigned int *src = stage + r * 64 + 4 * part16;
+			if ((part16 == 0 && !sec[0]) || (part16 == 15 && !sec[1])) {
+				if (part16 == 0)
+					dst[3] = src[3];
+				else
+					dst[60] = src[0];
+			}
+			else {
+				typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+				*reinterpret_cast<u32x4 *>(dst + 4 * part16) = *reinterpret_cast<const u32x4 *>(src);
+			}
+		}
+	}
+}
+
+// The straddling outputs: boundary k (0 .. tiles_x: 0 and tiles_x are the image's edges, where one tile holds the
+// whole sum) x output row x the six outputs, one RGBA pixel a thread: the two tiles' halves added (exact) and
+// rounded as every other output is (fin_pack).
+__global__ void __launch_bounds__(256)
+reduce_fused_edges(FusedArgs a, const float *__restrict__ parts)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	const int o = i % 6, k = (i / 6) % (a.tiles_x + 1), y = i / (6 * (a.tiles_x + 1));
+	if (y >= a.out_height)
+		return;
+	const int by = y / a.oht, yrel = y - by * a.oht;
+	const int xo = 64 * k - 3 + o;
+	if (xo < 0 || xo >= a.out_width)
+		return;
+	float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	if (k > 0) { // the tile on the left: its side 1
+		const float *p = parts + ((size_t) (by * a.tiles_x + k - 1) * a.oht + yrel) * XPART + 24 + o * 4;
+		const float4 v = *reinterpret_cast<const float4 *>(p);
+		sum = v;
+	}
+	if (k < a.tiles_x) { // the tile on the right: its side 0
+		const float *p = parts + ((size_t) (by * a.tiles_x + k) * a.oht + yrel) * XPART + o * 4;
+		const float4 v = *reinterpret_cast<const float4 *>(p);
+		sum.x += v.x;
+		sum.y += v.y;
+		sum.z += v.z;
+		sum.w += v.w;
+	}
+	typedef MfmaStep<6> Step;
+	unsigned int px = Step::fin_pack(sum.x, 0, 0);
+	px = Step::fin_pack(sum.y, 1, px);
+	px = Step::fin_pack(sum.z, 2, px);
+	px = Step::fin_pack(sum.w, 3, px);
+	*reinterpret_cast<unsigned int *>(a.out + (long long) y * a.out_stride + (long long) xo * 4) = px;
+}
 
 // ------------------------------------------------ vertical-only pass on the matrix cores
 //
@@ -1011,6 +1345,25 @@ static int launch_fused_mfma(const FusedArgs &args, int tiles, const MfmaTables 
 			hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
 		attr_set = true;
 	}
+	// $VIPS_HIP_FUSED_NB=2|4 (round 6 experiment): two blocks a CU with 2 / 4 row groups in flight per lane and
+	// tiles twice as tall (half the vertical halo; the geometry code picks 512 slots and the taller stage)
+	if (NTH == FUSED_THREADS && getenv("VIPS_HIP_FUSED_NB") && atoi(getenv("VIPS_HIP_FUSED_NB")) > 1) {
+		const int nb = atoi(getenv("VIPS_HIP_FUSED_NB"));
+		if (nb == 2) {
+			VH_CHECK(hipFuncSetAttribute((const void *) reduce_fused_u8x4_mfma<D, 2, 2, true, 0, true, FUSED_THREADS, 1>,
+				hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+			hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 2, 2, true, 0, true, FUSED_THREADS, 1>), dim3(grid),
+				dim3(FUSED_THREADS), lds, stream(), args, d_tables);
+		}
+		else {
+			VH_CHECK(hipFuncSetAttribute((const void *) reduce_fused_u8x4_mfma<D, 4, 2, true, 0, true, FUSED_THREADS, 1>,
+				hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+			hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 4, 2, true, 0, true, FUSED_THREADS, 1>), dim3(grid),
+				dim3(FUSED_THREADS), lds, stream(), args, d_tables);
+		}
+		VH_CHECK(hipGetLastError());
+		return 0;
+	}
 	// the shipped form: edge fix-up at the point of use (LATE) and streaming (nt) loads;
 	// VIPS_HIP_FUSED_LATE=0 / VIPS_HIP_FUSED_NT=0 select the round-2 forms for A/B runs
 	const bool late = !(getenv("VIPS_HIP_FUSED_LATE") && atoi(getenv("VIPS_HIP_FUSED_LATE")) == 0);
@@ -1037,6 +1390,154 @@ static int launch_fused_mfma(const FusedArgs &args, int tiles, const MfmaTables 
 			dim3(FUSED_THREADS), lds, stream(), args, d_tables);
 	VH_CHECK(hipGetLastError());
 	return 0;
+}
+
+// Does block b of a launch run on XCD b % 8 on this device?  (HIP promises nothing; the part's eight command
+// processors each take every eighth workgroup.)  One launch of 2 048 blocks, once per device.
+__global__ void xcc_census_kernel(int *wrong)
+{
+	if (threadIdx.x == 0 && VH_XCC_ID() != (int) (blockIdx.x & 7u))
+		atomicAdd(wrong, 1);
+}
+
+static bool xcd_placement_holds()
+{
+	constexpr int MAXDEV = 64;
+	static std::mutex mutex;
+	static signed char state[MAXDEV];
+	const int dev = current_device();
+	if (dev < 0 || dev >= MAXDEV)
+		return false;
+	std::lock_guard<std::mutex> lock(mutex);
+	if (state[dev] == 0) {
+		state[dev] = -1;
+		int zero = 0, wrong = 1;
+		int *d = (int *) upload(&zero, sizeof(zero));
+		if (d) {
+			hipLaunchKernelGGL(xcc_census_kernel, dim3(2048), dim3(64), 0, stream(), d);
+			if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&wrong, d, sizeof(wrong), hipMemcpyDeviceToHost, stream()) == hipSuccess &&
+				hipStreamSynchronize(stream()) == hipSuccess && wrong == 0)
+				state[dev] = 1;
+			vips_hip_free(d);
+		}
+		else
+			vips_hip_error_clear();
+	}
+	return state[dev] == 1;
+}
+
+// 0 launched, 1 not this kernel's case, -1 error
+static int launch_fused_mfma_x(const FusedArgs &all, const VipsHipRegion *in, const VipsHipRegion *out,
+	const MfmaTables *d_tables)
+{
+	const char *e = getenv("VIPS_HIP_FUSED_EXCH");
+	if (e && atoi(e) == 0)
+		return 1;
+	if (in->left != 0 || in->width != in->im_width || out->left != 0 || out->width != out->im_width ||
+		(in->im_width & 511) || out->width * 8 != in->im_width)
+		return 1;
+	if (all.fx0 < -(XH - 24) - 0 || all.fx0 > -16 || (all.fx0 & 3) || all.fx0 < -24)
+		return 1;
+	// (whole 128-byte lines per wave and row are the point of it; forced by the environment -- the parity tests on
+	// host fibers, whose "device" memory is malloc's -- 16 bytes do)
+	const uintptr_t in_mask = e ? 15 : 127;
+	if (((uintptr_t) in->data & in_mask) || (in->stride & in_mask) || ((uintptr_t) out->data & 15) || (out->stride & 15))
+		return 1;
+	FusedArgs a = all;
+	a.tiles_x = in->im_width / 512;
+	// one residency round of 2 blocks a CU: as many rows of tiles as 512 slots allow, tiles of 32 .. 128 rows
+	int tiles_y = 512 / a.tiles_x;
+	const int least = (out->height + XMAX_OHT - 1) / XMAX_OHT;
+	tiles_y = tiles_y < least ? least : tiles_y;
+	int oht = (out->height + tiles_y - 1) / tiles_y;
+	if (oht < 32)
+		oht = 32;
+	if (oht > XMAX_OHT)
+		return 1;
+	tiles_y = (out->height + oht - 1) / oht;
+	a.oht = oht;
+	a.owt = 64;
+	a.tiles = a.tiles_x * tiles_y;
+	const int want = e ? 1 : 384; // (by default only launches that fill most of the part; $VIPS_HIP_FUSED_EXCH=1: any)
+	if (a.tiles < want || a.tiles > 512)
+		return 1;
+	const size_t bytes = (size_t) a.tiles * a.oht * XPART * sizeof(float);
+	float *parts = (float *) vips_hip_malloc(bytes);
+	if (!parts)
+		return -1;
+	// the arrival counters: one int per tile boundary, zero once and for the life of the calling thread (a launch
+	// adds exactly two to each: see the kernel's end); per thread and device, as the stream the launches are
+	// ordered on is
+	constexpr int MAX_ARRIVALS = 2048;
+	if ((a.tiles_x + 1) * tiles_y > MAX_ARRIVALS) {
+		vips_hip_free(parts);
+		return 1;
+	}
+	static thread_local std::map<int, int *> arrivals_by_device;
+	int *&arrivals = arrivals_by_device[current_device()];
+	if (!arrivals) {
+		std::vector<int> zeros(MAX_ARRIVALS, 0);
+		arrivals = (int *) upload(zeros.data(), zeros.size() * sizeof(int)); // (kept: a thread's 8 KB)
+		if (!arrivals) {
+			vips_hip_free(parts);
+			return -1;
+		}
+	}
+	// the hand-off through the XCD's L2 (see the kernel): rows of tiles dealt whole to the XCDs, the placement checked
+	// once, a word of pinned host memory for a block that finds itself elsewhere.  $VIPS_HIP_FUSED_PLAIN=0: through memory
+	static thread_local std::map<int, int *> misplaced_by_device;
+	int *&misplaced = misplaced_by_device[current_device()];
+	if (!misplaced) {
+		misplaced = (int *) vips_hip_malloc_host(64);
+		if (misplaced)
+			*misplaced = 0;
+		else
+			vips_hip_error_clear();
+	}
+	static std::atomic<bool> plain_broken(false);
+	if (misplaced && *misplaced) {
+		*misplaced = 0;
+		if (!plain_broken.exchange(true))
+			fprintf(stderr, "vips-hip: reduce: a block ran on another XCD than its index says; the hand-off goes through memory from now on\n");
+	}
+	const char *pe = getenv("VIPS_HIP_FUSED_PLAIN");
+	const int plain = misplaced && !plain_broken.load() && !(pe && atoi(pe) == 0) && xcd_placement_holds() ? 1 : 0;
+	const size_t lds = xlds_bytes(a.oht);
+	const bool nb2 = getenv("VIPS_HIP_FUSED_NB") && atoi(getenv("VIPS_HIP_FUSED_NB")) == 2;
+	const int rows_per_xcd = (tiles_y + 7) / 8;
+	const int grid = 8 * rows_per_xcd * a.tiles_x; // (the kernel's numbering: XCD k takes rows k rows_per_xcd ...)
+	int rc = 0;
+	{
+		Gate gate("reduce_fused_u8_mfma_x");
+		hipError_t err;
+		if (nb2) {
+			err = hipFuncSetAttribute((const void *) reduce_fused_u8x4_mfma_x<6, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+				80 * 1024);
+			if (err == hipSuccess)
+				hipLaunchKernelGGL((reduce_fused_u8x4_mfma_x<6, 2, 2>), dim3(grid), dim3(FUSED_THREADS), lds, stream(), a, d_tables,
+					parts, arrivals, plain, misplaced);
+		}
+		else {
+			err = hipFuncSetAttribute((const void *) reduce_fused_u8x4_mfma_x<6, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+				80 * 1024);
+			if (err == hipSuccess)
+				hipLaunchKernelGGL((reduce_fused_u8x4_mfma_x<6, 4, 2>), dim3(grid), dim3(FUSED_THREADS), lds, stream(), a, d_tables,
+					parts, arrivals, plain, misplaced);
+		}
+		if (err != hipSuccess || hipGetLastError() != hipSuccess)
+			rc = -1;
+	}
+	if (rc == 0 && (a.debug & 32)) {
+		Gate gate("reduce_fused_edges");
+		const long long threads = (long long) out->height * (a.tiles_x + 1) * 6;
+		hipLaunchKernelGGL(reduce_fused_edges, dim3((unsigned int) ((threads + 255) / 256)), dim3(256), 0, stream(), a, parts);
+		if (hipGetLastError() != hipSuccess)
+			rc = -1;
+	}
+	vips_hip_free(parts); // (the pool hands the block to this thread's LATER work only: ordered on its stream)
+	if (rc)
+		error("reduce", "kernel launch failed");
+	return rc;
 }
 
 template <int S, int D>
@@ -1544,7 +2045,8 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 	// MFMA kernel: threads per block (VIPS_HIP_FUSED_NTH=256|512; tiles of 59 / 123 pixels)
 	const int nth = getenv("VIPS_HIP_FUSED_NTH") && atoi(getenv("VIPS_HIP_FUSED_NTH")) == 512 ? 512 : 256;
 	const int mfma_span = 2 * nth;
-	const int mfma_max_oht = nth == 512 ? MfmaGeo<512>::MAX_OHT : MfmaGeo<256>::MAX_OHT;
+	const bool deep = nth == 256 && getenv("VIPS_HIP_FUSED_NB") && atoi(getenv("VIPS_HIP_FUSED_NB")) > 1;
+	const int mfma_max_oht = deep ? 200 : nth == 512 ? MfmaGeo<512>::MAX_OHT : MfmaGeo<256>::MAX_OHT;
 
 	_VipsHipReduce *rv = const_cast<_VipsHipReduce *>(reducev);
 	// S = 8: both passes on the matrix cores when the exactness bounds hold
@@ -1600,7 +2102,7 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 				if (owt_env > 0 && owt_env < args.owt)
 					args.owt = owt_env;
 				args.tiles_x = (out->width + args.owt - 1) / args.owt;
-				const int slots = getenv("VIPS_HIP_FUSED_CAP") ? atoi(getenv("VIPS_HIP_FUSED_CAP")) : 256 * 4;
+				const int slots = getenv("VIPS_HIP_FUSED_CAP") ? atoi(getenv("VIPS_HIP_FUSED_CAP")) : deep ? 256 * 2 : 256 * 4;
 				const int base = slots / args.tiles_x > 0 ? slots / args.tiles_x : 1;
 				int oht = out->height;
 				for (int k = 1; k <= 4096; k++) {
@@ -1636,6 +2138,13 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 				}
 				else
 					d_tables = (const MfmaTables *) it->second;
+			}
+			// round 6: whole images whose width is a multiple of 512 -- tiles without a horizontal halo
+			// (reduce_fused_u8x4_mfma_x), the straddling outputs by a second small kernel
+			if (D == 6) {
+				const int r = launch_fused_mfma_x(args, in, out, d_tables);
+				if (r <= 0)
+					return r;
 			}
 			if (D == 6)
 				return nth == 512 ? launch_fused_mfma<6, 512>(args, tiles, d_tables)

@@ -22,6 +22,10 @@
 #define VH_MAD_U24(dst, a, b, c) ((dst) = ((unsigned int) (a) & 0xffffffu) * ((unsigned int) (b) & 0xffffffu) + (unsigned int) (c))
 #define VH_MUL_HI_U24(dst, a, b) \
 	((dst) = (unsigned int) (((unsigned long long) ((unsigned int) (a) & 0xffffffu) * ((unsigned int) (b) & 0xffffffu)) >> 32))
+#define VH_XCC_ID() ((int) (blockIdx.x & 7u))
+#define VH_STORE4_SYS(p, v) (*(p) = (v))
+#define VH_LOAD_SYS(p) (*(p))
+#define VH_STORE_SYS(p, v) (*(p) = (v))
 #define VH_STORE_BYTE(p, v) (*(unsigned char *) (p) = (unsigned char) (v))
 #define VH_ASM_MARK(text) ((void) 0)
 #define VH_VECTOR1(a) ((void) (a))

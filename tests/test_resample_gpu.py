@@ -255,6 +255,40 @@ def test_fused_reduce_rgba(shrink, size):
     assert_same(got, Port.reduce(src, shrink, shrink, "lanczos3"), str((shrink, size)))
 
 
+@pytest.mark.parametrize("nb,two_kernels", [(4, False), (2, False), (4, True)])
+@pytest.mark.parametrize("size", [(512, 264), (1024, 776), (2048, 1100), (1536, 2056), (4096, 8), (512, 4100)])
+def test_fused_reduce_exchange(size, nb, two_kernels, monkeypatch):
+    """Round 6: the matrix-core reduce WITHOUT the tiles' horizontal halo (reduce_fused_u8x4_mfma_x: a tile is 512
+    aligned columns and makes all 64 of its outputs, the six outputs that straddle a tile boundary as partial sums by
+    both tiles, added and rounded by whichever of the two arrives at the boundary LAST -- or, two_kernels, by
+    reduce_fused_edges behind it) -- and that TWICE in a row, the arrival counters live on) -- images one tile wide (both sides the image's edge:
+    vips_embed COPY through the replicated edge column), several tiles either way, heights the tile rows do not
+    divide (a last row of tiles walked bottom-up), 2 and 4 row groups in flight; against the port and against the
+    kernel with halos.  ($VIPS_HIP_FUSED_EXCH=1: by default only launches of 384 tiles and more take it.)"""
+    w, h = size
+    src = helpers.lcg_image(w, h, 4, np.uint8, 48)
+    im = Image.new_from_array(src)
+    monkeypatch.setenv("VIPS_HIP_FUSED_EXCH", "0")
+    old = im.reduce(8, 8, kernel="lanczos3").numpy()
+    monkeypatch.setenv("VIPS_HIP_FUSED_EXCH", "1")
+    monkeypatch.setenv("VIPS_HIP_FUSED_NB", str(nb))
+    if two_kernels:
+        monkeypatch.setenv("VIPS_HIP_FUSED_DEBUG", "32")
+    lib = libvips_amd.lib
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    try:
+        got = im.reduce(8, 8, kernel="lanczos3").numpy()
+        again = im.reduce(8, 8, kernel="lanczos3").numpy()
+        report = libvips_amd.gate_report()
+    finally:
+        lib.vips_hip_gate_enable(0)
+        lib.vips_hip_gate_reset()
+    assert sorted(report) == (["reduce_fused_edges"] if two_kernels else []) + ["reduce_fused_u8_mfma_x"], report
+    assert_same(got, Port.reduce(src, 8, 8, "lanczos3"), str(size))
+    assert np.array_equal(got, old) and np.array_equal(again, old)
+
+
 @pytest.mark.parametrize("kernel", ["lanczos3"])
 @pytest.mark.parametrize("size", [(4099, 3001), (2048, 1024), (1000, 8), (96, 2600), (9000, 700), (8192, 8197)])
 @pytest.mark.parametrize("align", [0, 1])
@@ -571,7 +605,8 @@ def test_resize_stream_batch_chunks(overlap, monkeypatch):
     finally:
         libvips_amd.lib.vips_hip_gate_enable(0)
         libvips_amd.lib.vips_hip_gate_reset()
-    assert sorted(report) == (["resize_sharpen_u8"] if overlap is None else ["resize_stream_u8", "sharpen_fused_u8"]), report
+    # (round 6: the one-kernel sharpen is the skip form -- colour.hip sharpen_fused_u8_kernel<*, true> -- by default)
+    assert sorted(report) == (["resize_sharpen_u8"] if overlap is None else ["resize_stream_u8", "sharpen_skip_u8"]), report
     for k in (0, 1, 63, 64, 69):
         assert np.array_equal(outs[k].numpy(), ims[k].resize(0.125).sharpen().numpy()), k
         assert np.array_equal(outs[k].numpy(), helpers.PortCC.sharpen(Port.resize(srcs[k], 0.125)))
