@@ -623,6 +623,17 @@ static int reduce_gen(const char *domain, const VipsHipReduce *reduce, const Vip
 			return 0;
 	}
 
+	if (fmt == VIPS_HIP_FORMAT_FLOAT && vertical && !format_iscomplex(out->format)) {
+		// one phase and an integer step: the streaming kernel (resample_f32.hip)
+		std::vector<ReducePos> host_pos;
+		reduce_positions(r, out->top, out->height, tile, host_pos);
+		const int done = reducev_f32_stream_try(r, in, out, host_pos, (const double *) table);
+		if (done < 0)
+			return -1;
+		if (done > 0)
+			return 0;
+	}
+
 #define DISPATCH(FN) \
 	switch (fmt) { \
 	case VIPS_HIP_FORMAT_UCHAR: return FN<unsigned char>(r, in, out, pos, table); \
@@ -872,6 +883,13 @@ static int shrink_gen(const char *domain, int shrink, const VipsHipRegion *in,
 	}
 	if (fmt == VIPS_HIP_FORMAT_UCHAR && !vertical) {
 		int done = shrinkh_u8_stream_try(shrink, in, out);
+		if (done < 0)
+			return -1;
+		if (done > 0)
+			return 0;
+	}
+	if (fmt == VIPS_HIP_FORMAT_FLOAT && vertical && !format_iscomplex(out->format)) { // (resample_f32.hip)
+		const int done = shrinkv_f32_stream_try(shrink, in, out);
 		if (done < 0)
 			return -1;
 		if (done > 0)

@@ -795,3 +795,62 @@ def test_resize_sharpen_batch_queued():
     for k in range(5):
         assert np.array_equal(outs[k].numpy(), want[k].numpy()), k
     assert outs[5].width == 80
+
+
+@pytest.mark.parametrize("shrink,kernel", [(8, "lanczos3"), (4, "lanczos3"), (2, "lanczos3"), (3, "lanczos3"), (5, "lanczos3"),
+                                           (6, "lanczos3"), (8, "cubic"), (4, "lanczos2"), (2, "mitchell")])
+def test_reducev_shrinkv_f32_stream(shrink, kernel, monkeypatch):
+    """Round 6: vips_reducev / vips_shrinkv of float images as streams (resample_f32.hip): integer shrinks with one
+    coefficient phase, the taps added in the reference's order in double (templates.h:183-194), every row read once a
+    segment; bit for bit the general kernels' and the port's results (float: 0 ULP, both are the same IEEE operations
+    in the same order) on an image with several lanes' worth of columns, heights the factor does and does not divide,
+    a region that starts below the top, values over many binades."""
+    rng = np.random.RandomState(7 + shrink)
+    for (w, h) in ((400, 64 * shrink), (344, 37 * shrink + 5)):
+        src = (rng.standard_normal((h, w, 3)) * np.exp2(rng.randint(-8, 8, (h, w, 3)))).astype(np.float32)
+        im = Image.new_from_array(src)
+        lib = libvips_amd.lib
+        for op, ref in ((lambda i: i.reducev(shrink, kernel=kernel), lambda a: Port.reducev(a, shrink, kernel)),
+                        (lambda i: i.shrinkv(shrink), lambda a: Port.shrinkv(a, shrink))):
+            lib.vips_hip_gate_reset()
+            lib.vips_hip_gate_enable(1)
+            try:
+                got = op(im).numpy()
+                report = libvips_amd.gate_report()
+            finally:
+                lib.vips_hip_gate_enable(0)
+                lib.vips_hip_gate_reset()
+            assert any(k.endswith("_f32_stream") for k in report), report
+            monkeypatch.setenv("VIPS_HIP_NO_F32_STREAM", "1")
+            old = op(im).numpy()
+            monkeypatch.delenv("VIPS_HIP_NO_F32_STREAM")
+            want = ref(src)
+            assert got.dtype == np.float32 and got.shape == want.shape
+            assert np.array_equal(got.view(np.int32), old.view(np.int32)), (shrink, kernel, w, h)
+            assert np.array_equal(got.view(np.int32), want.view(np.int32)), (shrink, kernel, w, h)
+
+
+@pytest.mark.parametrize("bands", [1, 2, 3, 4])
+def test_upsize_bicubic_walk(bands, monkeypatch):
+    """Round 6: bicubic enlargement of uchar images by a thread walking its output column down a segment of rows
+    with the four rounded horizontal sums in registers (upsize_bicubic_u8_walk): several segments, enlarging and
+    (vertically) reducing scales -- the window then moves by more than one input row a step --, against the kernel
+    that makes every pixel from scratch and against the port (resample/bicubic.cpp:482-600)."""
+    lib = libvips_amd.lib
+    for (w, h, hs, vs) in ((200, 150, 2.5, 2.5), (97, 260, 1.3, 3.7), (120, 400, 2.0, 0.45), (64, 90, 5.0, 1.0)):
+        src = helpers.lcg_image(w, h, bands, np.uint8, 91)
+        im = Image.new_from_array(src)
+        lib.vips_hip_gate_reset()
+        lib.vips_hip_gate_enable(1)
+        try:
+            got = im.resize(hs, vscale=vs, kernel="cubic").numpy()
+            report = libvips_amd.gate_report()
+        finally:
+            lib.vips_hip_gate_enable(0)
+            lib.vips_hip_gate_reset()
+        assert "upsize_bicubic_u8_walk" in report, report
+        monkeypatch.setenv("VIPS_HIP_NO_UPSIZE_WALK", "1")
+        old = im.resize(hs, vscale=vs, kernel="cubic").numpy()
+        monkeypatch.delenv("VIPS_HIP_NO_UPSIZE_WALK")
+        assert np.array_equal(got, old), (w, h, hs, vs)
+        assert np.array_equal(got, Port.resize(src, hs, vs, kernel="cubic")), (w, h, hs, vs)
