@@ -934,6 +934,11 @@ struct SharpenFusedArgs {
 	// full-rate v_mul_hi_u32_u24 instead of the quarter-rate v_mul_hi_u32; the host tried every n); sh24 < 0: no
 	unsigned int m24;
 	int sh24;
+	// SKIP on large images (round 6): a tile whose list is longer than defer_threshold is left to the all-in-LDS
+	// kernel -- its 64 x 64 tile goes on a device-side list (defer[0] the count, then one flag per such tile, then
+	// the list) that sharpen_quad_u8_kernel walks afterwards; nullptr: every tile is finished here
+	int *defer;
+	int defer_threshold, q_tiles_x, q_tiles_y;
 	ColourTables tables;
 };
 
@@ -1310,6 +1315,18 @@ sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 		// 4. the listed pixels, densely: forward for a, b, back from (sharpened L, a, b), patched into the stage
 		__syncthreads();
 		const int count = s_count;
+		if (a.defer && count > a.defer_threshold) {
+			// mostly edges or noise: the kernel with every table in LDS does such a tile faster (the whole 64 x 64
+			// tile this one is a half of; its other half may finish here: the same pixels either way)
+			if (t == 0) {
+				const int per = a.q_tiles_x * a.q_tiles_y;
+				const int qt = (int) blockIdx.z * per + (y0 / 64) * a.q_tiles_x + (int) blockIdx.x;
+				const int total = per * (int) gridDim.z;
+				if (atomicExch(a.defer + 1 + qt, 1) == 0)
+					a.defer[1 + total + atomicAdd(a.defer, 1)] = qt;
+			}
+			return;
+		}
 		unsigned char *bytes = reinterpret_cast<unsigned char *>(s_out);
 		for (int i = t; i < count; i += 256) {
 			const unsigned int e = s_list[i];
@@ -1396,6 +1413,7 @@ struct SharpenQuadArgs {
 	const short *lut_win; // lut_n entries from index lut_lo
 	int lut_lo, lut_n, lut_below, lut_above;
 	int tiles_x, tiles_y, n_images;
+	const int *defer; // list mode (see SharpenFusedArgs::defer): the tiles sharpen_fused_u8_kernel<*, true> left; else nullptr
 };
 
 // XYZ2Lab.c:109-138 on a small finite value: the table pair from LDS
@@ -1458,9 +1476,11 @@ sharpen_quad_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenQuadArgs q)
 	typedef unsigned char __attribute__((address_space(1))) *GlobalOut;
 	const int h = a.half;
 	const int rw = SQ_T + 2 * h;
-	const int tiles = q.tiles_x * q.tiles_y * q.n_images;
+	const int all_tiles = q.tiles_x * q.tiles_y * q.n_images;
+	const int tiles = q.defer ? q.defer[0] : all_tiles;
 	const int row = t >> 4, quad = t & 15;
-	for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+	for (int ti = blockIdx.x; ti < tiles; ti += gridDim.x) {
+		const int tile = q.defer ? q.defer[1 + all_tiles + ti] : ti;
 		const int img = tile / (q.tiles_x * q.tiles_y), tt = tile - img * (q.tiles_x * q.tiles_y);
 		const int ty = tt / q.tiles_x, tx = tt - ty * q.tiles_x;
 		const GlobalIn in = (GlobalIn) kp[img];
@@ -1724,6 +1744,20 @@ int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const
 	// thumbnails on its 64-CU partition 0.033 -> 0.049 ms per image: a thumbnail's values are few and near each
 	// other, the older kernel's table gathers hit its L1, and 106 KB of LDS per block leave that partition one block
 	// of 16 waves per CU to hide behind.  $VIPS_HIP_SHARPEN_QUAD=0 / 1 forces one or the other.
+	// the pixels the LUT leaves alone skip the way back (sharpen_fused_u8_kernel<*, true>) when the LUT has a zero
+	// window at all and sRGB -> LabS -> sRGB is the identity with this device's tables.  $VIPS_HIP_SHARPEN_SKIP=0:
+	// every pixel the whole way.
+	const char *skip_env = getenv("VIPS_HIP_SHARPEN_SKIP");
+	bool nonneg = true; // (a gaussian's integer mask: what lets the skip kernel divide without a sign)
+	for (int k = 0; k < n; k++)
+		nonneg = nonneg && coef[k] >= 0;
+	const bool small = (long long) a.height * a.in_stride < (1LL << 31) && a.in_stride < (1LL << 24) && a.height < (1 << 24) &&
+		a.in_stride >= 0;
+	const bool skip = nonneg && small && a.sh24 >= 0 && a.zero_lo <= 0 && a.zero_hi >= 0 && !(skip_env && atoi(skip_env) == 0) &&
+		sharpen_identity_proven(a.tables);
+	a.defer = nullptr;
+	a.defer_threshold = 0;
+	a.q_tiles_x = a.q_tiles_y = 0;
 	const char *quad_env = getenv("VIPS_HIP_SHARPEN_QUAD");
 	const bool want_quad = quad_env ? atoi(quad_env) != 0 : (long long) a.width * a.height >= 2048LL * 2048;
 	// (the LDS opt-in is per DEVICE: asked for on every device this code reaches; a device that refuses it keeps
@@ -1744,7 +1778,15 @@ int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const
 			q.tiles_y = (a.height + SQ_T - 1) / SQ_T;
 			const size_t lds = (size_t) (CBQ_BLOCKS * 4 + CBQ_RES_WORDS + 256 + 260) * 4 + (size_t) (SQ_MAXLUT + 8) * 2 +
 				(size_t) SQ_R * SQ_R * 2 + (size_t) SQ_T * SQ_T * 4 + (size_t) SQ_R * SQ_T * 2;
-			Gate gate("sharpen_quad_u8");
+			// Large images (round 6), ADAPTIVELY: what a photograph mostly is -- neighbouring pixels near each other,
+			// the LUT's flat centre -- is what the skip kernel is fast at (8192^2 smooth: 0.79 -> ~0.3 ms), noise and
+			// dense edges what this one is (0.83 against ~1.2).  So the skip kernel goes first and LEAVES the tiles
+			// whose list is long (more than defer_threshold of a 64 x 32 tile's 2 048 pixels) on a device-side list;
+			// this kernel then walks that list -- no host round trip, the count is read on the device.
+			// $VIPS_HIP_SHARPEN_ADAPTIVE=0: this kernel alone, every tile.
+			const char *ad = getenv("VIPS_HIP_SHARPEN_ADAPTIVE");
+			const bool adaptive = skip && a.n <= 5 && a.height > 16 && !(ad && atoi(ad) == 0);
+			q.defer = nullptr;
 			for (int base = 0; base < n_images; base += SF_MAXB) {
 				const int count = n_images - base < SF_MAXB ? n_images - base : SF_MAXB;
 				SharpenFusedPtrs p;
@@ -1755,27 +1797,53 @@ int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const
 				}
 				q.n_images = count;
 				const int tiles = q.tiles_x * q.tiles_y * count;
+				int *defer = nullptr;
+				if (adaptive) {
+					defer = (int *) vips_hip_malloc((size_t) (1 + 2 * tiles) * sizeof(int));
+					if (!defer)
+						return -1;
+					if (hipMemsetAsync(defer, 0, (size_t) (1 + tiles) * sizeof(int), stream()) != hipSuccess) {
+						vips_hip_free(defer);
+						error("sharpen", "memset failed");
+						return -1;
+					}
+					SharpenFusedArgs a1 = a;
+					a1.defer = defer;
+					a1.defer_threshold = getenv("VIPS_HIP_SHARPEN_DEFER") ? atoi(getenv("VIPS_HIP_SHARPEN_DEFER")) : 640;
+					a1.q_tiles_x = q.tiles_x;
+					a1.q_tiles_y = q.tiles_y;
+					dim3 grid1((a.width + SF_TW - 1) / SF_TW, (a.height + 31) / 32, count);
+					Gate gate1("sharpen_skip_u8");
+					if (a.n <= 3)
+						hipLaunchKernelGGL((sharpen_fused_u8_kernel<32, true, 3>), grid1, dim3(256, 1, 1), 0, stream(), p, a1);
+					else
+						hipLaunchKernelGGL((sharpen_fused_u8_kernel<32, true, 5>), grid1, dim3(256, 1, 1), 0, stream(), p, a1);
+					if (hipGetLastError() != hipSuccess) {
+						vips_hip_free(defer);
+						error("sharpen", "kernel launch failed");
+						return -1;
+					}
+				}
+				q.defer = defer;
 				const char *e = getenv("VIPS_HIP_SHARPEN_QUAD_GRID");
 				int grid = e && atoi(e) > 0 ? atoi(e) : 256;
 				grid = grid > tiles ? tiles : grid;
-				hipLaunchKernelGGL(sharpen_quad_u8_kernel, dim3(grid), dim3(SQ_NT), lds, stream(), p, q);
-				VH_CHECK(hipGetLastError());
+				{
+					Gate gate("sharpen_quad_u8");
+					hipLaunchKernelGGL(sharpen_quad_u8_kernel, dim3(grid), dim3(SQ_NT), lds, stream(), p, q);
+				}
+				const bool ok = hipGetLastError() == hipSuccess;
+				if (defer)
+					vips_hip_free(defer); // (reuse is ordered on this thread's stream)
+				if (!ok) {
+					error("sharpen", "kernel launch failed");
+					return -1;
+				}
 			}
 			return 0;
 		}
 		vips_hip_error_clear();
 	}
-	// the pixels the LUT leaves alone skip the way back (sharpen_fused_u8_kernel<*, true>) when the LUT has a zero
-	// window at all and sRGB -> LabS -> sRGB is the identity with this device's tables.  $VIPS_HIP_SHARPEN_SKIP=0:
-	// every pixel the whole way.
-	const char *skip_env = getenv("VIPS_HIP_SHARPEN_SKIP");
-	bool nonneg = true; // (a gaussian's integer mask: what lets the skip kernel divide without a sign)
-	for (int k = 0; k < n; k++)
-		nonneg = nonneg && coef[k] >= 0;
-	const bool small = (long long) a.height * a.in_stride < (1LL << 31) && a.in_stride < (1LL << 24) && a.height < (1 << 24) &&
-		a.in_stride >= 0;
-	const bool skip = nonneg && small && a.sh24 >= 0 && a.zero_lo <= 0 && a.zero_hi >= 0 && !(skip_env && atoi(skip_env) == 0) &&
-		sharpen_identity_proven(a.tables);
 	Gate gate(skip ? "sharpen_skip_u8" : "sharpen_fused_u8");
 	for (int base = 0; base < n_images; base += SF_MAXB) {
 		const int count = n_images - base < SF_MAXB ? n_images - base : SF_MAXB;

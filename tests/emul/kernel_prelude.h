@@ -95,6 +95,7 @@ struct ThreadIdx {
 #define __syncthreads() emul::barrier()
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 static inline unsigned int atomicAdd(unsigned int *p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline int atomicExch(int *p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 
 // ---- amdgcn builtins (wave-uniform values are uniform by construction in the kernels emulated here)
 #define __builtin_amdgcn_readfirstlane(x) (x)

@@ -230,7 +230,7 @@ def test_gaussblur_colourspace_fallbacks():
 @pytest.mark.parametrize("params", [dict(), dict(sigma=1.0), dict(sigma=0.3), dict(sigma=2.0),
                                     dict(sigma=0.8, x1=1.0, y2=20.0, y3=30.0, m1=0.5, m2=2.0),
                                     dict(x1=0.5, y2=80.0, y3=90.0, m2=1.0)])
-@pytest.mark.parametrize("quad", [True, False, "skip", "skip-blocky"])
+@pytest.mark.parametrize("quad", [True, False, "skip", "skip-blocky", "adaptive", "adaptive-blocky"])
 def test_sharpen_fused_uchar_srgb(size, params, quad, monkeypatch):
     """vips_sharpen on 3-band uchar sRGB in one kernel (colour.hip sharpen_fused_u8: the LabS round
     trip, the integer blur of L in LDS and the LUT step): tiles with partial edges, images smaller
@@ -243,11 +243,17 @@ def test_sharpen_fused_uchar_srgb(size, params, quad, monkeypatch):
     # (sharpen_fused_u8_kernel<*, true>; the default for images under 4 Mpixels) -- on noise nearly every pixel
     # is on the list that goes the whole way, on the blocky image (flat 8 x 8 blocks of slowly varying colour, with
     # a few hard edges) nearly none; True / False: the two older kernels, every pixel the whole way
-    monkeypatch.setenv("VIPS_HIP_SHARPEN_QUAD", "1" if quad is True else "0")
+    # adaptive: what large images take by default -- the skip kernel first, the tiles whose list is long (here: longer
+    # than 100 of 2 048 pixels, so that both kernels get tiles of one image) left on a device-side list for the
+    # all-in-LDS kernel
+    adaptive = isinstance(quad, str) and quad.startswith("adaptive")
+    monkeypatch.setenv("VIPS_HIP_SHARPEN_QUAD", "1" if quad is True or adaptive else "0")
     monkeypatch.setenv("VIPS_HIP_SHARPEN_SKIP", "1" if isinstance(quad, str) else "0")
+    if adaptive:
+        monkeypatch.setenv("VIPS_HIP_SHARPEN_DEFER", "100")
     w, h = size
     src = helpers.lcg_image(w, h, 3, np.uint8, 72)
-    if quad == "skip-blocky":
+    if isinstance(quad, str) and quad.endswith("blocky"):
         small = helpers.lcg_image((w + 7) // 8, (h + 7) // 8, 3, np.uint8, 73).astype(np.int32)
         ramp = (np.arange(small.shape[1])[None, :, None] * 3 + np.arange(small.shape[0])[:, None, None] * 2) % 200
         base = np.where(small > 240, small, 20 + ramp + small % 4).astype(np.uint8)  # (a few outliers: hard edges)
@@ -276,7 +282,10 @@ def test_sharpen_fused_uchar_srgb(size, params, quad, monkeypatch):
     if params.get("sigma", 0.5) <= 1.0:
         # (a LUT whose bending part is longer than 6144 entries -- the last two parameter sets -- does not fit LDS)
         wide_lut = "y3" in params
-        if isinstance(quad, str):
+        if adaptive and "y3" not in params:
+            # (an image of at most 16 rows: the all-in-LDS kernel alone)
+            assert sorted(report) == (["sharpen_quad_u8", "sharpen_skip_u8"] if h > 16 else ["sharpen_quad_u8"]), report
+        elif isinstance(quad, str):
             assert list(report) == ["sharpen_skip_u8"], report
         else:
             assert list(report) == ["sharpen_quad_u8" if quad and not wide_lut else "sharpen_fused_u8"], report
