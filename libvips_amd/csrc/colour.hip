@@ -1034,6 +1034,63 @@ sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 		}
 	};
 	if constexpr (SKIP) {
+		if (a.defer) {
+			// 0 (large images only). A tile of noise or dense edges goes to the all-in-LDS kernel anyway: find out
+			// from ONE row before paying for all of them -- L of the tile's middle row and the rows either side, the
+			// blur of the middle row, its pixels outside the LUT's zero window counted; more than half: the tile is
+			// deferred here and now.  (A heuristic for speed only: both kernels make the same pixels.)
+			const int ym = min(y0 + SF_TH / 2, a.height - 1);
+			const int nrow = 2 * h + 1;
+			for (int idx = t; idx < nrow * rw; idx += 256) {
+				const int rr = idx / rw, rx = idx - rr * rw;
+				const int x = min(max(x0 + rx - h, 0), a.width - 1);
+				const int y = min(max(ym + rr - h, 0), a.height - 1);
+				unsigned int off;
+				VH_MAD_U24(off, (unsigned int) y, (unsigned int) a.in_stride, (unsigned int) (3 * x));
+				const GlobalIn p = in + off;
+				short L, A = 0, B = 0;
+				srgb8_to_labs<false>(a.tables, s_v2Y, p[0], p[1], p[2], L, A, B);
+				s_lab[rr][rx][0] = L;
+			}
+			__syncthreads();
+			for (int idx = t; idx < nrow * SF_TW; idx += 256) {
+				const int rr = idx >> 6, cx = idx & 63;
+				unsigned int sum = (unsigned int) a.rounding;
+#pragma unroll
+				for (int k = 0; k < NT; k++)
+					VH_MAD_U24(sum, (unsigned int) (int) s_lab[rr][cx + k][0], (unsigned int) a.coef[k], sum);
+				s_h[rr][cx] = (short) sf_div_nonneg(sum, a);
+			}
+			__syncthreads();
+			if (t < SF_TW) {
+				unsigned int sum = (unsigned int) a.rounding;
+#pragma unroll
+				for (int k = 0; k < NT; k++)
+					VH_MAD_U24(sum, (unsigned int) (int) s_h[k][t], (unsigned int) a.coef[k], sum);
+				const int blur = (int) sf_div_nonneg(sum, a);
+				const int v1 = s_lab[h][t + h][0];
+				const int diff = (v1 & 0x7fff) - (blur & 0x7fff);
+				if ((diff < a.zero_lo || diff > a.zero_hi) && x0 + t < a.width)
+					atomicAdd(&s_count, 1);
+			}
+			__syncthreads();
+			const int sampled = s_count;
+			__syncthreads();
+			if (sampled > SF_TW / 2) {
+				if (t == 0) {
+					const int per = a.q_tiles_x * a.q_tiles_y;
+					const int qt = (int) blockIdx.z * per + (y0 / 64) * a.q_tiles_x + (int) blockIdx.x;
+					const int total = per * (int) gridDim.z;
+					if (atomicExch(a.defer + 1 + qt, 1) == 0)
+						a.defer[1 + total + atomicAdd(a.defer, 1)] = qt;
+				}
+				return;
+			}
+			if (t == 0)
+				s_count = 0;
+			// (the barrier in front of sweep 3's LDS writes orders this; s_lab / s_h rows 0 .. 2 are written anew)
+			__syncthreads();
+		}
 		// 1 (SKIP). L of the tile and its ring, IN THREE SWEEPS over the thread's pixels (4 per 16 rows of the tile
 		// and up to two of the ring): every pixel load, then every table index and its gather, then the
 		// interpolations -- two memory latencies a block instead of two per pixel group (the block's life is those
