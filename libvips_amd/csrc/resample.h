@@ -61,6 +61,8 @@ void reduce_make_mask(double *c, int kernel, int n_points, double shrink, double
 // float images as streams (resample_f32.hip): 1 launched, 0 not their case, -1 error
 int reducev_f32_stream_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out,
 	const std::vector<ReducePos> &pos, const double *coef /* device: the plan's double table */);
+int reduceh_f32_lds_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out,
+	const std::vector<ReducePos> &pos, const double *coef);
 int shrinkv_f32_stream_try(int vshrink, const VipsHipRegion *in, const VipsHipRegion *out);
 void reduce_positions(const _VipsHipReduce *r, int start, int count, int tile,
 	std::vector<ReducePos> &pos);

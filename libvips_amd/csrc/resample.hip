@@ -623,11 +623,15 @@ static int reduce_gen(const char *domain, const VipsHipReduce *reduce, const Vip
 			return 0;
 	}
 
-	if (fmt == VIPS_HIP_FORMAT_FLOAT && vertical && !format_iscomplex(out->format)) {
-		// one phase and an integer step: the streaming kernel (resample_f32.hip)
+	if (fmt == VIPS_HIP_FORMAT_FLOAT && !format_iscomplex(out->format)) {
+		// one phase and an integer step: the streaming / staged kernels (resample_f32.hip)
 		std::vector<ReducePos> host_pos;
-		reduce_positions(r, out->top, out->height, tile, host_pos);
-		const int done = reducev_f32_stream_try(r, in, out, host_pos, (const double *) table);
+		if (vertical)
+			reduce_positions(r, out->top, out->height, tile, host_pos);
+		else
+			reduce_positions(r, out->left, out->width, tile, host_pos);
+		const int done = vertical ? reducev_f32_stream_try(r, in, out, host_pos, (const double *) table)
+								  : reduceh_f32_lds_try(r, in, out, host_pos, (const double *) table);
 		if (done < 0)
 			return -1;
 		if (done > 0)

@@ -146,6 +146,70 @@ shrinkv_f32_stream(RfArgs a)
 	}
 }
 
+// reduceh_f32_lds<B>: the horizontal reduce with one phase and an integer step.  The general kernel's lanes gather
+// their taps straight from memory, S x B floats apart (a cache line per lane and tap: 0.19 ms for the 100 MB the
+// vertical pass leaves of 8192^2 x 3); here a block stages the columns its 256 / B output pixels touch, for four rows,
+// with coalesced loads (columns beyond the image: its edge column, vips_embed COPY), and a lane sums its element's
+// taps from LDS -- in tap order, in double, multiply and add rounded separately (templates.h:183-194).
+struct RhArgs {
+	const unsigned char *in;
+	unsigned char *out;
+	long long in_stride, out_stride;
+	int im_width, in_left;  // columns clamp to the image; the window's first column
+	int out_width, out_height;
+	int first0, step, n;    // first tap (image column) of the region's output column 0, columns per output, taps
+	int opb;                // output pixels per block
+	const double *coef;
+};
+
+template <int B>
+__global__ void __launch_bounds__(256)
+reduceh_f32_lds(RhArgs a)
+{
+	constexpr int ROWS = 4;
+	VH_DYNAMIC_LDS(unsigned char, rh_lds);
+	double *s_c = reinterpret_cast<double *>(rh_lds);                       // n coefficients (64 slots)
+	float *s_in = reinterpret_cast<float *>(rh_lds + 64 * sizeof(double));  // ROWS x span floats
+	const int t = threadIdx.x;
+	if (t < a.n)
+		s_c[t] = a.coef[t];
+	const int x0 = blockIdx.x * a.opb, nx = min(a.opb, a.out_width - x0);
+	const int span_px = (nx - 1) * a.step + a.n; // input pixels the block's outputs touch
+	const int span = span_px * B;
+	const int c0 = a.first0 + x0 * a.step;       // image column of the span's first pixel
+	const int xo = t / B, b = t - xo * B;        // this lane's output pixel of the block, band
+	for (int y0 = blockIdx.y * ROWS; y0 < a.out_height; y0 += gridDim.y * ROWS) {
+		__syncthreads(); // (the coefficients; the last rows' readers)
+		for (int e = t; e < span; e += 256) {
+			const int j = e / B, bb = e - j * B;
+			const int col = min(max(c0 + j, 0), a.im_width - 1) - a.in_left;
+#pragma unroll
+			for (int r = 0; r < ROWS; r++) {
+				const int y = min(y0 + r, a.out_height - 1);
+				s_in[r * span + e] = reinterpret_cast<const float *>(a.in + (long long) y * a.in_stride)[col * B + bb];
+			}
+		}
+		__syncthreads();
+		if (xo < nx) {
+			double sum[ROWS];
+#pragma unroll
+			for (int r = 0; r < ROWS; r++)
+				sum[r] = 0.0;
+			const float *p = s_in + xo * a.step * B + b;
+			for (int k = 0; k < a.n; k++) {
+				const double c = s_c[k];
+#pragma unroll
+				for (int r = 0; r < ROWS; r++)
+					sum[r] = __dadd_rn(sum[r], __dmul_rn(c, (double) p[r * span + k * B]));
+			}
+#pragma unroll
+			for (int r = 0; r < ROWS; r++)
+				if (y0 + r < a.out_height)
+					reinterpret_cast<float *>(a.out + (long long) (y0 + r) * a.out_stride)[(x0 + xo) * B + b] = (float) sum[r];
+		}
+	}
+}
+
 static bool rf_common(const VipsHipRegion *in, const VipsHipRegion *out, int per_lane, RfArgs *a)
 {
 	if (in->format != VIPS_HIP_FORMAT_FLOAT || out->format != VIPS_HIP_FORMAT_FLOAT || in->bands != out->bands)
@@ -222,6 +286,60 @@ int reducev_f32_stream_try(const _VipsHipReduce *r, const VipsHipRegion *in, con
 	RF_CASE(8, 33)
 #undef RF_CASE
 	return 0;
+}
+
+// the region's positions (host): out column k reads image columns pos[k].first ...; 1 launched, 0 not this kernel's case
+int reduceh_f32_lds_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out,
+	const std::vector<ReducePos> &pos, const double *coef)
+{
+	if (getenv("VIPS_HIP_NO_F32_STREAM") || pos.empty())
+		return 0;
+	if (in->format != VIPS_HIP_FORMAT_FLOAT || out->format != VIPS_HIP_FORMAT_FLOAT || in->bands != out->bands ||
+		in->bands < 1 || in->bands > 4 || out->width < 64)
+		return 0;
+	int step = 0;
+	for (size_t k = 1; k < pos.size(); k++) {
+		const int d = pos[k].first - pos[k - 1].first;
+		if (pos[k].phase != pos[0].phase || (step && d != step))
+			return 0;
+		step = d;
+	}
+	const int N = r->n_point, B = in->bands;
+	if (step < 1 || N > 64 || (size_t) (pos[0].phase + 1) * N > r->matrixf.size())
+		return 0;
+	RhArgs a;
+	// rows of the output region are rows out->top ... of the window (reduceh.cpp:237-240: same rows in and out)
+	a.in = (const unsigned char *) in->data + (long long) (out->top - in->top) * in->stride;
+	a.out = (unsigned char *) out->data;
+	a.in_stride = (long long) in->stride;
+	a.out_stride = (long long) out->stride;
+	a.im_width = in->im_width;
+	a.in_left = in->left;
+	a.out_width = out->width;
+	a.out_height = out->height;
+	a.first0 = pos[0].first;
+	a.step = step;
+	a.n = N;
+	a.opb = 256 / B;
+	a.coef = coef + (size_t) pos[0].phase * N;
+	const size_t span = (size_t) ((a.opb - 1) * step + N) * B;
+	const size_t lds = 64 * sizeof(double) + 4 * span * sizeof(float);
+	if (lds > 60 * 1024)
+		return 0;
+	const int gx = (out->width + a.opb - 1) / a.opb;
+	int gy = 4096 / gx;
+	gy = gy < 1 ? 1 : gy;
+	const int groups = (out->height + 3) / 4;
+	gy = gy > groups ? groups : gy;
+	Gate gate("reduceh_f32_lds");
+	switch (B) {
+	case 1: hipLaunchKernelGGL(reduceh_f32_lds<1>, dim3(gx, gy, 1), dim3(256), lds, stream(), a); break;
+	case 2: hipLaunchKernelGGL(reduceh_f32_lds<2>, dim3(gx, gy, 1), dim3(256), lds, stream(), a); break;
+	case 3: hipLaunchKernelGGL(reduceh_f32_lds<3>, dim3(gx, gy, 1), dim3(256), lds, stream(), a); break;
+	default: hipLaunchKernelGGL(reduceh_f32_lds<4>, dim3(gx, gy, 1), dim3(256), lds, stream(), a); break;
+	}
+	VH_CHECK(hipGetLastError());
+	return 1;
 }
 
 int shrinkv_f32_stream_try(int vshrink, const VipsHipRegion *in, const VipsHipRegion *out)
