@@ -92,6 +92,64 @@ def _case(rng, kind):
                 return helpers.Ref.run_mask("convsep", src, m[None, :], scale, 0.0, "precision=integer")
             return helpers.PortCC.convsep(src, m, scale=scale, precision="integer")
         return (kind, w, h, bands, mask, scale), lambda: im.convsep(mask, scale=scale, precision="integer"), ref
+    if kind == "resize":
+        # round 6: vips_resize across the SIZE threshold that picks the chain of band kernels
+        # (images of 8 MB and more, tools/band_threshold.py) or the one-kernel chain: images of 7 .. 9 MB
+        bands = rng.choice([3, 3, 4, 1])
+        target = rng.choice([7.0, 7.9, 8.0, 8.1, 9.0]) * (1 << 20)
+        w = rng.randrange(900, 2600)
+        w -= (w * bands) % 4 if rng.random() < 0.7 else 0  # (mostly rows of whole dwords: the streaming kernels' case)
+        h = max(64, int(target / (w * bands)) + rng.choice([-1, 0, 1]))
+        src = helpers.lcg_image(w, h, bands, np.uint8, seed)
+        scale = round(rng.choice([0.125, 0.25, 0.05 + 0.4 * rng.random(), 0.05 + 0.4 * rng.random()]), 4)
+        im = Image.new_from_array(src)
+        return (kind, w, h, bands, scale), lambda: im.resize(scale), \
+            lambda: _reference("resize:scale=%r" % scale, src, lambda: helpers.Port.resize(src, scale))
+    if kind == "float":
+        # the float streams of round 6 (resample_f32.hip) and what they decline: rows of odd element counts, images
+        # too narrow, fractional factors, other kernels
+        w, h = _size(rng, 16, 2200), _size(rng, 16, 600)
+        bands = rng.choice([1, 3, 3, 4])
+        src = (helpers.lcg_image(w, h, bands, np.uint8, seed).astype(np.float32) - 90.0) * np.float32(0.37)
+        op = rng.choice(["reducev", "reduceh", "reduce", "shrinkv", "shrink"])
+        im = Image.new_from_array(src)
+        if op.startswith("shrink"):
+            s1, s2 = rng.choice([2, 3, 4, 7, 8]), rng.choice([2, 3, 4, 8])
+            if op == "shrinkv":
+                return (kind, op, w, h, bands, s2), lambda: im.shrinkv(s2), \
+                    lambda: _reference("shrinkv:vshrink=%d" % s2, src, lambda: helpers.Port.shrinkv(src, s2))
+            return (kind, op, w, h, bands, s1, s2), lambda: im.shrink(s1, s2), \
+                lambda: _reference("shrink:hshrink=%d,vshrink=%d" % (s1, s2), src, lambda: helpers.Port.shrink(src, s1, s2))
+        shrink = round(rng.choice([2.0, 3.0, 4.0, 8.0, 8.0, 1.5 + 7 * rng.random()]), 3)
+        kernel = rng.choice(["lanczos3", "lanczos3", "lanczos2", "cubic", "linear"])
+        if op == "reducev":
+            return (kind, op, w, h, bands, shrink, kernel), lambda: im.reducev(shrink, kernel=kernel), \
+                lambda: _reference("reducev:vshrink=%r,kernel=%s" % (shrink, kernel), src, lambda: helpers.Port.reduce(src, 1.0, shrink, kernel))
+        if op == "reduceh":
+            return (kind, op, w, h, bands, shrink, kernel), lambda: im.reduceh(shrink, kernel=kernel), \
+                lambda: _reference("reduceh:hshrink=%r,kernel=%s" % (shrink, kernel), src, lambda: helpers.Port.reduce(src, shrink, 1.0, kernel))
+        return (kind, op, w, h, bands, shrink, kernel), lambda: im.reduce(shrink, shrink, kernel=kernel), \
+            lambda: _reference("reduce:hshrink=%r,vshrink=%r,kernel=%s" % (shrink, shrink, kernel), src,
+                               lambda: helpers.Port.reduce(src, shrink, shrink, kernel))
+    if kind == "upsize":
+        # bicubic enlargement of uchar by the column walk (upsize.hip), any bands, scales that move the window by
+        # 0 / 1 input rows a step and (below 1 on one axis) by more
+        w, h = _size(rng, 8, 400), _size(rng, 8, 300)
+        src = helpers.lcg_image(w, h, bands, np.uint8, seed)
+        hs = round(rng.choice([1.0 + 3 * rng.random(), 2.0, 2.5, 4.0]), 3)
+        vs = round(rng.choice([hs, 1.0 + 3 * rng.random(), 1.0]), 3)
+        im = Image.new_from_array(src)
+        chain = "resize:scale=%r,vscale=%r,kernel=cubic" % (hs, vs)
+        return (kind, w, h, bands, hs, vs), lambda: im.resize(hs, vscale=vs, kernel="cubic"), \
+            lambda: _reference(chain, src, lambda: helpers.Port.resize(src, hs, vs, kernel="cubic"))
+    if kind == "blur16":
+        # ushort gaussblur across the matrix-core kernel's limits (masks of up to 33 taps: sigma 9 and more fall back)
+        w, h = _size(rng, 8), _size(rng, 8)
+        src = helpers.lcg_image(w, h, bands, np.uint16, seed)
+        sigma = rng.choice([0.8, 1.5, 2.0, 4.0, 8.0, 8.9, 9.5, 11.0])
+        im = Image.new_from_array(src)
+        return (kind, w, h, bands, sigma), lambda: im.gaussblur(sigma), \
+            lambda: _reference("gaussblur:sigma=%r" % sigma, src, lambda: helpers.PortCC.gaussblur(src, sigma))
     # a small 2-D mask on uchar / ushort
     w, h = _size(rng, 8), _size(rng, 8)
     dt = rng.choice([np.uint8, np.uint16])
@@ -111,7 +169,8 @@ def _case(rng, kind):
 
 
 @pytest.mark.parametrize("kind,count,seed", [("reduce", 60, 501), ("shrink", 30, 502), ("blur", 40, 503),
-                                             ("convsep", 30, 504), ("conv", 30, 505)])
+                                             ("convsep", 30, 504), ("conv", 30, 505), ("resize", 14, 506),
+                                             ("float", 40, 507), ("upsize", 24, 508), ("blur16", 24, 509)])
 def test_fuzz_dispatch(kind, count, seed):
     rng = random.Random(seed)
     lib = libvips_amd.lib
@@ -131,7 +190,9 @@ def test_fuzz_dispatch(kind, count, seed):
             kernels[k] = kernels.get(k, 0) + 1
         want = ref()
         assert got.shape == want.shape and got.dtype == want.dtype, (desc, got.shape, want.shape)
+        if got.dtype == np.float32:  # (bit for bit, NaN-safe: the float paths are the reference's operations in its order)
+            got, want = got.view(np.int32), want.view(np.int32)
         bad = np.argwhere(got != want)
         assert len(bad) == 0, (desc, dict(report), len(bad), bad[:4].tolist())
     # the sweep must have reached the fast kernels AND their fall-backs
-    assert len(kernels) >= 3, kernels
+    assert len(kernels) >= {"upsize": 1, "blur16": 2}.get(kind, 3), kernels
