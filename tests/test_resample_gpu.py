@@ -306,6 +306,7 @@ def test_fused_reduce_mfma_variants(nth, late, align, size, kernel):
     w, h = size
     src = helpers.lcg_image(w, h, 4, np.uint8, 47)
     os.environ["VIPS_HIP_FUSED_ALIGN"] = str(align)
+    os.environ["VIPS_HIP_FUSED_EXCH"] = "0"  # (the kernel WITH halos and its variants; the other: test_fused_reduce_exchange)
     os.environ["VIPS_HIP_FUSED_NTH"] = str(nth)  # 59-pixel tiles (256 threads) / 123-pixel tiles (512)
     # the edge fix-up at the point of use + nt loads (the shipped form) / at the loads + plain loads (round 2)
     os.environ["VIPS_HIP_FUSED_LATE"] = os.environ["VIPS_HIP_FUSED_NT"] = str(late)
@@ -316,6 +317,7 @@ def test_fused_reduce_mfma_variants(nth, late, align, size, kernel):
         report = libvips_amd.gate_report()
     finally:
         del os.environ["VIPS_HIP_FUSED_ALIGN"]
+        del os.environ["VIPS_HIP_FUSED_EXCH"]
         del os.environ["VIPS_HIP_FUSED_NTH"]
         del os.environ["VIPS_HIP_FUSED_LATE"]
         del os.environ["VIPS_HIP_FUSED_NT"]
@@ -646,9 +648,9 @@ def test_resize_stream_general(bands, size, scale, vscale, monkeypatch):
 
 
 @pytest.mark.parametrize("scale,env,want", [
-    (0.07, "", ["resize_streamg_u8", "sharpen_fused_u8"]),
-    (0.07, "VIPS_HIP_NO_RESIZE_STREAMG", ["resize_tail_u8", "sharpen_fused_u8", "shrinkv_u8"]),
-    (0.3, "VIPS_HIP_NO_RESIZE_STREAMG", ["resize_tail_u8", "sharpen_fused_u8"])])
+    (0.07, "", ["resize_streamg_u8", "sharpen_skip_u8"]),
+    (0.07, "VIPS_HIP_NO_RESIZE_STREAMG", ["resize_tail_u8", "sharpen_skip_u8", "shrinkv_u8"]),
+    (0.3, "VIPS_HIP_NO_RESIZE_STREAMG", ["resize_tail_u8", "sharpen_skip_u8"])])
 def test_resize_batch_any_scale(scale, env, want, monkeypatch):
     """A uniform batch whose scale is not 1 / (2 k): the scheduled one-kernel chain
     (resize_streamg.hip), or without it the vertical box shrink and the fused tail (reducev ->
