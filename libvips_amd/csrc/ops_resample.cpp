@@ -627,6 +627,27 @@ int vips_hip_shrink(VipsHipImage *in, VipsHipImage **out, double hshrink, double
 			return -1;
 		return reduce_axis(t0.im, out, hshrink, VIPS_HIP_KERNEL_LANCZOS3, 1.0, false);
 	}
+	// ushort, both factors above 1: the two box shrinks in one kernel (resample16: the image read once, the
+	// 1 / vshrink-size intermediate never made)
+	if (in->format == VIPS_HIP_FORMAT_USHORT && hshrink_int > 1 && vshrink_int > 1) {
+		const int h1 = vips_hip_shrink_out_size(in->height, vshrink_int, ceil_mode);
+		const int w1 = vips_hip_shrink_out_size(in->width, hshrink_int, ceil_mode);
+		if (h1 > 0 && w1 > 0) {
+			ImageRef o(like(in, w1, h1));
+			if (!o.im)
+				return -1;
+			VipsHipRegion ri, ro;
+			vips_hip_image_region(in, &ri);
+			vips_hip_image_region(o.im, &ro);
+			const int done = vh::shrinkbox16_try(hshrink_int, vshrink_int, &ri, &ro);
+			if (done < 0)
+				return -1;
+			if (done > 0) {
+				*out = o.release();
+				return 0;
+			}
+		}
+	}
 	if (shrink_axis(in, &t0.im, vshrink_int, ceil_mode, true))
 		return -1;
 	return shrink_axis(t0.im, out, hshrink_int, ceil_mode, false);

@@ -53,6 +53,7 @@ int reduceh_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRe
 // vips_shrinkv(vs, ceil) + vips_reducev as one kernel (`in`: the image before the shrink; `r`: the reduce's plan)
 int shrinkv_reducev_band_try(_VipsHipReduce *r, int vs, int mid_height, const VipsHipRegion *in, const VipsHipRegion *out, int tile);
 int shrinkh16_stream_try(int hshrink, const VipsHipRegion *in, const VipsHipRegion *out);
+int shrinkbox16_try(int hshrink, int vshrink, const VipsHipRegion *in, const VipsHipRegion *out);
 // reduceh_u8.hip: vips_reduceh on uchar with one coefficient row and first taps 4 or 8 pixels apart,
 // packed bytes (whole rows); 1 = handled, 0 = not its case
 int reduceh_u8p_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out, int tile);

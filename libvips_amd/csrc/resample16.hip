@@ -39,6 +39,13 @@ shrinkh16(R16HArgs a)
 	shrinkh16_body<B>(a, (int) blockIdx.x, (int) blockIdx.y, (int) gridDim.y);
 }
 
+template <int B>
+__global__ void __launch_bounds__(R16_NT)
+shrinkbox16(R16HArgs a)
+{
+	shrinkbox16_body<B>(a, (int) blockIdx.x, (int) blockIdx.y, (int) gridDim.y);
+}
+
 } // namespace vh
 
 #include "resample16_host.h"
@@ -63,6 +70,8 @@ static int r16_launch_h(int which, int bands, const R16HArgs &a, int gx, int gy,
 	if (bands == B) { \
 		if (which == 0) \
 			hipLaunchKernelGGL(reduceh16<B>, grid, block, lds, stream(), a); \
+		else if (which == 2) \
+			hipLaunchKernelGGL(shrinkbox16<B>, grid, block, 0, stream(), a); \
 		else \
 			hipLaunchKernelGGL(shrinkh16<B>, grid, block, 0, stream(), a); \
 		return hipGetLastError() != hipSuccess ? -1 : 0; \

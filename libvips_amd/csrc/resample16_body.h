@@ -308,6 +308,9 @@ struct R16HArgs {
 	const short *table;  // [phase][n_point]
 	int hshrink;         // shrinkh
 	unsigned int mult;
+	int vshrink, in_height; // shrinkbox16: the vertical box in front of the horizontal one
+	unsigned int multv;
+	int aligned16;          // shrinkbox16: rows start on 16 bytes (the box's bytes as they lie, 16 per load)
 };
 
 // byte offset of input byte `b` of a staged row (8 bytes of padding after every 64)
@@ -456,6 +459,78 @@ static __device__ __forceinline__ void shrinkh16_body(const R16HArgs &a, int bx,
 				r16_store_px<B>(dst, v);
 			}
 		}
+	}
+}
+
+// ---- vips_shrink (shrink.c:77-119: shrinkv, then shrinkh) in ONE kernel (round 6): a thread per output pixel sums
+// the vshrink rows of each of its hshrink columns, rounds that sum the way shrinkv does (shrinkv.c:233-244), adds the
+// rounded column sums and rounds as shrinkh does (shrinkh.c:98-112) -- the image is read once and the 1 / vshrink-size
+// intermediate (537 MB for 16384^2 RGBA ushort by 4) never exists: 0.62 ms for the pair of kernels, of which the
+// second one's re-read was a quarter.
+template <int B>
+static __device__ __forceinline__ void shrinkbox16_body(const R16HArgs &a, int bx, int by, int gy)
+{
+	const int x = bx * R16_NT + tid();
+	if (x >= a.out_width)
+		return;
+	constexpr int PB = 2 * B;
+	const int hs = a.hshrink, vs = a.vshrink;
+	const int box_bytes = hs * PB;
+	const bool wide = a.aligned16 && B % 2 == 0 && box_bytes % 16 == 0 && (x + 1) * hs <= a.in_width;
+	auto round_v = [&](unsigned int sum) -> unsigned int {
+		const unsigned int v = sum + (unsigned int) (vs >> 1);
+		return (vs == 1 ? v : umulhi(v, a.multv)) & 0xffffu;
+	};
+	for (int y = by; y < a.height; y += gy) {
+		unsigned int tot[B];
+#pragma unroll
+		for (int b = 0; b < B; b++)
+			tot[b] = (unsigned int) (hs >> 1);
+		if (wide) {
+			// 16 bytes = 8 elements of the box at a time (their bands: element e of a group is band e % B, B = 2 or 4)
+			for (int c = 0; c < box_bytes; c += 16) {
+				unsigned int v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+				for (int k = 0; k < vs; k++) {
+					const int row = min(y * vs + k, a.in_height - 1);
+					const gptr_in line = gptr_in_of((unsigned long long) a.in) + (long long) row * a.in_stride;
+					unsigned int w[4];
+					gload128(line, (unsigned int) (x * box_bytes + c), w);
+#pragma unroll
+					for (int d = 0; d < 4; d++) {
+						v[2 * d] += w[d] & 0xffffu;
+						v[2 * d + 1] += w[d] >> 16;
+					}
+				}
+#pragma unroll
+				for (int e = 0; e < 8; e++)
+					tot[e % B] += round_v(v[e]);
+			}
+		}
+		else {
+			for (int k = 0; k < hs; k++) {
+				const int px = min(x * hs + k, a.in_width - 1);
+				unsigned int v[B];
+#pragma unroll
+				for (int b = 0; b < B; b++)
+					v[b] = 0;
+				for (int j = 0; j < vs; j++) {
+					const int row = min(y * vs + j, a.in_height - 1);
+					const gptr_in line = gptr_in_of((unsigned long long) a.in) + (long long) row * a.in_stride;
+#pragma unroll
+					for (int b = 0; b < B; b++)
+						v[b] += gload16(line, (unsigned int) (px * PB + 2 * b));
+				}
+#pragma unroll
+				for (int b = 0; b < B; b++)
+					tot[b] += round_v(v[b]);
+			}
+		}
+		const gptr_out dst = gptr_out_of((unsigned long long) a.out) + (long long) y * a.out_stride + (long long) x * PB;
+		unsigned int o[B];
+#pragma unroll
+		for (int b = 0; b < B; b++)
+			o[b] = (hs == 1 ? tot[b] : umulhi(tot[b], a.mult)) & 0xffffu;
+		r16_store_px<B>(dst, o);
 	}
 }
 

@@ -318,6 +318,46 @@ int reduceh16_stream_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsH
 	return rc ? -1 : 1;
 }
 
+// vips_shrink on a whole ushort image in one kernel (shrinkbox16_body): 1 launched, 0 not its case, -1 error
+int shrinkbox16_try(int hshrink, int vshrink, const VipsHipRegion *in, const VipsHipRegion *out)
+{
+	if (getenv("VIPS_HIP_NO_STREAM16") || getenv("VIPS_HIP_NO_SHRINKBOX16") || hshrink < 2 || vshrink < 2 || hshrink > 4096 ||
+		vshrink > 4096)
+		return 0;
+	if (in->format != VIPS_HIP_FORMAT_USHORT || out->format != VIPS_HIP_FORMAT_USHORT || in->bands != out->bands ||
+		in->bands < 1 || in->bands > 4)
+		return 0;
+	if (in->left || in->top || out->left || out->top || in->width != in->im_width || in->height != in->im_height ||
+		out->width != out->im_width || out->height != out->im_height)
+		return 0;
+	// (the pixel stores: dwords for an even band count; the wide loads want rows that start on 16 bytes)
+	if ((((uintptr_t) in->data | in->stride) & 1) || (((uintptr_t) out->data | out->stride) & (in->bands % 2 == 0 ? 3 : 1)))
+		return 0;
+	R16HArgs a;
+	memset(&a, 0, sizeof(a));
+	a.in = (const unsigned char *) in->data;
+	a.out = (unsigned char *) out->data;
+	a.in_stride = (long long) in->stride;
+	a.out_stride = (long long) out->stride;
+	a.in_width = in->width;
+	a.in_height = in->height;
+	a.out_width = out->width;
+	a.height = out->height;
+	a.bands = in->bands;
+	a.hshrink = hshrink;
+	a.vshrink = vshrink;
+	a.aligned16 = !(((uintptr_t) in->data | in->stride) & 15);
+	a.mult = (unsigned int) (((1ULL << 32) + hshrink - 1) / hshrink);
+	a.multv = (unsigned int) (((1ULL << 32) + vshrink - 1) / vshrink);
+	const int gx = (out->width + R16_NT - 1) / R16_NT;
+	int gy = 16384 / gx;
+	gy = gy < 1 ? 1 : gy;
+	gy = out->height < gy ? out->height : gy;
+	Gate gate("shrinkbox_u16");
+	const int rc = r16_launch_h(2, in->bands, a, gx, gy, 0);
+	return rc ? -1 : 1;
+}
+
 int shrinkh16_stream_try(int hshrink, const VipsHipRegion *in, const VipsHipRegion *out)
 {
 	if (getenv("VIPS_HIP_NO_STREAM16") || !r16_whole(in, out, false) || hshrink < 1 || hshrink > 32768)

@@ -56,6 +56,8 @@ static int r16_launch_h(int which, int bands, const R16HArgs &a, int gx, int gy,
 		r16_run(gx * gy, lds, [&](int wg, unsigned int *l) { \
 			if (which == 0) \
 				reduceh16_body<B>(a, wg % gx, wg / gx, gy, l); \
+			else if (which == 2) \
+				shrinkbox16_body<B>(a, wg % gx, wg / gx, gy); \
 			else \
 				shrinkh16_body<B>(a, wg % gx, wg / gx, gy); \
 		}); \

@@ -58,3 +58,34 @@ def test_ushort_streaming(case, seg, monkeypatch):
     assert len(bad) == 0, (len(bad), bad[:5])
     monkeypatch.setenv("VIPS_HIP_NO_STREAM16", "1")
     assert np.array_equal(got, getattr(im, op)(*args).numpy())
+
+
+@pytest.mark.parametrize("bands", [1, 2, 3, 4])
+def test_shrinkbox16(bands, monkeypatch):
+    """Round 6: vips_shrink on ushort in ONE kernel (shrinkbox16: a thread per output pixel, the vertical sums of its
+    columns rounded as shrinkv rounds, their sum as shrinkh does -- shrink.c:77-119, shrinkv.c:233-244,
+    shrinkh.c:98-112): factors whose boxes are and are not whole 16-byte groups, sizes the factors do not divide
+    (floor and ceil), against the port and against the pair of kernels."""
+    import libvips_amd
+    from libvips_amd import Image
+
+    lib = libvips_amd.lib
+    for (w, h, hs, vs, ceil) in ((512, 256, 4, 4, False), (515, 259, 4, 4, True), (300, 200, 2, 3, False),
+                                 (301, 203, 3, 2, True), (640, 96, 8, 5, False), (129, 67, 6, 7, True)):
+        src = helpers.lcg_image(w, h, bands, np.uint16, 120 + hs)
+        im = Image.new_from_array(src)
+        lib.vips_hip_gate_reset()
+        lib.vips_hip_gate_enable(1)
+        try:
+            got = im.shrink(hs, vs, ceil=ceil).numpy()
+            report = libvips_amd.gate_report()
+        finally:
+            lib.vips_hip_gate_enable(0)
+            lib.vips_hip_gate_reset()
+        assert list(report) == ["shrinkbox_u16"], report
+        monkeypatch.setenv("VIPS_HIP_NO_SHRINKBOX16", "1")
+        old = im.shrink(hs, vs, ceil=ceil).numpy()
+        monkeypatch.delenv("VIPS_HIP_NO_SHRINKBOX16")
+        want = helpers.Port.shrink(src, hs, vs, ceil=ceil)
+        assert got.shape == want.shape and np.array_equal(got, want), (w, h, hs, vs, ceil)
+        assert np.array_equal(got, old)
