@@ -46,6 +46,13 @@ shrinkbox16(R16HArgs a)
 	shrinkbox16_body<B>(a, (int) blockIdx.x, (int) blockIdx.y, (int) gridDim.y);
 }
 
+template <int B, int L>
+__global__ void __launch_bounds__(R16_NT)
+shrinkbox16c(R16HArgs a)
+{
+	shrinkbox16c_body<B, L>(a, (int) blockIdx.x, (int) blockIdx.y, (int) gridDim.y);
+}
+
 } // namespace vh
 
 #include "resample16_host.h"
@@ -78,6 +85,19 @@ static int r16_launch_h(int which, int bands, const R16HArgs &a, int gx, int gy,
 	}
 	R16_H(1) R16_H(2) R16_H(3) R16_H(4)
 #undef R16_H
+	return -1;
+}
+
+static int r16_launch_boxc(int bands, int lanes_per_box, const R16HArgs &a, int gx, int gy)
+{
+	const dim3 grid(gx, gy, 1), block(R16_NT, 1, 1);
+#define R16_C(B, L) \
+	if (bands == B && lanes_per_box == L) { \
+		hipLaunchKernelGGL((shrinkbox16c<B, L>), grid, block, 0, stream(), a); \
+		return hipGetLastError() != hipSuccess ? -1 : 0; \
+	}
+	R16_C(1, 1) R16_C(1, 2) R16_C(1, 4) R16_C(2, 1) R16_C(2, 2) R16_C(2, 4) R16_C(4, 1) R16_C(4, 2) R16_C(4, 4)
+#undef R16_C
 	return -1;
 }
 

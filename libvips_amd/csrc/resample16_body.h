@@ -311,6 +311,8 @@ struct R16HArgs {
 	int vshrink, in_height; // shrinkbox16: the vertical box in front of the horizontal one
 	unsigned int multv;
 	int aligned16;          // shrinkbox16: rows start on 16 bytes (the box's bytes as they lie, 16 per load)
+	int x_first;            // shrinkbox16: the first output column this launch makes (behind shrinkbox16c: the ragged one)
+	int x_full;             // shrinkbox16c: output columns whose box lies inside the image
 };
 
 // byte offset of input byte `b` of a staged row (8 bytes of padding after every 64)
@@ -470,7 +472,7 @@ static __device__ __forceinline__ void shrinkh16_body(const R16HArgs &a, int bx,
 template <int B>
 static __device__ __forceinline__ void shrinkbox16_body(const R16HArgs &a, int bx, int by, int gy)
 {
-	const int x = bx * R16_NT + tid();
+	const int x = a.x_first + bx * R16_NT + tid();
 	if (x >= a.out_width)
 		return;
 	constexpr int PB = 2 * B;
@@ -531,6 +533,67 @@ static __device__ __forceinline__ void shrinkbox16_body(const R16HArgs &a, int b
 		for (int b = 0; b < B; b++)
 			o[b] = (hs == 1 ? tot[b] : umulhi(tot[b], a.mult)) & 0xffffu;
 		r16_store_px<B>(dst, o);
+	}
+}
+
+// ... with the lanes on CONSECUTIVE 16-byte groups of the row, as shrinkv16 has them (a thread per output pixel reads
+// 32 bytes a row for RGBA by 4: every other 16 bytes of a wave's load instruction -- 0.61 ms, no faster than the two
+// kernels): a lane sums its group's 8 elements down the vshrink rows, rounds them (shrinkv), adds the pixels of its
+// group per band, and the L = box bytes / 16 lanes of a box add theirs with wave shifts; the box's first lane rounds
+// (shrinkh) and stores.  Boxes of 16, 32 or 64 bytes, 1 / 2 / 4 bands, rows on 16 bytes; the ragged last column of a
+// ceil shrink is shrinkbox16_body's.
+template <int B, int L>
+static __device__ __forceinline__ void shrinkbox16c_body(const R16HArgs &a, int bx, int by, int gy)
+{
+	const int lane = bx * R16_NT + tid();
+	const int vs = a.vshrink, hs = a.hshrink;
+	const unsigned int col = (unsigned int) lane * 16u;
+	const unsigned int full_bytes = (unsigned int) a.x_full * (unsigned int) (hs * 2 * B);
+	const bool live = col + 16u <= full_bytes;
+	const unsigned int lcol = live ? col : 0u;
+	for (int y = by; y < a.height; y += gy) {
+		unsigned int s[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+		for (int k = 0; k < vs; k++) {
+			const int row = min(y * vs + k, a.in_height - 1);
+			const gptr_in line = gptr_in_of((unsigned long long) a.in) + (long long) row * a.in_stride;
+			unsigned int w[4];
+			gload128(line, lcol, w);
+#pragma unroll
+			for (int d = 0; d < 4; d++) {
+				s[2 * d] += w[d] & 0xffffu;
+				s[2 * d + 1] += w[d] >> 16;
+			}
+		}
+		unsigned int p[B];
+#pragma unroll
+		for (int b = 0; b < B; b++)
+			p[b] = 0;
+#pragma unroll
+		for (int e = 0; e < 8; e++) {
+			const unsigned int v = s[e] + (unsigned int) (vs >> 1);
+			p[e % B] += (vs == 1 ? v : umulhi(v, a.multv)) & 0xffffu;
+		}
+		if constexpr (L >= 2) {
+#pragma unroll
+			for (int b = 0; b < B; b++)
+				p[b] += lane_next(p[b]);
+		}
+		if constexpr (L >= 4) {
+#pragma unroll
+			for (int b = 0; b < B; b++)
+				p[b] += lane_from(p[b], 2);
+		}
+		if (live && (tid() & (L - 1)) == 0) {
+			const int x = lane / L;
+			const gptr_out dst = gptr_out_of((unsigned long long) a.out) + (long long) y * a.out_stride + (long long) x * (2 * B);
+			unsigned int o[B];
+#pragma unroll
+			for (int b = 0; b < B; b++) {
+				const unsigned int t = p[b] + (unsigned int) (hs >> 1);
+				o[b] = (hs == 1 ? t : umulhi(t, a.mult)) & 0xffffu;
+			}
+			r16_store_px<B>(dst, o);
+		}
 	}
 }
 

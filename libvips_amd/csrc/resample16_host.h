@@ -18,6 +18,7 @@ namespace vh {
 // defined by the including file; 0 on success
 static int r16_launch_v(int which, const R16VArgs &a, int gx, int gy);
 static int r16_launch_h(int which, int bands, const R16HArgs &a, int gx, int gy, size_t lds);
+static int r16_launch_boxc(int bands, int lanes_per_box, const R16HArgs &a, int gx, int gy);
 
 namespace {
 
@@ -349,11 +350,31 @@ int shrinkbox16_try(int hshrink, int vshrink, const VipsHipRegion *in, const Vip
 	a.aligned16 = !(((uintptr_t) in->data | in->stride) & 15);
 	a.mult = (unsigned int) (((1ULL << 32) + hshrink - 1) / hshrink);
 	a.multv = (unsigned int) (((1ULL << 32) + vshrink - 1) / vshrink);
-	const int gx = (out->width + R16_NT - 1) / R16_NT;
+	Gate gate("shrinkbox_u16");
+	// boxes of 16 / 32 / 64 bytes on 16-byte rows: the lanes on consecutive 16-byte groups (shrinkbox16c), the ragged
+	// last column of a ceil shrink by the thread-per-pixel form
+	const int box_bytes = hshrink * in->bands * 2;
+	a.x_first = 0;
+	a.x_full = in->width / hshrink;
+	if (a.aligned16 && in->bands != 3 && (box_bytes == 16 || box_bytes == 32 || box_bytes == 64) && a.x_full > 0 &&
+		!getenv("VIPS_HIP_NO_SHRINKBOX16C")) {
+		const int xf = a.x_full < out->width ? a.x_full : out->width;
+		a.x_full = xf;
+		const long long lanes = (long long) xf * (box_bytes / 16);
+		const int gx = (int) ((lanes + R16_NT - 1) / R16_NT);
+		int gy = 32768 / gx;
+		gy = gy < 1 ? 1 : gy > out->height ? out->height : gy;
+		if (r16_launch_boxc(in->bands, box_bytes / 16, a, gx, gy))
+			return -1;
+		if (xf >= out->width)
+			return 1;
+		a.x_first = xf;
+	}
+	const int cols = out->width - a.x_first;
+	const int gx = (cols + R16_NT - 1) / R16_NT;
 	int gy = 16384 / gx;
 	gy = gy < 1 ? 1 : gy;
 	gy = out->height < gy ? out->height : gy;
-	Gate gate("shrinkbox_u16");
 	const int rc = r16_launch_h(2, in->bands, a, gx, gy, 0);
 	return rc ? -1 : 1;
 }

@@ -68,4 +68,16 @@ static int r16_launch_h(int which, int bands, const R16HArgs &a, int gx, int gy,
 	return -1;
 }
 
+static int r16_launch_boxc(int bands, int lanes_per_box, const R16HArgs &a, int gx, int gy)
+{
+#define R16_C(B, L) \
+	if (bands == B && lanes_per_box == L) { \
+		r16_run(gx * gy, 64, [&](int wg, unsigned int *) { shrinkbox16c_body<B, L>(a, wg % gx, wg / gx, gy); }); \
+		return 0; \
+	}
+	R16_C(1, 1) R16_C(1, 2) R16_C(1, 4) R16_C(2, 1) R16_C(2, 2) R16_C(2, 4) R16_C(4, 1) R16_C(4, 2) R16_C(4, 4)
+#undef R16_C
+	return -1;
+}
+
 } // namespace vh
