@@ -58,7 +58,7 @@ def _run(cases, tmp_path, extra_env=None):
     with open(script, "w") as f:
         f.write(CHILD % {"root": helpers.ROOT, "cases": cases})
     # (the vector-ALU kernels: the matrix-core ones, tests/test_emul_reduce_band.py, take ushort reduces first)
-    env = dict(os.environ, LD_PRELOAD=MOCK_SO, VIPS_HIP_LIBRARY=EMUL_SO, VIPS_HIP_REDUCE_BAND="0")
+    env = dict(os.environ, LD_PRELOAD=MOCK_SO, VIPS_HIP_LIBRARY=EMUL_SO, VIPS_HIP_REDUCE_BAND="0", VIPS_HIP_NO_SHRINKBOX16="1")  # (the pair of box kernels; the one-kernel form: test_shrinkbox16)
     env.update(extra_env or {})
     proc = subprocess.run([sys.executable, script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                           env=env, timeout=1800)

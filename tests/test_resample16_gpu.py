@@ -24,6 +24,7 @@ BIG = [
 @pytest.mark.parametrize("seg", [None, "5"])
 def test_ushort_streaming(case, seg, monkeypatch):
     monkeypatch.setenv("VIPS_HIP_REDUCE_BAND", "0")  # (the vector-ALU kernels; the matrix-core ones: test_reduce_band_gpu.py)
+    monkeypatch.setenv("VIPS_HIP_NO_SHRINKBOX16", "1")  # (vips_shrink as its two kernels; in one: test_shrinkbox16)
     op, w, h, bands, args, gates = (CASES + BIG)[case]
     if seg:
         if case >= len(CASES) or op not in ("reducev", "shrinkv", "reduce"):
