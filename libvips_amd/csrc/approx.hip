@@ -1110,6 +1110,20 @@ int vips_hip_convasep_gen(const VipsHipConva *plan, const VipsHipRegion *in, con
 
 namespace vh {
 
+// A whole uchar image whose conva pass IS an integer convolution (the fast path above): the matrix-core 2-D kernel
+// (conv_u8_mfma.hip) instead of the general convi one when its exactness bounds and its rounding ((sum + scale / 2) /
+// scale: conva's (divisor + 1) / 2 is that for an even divisor) hold.  1: not covered (nothing launched).
+int conva_fast_image(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConva *plan)
+{
+	_VipsHipConva *c = const_cast<_VipsHipConva *>(plan);
+	if (c->separable || in->format != VIPS_HIP_FORMAT_UCHAR || !fast_ok(c, VIPS_HIP_FORMAT_UCHAR) || getenv("VIPS_HIP_NO_CONVA_MFMA"))
+		return 1;
+	if (plan_device("conva", &plan->device) || fast_plans(c))
+		return -1;
+	return conv_u8_mfma_2d_try(in, out, c->fast[0]);
+}
+
+
 // Image-level halves used by ops_colour_conv.cpp.
 
 // Both passes of a convasep through the fused separable kernel; 1 when not covered.

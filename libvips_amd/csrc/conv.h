@@ -60,5 +60,7 @@ int conv_u16_2d_try(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipC
 
 // approx.hip: both passes of a convasep plan through the fused kernel above; 1 when not covered.
 int convasep_fused(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConva *plan);
+// approx.hip: a conva plan's pass on a whole uchar image through conv_u8_mfma_2d; 1 when not covered.
+int conva_fast_image(const _VipsHipImage *in, _VipsHipImage *out, const _VipsHipConva *plan);
 
 } // namespace vh

@@ -304,7 +304,10 @@ bool cm_common(const _VipsHipImage *in, const _VipsHipImage *out, const _VipsHip
 	if ((long long) in->stride * 42 >= (1LL << 31) || in->width < 32 || in->height < 8)
 		return false;
 	// the rounding of conv_u8_body.h: offset 0, 1 <= scale <= 8000, numerators below 2^24
-	if (c->offset_i != 0 || (int) rint(offset2) != 0 || c->scale_i < 1 || c->scale_i > 8000 || c->rounding != c->scale_i / 2)
+	// (the rounding term: convi's scale / 2, or conva's (divisor + 1) / 2 -- approx.hip's fast path --: whatever it is,
+	// cm_rounding walks every sum for it before the kernel is enabled)
+	if (c->offset_i != 0 || (int) rint(offset2) != 0 || c->scale_i < 1 || c->scale_i > 8000 || c->rounding < 0 ||
+		c->rounding > c->scale_i)
 		return false;
 	long long abs_sum = 0;
 	for (int k = 0; k < c->nnz; k++) {

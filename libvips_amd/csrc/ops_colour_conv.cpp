@@ -560,6 +560,15 @@ int vips_hip_conva(VipsHipImage *in, VipsHipImage **out, const double *mask, int
 	ImageRef o(vips_hip_image_new(in->width, in->height, in->bands, in->format, in->interpretation));
 	if (!o.im)
 		return -1;
+	{
+		const int r = vh::conva_fast_image(in, o.im, c.get());
+		if (r < 0)
+			return -1;
+		if (r == 0) {
+			*out = o.release();
+			return 0;
+		}
+	}
 	VipsHipRegion ri, ro;
 	vips_hip_image_region(in, &ri);
 	vips_hip_image_region(o.im, &ro);

@@ -625,3 +625,39 @@ def test_premultiply_rgba_rows(src_dtype, inverse, monkeypatch):
     old = (im.unpremultiply() if inverse else im.premultiply()).numpy()
     assert got.dtype == np.float32 and np.array_equal(got.view(np.int32), want.view(np.int32))
     assert np.array_equal(got.view(np.int32), old.view(np.int32))
+
+
+@pytest.mark.parametrize("params", [dict(), dict(sigma=1.0, x1=1.0, m2=2.0)])
+def test_sharpen_adaptive_large_mixed(params):
+    """Round 6: an image of 4 Mpixels and more takes the adaptive pair by default -- the skip kernel first, the tiles
+    whose sampled row is mostly outside the LUT's flat centre left on a device-side list for the all-in-LDS kernel.
+    A 2 304 x 2 100 image that is smooth on the left, noise on the right and striped (a hard edge every 8 rows: tiles
+    whose SAMPLED row says little about the rest) at the bottom: both kernels make tiles of one image, some 64 x 64
+    tiles half by one and half by the other; against the compiled reference / the port, whole image."""
+    w, h = 2304, 2100
+    noise = helpers.lcg_image(w, h, 3, np.uint8, 97)
+    small = helpers.lcg_image(w // 8 + 1, h // 8 + 1, 3, np.uint8, 98).astype(np.float32)
+    smooth = np.kron(small, np.ones((8, 8, 1), np.float32))[:h, :w]
+    # (a box blur of the blocks along x: neighbouring pixels near each other, as a resized photograph's are)
+    smooth = (smooth + np.roll(smooth, 1, 1) + np.roll(smooth, 2, 1) + np.roll(smooth, 3, 1)) / 4.0
+    src = smooth.astype(np.uint8)
+    src[:, w // 2:] = noise[:, w // 2:]
+    stripes = (np.arange(h) // 8 % 2 * 200 + 20).astype(np.uint8)
+    src[3 * h // 4:, : w // 2] = stripes[3 * h // 4:, None, None]
+    lib = _ffi.lib
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    try:
+        got = Image.new_from_array(src, interpretation="srgb").sharpen(**params).numpy()
+        report = libvips_amd.gate_report()
+    finally:
+        lib.vips_hip_gate_enable(0)
+        lib.vips_hip_gate_reset()
+    assert sorted(report) == ["sharpen_quad_u8", "sharpen_skip_u8"], report
+    if helpers.have_ref():
+        args = ",".join("%s=%s" % kv for kv in params.items())
+        want = Ref.run("sharpen", src, args, cases.INTERP["srgb"])
+    else:
+        want = PortCC.sharpen(src, "srgb", **params)
+    bad = np.argwhere((got != want).any(axis=-1))
+    assert len(bad) == 0, (len(bad), bad[:5].tolist())
