@@ -1345,25 +1345,6 @@ static int launch_fused_mfma(const FusedArgs &args, int tiles, const MfmaTables 
 			hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
 		attr_set = true;
 	}
-	// $VIPS_HIP_FUSED_NB=2|4 (round 6 experiment): two blocks a CU with 2 / 4 row groups in flight per lane and
-	// tiles twice as tall (half the vertical halo; the geometry code picks 512 slots and the taller stage)
-	if (NTH == FUSED_THREADS && getenv("VIPS_HIP_FUSED_NB") && atoi(getenv("VIPS_HIP_FUSED_NB")) > 1) {
-		const int nb = atoi(getenv("VIPS_HIP_FUSED_NB"));
-		if (nb == 2) {
-			VH_CHECK(hipFuncSetAttribute((const void *) reduce_fused_u8x4_mfma<D, 2, 2, true, 0, true, FUSED_THREADS, 1>,
-				hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-			hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 2, 2, true, 0, true, FUSED_THREADS, 1>), dim3(grid),
-				dim3(FUSED_THREADS), lds, stream(), args, d_tables);
-		}
-		else {
-			VH_CHECK(hipFuncSetAttribute((const void *) reduce_fused_u8x4_mfma<D, 4, 2, true, 0, true, FUSED_THREADS, 1>,
-				hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-			hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 4, 2, true, 0, true, FUSED_THREADS, 1>), dim3(grid),
-				dim3(FUSED_THREADS), lds, stream(), args, d_tables);
-		}
-		VH_CHECK(hipGetLastError());
-		return 0;
-	}
 	// the shipped form: edge fix-up at the point of use (LATE) and streaming (nt) loads;
 	// VIPS_HIP_FUSED_LATE=0 / VIPS_HIP_FUSED_NT=0 select the round-2 forms for A/B runs
 	const bool late = !(getenv("VIPS_HIP_FUSED_LATE") && atoi(getenv("VIPS_HIP_FUSED_LATE")) == 0);
@@ -1503,21 +1484,13 @@ static int launch_fused_mfma_x(const FusedArgs &all, const VipsHipRegion *in, co
 	const char *pe = getenv("VIPS_HIP_FUSED_PLAIN");
 	const int plain = misplaced && !plain_broken.load() && !(pe && atoi(pe) == 0) && xcd_placement_holds() ? 1 : 0;
 	const size_t lds = xlds_bytes(a.oht);
-	const bool nb2 = getenv("VIPS_HIP_FUSED_NB") && atoi(getenv("VIPS_HIP_FUSED_NB")) == 2;
 	const int rows_per_xcd = (tiles_y + 7) / 8;
 	const int grid = 8 * rows_per_xcd * a.tiles_x; // (the kernel's numbering: XCD k takes rows k rows_per_xcd ...)
 	int rc = 0;
 	{
 		Gate gate("reduce_fused_u8_mfma_x");
 		hipError_t err;
-		if (nb2) {
-			err = hipFuncSetAttribute((const void *) reduce_fused_u8x4_mfma_x<6, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-				80 * 1024);
-			if (err == hipSuccess)
-				hipLaunchKernelGGL((reduce_fused_u8x4_mfma_x<6, 2, 2>), dim3(grid), dim3(FUSED_THREADS), lds, stream(), a, d_tables,
-					parts, arrivals, plain, misplaced);
-		}
-		else {
+		{
 			err = hipFuncSetAttribute((const void *) reduce_fused_u8x4_mfma_x<6, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
 				80 * 1024);
 			if (err == hipSuccess)
@@ -2045,8 +2018,7 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 	// MFMA kernel: threads per block (VIPS_HIP_FUSED_NTH=256|512; tiles of 59 / 123 pixels)
 	const int nth = getenv("VIPS_HIP_FUSED_NTH") && atoi(getenv("VIPS_HIP_FUSED_NTH")) == 512 ? 512 : 256;
 	const int mfma_span = 2 * nth;
-	const bool deep = nth == 256 && getenv("VIPS_HIP_FUSED_NB") && atoi(getenv("VIPS_HIP_FUSED_NB")) > 1;
-	const int mfma_max_oht = deep ? 200 : nth == 512 ? MfmaGeo<512>::MAX_OHT : MfmaGeo<256>::MAX_OHT;
+	const int mfma_max_oht = nth == 512 ? MfmaGeo<512>::MAX_OHT : MfmaGeo<256>::MAX_OHT;
 
 	_VipsHipReduce *rv = const_cast<_VipsHipReduce *>(reducev);
 	// S = 8: both passes on the matrix cores when the exactness bounds hold
@@ -2102,7 +2074,7 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 				if (owt_env > 0 && owt_env < args.owt)
 					args.owt = owt_env;
 				args.tiles_x = (out->width + args.owt - 1) / args.owt;
-				const int slots = getenv("VIPS_HIP_FUSED_CAP") ? atoi(getenv("VIPS_HIP_FUSED_CAP")) : deep ? 256 * 2 : 256 * 4;
+				const int slots = getenv("VIPS_HIP_FUSED_CAP") ? atoi(getenv("VIPS_HIP_FUSED_CAP")) : 256 * 4;
 				const int base = slots / args.tiles_x > 0 ? slots / args.tiles_x : 1;
 				int oht = out->height;
 				for (int k = 1; k <= 4096; k++) {
