@@ -242,8 +242,10 @@ int reduce_axis(VipsHipImage *in, VipsHipImage **out, double shrink, int kernel,
 
 // n uchar images of one size through vips_resize's whole downsizing chain in one launch
 // (resize_stream.hip): 0 = done (out[] filled), 1 = not that kernel's case (nothing done), -1 = error
+// premul: the images are RGBA and vips_premultiply(uchar) comes first (vips_thumbnail_image, thumbnail.c:848-860): only
+// the chain of band kernels can do that on its loads -- anything else answers 1 and the caller premultiplies itself
 int resize_down_u8_stream(VipsHipImage *const *in, int n, VipsHipImage **out, const AxisPlan &pv, const AxisPlan &ph,
-	int shrunk_width, int kernel)
+	int shrunk_width, int kernel, bool premul = false)
 {
 	if (pv.residual == 1.0 || ph.residual == 1.0 || kernel == VIPS_HIP_KERNEL_NEAREST || n < 1)
 		return 1;
@@ -273,7 +275,7 @@ int resize_down_u8_stream(VipsHipImage *const *in, int n, VipsHipImage **out, co
 	// residual reduces of exactly 2 on both axes: the static-rotation kernel (resize_stream.hip);
 	// any other: the scheduled one (resize_streamg.hip)
 	int done = 0;
-	if (pv.residual == 2.0 && ph.residual == 2.0)
+	if (pv.residual == 2.0 && ph.residual == 2.0 && !premul)
 		done = resize_stream_u8_try(rv.get(), pv.int_shrink, rh.get(), ph.int_shrink, shrunk_height, shrunk_width,
 			pi.data(), po.data(), n, g_fatstrip_height);
 	// any other residual (a size that does not divide the image): shrinkv + reducev as one matrix-core kernel, then
@@ -285,7 +287,7 @@ int resize_down_u8_stream(VipsHipImage *const *in, int n, VipsHipImage **out, co
 	// one-kernel chain, 64 images a launch.  VIPS_HIP_RESIZE_BAND_MIN = that size in bytes)
 	const long long band_min = getenv("VIPS_HIP_RESIZE_BAND_MIN") ? atoll(getenv("VIPS_HIP_RESIZE_BAND_MIN")) : 8LL << 20;
 	if (done == 0 && !getenv("VIPS_HIP_NO_RESIZE_BAND") && !getenv("VIPS_HIP_STREAMG_ALWAYS") &&
-		(n < 4 || (long long) in[0]->width * in[0]->height * in[0]->bands >= band_min)) {
+		(premul || n < 4 || (long long) in[0]->width * in[0]->height * in[0]->bands >= band_min)) {
 		done = 1;
 		for (int i = 0; i < n && done == 1; i++) {
 			ImageRef t1(like(in[i], in[i]->width, pv.size));
@@ -293,7 +295,7 @@ int resize_down_u8_stream(VipsHipImage *const *in, int n, VipsHipImage **out, co
 				return -1;
 			VipsHipRegion r1;
 			vips_hip_image_region(t1.im, &r1);
-			const int d = shrinkv_reducev_band_try(rv.get(), pv.int_shrink, shrunk_height, pi[i], &r1, g_fatstrip_height);
+			const int d = shrinkv_reducev_band_try(rv.get(), pv.int_shrink, shrunk_height, pi[i], &r1, g_fatstrip_height, premul);
 			if (d < 0)
 				return -1;
 			if (d == 0) {
@@ -319,6 +321,8 @@ int resize_down_u8_stream(VipsHipImage *const *in, int n, VipsHipImage **out, co
 				return -1;
 		}
 	}
+	if (done == 0 && premul)
+		return 1; // (un-premultiplied pixels may have reached outputs of the batch: they are dropped with o[])
 	if (done == 0)
 		done = resize_streamg_u8_try(rv.get(), pv.int_shrink, rh.get(), ph.int_shrink, shrunk_height, shrunk_width,
 			pi.data(), po.data(), n, g_fatstrip_height);
@@ -393,7 +397,8 @@ int resize_down_u8_tail_batch(VipsHipImage *const *in, int n, VipsHipImage **out
 // vips_resize's downsizing of a uchar image on both axes (resize.c:207-228: reducev with its
 // box pre-shrink, then reduceh with its own): the vertical box shrink, then everything else in
 // one kernel (resize_tail.hip) when the geometry fits it.  1 = not this function's case.
-int resize_down_u8(VipsHipImage *in, VipsHipImage **out, double vshrink, double hshrink, int kernel, double gap)
+int resize_down_u8(VipsHipImage *in, VipsHipImage **out, double vshrink, double hshrink, int kernel, double gap,
+	bool premul = false)
 {
 	AxisPlan pv, ph;
 	if (plan_axis("reducev", in->height, vshrink, kernel, gap, &pv) ||
@@ -406,8 +411,8 @@ int resize_down_u8(VipsHipImage *in, VipsHipImage **out, double vshrink, double 
 		return 1;
 	{
 		// all four operations in one kernel (resize_stream.hip, resize_streamg.hip)
-		const int done = resize_down_u8_stream(&in, 1, out, pv, ph, shrunk_width, kernel);
-		if (done <= 0)
+		const int done = resize_down_u8_stream(&in, 1, out, pv, ph, shrunk_width, kernel, premul);
+		if (done <= 0 || premul)
 			return done;
 	}
 	ImageRef pre;
@@ -528,6 +533,20 @@ int resize_sharpen_batch_u8(VipsHipImage *const *in, int n, VipsHipImage **out, 
 	for (int i = 0; i < n; i++)
 		out[i] = o[i].release();
 	return 0;
+}
+
+// vips_premultiply(uchar) + vips_resize(hscale, vscale, lanczos3, gap 2) of an RGBA uchar image (max_alpha 255) with the
+// premultiply on the loads of the first kernel (reduce_band.hip: thumbnail.c:848-860 makes a whole premultiplied image
+// first).  0 done, 1 not covered (the caller runs the two operations), -1 error.
+int resize_premul_u8(VipsHipImage *in, VipsHipImage **out, double hscale, double vscale)
+{
+	if (!in || !out || in->format != VIPS_HIP_FORMAT_UCHAR || in->bands != 4 || !(hscale > 0.0 && hscale < 1.0) ||
+		!(vscale > 0.0 && vscale < 1.0))
+		return 1;
+	// (vips_resize_build's floors: "Don't let either axis drop below 1 px")
+	if (hscale < 1.0 / in->width || vscale < 1.0 / in->height)
+		return 1;
+	return resize_down_u8(in, out, 1.0 / vscale, 1.0 / hscale, VIPS_HIP_KERNEL_LANCZOS3, 2.0, true);
 }
 
 } // namespace vh

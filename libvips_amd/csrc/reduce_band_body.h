@@ -41,6 +41,7 @@ struct RbArgs {
 	int strips;       // of 128 bytes
 	int nblocks;      // of 32 output rows
 	int alternate;    // every other block of rows is walked from the bottom up
+	int premul;       // RGBA uchar, box kernel: vips_premultiply's uchar fast path (max_alpha 255) on every loaded pixel
 	const RbBlock *blk;
 	const unsigned int *tab; // [coefficient block][64 lanes][4 dwords]
 };
@@ -77,6 +78,18 @@ VH_DEV unsigned int rb_box2(unsigned int sums, unsigned int mult)
 // image (resize.c:207-228: shrinkv, then reducev): a row the products read is the box sum of VS image rows, made
 // from the loaded dwords as two 16-bit lanes per dword (even and odd byte columns) and rounded as shrinkv does; the
 // 1 / VS-size intermediate image never exists.  Rows past the image are the last row (shrinkv's own embed, ceil).
+// vips_premultiply on one RGBA uchar pixel (premultiply.c:163-176 with the table of :252-258 for max_alpha 255:
+// scale[a] = (int) (256 a / 255.0) = a + (a == 255)): c' = (c scale + 128) >> 8, alpha kept.  R and B together in the
+// 16-bit halves of one 24-bit multiply (255 * 256 + 128 < 2^16), G on its own.
+VH_DEV unsigned int rb_premul(unsigned int v)
+{
+	const unsigned int al = v >> 24;
+	const unsigned int sc = al + (al == 255u ? 1u : 0u);
+	const unsigned int rb = (((v & 0x00ff00ffu) * sc + 0x00800080u) >> 8) & 0x00ff00ffu;
+	const unsigned int g = ((((v >> 8) & 0xffu) * sc + 128u) >> 8) << 8;
+	return rb | g | (v & 0xff000000u);
+}
+
 template <int VS>
 VH_DEV void reducev_box_band_wave(const RbArgs &a, int strip, int g, bool rev)
 {
@@ -146,11 +159,14 @@ VH_DEV void reducev_box_band_wave(const RbArgs &a, int strip, int g, bool rev)
 			const unsigned int keep = NC * CH == VS || c * CH + k < VS ? 0x00ff00ffu : 0u;
 #pragma unroll
 			for (int i = 0; i < 8; i++) {
-				ev[i] += raw[i * CH + k] & keep;
+				// (the premultiply of an RGBA thumbnail -- thumbnail.c:848-860 -- where the pixel is USED: the loads
+				// of the next chunk stay in flight; a dword is a pixel, rows are whole pixels: host)
+				const unsigned int w = a.premul ? rb_premul(raw[i * CH + k]) : raw[i * CH + k];
+				ev[i] += w & keep;
 				if constexpr (NC * CH == VS)
-					od[i] += perm(raw[i * CH + k], raw[i * CH + k], 0x0c030c01u); // (bytes 1 and 3 in one instruction)
+					od[i] += perm(w, w, 0x0c030c01u); // (bytes 1 and 3 in one instruction)
 				else
-					od[i] += (raw[i * CH + k] >> 8) & keep;
+					od[i] += (w >> 8) & keep;
 			}
 		}
 		int c1 = c + 1, j1 = j;

@@ -242,21 +242,26 @@ int reduceh_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRe
 	return rc ? -1 : 1;
 }
 
-int shrinkv_reducev_band_try(_VipsHipReduce *r, int vs, int mid_height, const VipsHipRegion *in, const VipsHipRegion *out, int tile);
+int shrinkv_reducev_band_try(_VipsHipReduce *r, int vs, int mid_height, const VipsHipRegion *in, const VipsHipRegion *out, int tile,
+	bool premul);
 
 // vips_reducev of a whole uchar image with a coefficient row per output row; 1 = done, 0 = not this
 // kernel's case, -1 = error
 int reducev_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out, int tile)
 {
-	return shrinkv_reducev_band_try(r, 1, 0, in, out, tile);
+	return shrinkv_reducev_band_try(r, 1, 0, in, out, tile, false);
 }
 
 // ... with a vips_shrinkv(vs, ceil) in front, the two as one kernel: `in` is the image BEFORE the shrink, `r` the
 // plan of the reduce on the image after it (mid_height rows); vs = 1: the reduce alone
-int shrinkv_reducev_band_try(_VipsHipReduce *r, int vs, int mid_height, const VipsHipRegion *in, const VipsHipRegion *out, int tile)
+// premul: vips_premultiply(uchar fast path, max_alpha 255) of an RGBA image in front of both, on the loaded pixels
+int shrinkv_reducev_band_try(_VipsHipReduce *r, int vs, int mid_height, const VipsHipRegion *in, const VipsHipRegion *out, int tile,
+	bool premul)
 {
 	const char *env = getenv("VIPS_HIP_REDUCE_BAND");
 	if (env && atoi(env) == 0)
+		return 0;
+	if (premul && (vs < 2 || in->bands != 4 || in->format != VIPS_HIP_FORMAT_UCHAR || getenv("VIPS_HIP_NO_BAND_PREMUL")))
 		return 0;
 	const bool u16 = in->format == VIPS_HIP_FORMAT_USHORT;
 	if ((in->format != VIPS_HIP_FORMAT_UCHAR && !u16) || out->format != in->format || in->bands != out->bands)
@@ -296,6 +301,7 @@ int shrinkv_reducev_band_try(_VipsHipReduce *r, int vs, int mid_height, const Vi
 	const int groups = (((a.strips + 3) / 4) + 7) & ~7; // blocks of 4 waves = 4 neighbouring strips; a multiple of 8
 	Gate gate(vs > 1 ? "shrinkv_reducev_u8_band" : u16 ? "reducev_u16_band" : "reducev_u8_band");
 	a.alternate = !getenv("VIPS_HIP_BAND_NO_ALTERNATE");
+	a.premul = premul ? 1 : 0;
 	const int rc = rb_launch(a, groups, a.nblocks, u16);
 	return rc ? -1 : 1;
 }

@@ -35,6 +35,9 @@ int resize_streamg_u8_try(_VipsHipReduce *rv, int vshrink, _VipsHipReduce *rh, i
 	int shrunk_width, const VipsHipRegion *const *in, const VipsHipRegion *const *out, int n, int tile);
 // the same from images (ops_resample.cpp); 0 = done, 1 = not its case, -1 = error
 int resize_batch_u8(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel, double gap);
+// ops_resample.cpp: vips_premultiply(uchar) + vips_resize of an RGBA uchar image, the premultiply on the first kernel's
+// loads; 0 done, 1 not covered, -1 error
+int resize_premul_u8(VipsHipImage *in, VipsHipImage **out, double hscale, double vscale);
 // ... followed by vips_sharpen, in ONE kernel (resize_sharpen.hip); the blur mask as convi's integers,
 // sharpen.c's LUT as 65536 host ints; 0 = done, 1 = not its case, -1 = error
 int resize_sharpen_batch_u8(VipsHipImage *const *in, int n, VipsHipImage **out, double scale, int kernel, double gap,
@@ -51,7 +54,8 @@ int reducev8_stream_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHi
 int reducev_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out, int tile);
 int reduceh_band_try(_VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out, int tile);
 // vips_shrinkv(vs, ceil) + vips_reducev as one kernel (`in`: the image before the shrink; `r`: the reduce's plan)
-int shrinkv_reducev_band_try(_VipsHipReduce *r, int vs, int mid_height, const VipsHipRegion *in, const VipsHipRegion *out, int tile);
+int shrinkv_reducev_band_try(_VipsHipReduce *r, int vs, int mid_height, const VipsHipRegion *in, const VipsHipRegion *out, int tile,
+	bool premul = false);
 int shrinkh16_stream_try(int hshrink, const VipsHipRegion *in, const VipsHipRegion *out);
 int shrinkbox16_try(int hshrink, int vshrink, const VipsHipRegion *in, const VipsHipRegion *out);
 // reduceh_u8.hip: vips_reduceh on uchar with one coefficient row and first taps 4 or 8 pixels apart,

@@ -856,3 +856,40 @@ def test_upsize_bicubic_walk(bands, monkeypatch):
         monkeypatch.delenv("VIPS_HIP_NO_UPSIZE_WALK")
         assert np.array_equal(got, old), (w, h, hs, vs)
         assert np.array_equal(got, Port.resize(src, hs, vs, kernel="cubic")), (w, h, hs, vs)
+
+
+@pytest.mark.parametrize("size,width", [((1024, 700), 100), ((2047, 1233), 250), ((640, 480), 64), ((3000, 501), 333)])
+def test_thumbnail_rgba_premultiply_on_load(size, width, monkeypatch):
+    """Round 6: vips_thumbnail_image of an RGBA uchar image (thumbnail.c:848-904: premultiply -> resize -> unpremultiply)
+    with vips_premultiply's uchar fast path applied to the pixels the resize's FIRST kernel loads
+    (reduce_band_body.h rb_premul: no premultiplied image in between) -- every alpha value, alpha 0 and 255 runs, sizes
+    whose box shrink is 2 .. 9; against the port (pinned on the compiled reference: goldens thumbnail|rgba) / the
+    reference, and against the separate premultiply kernel."""
+    w, h = size
+    src = helpers.lcg_image(w, h, 4, np.uint8, 31 + width)
+    src[: h // 4, : w // 3, 3] = 255
+    src[h // 4: h // 2, : w // 3, 3] = 0
+    src[0, :256, 3] = np.arange(256)
+    im = Image.new_from_array(src, interpretation="srgb")
+    lib = libvips_amd.lib
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    try:
+        got = im.thumbnail_image(width).numpy()
+        report = libvips_amd.gate_report()
+    finally:
+        lib.vips_hip_gate_enable(0)
+        lib.vips_hip_gate_reset()
+    # (a residual of exactly 2 -- 640 -> 64 -- is the one-kernel chain's: the premultiply stays its own kernel there)
+    if width != 64:
+        assert "premultiply" not in report and "shrinkv_reducev_u8_band" in report and "unpremultiply" in report, report
+    else:
+        assert "premultiply" in report, report
+    monkeypatch.setenv("VIPS_HIP_NO_BAND_PREMUL", "1")
+    old = im.thumbnail_image(width).numpy()
+    assert np.array_equal(got, old)
+    if helpers.have_ref():
+        want = helpers.Ref.run("thumbnail_image", src, "width=%d" % width, helpers.INTERP["srgb"])
+    else:
+        want = helpers.PortCC.thumbnail_image(src, "srgb", width)
+    assert got.shape == want.shape and np.array_equal(got, want)
