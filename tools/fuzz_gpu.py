@@ -39,7 +39,7 @@ def main():
     n = bad = 0
     while time.time() - t0 < budget:
         kind = rng.choice(["reduce8", "reduce", "resize", "upsize", "gaussblur", "conv", "shrink", "thumb",
-                           "approx", "resize2k"])
+                           "approx", "resize2k", "sharpen"])
         if len(sys.argv) > 3:
             kind = sys.argv[3]
         seed = rng.randrange(1 << 30)
@@ -134,6 +134,28 @@ def main():
                     got = Image.new_from_array(src).gaussblur(sigma, precision="approximate").numpy()
                     want = PortCC.gaussblur(src, sigma, precision="approximate")
                     desc = (kind, "gaussblur", w, h, b, dt.__name__, sigma)
+            elif kind == "sharpen":
+                # round 6: vips_sharpen on sRGB uchar over smooth / noisy / striped content (the skip kernel's list
+                # from empty to full), sizes either side of the 4 Mpixel switch to the adaptive pair now and then
+                big = rng.random() < 0.15
+                w = rng.randrange(2048, 2500) if big else rng.randrange(3, 900)
+                h = rng.randrange(2048, 2300) if big else rng.randrange(3, 700)
+                noise = helpers.lcg_image(w, h, 3, np.uint8, seed)
+                small = helpers.lcg_image(w // 8 + 2, h // 8 + 2, 3, np.uint8, seed + 1).astype(np.float32)
+                smooth = np.kron(small, np.ones((8, 8, 1), np.float32))[:h, :w]
+                smooth = (smooth + np.roll(smooth, 1, 1) + np.roll(smooth, 2, 1) + np.roll(smooth, 1, 0)) / 4.0
+                src = smooth.astype(np.uint8)
+                cut = rng.randrange(0, w + 1)
+                src[:, cut:] = noise[:, cut:]
+                if rng.random() < 0.3:
+                    src[rng.randrange(0, h):, : w // 2] = (np.arange(h) // 5 % 2 * 180 + 30).astype(np.uint8)[-1, None, None]
+                params = {}
+                if rng.random() < 0.5:
+                    params = dict(sigma=rng.choice([0.3, 0.5, 0.8, 1.0, 1.4]), x1=rng.choice([0.5, 1.0, 2.0, 3.0]),
+                                  m1=rng.choice([0.0, 0.0, 0.3]), m2=rng.choice([1.0, 3.0, 5.0]))
+                got = Image.new_from_array(src, interpretation="srgb").sharpen(**params).numpy()
+                want = PortCC.sharpen(src, "srgb", **params)
+                desc = (kind, w, h, cut, params)
             elif kind == "shrink":
                 w, h, b = rng.randrange(1, 500), rng.randrange(1, 500), rng.randrange(1, 5)
                 dt = rng.choice(ALL_TYPES)
