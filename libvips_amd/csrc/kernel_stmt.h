@@ -41,6 +41,13 @@
 #define VH_XCC_ID() ((int) (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u))
 #define VH_STORE_BYTE(p, v) asm volatile("global_store_byte %0, %1, off" : : "v"(p), "v"(v) : "memory")
 // a marker that keeps two otherwise identical arms of a switch apart (merged, their register index is dynamic)
+// LDS written by this wave is read back by this wave only: its LDS operations complete in order, the compiler must
+// not move them across this point
+#define VH_WAVE_LDS_FENCE() \
+	do { \
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+		__builtin_amdgcn_wave_barrier(); \
+	} while (0)
 #define VH_ASM_MARK(text) asm volatile("; " text)
 // the block's dynamic LDS, and the LDS byte address of a pointer into LDS
 #define VH_DYNAMIC_LDS(T, name) extern __shared__ __attribute__((aligned(16))) T name[]

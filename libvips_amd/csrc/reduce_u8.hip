@@ -1244,6 +1244,317 @@ reducev_u8_mfma(VStreamArgs a, const MfmaTables *__restrict__ tables)
 	}
 }
 
+// ------------------------------------------------ vips_reduce by 8 on THREE interleaved bands, one kernel (round 6)
+//
+// reduce_fused_u8x3_mfma<D>: the vertical pass is reducev_u8_mfma's (a scanline is a byte array to a vertical
+// filter: a lane owns 8 consecutive BYTES of the row), but the finished T row goes to LDS, interleaved as it lies in
+// memory, and every eight T rows the block makes their output pixels: lane (row, segment of 8 outputs, band) walks
+// the segment's 13 groups of 8 pixels = 24 bytes with the same rotating accumulators, its band's bytes picked out of
+// the three 8-byte LDS reads by two v_perm selectors.  A tile is 2 048 bytes of the row = 682 pixels and makes 80
+// outputs (640 + 40 pixels of taps): tiles step by 1 920 bytes, 15 whole lines.  Output rows wait in LDS and leave
+// in one burst at the tile's end.  The 25 MB image between reducev and reduceh (8192 x 8192 x 3) is never made.
+// Columns outside the image (vips_embed COPY, reduceh.cpp:488-497): their T bytes are the edge pixel's, copied in
+// LDS before the horizontal walk; the loads behind them are clamped to any valid dword.  Everything the host
+// checks is in launch_fused_u8x3.
+struct FusedIArgs {
+	const unsigned char *in; // byte 0 of a window row (column in_left), row in_top of the image
+	unsigned char *out;
+	long long in_stride, out_stride;
+	int in_top, im_height;
+	int blo, bhi;            // the bytes of a window row that hold image columns: [blo, bhi), multiples of 4
+	int tile_b0;             // byte of the first tap of output column 0 (3 (fx0 - in_left): may be negative), a multiple of 4
+	int fy0;
+	int out_width, out_height;
+	int oht, tiles_x, tiles;
+	int alternate;
+	int aligned16;           // out and out_stride are multiples of 16
+};
+
+constexpr int F3_BANDS = 3;
+constexpr int F3_OWT = 80;                      // outputs per tile
+constexpr int F3_ROW = 8 * FUSED_THREADS;       // bytes of a T row
+constexpr int F3_TPITCH = F3_ROW + 8;           // 514 dwords: rows 2 banks apart
+constexpr int F3_SPITCH = F3_OWT * F3_BANDS;    // bytes per staged output row (15 x 16)
+constexpr int F3_MAX_OHT = 128;
+static constexpr size_t f3_lds_bytes(int oht)
+{
+	return (size_t) 2 * MFMA_SLOTS * F3_TPITCH + 2 * MFMA_TABLE_ENTRIES * 8 + (size_t) oht * F3_SPITCH;
+}
+
+template <int D>
+struct FusedIStep {
+	typedef MfmaStep<D> Base;
+	static constexpr int S = 8;
+
+	template <int I0, int N>
+	static __device__ __forceinline__ void load_rows(const FusedIArgs &a, uint2 (&px)[S], int first_row, int dir,
+		unsigned int o0, unsigned int o1, bool interior)
+	{
+		const unsigned int stride32 = (unsigned int) a.in_stride;
+		typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+		typedef u32x2 __attribute__((aligned(4))) u32x2_a4;
+		if (interior) {
+#pragma unroll
+			for (int i = I0; i < I0 + N; i++) {
+				const int row = min(max(first_row + dir * i, 0), a.im_height - 1) - a.in_top;
+				const u32x2 v = *reinterpret_cast<const u32x2_a4 *>(a.in + (size_t) ((unsigned int) row * stride32 + o0));
+				px[i] = make_uint2(v.x, v.y);
+			}
+		}
+		else {
+#pragma unroll
+			for (int i = I0; i < I0 + N; i++) {
+				const int row = min(max(first_row + dir * i, 0), a.im_height - 1) - a.in_top;
+				const unsigned int base = (unsigned int) row * stride32;
+				px[i].x = *reinterpret_cast<const unsigned int *>(a.in + (size_t) (base + o0));
+				px[i].y = *reinterpret_cast<const unsigned int *>(a.in + (size_t) (base + o1));
+			}
+		}
+	}
+
+	template <int ROT, int Q>
+	static __device__ __forceinline__ void quad(const FusedIArgs &a, uint2 (&px)[S], float4v (&acc)[8][2],
+		const half4v *lane_a, bool more, int next_row, int dir, unsigned int o0, unsigned int o1, bool interior)
+	{
+		const half4v a0 = lane_a[((ROT * 2 + Q) * 2 + 0) * 4];
+		const half4v a1 = lane_a[((ROT * 2 + Q) * 2 + 1) * 4];
+#pragma unroll
+		for (int p = 0; p < 2; p++) {
+			const unsigned int r0 = p ? px[4 * Q + 0].y : px[4 * Q + 0].x;
+			const unsigned int r1 = p ? px[4 * Q + 1].y : px[4 * Q + 1].x;
+			const unsigned int r2 = p ? px[4 * Q + 2].y : px[4 * Q + 2].x;
+			const unsigned int r3 = p ? px[4 * Q + 3].y : px[4 * Q + 3].x;
+			half4v b[4];
+			b[0] = Base::template make_b<0>(r0, r1, r2, r3);
+			b[1] = Base::template make_b<1>(r0, r1, r2, r3);
+			b[2] = Base::template make_b<2>(r0, r1, r2, r3);
+			b[3] = Base::template make_b<3>(r0, r1, r2, r3);
+			if (p == 1 && more)
+				load_rows<4 * Q, 4>(a, px, next_row, dir, o0, o1, interior);
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				acc[p * 4 + c][0] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, b[c], acc[p * 4 + c][0], 0, 0, 0);
+				acc[p * 4 + c][1] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, b[c], acc[p * 4 + c][1], 0, 0, 0);
+			}
+		}
+	}
+
+	// slot (ROT - (D - 1)) mod 8 has seen all its taps: its 8 bytes into T row ROT
+	template <int ROT>
+	static __device__ __forceinline__ void retire(float4v (&acc)[8][2], unsigned char *trow_lane, bool store)
+	{
+		constexpr int SLOT = (ROT - (D - 1) + 2 * MFMA_SLOTS) % MFMA_SLOTS;
+		constexpr int H = SLOT >> 2, I = SLOT & 3;
+		if (store) {
+			uint2 v;
+			v.x = Base::fin_pack(acc[3][H][I], 3,
+				Base::fin_pack(acc[2][H][I], 2, Base::fin_pack(acc[1][H][I], 1, Base::fin_pack(acc[0][H][I], 0, 0))));
+			v.y = Base::fin_pack(acc[7][H][I], 3,
+				Base::fin_pack(acc[6][H][I], 2, Base::fin_pack(acc[5][H][I], 1, Base::fin_pack(acc[4][H][I], 0, 0))));
+			*reinterpret_cast<uint2 *>(trow_lane + ROT * F3_TPITCH) = v;
+		}
+#pragma unroll
+		for (int o = 0; o < 8; o++)
+			acc[o][H][I] = 0.0f;
+	}
+
+	// NB = prefetch depth: group g lives in ring buffer g mod NB (NB divides 8) and each of its quads is refilled
+	// with group g + NB as soon as it has been consumed
+	template <int ROT, int NB>
+	static __device__ __forceinline__ void batch(const FusedIArgs &a, uint2 (&px)[NB][S], int g0, int ngroups,
+		float4v (&acc)[8][2], const half4v *lane_a, int row0, int dir, unsigned int o0, unsigned int o1, bool interior,
+		unsigned char *trow_lane, int oh)
+	{
+		if constexpr (ROT < MFMA_SLOTS) {
+			const int g = g0 + ROT;
+			if (g < ngroups) {
+				const bool more = g + NB < ngroups;
+				const int next_row = row0 + dir * S * (g + NB);
+				quad<ROT, 0>(a, px[ROT % NB], acc, lane_a, more, next_row, dir, o0, o1, interior);
+				quad<ROT, 1>(a, px[ROT % NB], acc, lane_a, more, next_row, dir, o0, o1, interior);
+				const int j = g - (D - 1);
+				retire<ROT>(acc, trow_lane, j >= 0 && j < oh);
+			}
+			batch<ROT + 1, NB>(a, px, g0, ngroups, acc, lane_a, row0, dir, o0, o1, interior, trow_lane, oh);
+		}
+	}
+
+	// the horizontal walk of one (T row, segment, band): group G = pixels 8 G .. 8 G + 7 of the segment = 24 bytes;
+	// the band's bytes are c, c + 3, ... : pixels (0, 1) out of dwords (0, 1), (2, 3) out of (1, 2), (4, 5) out
+	// of (3, 4), (6, 7) out of (4, 5) -- selectors sel_a (bytes c, c + 3) and sel_b (bytes c + 2, c + 5)
+	template <int G, int FENCE>
+	static __device__ __forceinline__ void hwalk(float4v (&hacc)[2], const unsigned char *line, const half4v *lane_ah,
+		unsigned int sel_a, unsigned int sel_b, unsigned int (&outb)[HSEG_OUT])
+	{
+		constexpr int NG = HSEG_OUT + D - 1;
+		if constexpr (G < NG) {
+			constexpr int ROT = G % MFMA_SLOTS;
+			const uint2 w01 = *reinterpret_cast<const uint2 *>(line + 24 * G);
+			const uint2 w23 = *reinterpret_cast<const uint2 *>(line + 24 * G + 8);
+			const uint2 w45 = *reinterpret_cast<const uint2 *>(line + 24 * G + 16);
+			uint2 v0, v1;
+			v0.x = __builtin_amdgcn_perm(w01.y, w01.x, sel_a);
+			v0.y = __builtin_amdgcn_perm(w23.x, w01.y, sel_b);
+			v1.x = __builtin_amdgcn_perm(w45.x, w23.y, sel_a);
+			v1.y = __builtin_amdgcn_perm(w45.y, w45.x, sel_b);
+			const half4v b0 = __builtin_bit_cast(half4v, v0);
+			const half4v b1 = __builtin_bit_cast(half4v, v1);
+			hacc[0] = __builtin_amdgcn_mfma_f32_4x4x4f16(lane_ah[((ROT * 2 + 0) * 2 + 0) * 4], b0, hacc[0], 0, 0, 0);
+			hacc[1] = __builtin_amdgcn_mfma_f32_4x4x4f16(lane_ah[((ROT * 2 + 0) * 2 + 1) * 4], b0, hacc[1], 0, 0, 0);
+			hacc[0] = __builtin_amdgcn_mfma_f32_4x4x4f16(lane_ah[((ROT * 2 + 1) * 2 + 0) * 4], b1, hacc[0], 0, 0, 0);
+			hacc[1] = __builtin_amdgcn_mfma_f32_4x4x4f16(lane_ah[((ROT * 2 + 1) * 2 + 1) * 4], b1, hacc[1], 0, 0, 0);
+			constexpr int SLOT = (ROT - (D - 1) + 2 * MFMA_SLOTS) % MFMA_SLOTS;
+			constexpr int H = SLOT >> 2, I = SLOT & 3;
+			if constexpr (G >= D - 1)
+				outb[G - (D - 1)] = Base::fin_pack(hacc[H][I], 0, 0);
+			hacc[H][I] = 0.0f;
+			if constexpr (FENCE > 0 && (G % (FENCE > 0 ? FENCE : 1)) == FENCE - 1)
+				__builtin_amdgcn_sched_barrier(0); // keep the unrolled walk's LDS reads from piling up
+			hwalk<G + 1, FENCE>(hacc, line, lane_ah, sel_a, sel_b, outb);
+		}
+	}
+};
+
+template <int D, int NB, int OCC, int FENCE>
+__global__ void __launch_bounds__(FUSED_THREADS, OCC)
+reduce_fused_u8x3_mfma(FusedIArgs a, const MfmaTables *__restrict__ tables)
+{
+	constexpr int S = 8;
+	typedef FusedIStep<D> Step;
+	VH_DYNAMIC_LDS(unsigned char, lds_raw);
+	unsigned char *trows = lds_raw; // two buffers of 8 T rows: batch b's go to buffer b & 1
+	half4v *lds_a = reinterpret_cast<half4v *>(lds_raw + 2 * MFMA_SLOTS * F3_TPITCH);
+	half4v *lds_ah = lds_a + MFMA_TABLE_ENTRIES;
+	unsigned char *stage = reinterpret_cast<unsigned char *>(lds_ah + MFMA_TABLE_ENTRIES);
+
+	// each XCD takes a contiguous range of tiles (row-major: a tile row shares input rows)
+	const int per_xcd = gridDim.x / 8;
+	const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+	if (tile >= a.tiles)
+		return;
+	const int t = threadIdx.x;
+	const int by = tile / a.tiles_x;
+	const int bx = tile - by * a.tiles_x;
+	const int x0 = bx * F3_OWT;
+	const int y0 = by * a.oht;
+	const int ow = min(F3_OWT, a.out_width - x0);
+	const int oh = min(a.oht, a.out_height - y0);
+
+	// byte of a window row the tile's T rows start at, and this lane's two dwords of it (clamped into the image's
+	// bytes: a clamped dword is overwritten in LDS)
+	const int tb = a.tile_b0 + 8 * F3_BANDS * x0;
+	const bool interior = tb >= a.blo && tb + F3_ROW <= a.bhi;
+	const unsigned int o0 = (unsigned int) min(max(tb + 8 * t, a.blo), a.bhi - 4);
+	const unsigned int o1 = (unsigned int) min(max(tb + 8 * t + 4, a.blo), a.bhi - 4);
+
+	const bool flip = a.alternate && (by & 1);
+	const int dir = flip ? -1 : 1;
+	const int row0 = flip ? a.fy0 + S * (y0 + oh - 1) + S * D - 1 : a.fy0 + S * y0;
+
+	if (t < MFMA_TABLE_ENTRIES) {
+		reinterpret_cast<uint2 *>(lds_a)[t] = reinterpret_cast<const uint2 *>(tables->a[flip ? 1 : 0])[t];
+		reinterpret_cast<uint2 *>(lds_ah)[t] = reinterpret_cast<const uint2 *>(tables->ah)[t];
+	}
+	const half4v *lane_a = lds_a + (t & 3);
+	const half4v *lane_ah = lds_ah + (t & 3);
+
+	float4v acc[8][2];
+#pragma unroll
+	for (int o = 0; o < 8; o++)
+#pragma unroll
+		for (int h = 0; h < 2; h++)
+			acc[o][h] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+
+	const int ngroups = oh + D - 1;
+	uint2 px[NB][S];
+#pragma unroll
+	for (int b = 0; b < NB; b++)
+		if (b < ngroups)
+			Step::template load_rows<0, S>(a, px[b], row0 + dir * S * b, dir, o0, o1, interior);
+	__syncthreads();
+
+	// thread -> (T row, segment of 8 outputs, band); the last 16 threads walk with thread 239's addresses (their
+	// matrix instructions carry no one else's operands, but every lane must hold a valid address) and store nothing
+	const int hu = min(t / F3_BANDS, 8 * (F3_OWT / HSEG_OUT) - 1);
+	const int hc = t - F3_BANDS * (t / F3_BANDS), hr = hu & 7, hseg = hu >> 3;
+	const bool hlane = t < F3_BANDS * 8 * (F3_OWT / HSEG_OUT);
+	const unsigned int sel_a = 0x0c000c00u | (unsigned int) hc | ((unsigned int) (hc + 3) << 16);
+	const unsigned int sel_b = 0x0c000c00u | (unsigned int) (hc + 2) | ((unsigned int) (hc + 5) << 16);
+
+	// One barrier a batch: a wave that is through its horizontal pass goes on walking into the OTHER buffer while
+	// the block's slower waves still read this one; it cannot reach this buffer again before the next barrier.
+	for (int g0 = 0; g0 < ngroups; g0 += MFMA_SLOTS) {
+		unsigned char *tbuf = trows + ((g0 / MFMA_SLOTS) & 1) * (MFMA_SLOTS * F3_TPITCH);
+		Step::template batch<0, NB>(a, px, g0, ngroups, acc, lane_a, row0, dir, o0, o1, interior, tbuf + 8 * t, oh);
+		__syncthreads();
+
+		// ---- horizontal pass over the rows this batch completed (T row r <-> group g0 + r); the loads of the next
+		// NB groups are in flight across it
+		const int jlo = max(g0 - (D - 1), 0);
+		const int jhi = min(g0 + MFMA_SLOTS - 1 - (D - 1), oh - 1); // inclusive
+		if (jhi < jlo)
+			continue;
+		const int nrows = jhi - jlo + 1;
+		const int r_lo = jlo - (g0 - (D - 1));
+		if (!interior) {
+			// columns left of the image's first / right of its last: the edge pixel's three bytes
+			if (tb < a.blo) {
+				const int n = a.blo - tb; // a multiple of 3 (and of 4)
+				for (int i = t; i < nrows * n; i += FUSED_THREADS) {
+					const int r = i / n, k = i - r * n;
+					unsigned char *row = tbuf + (r_lo + r) * F3_TPITCH;
+					row[k] = row[n + k % F3_BANDS];
+				}
+			}
+			if (tb + F3_ROW > a.bhi) {
+				const int k0 = max(a.bhi - tb, F3_BANDS), n = F3_ROW - k0;
+				for (int i = t; i < nrows * n; i += FUSED_THREADS) {
+					const int r = i / n, k = i - r * n;
+					unsigned char *row = tbuf + (r_lo + r) * F3_TPITCH;
+					row[k0 + k] = row[k0 - F3_BANDS + k % F3_BANDS];
+				}
+			}
+			__syncthreads();
+		}
+		{
+			const bool row_ok = hr < nrows;
+			const int lrow = r_lo + (row_ok ? hr : 0);
+			const unsigned char *line = tbuf + lrow * F3_TPITCH + 8 * F3_BANDS * HSEG_OUT * hseg;
+			float4v hacc[2];
+			hacc[0] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+			hacc[1] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+			unsigned int outb[HSEG_OUT];
+			Step::template hwalk<0, FENCE>(hacc, line, lane_ah, sel_a, sel_b, outb);
+			if (row_ok && hlane) {
+				unsigned char *srow = stage + (jlo + hr) * F3_SPITCH + F3_BANDS * HSEG_OUT * hseg + hc;
+#pragma unroll
+				for (int k = 0; k < HSEG_OUT; k++)
+					srow[F3_BANDS * k] = (unsigned char) outb[k];
+			}
+		}
+	}
+	__syncthreads();
+
+	// ---- the tile's rows leave in one burst: 16 lanes a row, 16 bytes a lane
+	{
+		const int part = t & 15, nbytes = F3_BANDS * ow;
+		for (int r = t >> 4; r < oh; r += FUSED_THREADS / 16) {
+			if (16 * part >= nbytes)
+				continue;
+			unsigned char *dst =
+				a.out + (long long) (y0 + (flip ? oh - 1 - r : r)) * a.out_stride + (long long) x0 * F3_BANDS + 16 * part;
+			const unsigned char *src = stage + r * F3_SPITCH + 16 * part;
+			if (a.aligned16 && 16 * part + 16 <= nbytes)
+				*reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
+			else {
+				const int n = min(16, nbytes - 16 * part);
+				for (int k = 0; k < n; k++)
+					dst[k] = src[k];
+			}
+		}
+	}
+}
+
 // Is pos[] an arithmetic progression first0 + S*k with one phase?  (What an
 // integer shrink of a size-divisible image produces.)
 static bool positions_regular(const std::vector<ReducePos> &pos, int *first0, int *step, int *phase)
@@ -1511,6 +1822,87 @@ static int launch_fused_mfma_x(const FusedArgs &all, const VipsHipRegion *in, co
 	if (rc)
 		error("reduce", "kernel launch failed");
 	return rc;
+}
+
+// vips_reduce by 8 on a 3-band uchar region in one kernel (reduce_fused_u8x3_mfma).  0: launched; 1: not this
+// kernel's case (the caller goes on to reducev, then reduceh); -1: error.  What the kernel assumes and this checks:
+// every dword of a window row lies wholly inside or wholly outside the image's columns, and wholly inside or outside
+// a tile -- base, stride, the window's first and last image byte and the first tap's byte are multiples of 4
+// (a whole image whose width is a multiple of 4 at a 4-byte base always is: the first tap of vips_reduce(8) is
+// column -20 or -24); byte offsets fit 32 bits.
+static int launch_fused_u8x3(int D, const VipsHipRegion *in, const VipsHipRegion *out, int fx0, int fy0,
+	const MfmaTables *d_tables)
+{
+	if (getenv("VIPS_HIP_NO_FUSED3") || in->bands != F3_BANDS || (D != 6 && D != 7))
+		return 1;
+	if (!(in->stride > 0 && (long long) in->stride * in->height < (1LL << 31)))
+		return 1;
+	if (((uintptr_t) in->data & 3) || (in->stride & 3))
+		return 1;
+	const int lo = in->left > 0 ? in->left : 0;
+	const int hi1 = in->im_width < in->left + in->width ? in->im_width : in->left + in->width;
+	const long long blo = 3LL * (lo - in->left), bhi = 3LL * (hi1 - in->left), tb0 = 3LL * ((long long) fx0 - in->left);
+	if ((blo & 3) || (bhi & 3) || (tb0 & 3) || bhi - blo < 8 || tb0 < -(1LL << 30) || tb0 > (1LL << 30))
+		return 1;
+	FusedIArgs a;
+	a.in = (const unsigned char *) in->data;
+	a.out = (unsigned char *) out->data;
+	a.in_stride = (long long) in->stride;
+	a.out_stride = (long long) out->stride;
+	a.in_top = in->top;
+	a.im_height = in->im_height;
+	a.blo = (int) blo;
+	a.bhi = (int) bhi;
+	a.tile_b0 = (int) tb0;
+	a.fy0 = fy0;
+	a.out_width = out->width;
+	a.out_height = out->height;
+	a.tiles_x = (out->width + F3_OWT - 1) / F3_OWT;
+	// a tile re-reads 8 (D - 1) rows of the one above (an L2 hit when the two walk towards each other): the tallest
+	// tile that still leaves 1.5 tiles a CU, as reducev_u8_mfma
+	// Tile height.  A tile re-reads 8 (D - 1) rows of the one above (an L2 hit when the two walk towards each
+	// other), and the launch takes as long as its busiest CU: the tiles it gets -- never fewer than two at a time,
+	// one block cannot keep a CU's memory pipe busy -- times the row groups a tile walks.  The height with the
+	// smallest product (profiles/r06e_reduce_rgb_sizes*.txt: 1024 ... 20480 squared, the model against the clock).
+	int oht = 32;
+	auto tiles_at = [&](int h) { return (long long) a.tiles_x * ((out->height + h - 1) / h); };
+	{
+		long long best = -1;
+		for (int h : { 8, 12, 16, 20, 24, 28, 32, 40, 48 }) {
+			const long long per_cu = (tiles_at(h) + 255) / 256;
+			const long long cost = (2 * (per_cu < 2 ? 2 : per_cu) + 1) * (h + D - 1); // (+ half a tile: the ragged end)
+			if (best < 0 || cost <= best) {
+				best = cost;
+				oht = h;
+			}
+		}
+	}
+	if (const char *e = getenv("VIPS_HIP_FUSED3_OHT"))
+		oht = atoi(e) > 0 && atoi(e) <= F3_MAX_OHT ? atoi(e) : oht;
+	a.oht = oht;
+	a.alternate = !getenv("VIPS_HIP_BAND_NO_ALTERNATE");
+	a.aligned16 = !(((uintptr_t) out->data & 15) || (out->stride & 15));
+	a.tiles = a.tiles_x * ((out->height + oht - 1) / oht);
+	const int grid = (a.tiles + 7) / 8 * 8;
+	const size_t lds = f3_lds_bytes(oht);
+	Gate gate("reduce_fused_u8x3_mfma");
+	// two tiles a CU or fewer: two row groups in flight a lane and the horizontal walk's LDS reads all up front
+	// (0.0484 -> 0.0456 ms on 8192 x 8192 x 3); more: three blocks a CU with one group in flight (16384 x 16384 x 3:
+	// 0.187 ms against 0.206 the other way round) -- profiles/r06e_reduce_rgb.txt
+	const bool deep = getenv("VIPS_HIP_FUSED3_DEEP") ? atoi(getenv("VIPS_HIP_FUSED3_DEEP")) != 0 : a.tiles <= 512;
+#define F3_GO(DD, NBB, OCC, FF) \
+	hipLaunchKernelGGL((reduce_fused_u8x3_mfma<DD, NBB, OCC, FF>), dim3(grid), dim3(FUSED_THREADS), lds, stream(), a, d_tables)
+	if (D == 6 && deep)
+		F3_GO(6, 2, 2, 0);
+	else if (D == 6)
+		F3_GO(6, 1, 3, 2);
+	else if (deep)
+		F3_GO(7, 2, 2, 0);
+	else
+		F3_GO(7, 1, 3, 2);
+#undef F3_GO
+	VH_CHECK(hipGetLastError());
+	return 0;
 }
 
 template <int S, int D>
@@ -1934,15 +2326,16 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 	if (check_region(domain, in) || check_region(domain, out))
 		return -1;
 	if (in->format != VIPS_HIP_FORMAT_UCHAR || out->format != VIPS_HIP_FORMAT_UCHAR ||
-		in->bands != 4 || out->bands != 4)
+		(in->bands != 4 && in->bands != F3_BANDS) || out->bands != in->bands)
 		return 1;
+	const bool three = in->bands == F3_BANDS; // the matrix-core kernel for interleaved bands, or nothing
 	if (in->im_height != reducev->in_size || out->im_height != reducev->out_size ||
 		in->im_width != reduceh->in_size || out->im_width != reduceh->out_size) {
 		error(domain, "region does not belong to an image of the size these reduces were built for");
 		return -1;
 	}
-	if (((uintptr_t) in->data & 3) || (in->stride & 3) || ((uintptr_t) out->data & 3) ||
-		(out->stride & 3))
+	if (((uintptr_t) in->data & 3) || (in->stride & 3) ||
+		(!three && (((uintptr_t) out->data & 3) || (out->stride & 3))))
 		return 1;
 
 	// Geometry: both axes must step by the same even integer with one phase.
@@ -1965,6 +2358,8 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 	const int D = (nmax + S - 1) / S;
 	if (!((S == 8 && (D == 6 || D == 7)) || (S == 4 && (D == 6 || D == 7)) ||
 			(S == 2 && (D == 6 || D == 7))))
+		return 1;
+	if (three && (S != 8 || getenv("VIPS_HIP_NO_MFMA") || getenv("VIPS_HIP_NO_FUSED3")))
 		return 1;
 
 	// the input window must cover what the two gens need
@@ -2023,7 +2418,7 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 	_VipsHipReduce *rv = const_cast<_VipsHipReduce *>(reducev);
 	// S = 8: both passes on the matrix cores when the exactness bounds hold
 	// (|c| < 2048 is an exact half, sum |c| * 255 < 2^23 keeps 2n + 1 in 24 bits)
-	if (S == 8 && args.small_window && args.pairs && !getenv("VIPS_HIP_NO_MFMA")) {
+	if (S == 8 && args.small_window && (args.pairs || three) && !getenv("VIPS_HIP_NO_MFMA")) {
 		const short *c = &rv->matrixs[(size_t) phase_y * rv->n_point];
 		const short *ch = &reduceh->matrixs[(size_t) phase_x * reduceh->n_point];
 		std::vector<int> taps(8 * D, 0), taps_h(8 * D, 0);
@@ -2040,6 +2435,28 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 			abs_sum_h += ah;
 			abs_max = av > abs_max ? av : abs_max;
 			abs_max = ah > abs_max ? ah : abs_max;
+		}
+		if (three && !(abs_max < 2048 && abs_sum * 255 < (1 << 23) && abs_sum_h * 255 < (1 << 23)))
+			return 1;
+		if (three) {
+			const MfmaTables *d_tables;
+			{
+				std::lock_guard<std::mutex> lock(rv->mutex);
+				auto key = std::make_tuple(-3, phase_y * 128 + phase_x, 8 * D);
+				auto it = rv->pos_cache.find(key);
+				if (it == rv->pos_cache.end()) {
+					MfmaTables tab;
+					mfma_build_tables(taps, taps_h, D, &tab);
+					void *d = upload(&tab, sizeof(tab));
+					if (!d)
+						return -1;
+					rv->pos_cache[key] = (ReducePos *) d;
+					d_tables = (const MfmaTables *) d;
+				}
+				else
+					d_tables = (const MfmaTables *) it->second;
+			}
+			return launch_fused_u8x3(D, in, out, fx0, fy0, d_tables);
 		}
 		if (abs_max < 2048 && abs_sum * 255 < (1 << 23) && abs_sum_h * 255 < (1 << 23)) {
 			// Tile height: ONE residency round (256 CUs x 4 blocks) when the staged rows fit in
@@ -2127,6 +2544,8 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 		}
 	}
 
+	if (three)
+		return 1;
 	// The VALU kernel.  Tile height: tall tiles amortise the (D-1)*S-row vertical halo; short
 	// tiles balance the 256 CUs better.  Measured on C2: two residency rounds (256 CUs x
 	// 4 resident blocks x 2) is the sweet spot -- 0.249 ms vs 0.259 ms at one round.

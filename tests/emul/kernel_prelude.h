@@ -46,6 +46,7 @@ static inline void emul_lds_dma_dword(const void *src, unsigned int voff, unsign
 	memcpy(emul::lds_base() + at, (const char *) src + voff, 4);
 }
 #define VH_LDS_DMA_DWORD(src, voff, lds_dst) emul_lds_dma_dword(src, voff, lds_dst)
+#define VH_WAVE_LDS_FENCE() ((void) emul::wave_share(nullptr, 0, true))
 #define VH_DYNAMIC_LDS(T, name) T *name = reinterpret_cast<T *>(emul::lds_base())
 #define VH_LDS_ADDR(p) ((unsigned int) (reinterpret_cast<unsigned char *>(p) - emul::lds_base()))
 

@@ -287,6 +287,45 @@ def test_fused_reduce_exchange(size, two_kernels, monkeypatch):
     assert np.array_equal(got, old) and np.array_equal(again, old)
 
 
+@pytest.mark.parametrize("oht,deep", [(0, None), (8, 0), (128, 1), (0, 0)])
+@pytest.mark.parametrize(
+    "size", [(640, 264), (680, 72), (1280, 1100), (2048, 1029), (3000, 520), (96, 2056), (24, 16), (5124, 301), (1282, 400)]
+)
+def test_fused_reduce_rgb(size, oht, deep, monkeypatch):
+    """Round 6: vips_reduce by 8 on THREE interleaved bands in one kernel (reduce_fused_u8x3_mfma: the vertical pass
+    on the row's bytes, the T rows in LDS as they lie in memory, the horizontal walk picking its band's bytes out
+    of 24-byte groups) -- images one tile wide (both of the image's edges in the same T row), several tiles either
+    way, a last tile of fewer than 80 outputs, heights the tile rows do not divide (a last row of tiles walked
+    bottom-up), sizes that are not multiples of 8 (a constant non-zero phase, seven groups of taps), tiles of 8 and
+    of 128 rows, both depths of the row ring; against the port and against reducev + reduceh.  A width that is not a multiple of 8 is not the
+    kernel's case (the first tap moves off a dword boundary, or the last dword straddles the image's edge)."""
+    w, h = size
+    src = helpers.lcg_image(w, h, 3, np.uint8, 49)
+    im = Image.new_from_array(src)
+    monkeypatch.setenv("VIPS_HIP_NO_FUSED3", "1")
+    two = im.reduce(8, 8, kernel="lanczos3").numpy()
+    monkeypatch.delenv("VIPS_HIP_NO_FUSED3")
+    if oht:
+        monkeypatch.setenv("VIPS_HIP_FUSED3_OHT", str(oht))
+    if deep is not None:  # (two row groups in flight a lane, what launches of under 768 tiles take / one)
+        monkeypatch.setenv("VIPS_HIP_FUSED3_DEEP", str(deep))
+    lib = libvips_amd.lib
+    lib.vips_hip_gate_reset()
+    lib.vips_hip_gate_enable(1)
+    try:
+        got = im.reduce(8, 8, kernel="lanczos3").numpy()
+        report = libvips_amd.gate_report()
+    finally:
+        lib.vips_hip_gate_enable(0)
+        lib.vips_hip_gate_reset()
+    if w % 8 == 0:
+        assert sorted(report) == ["reduce_fused_u8x3_mfma"], report
+    else:
+        assert "reduce_fused_u8x3_mfma" not in report, report
+    assert_same(got, Port.reduce(src, 8, 8, "lanczos3"), str(size))
+    assert np.array_equal(got, two)
+
+
 @pytest.mark.parametrize("kernel", ["lanczos3"])
 @pytest.mark.parametrize("size", [(4099, 3001), (2048, 1024), (1000, 8), (96, 2600), (9000, 700), (8192, 8197)])
 @pytest.mark.parametrize("align", [0, 1])
