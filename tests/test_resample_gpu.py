@@ -403,6 +403,56 @@ def test_fused_reduce_region_windows(nth, align):
         lib.vips_hip_reduce_free(rh)
 
 
+def test_fused_reduce_rgb_region_windows():
+    """The three-band kernel on vips_hip_reduce_gen's sub-rects (a strip owner's call, the module's strips): an
+    input window that only just covers what the rect needs -- its first column is the rect's first tap, so the
+    window's byte 0 is a tile's -- at the image's left, right, top and bottom edges and in the middle; must equal
+    the same rect of the whole-image result.  A return of 1 (not this kernel's case: the caller runs reducev, then
+    reduceh) is allowed, but not for every rect."""
+    lib = _ffi.lib
+    w, h = 2400, 1608
+    src = helpers.lcg_image(w, h, 3, np.uint8, 50)
+    full = Image.new_from_array(src).reduce(8, 8, kernel="lanczos3").numpy()
+    assert np.array_equal(full, Port.reduce(src, 8, 8, "lanczos3"))
+    oh, ow = full.shape[:2]
+    rv = _ffi.check_handle(lib.vips_hip_reduce_new(5, 8.0, h, oh, math.nan))
+    rh = _ffi.check_handle(lib.vips_hip_reduce_new(5, 8.0, w, ow, math.nan))
+    taken = 0
+    try:
+        for (left, top, width, height, widen) in ((0, 0, ow, 37, 0), (0, 37, ow, oh - 37, 0), (10, 50, 200, 100, 1),
+                                                  (10, 50, 200, 100, 0), (ow - 61, oh - 40, 61, 40, 0), (0, 100, 59, 1, 1),
+                                                  (85, 3, 163, 70, 1)):
+            t0, tn, l0, ln = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            lib.vips_hip_reducev_need(rv, top, height, ctypes.byref(t0), ctypes.byref(tn))
+            lib.vips_hip_reduceh_need(rh, left, width, ctypes.byref(l0), ctypes.byref(ln))
+            if widen:  # (a window of whole dwords: the kernel's case)
+                ln.value = min((ln.value + 3) & ~3, w - l0.value)
+            win = np.ascontiguousarray(src[t0.value:t0.value + tn.value, l0.value:l0.value + ln.value])
+            dwin = Image.new_from_array(win)
+            rin = dwin.region()
+            rin.left, rin.top, rin.im_width, rin.im_height = l0.value, t0.value, w, h
+            dout = Image.new_from_array(np.full((height, width, 3), 77, np.uint8))
+            rout = dout.region()
+            rout.left, rout.top, rout.im_width, rout.im_height = left, top, ow, oh
+            lib.vips_hip_gate_reset()
+            lib.vips_hip_gate_enable(1)
+            try:
+                r = lib.vips_hip_reduce_gen(rv, rh, ctypes.byref(rin), ctypes.byref(rout))
+                report = libvips_amd.gate_report()
+            finally:
+                lib.vips_hip_gate_enable(0)
+                lib.vips_hip_gate_reset()
+            assert r in (0, 1), (r, _ffi.error_buffer())
+            if r == 0:
+                assert sorted(report) == ["reduce_fused_u8x3_mfma"], report
+                taken += 1
+                assert np.array_equal(dout.numpy(), full[top:top + height, left:left + width]), (left, top, width, height)
+    finally:
+        lib.vips_hip_reduce_free(rv)
+        lib.vips_hip_reduce_free(rh)
+    assert taken >= 5, taken
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32, np.float32])
 @pytest.mark.parametrize("kernel", ["nearest", "linear", "cubic", "lanczos3"])
 def test_resize_upsizing_vs_port(dtype, kernel):
