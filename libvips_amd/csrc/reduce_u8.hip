@@ -1830,10 +1830,14 @@ static int launch_fused_mfma_x(const FusedArgs &all, const VipsHipRegion *in, co
 // a tile -- base, stride, the window's first and last image byte and the first tap's byte are multiples of 4
 // (a whole image whose width is a multiple of 4 at a 4-byte base always is: the first tap of vips_reduce(8) is
 // column -20 or -24); byte offsets fit 32 bits.
-static int launch_fused_u8x3(int D, const VipsHipRegion *in, const VipsHipRegion *out, int fx0, int fy0,
+static int launch_fused_u8x3(int D, int taps_h, const VipsHipRegion *in, const VipsHipRegion *out, int fx0, int fy0,
 	const MfmaTables *d_tables)
 {
 	if (getenv("VIPS_HIP_NO_FUSED3") || in->bands != F3_BANDS || (D != 6 && D != 7))
+		return 1;
+	// the last output of a tile must find its taps inside the tile's T row (the walk reads 8 D columns: past the
+	// last real tap the coefficients are zero and what it reads there -- any bytes, finite as halves -- counts for nothing)
+	if (F3_BANDS * (8 * (F3_OWT - 1) + taps_h) > F3_ROW)
 		return 1;
 	if (!(in->stride > 0 && (long long) in->stride * in->height < (1LL << 31)))
 		return 1;
@@ -2456,7 +2460,7 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 				else
 					d_tables = (const MfmaTables *) it->second;
 			}
-			return launch_fused_u8x3(D, in, out, fx0, fy0, d_tables);
+			return launch_fused_u8x3(D, nh, in, out, fx0, fy0, d_tables);
 		}
 		if (abs_max < 2048 && abs_sum * 255 < (1 << 23) && abs_sum_h * 255 < (1 << 23)) {
 			// Tile height: ONE residency round (256 CUs x 4 blocks) when the staged rows fit in
