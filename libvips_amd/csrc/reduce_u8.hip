@@ -1172,29 +1172,31 @@ struct VStreamStep {
 			acc[o][H][I] = 0.0f;
 	}
 
-	template <int ROT>
-	static __device__ __forceinline__ void batch(const VStreamArgs &a, uint2 (&px)[S], int g0, int ngroups,
+	// NB = prefetch depth: group g lives in ring buffer g mod NB (NB divides 8) and each of its quads is refilled
+	// with group g + NB as soon as it has been consumed
+	template <int ROT, int NB>
+	static __device__ __forceinline__ void batch(const VStreamArgs &a, uint2 (&px)[NB][S], int g0, int ngroups,
 		float4v (&acc)[8][2], const half4v *lane_a, int row0, int dir, unsigned int coff, unsigned char *out_col,
 		int oh, bool active)
 	{
 		if constexpr (ROT < MFMA_SLOTS) {
 			const int g = g0 + ROT;
 			if (g < ngroups) {
-				const bool more = g + 1 < ngroups;
-				const int next_row = row0 + dir * S * (g + 1);
-				quad<ROT, 0>(a, px, acc, lane_a, more, next_row, dir, coff);
-				quad<ROT, 1>(a, px, acc, lane_a, more, next_row, dir, coff);
+				const bool more = g + NB < ngroups;
+				const int next_row = row0 + dir * S * (g + NB);
+				quad<ROT, 0>(a, px[ROT % NB], acc, lane_a, more, next_row, dir, coff);
+				quad<ROT, 1>(a, px[ROT % NB], acc, lane_a, more, next_row, dir, coff);
 				const int j = g - (D - 1); // row of the (possibly flipped) tile
 				retire<ROT>(acc, out_col + (long long) (dir < 0 ? oh - 1 - j : j) * a.out_stride,
 					active && j >= 0 && j < oh);
 			}
-			batch<ROT + 1>(a, px, g0, ngroups, acc, lane_a, row0, dir, coff, out_col, oh, active);
+			batch<ROT + 1, NB>(a, px, g0, ngroups, acc, lane_a, row0, dir, coff, out_col, oh, active);
 		}
 	}
 };
 
-template <int D>
-__global__ void __launch_bounds__(FUSED_THREADS, 4)
+template <int D, int NB, int OCC>
+__global__ void __launch_bounds__(FUSED_THREADS, OCC)
 reducev_u8_mfma(VStreamArgs a, const MfmaTables *__restrict__ tables)
 {
 	constexpr int S = 8;
@@ -1234,13 +1236,16 @@ reducev_u8_mfma(VStreamArgs a, const MfmaTables *__restrict__ tables)
 			acc[o][h] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
 
 	const int ngroups = oh + D - 1;
-	uint2 px[S];
-	Step::template load_rows<0, S>(a, px, row0, dir, coff);
+	uint2 px[NB][S];
+#pragma unroll
+	for (int b = 0; b < NB; b++)
+		if (b < ngroups)
+			Step::template load_rows<0, S>(a, px[b], row0 + dir * S * b, dir, coff);
 	__syncthreads();
 
 	unsigned char *out_col = a.out + (long long) y0 * a.out_stride + coff;
 	for (int g0 = 0; g0 < ngroups; g0 += MFMA_SLOTS) {
-		Step::template batch<0>(a, px, g0, ngroups, acc, lane_a, row0, dir, coff, out_col, oh, active);
+		Step::template batch<0, NB>(a, px, g0, ngroups, acc, lane_a, row0, dir, coff, out_col, oh, active);
 	}
 }
 
@@ -2202,10 +2207,18 @@ static int reducev_stream_try(const _VipsHipReduce *rc, const VipsHipRegion *in,
 	a.tiles = a.tiles_x * tiles_y;
 	const int grid = (a.tiles + 7) / 8 * 8;
 	Gate gate("reducev_u8_mfma");
-	if (D == 6)
-		hipLaunchKernelGGL((reducev_u8_mfma<6>), dim3(grid), dim3(FUSED_THREADS), 0, stream(), a, d_tables);
+	// at most a tile a CU (images of a few tens of MB): four row groups in flight a lane, two blocks a CU's worth of
+	// registers -- 4096 x 4096 x 3: 0.0166 -> 0.0129 ms; from 1.5 tiles a CU on it changes nothing
+	// (profiles/r06f_reducev_nb.txt)
+	const bool deep = getenv("VIPS_HIP_REDUCEV8_NB") ? atoi(getenv("VIPS_HIP_REDUCEV8_NB")) == 4 : a.tiles <= 256;
+	if (D == 6 && deep)
+		hipLaunchKernelGGL((reducev_u8_mfma<6, 4, 2>), dim3(grid), dim3(FUSED_THREADS), 0, stream(), a, d_tables);
+	else if (D == 6)
+		hipLaunchKernelGGL((reducev_u8_mfma<6, 1, 4>), dim3(grid), dim3(FUSED_THREADS), 0, stream(), a, d_tables);
+	else if (deep)
+		hipLaunchKernelGGL((reducev_u8_mfma<7, 4, 2>), dim3(grid), dim3(FUSED_THREADS), 0, stream(), a, d_tables);
 	else
-		hipLaunchKernelGGL((reducev_u8_mfma<7>), dim3(grid), dim3(FUSED_THREADS), 0, stream(), a, d_tables);
+		hipLaunchKernelGGL((reducev_u8_mfma<7, 1, 4>), dim3(grid), dim3(FUSED_THREADS), 0, stream(), a, d_tables);
 	if (hipGetLastError() != hipSuccess) {
 		error("reducev", "kernel launch failed");
 		return -1;

@@ -510,12 +510,18 @@ def test_upsize_region_rects_and_reference():
         assert np.array_equal(got, Ref.run("resize", big, "scale=2,kernel=lanczos3"))
 
 
+@pytest.mark.parametrize("ring", [None, 1, 4])
 @pytest.mark.parametrize("bands", [1, 2, 3, 4])
-def test_reducev_mfma_any_bands(bands):
+def test_reducev_mfma_any_bands(bands, ring, monkeypatch):
     """reducev_u8_mfma: the vertical pass on the matrix cores for uchar images of any band
     count (integer-8 shrink, one phase, rows of whole 8-byte columns), alone and as the first
-    half of vips_reduce on RGB; several tiles wide and tall, ragged heights, clamped edges."""
+    half of vips_reduce on RGB; several tiles wide and tall, ragged heights, clamped edges; one and four
+    row groups in flight a lane (round 6: launches of at most a tile a CU take four)."""
     from libvips_amd import lib
+
+    if ring:
+        monkeypatch.setenv("VIPS_HIP_REDUCEV8_NB", str(ring))
+    monkeypatch.setenv("VIPS_HIP_NO_FUSED3", "1")  # (the one-kernel form of RGB: test_fused_reduce_rgb)
 
     for (w, h) in ((2048, 1603), (8 * 40 // bands * bands if bands != 3 else 640, 4099), (4096, 200)):
         if (w * bands) % 8:
