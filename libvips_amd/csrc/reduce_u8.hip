@@ -1645,46 +1645,20 @@ static void mfma_build_tables(const std::vector<int> &taps, const std::vector<in
 					}
 }
 
-template <int D, int NTH>
+// The kernel with halos, in its shipped form only: whole-pair loads, the edge fix-up at the point of use, streaming
+// (nt) loads, 256 threads.  (Rounds 2-5 kept the A/B forms -- the fix-up at the loads, plain loads, 512 threads,
+// arithmetic-only and loads-only profiling builds -- behind VIPS_HIP_FUSED_LATE / _NT / _NTH / _DEBUG=8|16; their
+// measurements are in profiles/NOTES.md 3.1, the forms are gone.)
+template <int D>
 static int launch_fused_mfma(const FusedArgs &args, int tiles, const MfmaTables *d_tables)
 {
 	Gate gate("reduce_fused_u8_mfma");
-	typedef MfmaGeo<NTH> Geo;
+	typedef MfmaGeo<FUSED_THREADS> Geo;
 	const int grid = (tiles + 7) / 8 * 8; // XCD remap wants a multiple of 8
 	const int stage_rows = args.burst_rows + 7 < args.oht ? args.burst_rows + 7 : args.oht;
 	const size_t lds = Geo::lds_bytes(stage_rows);
-	static bool attr_set = false; // per instantiation: above 64 KB of dynamic LDS needs the opt-in
-	if (!attr_set && lds > 64 * 1024) {
-		VH_CHECK(hipFuncSetAttribute((const void *) reduce_fused_u8x4_mfma<D, 1, 4, false, 0, true, NTH>,
-			hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-		VH_CHECK(hipFuncSetAttribute((const void *) reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true, NTH>,
-			hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-		attr_set = true;
-	}
-	// the shipped form: edge fix-up at the point of use (LATE) and streaming (nt) loads;
-	// VIPS_HIP_FUSED_LATE=0 / VIPS_HIP_FUSED_NT=0 select the round-2 forms for A/B runs
-	const bool late = !(getenv("VIPS_HIP_FUSED_LATE") && atoi(getenv("VIPS_HIP_FUSED_LATE")) == 0);
-	const bool nt = (args.debug & 4) || !(getenv("VIPS_HIP_FUSED_NT") && atoi(getenv("VIPS_HIP_FUSED_NT")) == 0);
-	if (NTH == FUSED_THREADS && (args.debug & 24) == 8) // profiling builds: arithmetic only / loads only
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 8, true>), dim3(grid), dim3(FUSED_THREADS), lds,
-			stream(), args, d_tables);
-	else if (NTH == FUSED_THREADS && (args.debug & 24) == 16)
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 16, true>), dim3(grid), dim3(FUSED_THREADS), lds,
-			stream(), args, d_tables);
-	else if (NTH != FUSED_THREADS || !late) {
-		if (nt)
-			hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true, NTH>), dim3(grid), dim3(NTH), lds,
-				stream(), args, d_tables);
-		else
-			hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, false, 0, true, NTH>), dim3(grid), dim3(NTH), lds,
-				stream(), args, d_tables);
-	}
-	else if (nt)
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true, FUSED_THREADS, 1>), dim3(grid),
-			dim3(FUSED_THREADS), lds, stream(), args, d_tables);
-	else
-		hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, false, 0, true, FUSED_THREADS, 1>), dim3(grid),
-			dim3(FUSED_THREADS), lds, stream(), args, d_tables);
+	hipLaunchKernelGGL((reduce_fused_u8x4_mfma<D, 1, 4, true, 0, true, FUSED_THREADS, 1>), dim3(grid), dim3(FUSED_THREADS),
+		lds, stream(), args, d_tables);
 	VH_CHECK(hipGetLastError());
 	return 0;
 }
@@ -2427,10 +2401,8 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 	args.burst_rows = 1 << 20;
 	args.owt = FUSED_SPAN / S - D + 1;
 	args.tiles_x = (out->width + args.owt - 1) / args.owt;
-	// MFMA kernel: threads per block (VIPS_HIP_FUSED_NTH=256|512; tiles of 59 / 123 pixels)
-	const int nth = getenv("VIPS_HIP_FUSED_NTH") && atoi(getenv("VIPS_HIP_FUSED_NTH")) == 512 ? 512 : 256;
-	const int mfma_span = 2 * nth;
-	const int mfma_max_oht = nth == 512 ? MfmaGeo<512>::MAX_OHT : MfmaGeo<256>::MAX_OHT;
+	const int mfma_span = 2 * FUSED_THREADS;
+	const int mfma_max_oht = MfmaGeo<FUSED_THREADS>::MAX_OHT;
 
 	_VipsHipReduce *rv = const_cast<_VipsHipReduce *>(reducev);
 	// S = 8: both passes on the matrix cores when the exactness bounds hold
@@ -2553,11 +2525,9 @@ int vips_hip_reduce_gen_tiled(const VipsHipReduce *reducev, const VipsHipReduce 
 					return r;
 			}
 			if (D == 6)
-				return nth == 512 ? launch_fused_mfma<6, 512>(args, tiles, d_tables)
-								  : launch_fused_mfma<6, 256>(args, tiles, d_tables);
+				return launch_fused_mfma<6>(args, tiles, d_tables);
 			if (D == 7)
-				return nth == 512 ? launch_fused_mfma<7, 512>(args, tiles, d_tables)
-								  : launch_fused_mfma<7, 256>(args, tiles, d_tables);
+				return launch_fused_mfma<7>(args, tiles, d_tables);
 		}
 	}
 

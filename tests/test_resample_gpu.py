@@ -329,35 +329,26 @@ def test_fused_reduce_rgb(size, oht, deep, monkeypatch):
 @pytest.mark.parametrize("kernel", ["lanczos3"])
 @pytest.mark.parametrize("size", [(4099, 3001), (2048, 1024), (1000, 8), (96, 2600), (9000, 700), (8192, 8197)])
 @pytest.mark.parametrize("align", [0, 1])
-@pytest.mark.parametrize("nth,late", [(256, 1), (256, 0), (512, 1)])
-def test_fused_reduce_mfma_variants(nth, late, align, size, kernel):
-    """Both tile layouts of the matrix-core kernel on the same inputs: line-aligned tiles (lanes
+def test_fused_reduce_mfma_variants(align, size, kernel, monkeypatch):
+    """Both tile layouts of the matrix-core kernel with halos on the same inputs: line-aligned tiles (lanes
     start on the 128-byte line holding the first tap; the default when base and stride allow)
     and tiles that start at the first tap (VIPS_HIP_FUSED_ALIGN=0: what windows with an odd
     base get), shrink 8, sizes with partial tiles on every side, several tiles in both
-    directions, 6 and 7 tap groups (phase 0 and a constant non-zero phase), all edges clamped."""
-    import os
-
+    directions, 6 and 7 tap groups (phase 0 and a constant non-zero phase), all edges clamped.
+    (Rounds 2-5 also ran the kernel's retired A/B forms here -- 512 threads, the edge fix-up at the loads, plain
+    loads; round 6 deleted them.)"""
     from libvips_amd import lib
 
     w, h = size
     src = helpers.lcg_image(w, h, 4, np.uint8, 47)
-    os.environ["VIPS_HIP_FUSED_ALIGN"] = str(align)
-    os.environ["VIPS_HIP_FUSED_EXCH"] = "0"  # (the kernel WITH halos and its variants; the other: test_fused_reduce_exchange)
-    os.environ["VIPS_HIP_FUSED_NTH"] = str(nth)  # 59-pixel tiles (256 threads) / 123-pixel tiles (512)
-    # the edge fix-up at the point of use + nt loads (the shipped form) / at the loads + plain loads (round 2)
-    os.environ["VIPS_HIP_FUSED_LATE"] = os.environ["VIPS_HIP_FUSED_NT"] = str(late)
+    monkeypatch.setenv("VIPS_HIP_FUSED_ALIGN", str(align))
+    monkeypatch.setenv("VIPS_HIP_FUSED_EXCH", "0")  # (the kernel WITH halos; the other: test_fused_reduce_exchange)
     lib.vips_hip_gate_reset()
     lib.vips_hip_gate_enable(1)
     try:
         got = Image.new_from_array(src).reduce(8, 8, kernel=kernel).numpy()
         report = libvips_amd.gate_report()
     finally:
-        del os.environ["VIPS_HIP_FUSED_ALIGN"]
-        del os.environ["VIPS_HIP_FUSED_EXCH"]
-        del os.environ["VIPS_HIP_FUSED_NTH"]
-        del os.environ["VIPS_HIP_FUSED_LATE"]
-        del os.environ["VIPS_HIP_FUSED_NT"]
         lib.vips_hip_gate_enable(0)
         lib.vips_hip_gate_reset()
     assert list(report) == ["reduce_fused_u8_mfma"], report
@@ -365,8 +356,7 @@ def test_fused_reduce_mfma_variants(nth, late, align, size, kernel):
 
 
 @pytest.mark.parametrize("align", [0, 1])
-@pytest.mark.parametrize("nth", [256, 512])
-def test_fused_reduce_region_windows(nth, align):
+def test_fused_reduce_region_windows(align):
     """vips_hip_reduce_gen the way a strip owner (one GPU of several, libvips_amd/sharding.py)
     calls it: an output sub-rect and an input window that only just covers the rows and
     columns vips_hip_reduce{v,h}_need report, at image edges and in the middle; must equal
@@ -379,7 +369,6 @@ def test_fused_reduce_region_windows(nth, align):
     rv = _ffi.check_handle(lib.vips_hip_reduce_new(5, 8.0, h, oh, math.nan))
     rh = _ffi.check_handle(lib.vips_hip_reduce_new(5, 8.0, w, ow, math.nan))
     os.environ["VIPS_HIP_FUSED_ALIGN"] = str(align)
-    os.environ["VIPS_HIP_FUSED_NTH"] = str(nth)
     try:
         for (left, top, width, height) in ((0, 0, ow, 37), (0, 37, ow, oh - 37), (10, 50, 200, 100),
                                            (ow - 61, oh - 40, 61, 40), (0, 100, 59, 1)):
@@ -398,7 +387,6 @@ def test_fused_reduce_region_windows(nth, align):
             assert np.array_equal(dout.numpy(), full[top:top + height, left:left + width]), (left, top, width, height)
     finally:
         del os.environ["VIPS_HIP_FUSED_ALIGN"]
-        del os.environ["VIPS_HIP_FUSED_NTH"]
         lib.vips_hip_reduce_free(rv)
         lib.vips_hip_reduce_free(rh)
 

@@ -18,7 +18,7 @@ from bench import lcg_image_device  # noqa: E402
 from libvips_amd import Image, lib  # noqa: E402
 
 KNOBS = ("VIPS_HIP_FUSED_DEBUG", "VIPS_HIP_FUSED_CAP", "VIPS_HIP_NO_MFMA", "VIPS_HIP_FUSED_ALIGN",
-         "VIPS_HIP_FUSED_OWT", "VIPS_HIP_FUSED_STAGGER", "VIPS_HIP_FUSED_BURST", "VIPS_HIP_FUSED_NTH", "VIPS_HIP_FUSED_LATE", "VIPS_HIP_FUSED_NT", "VIPS_HIP_FUSED_EXCH",
+         "VIPS_HIP_FUSED_OWT", "VIPS_HIP_FUSED_STAGGER", "VIPS_HIP_FUSED_BURST", "VIPS_HIP_FUSED_EXCH",
          "VIPS_HIP_FUSED_PLAIN")
 ROUNDS = int(os.environ.get("TUNE_ROUNDS", "5"))
 LAUNCHES = int(os.environ.get("TUNE_LAUNCHES", "15"))
