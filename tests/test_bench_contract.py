@@ -33,7 +33,7 @@ def test_traffic_stamp_matches_the_built_kernel():
 def test_isa_hash_is_of_machine_code_not_of_a_name():
     assert bench.kernel_isa_sha("no_such_kernel_in_the_library") is None
     a = bench.kernel_isa_sha("reduce_fused_u8x4_mfmaILi6ELi1ELi4ELb1ELi0ELb1ELi256ELi1EE")
-    b = bench.kernel_isa_sha("reduce_fused_u8x4_mfmaILi6ELi1ELi4ELb0ELi0ELb1ELi256ELi1EE")
+    b = bench.kernel_isa_sha("reduce_fused_u8x4_mfmaILi7ELi1ELi4ELb1ELi0ELb1ELi256ELi1EE")
     assert a and b and a != b  # (two instantiations of one source: different instructions, different stamps)
 
 
