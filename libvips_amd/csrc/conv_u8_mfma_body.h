@@ -64,6 +64,9 @@ struct CmArgs {
 	int rnd;             // ushort: (S + rnd) / scale as ((S + rnd) * div_m) >> (32 + div_s), S + rnd < 2^31 (div_m = 0: scale 1)
 	unsigned int div_m;
 	int div_s;
+	int fin64;           // ushort: the quotient in doubles instead (cm_fin16)
+	double div_inv;      // RN(1 / scale)
+	double rnd_half;     // rnd + 0.5
 	const unsigned int *tz;      // the Toeplitz operands: 4 tables of [4 k-steps][64 lanes][4 dwords]: the mask's, and
 	int edge_wave[3];            // pass 1's for the tiles 32 edge_wave[k] .. + 32 whose windows hang over an edge (-1: none)
 };
@@ -89,8 +92,18 @@ VH_DEV void cm_halves(const unsigned int (&raw)[B], int b, unsigned int &a0, uns
 // exact sums of a sample -- of the low and of the high bytes, each n 2^-24 -- to clip((256 S_hi + S_lo + rnd) / scale,
 // 0, 65535) in 32-bit integers (convi.c:698-716 for unsigned short: int sums, C division -- a negative numerator
 // gives a quotient <= 0, clipped to 0 either way); the host keeps 256 S_hi + S_lo + rnd below 2^31
+// (fin64: the same quotient in doubles -- S + rnd + 0.5 exactly (both sums are integers below 2^24 in units of
+// 2^-24, so 2^32 hi + 2^24 lo + rnd + 0.5 is a half-integer below 2^33), times RN(1 / scale): (S + rnd + 0.5) / scale
+// lies at least 0.5 / scale from an integer on either side and the two roundings move the product by less than
+// 2^31 2^-52 / scale, so its floor is the quotient's; a negative numerator converts to 0.  Seven instructions, none at
+// a quarter rate, against ~15 issue slots)
 VH_DEV unsigned int cm_fin16(float lo, float hi, const CmArgs &a)
 {
+	if (a.fin64) {
+		const double t = __builtin_fma((double) hi, 4294967296.0, a.rnd_half);
+		const double u = __builtin_fma((double) lo, 16777216.0, t);
+		return min(vh::cvt_u32(u * a.div_inv), 65535u);
+	}
 	const int s = (vh::cvt_i32(hi * 16777216.0f) << 8) + vh::cvt_i32(lo * 16777216.0f) + a.rnd;
 	if (s <= 0)
 		return 0u;

@@ -98,7 +98,7 @@ CASES16 = [
 
 
 @pytest.mark.parametrize("case", range(len(CASES16)))
-@pytest.mark.parametrize("env", [{}, {"VIPS_HIP_CONV_MFMA_SEG": "2"}, {"VIPS_HIP_CONV_MFMA_NARROW": "1"}])
+@pytest.mark.parametrize("env", [{}, {"VIPS_HIP_CONV_MFMA_SEG": "2"}, {"VIPS_HIP_CONV_MFMA_NARROW": "1"}, {"VIPS_HIP_U16_FIN64": "1"}, {"VIPS_HIP_U16_FIN64": "0"}])
 def test_conv_u16_separable_on_the_matrix_cores(case, env, monkeypatch):
     """vips_gaussblur / vips_convsep (precision integer) on ushort images: conv_u8_mfma_body.h with the image's bytes
     as 2 x bands planes, two exact products per sample and pass -- against the compiled reference and against the
