@@ -11,6 +11,7 @@
 
 namespace vh {
 
+int reduceh_u8x3_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out, int tile);
 int reducev_u8_try(const _VipsHipReduce *r, const VipsHipRegion *in, const VipsHipRegion *out,
 	const ReducePos *pos, const short *table, int tile);
 int shrinkv_u8_try(int vshrink, const VipsHipRegion *in, const VipsHipRegion *out);

@@ -1560,6 +1560,159 @@ reduce_fused_u8x3_mfma(FusedIArgs a, const MfmaTables *__restrict__ tables)
 	}
 }
 
+// ------------------------------------------------ vips_reduceh by 8 on three interleaved bands (round 6)
+//
+// reduceh_u8x3_mfma<D>: the horizontal half of reduce_fused_u8x3_mfma on its own -- the rows of the image take the
+// place of the T rows.  A lane copies its 8 bytes of eight rows into LDS (whole-line loads: the packed vector-ALU
+// kernel this replaces and the banded matrix kernel both read a row a lane or stage through bytes), then lane (row,
+// segment of 8 outputs, band) walks its 24-byte groups; two batches of rows in flight a lane, two LDS buffers, one
+// barrier a batch, the tile's output rows in one burst.  No vertical halo, so a tile is as tall as fills the chip.
+struct RhIArgs {
+	const unsigned char *in; // byte 0 of a window row (column in_left), the rect's first row
+	unsigned char *out;
+	long long in_stride, out_stride;
+	int blo, bhi, tile_b0;   // as FusedIArgs
+	int out_width, rows;
+	int oht, tiles_x, tiles;
+	int aligned16;
+};
+
+constexpr int RH3_NB = 2; // batches of 8 rows in flight a lane
+static constexpr size_t rh3_lds_bytes(int oht)
+{
+	return (size_t) 2 * MFMA_SLOTS * F3_TPITCH + MFMA_TABLE_ENTRIES * 8 + (size_t) oht * F3_SPITCH;
+}
+
+template <int D>
+__global__ void __launch_bounds__(FUSED_THREADS, 3)
+reduceh_u8x3_mfma(RhIArgs a, const MfmaTables *__restrict__ tables)
+{
+	typedef FusedIStep<D> Step;
+	VH_DYNAMIC_LDS(unsigned char, lds_raw);
+	unsigned char *trows = lds_raw; // two buffers of 8 rows
+	half4v *lds_ah = reinterpret_cast<half4v *>(lds_raw + 2 * MFMA_SLOTS * F3_TPITCH);
+	unsigned char *stage = reinterpret_cast<unsigned char *>(lds_ah + MFMA_TABLE_ENTRIES);
+
+	const int per_xcd = gridDim.x / 8;
+	const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+	if (tile >= a.tiles)
+		return;
+	const int t = threadIdx.x;
+	const int by = tile / a.tiles_x;
+	const int bx = tile - by * a.tiles_x;
+	const int x0 = bx * F3_OWT;
+	const int y0 = by * a.oht;
+	const int ow = min(F3_OWT, a.out_width - x0);
+	const int oh = min(a.oht, a.rows - y0);
+
+	const int tb = a.tile_b0 + 8 * F3_BANDS * x0;
+	const bool interior = tb >= a.blo && tb + F3_ROW <= a.bhi;
+	const unsigned int o0 = (unsigned int) min(max(tb + 8 * t, a.blo), a.bhi - 4);
+	const unsigned int o1 = (unsigned int) min(max(tb + 8 * t + 4, a.blo), a.bhi - 4);
+
+	if (t < MFMA_TABLE_ENTRIES)
+		reinterpret_cast<uint2 *>(lds_ah)[t] = reinterpret_cast<const uint2 *>(tables->ah)[t];
+	const half4v *lane_ah = lds_ah + (t & 3);
+
+	// rows y0 + 8 k + i of the rect (past the tile's last: that one again, never walked)
+	const unsigned int stride32 = (unsigned int) a.in_stride;
+	auto load = [&](uint2 (&px)[8], int k) {
+		typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+		typedef u32x2 __attribute__((aligned(4))) u32x2_a4;
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			const unsigned int base = (unsigned int) (y0 + min(8 * k + i, oh - 1)) * stride32;
+			if (interior) {
+				const u32x2 v = *reinterpret_cast<const u32x2_a4 *>(a.in + (size_t) (base + o0));
+				px[i] = make_uint2(v.x, v.y);
+			}
+			else {
+				px[i].x = *reinterpret_cast<const unsigned int *>(a.in + (size_t) (base + o0));
+				px[i].y = *reinterpret_cast<const unsigned int *>(a.in + (size_t) (base + o1));
+			}
+		}
+	};
+	const int nb = (oh + 7) / 8;
+	uint2 px[RH3_NB][8];
+#pragma unroll
+	for (int p = 0; p < RH3_NB; p++)
+		if (p < nb)
+			load(px[p], p);
+	__syncthreads();
+
+	const int hu = min(t / F3_BANDS, 8 * (F3_OWT / HSEG_OUT) - 1);
+	const int hc = t - F3_BANDS * (t / F3_BANDS), hr = hu & 7, hseg = hu >> 3;
+	const bool hlane = t < F3_BANDS * 8 * (F3_OWT / HSEG_OUT);
+	const unsigned int sel_a = 0x0c000c00u | (unsigned int) hc | ((unsigned int) (hc + 3) << 16);
+	const unsigned int sel_b = 0x0c000c00u | (unsigned int) (hc + 2) | ((unsigned int) (hc + 5) << 16);
+
+	for (int k0 = 0; k0 < nb; k0 += RH3_NB) {
+#pragma unroll
+		for (int p = 0; p < RH3_NB; p++) {
+			const int k = k0 + p;
+			if (k >= nb)
+				break;
+			unsigned char *tbuf = trows + (k & 1) * (MFMA_SLOTS * F3_TPITCH);
+#pragma unroll
+			for (int i = 0; i < 8; i++)
+				*reinterpret_cast<uint2 *>(tbuf + i * F3_TPITCH + 8 * t) = px[p][i];
+			if (k + RH3_NB < nb)
+				load(px[p], k + RH3_NB);
+			__syncthreads();
+			const int nrows = min(8, oh - 8 * k);
+			if (!interior) {
+				if (tb < a.blo) {
+					const int n = a.blo - tb;
+					for (int i = t; i < nrows * n; i += FUSED_THREADS) {
+						const int r = i / n, kk = i - r * n;
+						unsigned char *row = tbuf + r * F3_TPITCH;
+						row[kk] = row[n + kk % F3_BANDS];
+					}
+				}
+				if (tb + F3_ROW > a.bhi) {
+					const int c0 = max(a.bhi - tb, F3_BANDS), n = F3_ROW - c0;
+					for (int i = t; i < nrows * n; i += FUSED_THREADS) {
+						const int r = i / n, kk = i - r * n;
+						unsigned char *row = tbuf + r * F3_TPITCH;
+						row[c0 + kk] = row[c0 - F3_BANDS + kk % F3_BANDS];
+					}
+				}
+				__syncthreads();
+			}
+			const bool row_ok = hr < nrows;
+			const unsigned char *line = tbuf + (row_ok ? hr : 0) * F3_TPITCH + 8 * F3_BANDS * HSEG_OUT * hseg;
+			float4v hacc[2];
+			hacc[0] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+			hacc[1] = (float4v){ 0.0f, 0.0f, 0.0f, 0.0f };
+			unsigned int outb[HSEG_OUT];
+			Step::template hwalk<0, 0>(hacc, line, lane_ah, sel_a, sel_b, outb);
+			if (row_ok && hlane) {
+				unsigned char *srow = stage + (8 * k + hr) * F3_SPITCH + F3_BANDS * HSEG_OUT * hseg + hc;
+#pragma unroll
+				for (int q = 0; q < HSEG_OUT; q++)
+					srow[F3_BANDS * q] = (unsigned char) outb[q];
+			}
+		}
+	}
+	__syncthreads();
+	{
+		const int part = t & 15, nbytes = F3_BANDS * ow;
+		for (int r = t >> 4; r < oh; r += FUSED_THREADS / 16) {
+			if (16 * part >= nbytes)
+				continue;
+			unsigned char *dst = a.out + (long long) (y0 + r) * a.out_stride + (long long) x0 * F3_BANDS + 16 * part;
+			const unsigned char *src = stage + r * F3_SPITCH + 16 * part;
+			if (a.aligned16 && 16 * part + 16 <= nbytes)
+				*reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
+			else {
+				const int n = min(16, nbytes - 16 * part);
+				for (int q = 0; q < n; q++)
+					dst[q] = src[q];
+			}
+		}
+	}
+}
+
 // Is pos[] an arithmetic progression first0 + S*k with one phase?  (What an
 // integer shrink of a size-divisible image produces.)
 static bool positions_regular(const std::vector<ReducePos> &pos, int *first0, int *step, int *phase)
@@ -2195,6 +2348,101 @@ static int reducev_stream_try(const _VipsHipReduce *rc, const VipsHipRegion *in,
 		hipLaunchKernelGGL((reducev_u8_mfma<7, 1, 4>), dim3(grid), dim3(FUSED_THREADS), 0, stream(), a, d_tables);
 	if (hipGetLastError() != hipSuccess) {
 		error("reducev", "kernel launch failed");
+		return -1;
+	}
+	return 1;
+}
+
+// vips_reduceh by 8 with one phase on a 3-band uchar region on the matrix cores (reduceh_u8x3_mfma).  1: launched;
+// 0: not this kernel's case; -1: error.  The conditions are launch_fused_u8x3's.
+int reduceh_u8x3_try(const _VipsHipReduce *rc, const VipsHipRegion *in, const VipsHipRegion *out, int tile)
+{
+	if (getenv("VIPS_HIP_NO_MFMA") || getenv("VIPS_HIP_NO_REDUCEH3") || in->bands != F3_BANDS || out->bands != F3_BANDS)
+		return 0;
+	{
+		// from ~100 MB of input on (8192 x 8192 x 3: 0.061 -> 0.051 ms, 16384 x 16384 x 3: 0.291 -> 0.203); below, the
+		// packed vector-ALU kernel's few long blocks are the faster (4096 x 4096 x 3: 0.0216 against 0.0233 ms)
+		const long long min_bytes = getenv("VIPS_HIP_REDUCEH3_MIN") ? atoll(getenv("VIPS_HIP_REDUCEH3_MIN")) : 96LL << 20;
+		if ((long long) out->height * in->width * F3_BANDS < min_bytes)
+			return 0;
+	}
+	_VipsHipReduce *r = const_cast<_VipsHipReduce *>(rc);
+	if (!(in->stride > 0 && (long long) in->stride * in->height < (1LL << 31)))
+		return 0;
+	if (((uintptr_t) in->data & 3) || (in->stride & 3) || out->top < in->top || out->top + out->height > in->top + in->height)
+		return 0;
+	std::vector<ReducePos> ph;
+	reduce_positions(r, out->left, out->width, tile, ph);
+	int fx0, sx, phase;
+	if (!positions_regular(ph, &fx0, &sx, &phase) || (out->width > 1 && sx != 8))
+		return 0;
+	const int nh = effective_taps(r, phase);
+	const int D = (nh + 7) / 8;
+	if ((D != 6 && D != 7) || F3_BANDS * (8 * (F3_OWT - 1) + nh) > F3_ROW)
+		return 0;
+	const short *c = &r->matrixs[(size_t) phase * r->n_point];
+	std::vector<int> taps(8 * D, 0);
+	long long abs_sum = 0;
+	int abs_max = 0;
+	for (int k = 0; k < 8 * D; k++) {
+		if (k < r->n_point)
+			taps[k] = c[k];
+		const int av = taps[k] < 0 ? -taps[k] : taps[k];
+		abs_sum += av;
+		abs_max = av > abs_max ? av : abs_max;
+	}
+	if (!(abs_max < 2048 && abs_sum * 255 < (1 << 23)))
+		return 0;
+	const int lo = in->left > 0 ? in->left : 0;
+	const int hi1 = in->im_width < in->left + in->width ? in->im_width : in->left + in->width;
+	const long long blo = 3LL * (lo - in->left), bhi = 3LL * (hi1 - in->left), tb0 = 3LL * ((long long) fx0 - in->left);
+	if ((blo & 3) || (bhi & 3) || (tb0 & 3) || bhi - blo < 8 || tb0 < -(1LL << 30) || tb0 > (1LL << 30))
+		return 0;
+	const MfmaTables *d_tables;
+	{
+		std::lock_guard<std::mutex> lock(r->mutex);
+		auto key = std::make_tuple(-5, phase, 8 * D);
+		auto it = r->pos_cache.find(key);
+		if (it == r->pos_cache.end()) {
+			MfmaTables tab;
+			mfma_build_tables(taps, taps, D, &tab);
+			void *d = upload(&tab, sizeof(tab));
+			if (!d)
+				return -1;
+			r->pos_cache[key] = (ReducePos *) d;
+			d_tables = (const MfmaTables *) d;
+		}
+		else
+			d_tables = (const MfmaTables *) it->second;
+	}
+	RhIArgs a;
+	a.in = (const unsigned char *) in->data + (size_t) (out->top - in->top) * in->stride;
+	a.out = (unsigned char *) out->data;
+	a.in_stride = (long long) in->stride;
+	a.out_stride = (long long) out->stride;
+	a.blo = (int) blo;
+	a.bhi = (int) bhi;
+	a.tile_b0 = (int) tb0;
+	a.out_width = out->width;
+	a.rows = out->height;
+	a.tiles_x = (out->width + F3_OWT - 1) / F3_OWT;
+	// no row is read twice whatever the height, and short tiles -- many blocks -- are what hides the walk: 16 rows
+	// (8192 x 8192 x 3: 8 rows 0.0539 ms, 16 0.0510, 24 0.0527, 64 0.0664; profiles/r06l_reduceh3*.txt)
+	int oht = 16;
+	if (const char *e = getenv("VIPS_HIP_REDUCEH3_OHT"))
+		oht = atoi(e) >= 8 && atoi(e) <= 128 ? atoi(e) / 8 * 8 : oht;
+	a.oht = oht;
+	a.tiles = a.tiles_x * ((out->height + oht - 1) / oht);
+	a.aligned16 = !(((uintptr_t) out->data & 15) || (out->stride & 15));
+	const int grid = (a.tiles + 7) / 8 * 8;
+	const size_t lds = rh3_lds_bytes(oht);
+	Gate gate("reduceh_u8x3_mfma");
+	if (D == 6)
+		hipLaunchKernelGGL((reduceh_u8x3_mfma<6>), dim3(grid), dim3(FUSED_THREADS), lds, stream(), a, d_tables);
+	else
+		hipLaunchKernelGGL((reduceh_u8x3_mfma<7>), dim3(grid), dim3(FUSED_THREADS), lds, stream(), a, d_tables);
+	if (hipGetLastError() != hipSuccess) {
+		error("reduceh", "kernel launch failed");
 		return -1;
 	}
 	return 1;

@@ -597,7 +597,9 @@ static int reduce_gen(const char *domain, const VipsHipReduce *reduce, const Vip
 			// factor: the matrix cores (reduce_band.hip).  $VIPS_HIP_REDUCEH_FIRST=band for the other order
 			const char *first = getenv("VIPS_HIP_REDUCEH_FIRST");
 			const bool packed_first = !(first && !strcmp(first, "band"));
-			if (packed_first)
+			// three bands, a factor of 8: the fused reduce's horizontal walk on rows staged with whole-line loads (round 6)
+			done = reduceh_u8x3_try(r, in, out, tile);
+			if (!done && packed_first)
 				done = reduceh_u8p_try(r, in, out, tile);
 			if (!done)
 				done = reduceh_band_try(r, in, out, tile);

@@ -64,8 +64,9 @@ def test_reduceh_u8_packed(tmp_path):
     script = os.path.join(str(tmp_path), "child.py")
     with open(script, "w") as f:
         f.write(CHILD % {"root": helpers.ROOT, "cases": CASES})
-    # (the fall-backs of THIS kernel: the banded matrix-core one, tests/test_emul_reduce_band.py, is off)
-    env = dict(os.environ, LD_PRELOAD=MOCK_SO, VIPS_HIP_LIBRARY=EMUL_SO, VIPS_HIP_REDUCE_BAND="0")
+    # (the fall-backs of THIS kernel: the banded matrix-core one, tests/test_emul_reduce_band.py, is off, and so is
+    # round 6's matrix-core kernel for three bands by 8, tests/test_reduceh_u8_gpu.py)
+    env = dict(os.environ, LD_PRELOAD=MOCK_SO, VIPS_HIP_LIBRARY=EMUL_SO, VIPS_HIP_REDUCE_BAND="0", VIPS_HIP_NO_REDUCEH3="1")
     proc = subprocess.run([sys.executable, script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                           env=env, timeout=1800)
     assert proc.returncode == 0 and "CHILD-OK" in proc.stdout, proc.stdout[-3000:]
