@@ -939,6 +939,7 @@ struct SharpenFusedArgs {
 	// the list) that sharpen_quad_u8_kernel walks afterwards; nullptr: every tile is finished here
 	int *defer;
 	int defer_threshold, q_tiles_x, q_tiles_y;
+	int defer_raw;     // > 0: the tile is judged by its middle row's raw bytes (green of neighbours more than this apart)
 	ColourTables tables;
 };
 
@@ -982,6 +983,60 @@ static __device__ __forceinline__ unsigned int sf_div_nonneg(unsigned int n, con
 // are appended to a list (LDS atomic), taken through the full forward and backward path DENSELY (a wave of list
 // entries, not a wave of tile pixels 4 % of which are live) and patched into the staged bytes.
 // (NT = taps the SKIP kernel's blur passes compute: 3 or 5; the other kernel always runs five, zeros included)
+// (a flag another kernel of the stream wrote: the same for every lane)
+static __device__ __forceinline__ int uniform_flag(const int *p)
+{
+	return __builtin_amdgcn_readfirstlane(*p);
+}
+
+// Large images, before sharpen_fused_u8_kernel<32, true>: which tiles are noise or dense edges -- the all-in-LDS
+// kernel's anyway -- judged from the raw bytes of ONE row: a THREAD per 64 x 32 tile walks its middle row and counts
+// the horizontal neighbours whose green differs by more than `raw`; more than half: the tile's 64 x 64 parent goes on
+// the device-side list (SharpenFusedArgs::defer) and both kernels know.  A heuristic for speed only: both kernels make
+// the same pixels.  The list's slots are handed out a wave at a time (one atomic on the counter per wave that has any):
+// round 6's first form judged inside the skip kernel, a block a tile, and what a noisy 8192 x 8192 image paid 0.19 ms
+// for was 16 384 atomics on ONE counter -- measured again with a wave a tile in this kernel: the same 0.19 ms.
+__global__ void __launch_bounds__(256)
+sharpen_survey_kernel(SharpenFusedPtrs ptrs_by_value, int width, int height, long long in_stride, int raw, int *defer,
+	int q_tiles_x, int q_tiles_y, int tiles_x, int tiles_y)
+{
+	__shared__ int s_base[4];
+	(void) ptrs_by_value;
+	typedef const unsigned long long __attribute__((address_space(4))) *KernargPtrs;
+	const KernargPtrs kp = (KernargPtrs) __builtin_amdgcn_kernarg_segment_ptr();
+	typedef const unsigned char __attribute__((address_space(1))) *GlobalIn;
+	const GlobalIn in = (GlobalIn) kp[blockIdx.z];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int tile = (int) blockIdx.x * 256 + (int) threadIdx.x;
+	const bool valid = tile < tiles_x * tiles_y;
+	const int tc = valid ? tile : 0;
+	const int ty = tc / tiles_x, tx = tc - ty * tiles_x;
+	const int x0 = tx * SF_TW, y0 = ty * 32;
+	const int ym = min(y0 + 16, height - 1);
+	const GlobalIn row = in + (long long) ym * in_stride;
+	int count = 0;
+	int prev = row[3 * x0 + 1];
+	for (int j = 1; j <= SF_TW; j++) {
+		const int g = row[3 * min(x0 + j, width - 1) + 1];
+		count += (x0 + j - 1 < width && abs(g - prev) > raw) ? 1 : 0;
+		prev = g;
+	}
+	const int per = q_tiles_x * q_tiles_y;
+	const int qt = (int) blockIdx.z * per + (y0 / 64) * q_tiles_x + tx;
+	const int total = per * (int) gridDim.z;
+	bool fresh = false;
+	if (valid && count > SF_TW / 2)
+		fresh = atomicExch(defer + 1 + qt, 1) == 0; // (a 64 x 64 parent has two tiles: the first one lists it)
+	const unsigned long long mask = __builtin_amdgcn_ballot_w64(fresh);
+	const int n = __builtin_popcountll(mask);
+	const int rank = __builtin_popcountll(mask & ((1ULL << lane) - 1ULL));
+	if (lane == 0 && n)
+		s_base[wave] = atomicAdd(defer, n);
+	__syncthreads();
+	if (fresh)
+		defer[1 + total + s_base[wave] + rank] = qt;
+}
+
 template <int SF_TH, bool SKIP, int NT = 2 * SF_MAXHALF + 1>
 __global__ void __launch_bounds__(256)
 sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
@@ -998,13 +1053,6 @@ sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 	__shared__ unsigned int s_list[SKIP ? SF_TH * SF_TW : 1];  // SKIP: (LUT index << 11) | row << 6 | column
 	__shared__ int s_count;
 	(void) ptrs_by_value;
-	s_v2Y[threadIdx.x] = a.tables.v2Y_8[threadIdx.x];
-	s_Y2v[threadIdx.x] = a.tables.Y2v_8[threadIdx.x];
-	if (threadIdx.x == 0) {
-		s_Y2v[256] = a.tables.Y2v_8[256];
-		s_count = 0;
-	}
-	__syncthreads();
 	typedef const unsigned long long __attribute__((address_space(4))) *KernargPtrs;
 	const KernargPtrs kp = (KernargPtrs) __builtin_amdgcn_kernarg_segment_ptr();
 	// (pointers made from integers are generic to the compiler: say they are global)
@@ -1016,6 +1064,23 @@ sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 	const int x0 = blockIdx.x * SF_TW, y0 = blockIdx.y * SF_TH;
 	const int h = a.half;
 	const int rw = SF_TW + 2 * h, rh = SF_TH + 2 * h;
+	if constexpr (SKIP) {
+		if (a.defer && a.defer_raw > 0) {
+			// 0' (large images only): sharpen_survey_kernel has judged every tile already; one that is on the list is
+			// the all-in-LDS kernel's -- leave before the block has touched anything
+			const int per = a.q_tiles_x * a.q_tiles_y;
+			const int qt = (int) blockIdx.z * per + (y0 / 64) * a.q_tiles_x + (int) blockIdx.x;
+			if (uniform_flag(a.defer + 1 + qt))
+				return;
+		}
+	}
+	s_v2Y[threadIdx.x] = a.tables.v2Y_8[threadIdx.x];
+	s_Y2v[threadIdx.x] = a.tables.Y2v_8[threadIdx.x];
+	if (threadIdx.x == 0) {
+		s_Y2v[256] = a.tables.Y2v_8[256];
+		s_count = 0;
+	}
+	__syncthreads();
 
 	// ring pixel idx -> its place in the region (the frame of h pixels around the tile)
 	auto ring_place = [&](int idx, int &ry, int &rx) {
@@ -1034,8 +1099,8 @@ sharpen_fused_u8_kernel(SharpenFusedPtrs ptrs_by_value, SharpenFusedArgs a)
 		}
 	};
 	if constexpr (SKIP) {
-		if (a.defer) {
-			// 0 (large images only). A tile of noise or dense edges goes to the all-in-LDS kernel anyway: find out
+		if (a.defer && a.defer_raw <= 0) {
+			// 0 (large images only; $VIPS_HIP_SHARPEN_DEFER_RAW=0). A tile of noise or dense edges goes to the all-in-LDS kernel anyway: find out
 			// from ONE row before paying for all of them -- L of the tile's middle row and the rows either side, the
 			// blur of the middle row, its pixels outside the LUT's zero window counted; more than half: the tile is
 			// deferred here and now.  (A heuristic for speed only: both kernels make the same pixels.)
@@ -1814,6 +1879,7 @@ int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const
 		sharpen_identity_proven(a.tables);
 	a.defer = nullptr;
 	a.defer_threshold = 0;
+	a.defer_raw = 0;
 	a.q_tiles_x = a.q_tiles_y = 0;
 	const char *quad_env = getenv("VIPS_HIP_SHARPEN_QUAD");
 	const bool want_quad = quad_env ? atoi(quad_env) != 0 : (long long) a.width * a.height >= 2048LL * 2048;
@@ -1867,9 +1933,16 @@ int sharpen_fused_u8(const VipsHipRegion *const *ins, const VipsHipRegion *const
 					SharpenFusedArgs a1 = a;
 					a1.defer = defer;
 					a1.defer_threshold = getenv("VIPS_HIP_SHARPEN_DEFER") ? atoi(getenv("VIPS_HIP_SHARPEN_DEFER")) : 640;
+					a1.defer_raw = getenv("VIPS_HIP_SHARPEN_DEFER_RAW") ? atoi(getenv("VIPS_HIP_SHARPEN_DEFER_RAW")) : 24; // (12 sends a fifth of a smooth image's tiles the slow way: profiles/r06n_sharpen_raw.txt)
 					a1.q_tiles_x = q.tiles_x;
 					a1.q_tiles_y = q.tiles_y;
 					dim3 grid1((a.width + SF_TW - 1) / SF_TW, (a.height + 31) / 32, count);
+					if (a1.defer_raw > 0) {
+						Gate gate0("sharpen_survey");
+						const int stx = (int) grid1.x, sty = (int) grid1.y;
+						hipLaunchKernelGGL(sharpen_survey_kernel, dim3((stx * sty + 255) / 256, 1, count), dim3(256, 1, 1), 0, stream(), p,
+							a.width, a.height, (long long) a.in_stride, a1.defer_raw, defer, q.tiles_x, q.tiles_y, stx, sty);
+					}
 					Gate gate1("sharpen_skip_u8");
 					if (a.n <= 3)
 						hipLaunchKernelGGL((sharpen_fused_u8_kernel<32, true, 3>), grid1, dim3(256, 1, 1), 0, stream(), p, a1);

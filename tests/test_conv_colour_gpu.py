@@ -249,8 +249,12 @@ def test_sharpen_fused_uchar_srgb(size, params, quad, monkeypatch):
     adaptive = isinstance(quad, str) and quad.startswith("adaptive")
     monkeypatch.setenv("VIPS_HIP_SHARPEN_QUAD", "1" if quad is True or adaptive else "0")
     monkeypatch.setenv("VIPS_HIP_SHARPEN_SKIP", "1" if isinstance(quad, str) else "0")
+    survey = quad == "adaptive-blocky"
     if adaptive:
         monkeypatch.setenv("VIPS_HIP_SHARPEN_DEFER", "100")
+        # who judges a tile first: sharpen_survey_kernel from the raw bytes of one row (the default) / the skip kernel
+        # itself from L of three rows (round 6's first form)
+        monkeypatch.setenv("VIPS_HIP_SHARPEN_DEFER_RAW", "12" if survey else "0")
     w, h = size
     src = helpers.lcg_image(w, h, 3, np.uint8, 72)
     if isinstance(quad, str) and quad.endswith("blocky"):
@@ -284,7 +288,8 @@ def test_sharpen_fused_uchar_srgb(size, params, quad, monkeypatch):
         wide_lut = "y3" in params
         if adaptive and "y3" not in params:
             # (an image of at most 16 rows: the all-in-LDS kernel alone)
-            assert sorted(report) == (["sharpen_quad_u8", "sharpen_skip_u8"] if h > 16 else ["sharpen_quad_u8"]), report
+            both = ["sharpen_quad_u8", "sharpen_skip_u8"] + (["sharpen_survey"] if survey else [])
+            assert sorted(report) == (both if h > 16 else ["sharpen_quad_u8"]), report
         elif isinstance(quad, str):
             assert list(report) == ["sharpen_skip_u8"], report
         else:
@@ -627,13 +632,19 @@ def test_premultiply_rgba_rows(src_dtype, inverse, monkeypatch):
     assert np.array_equal(got.view(np.int32), old.view(np.int32))
 
 
+@pytest.mark.parametrize("raw", [None, 0])
 @pytest.mark.parametrize("params", [dict(), dict(sigma=1.0, x1=1.0, m2=2.0)])
-def test_sharpen_adaptive_large_mixed(params):
+def test_sharpen_adaptive_large_mixed(params, raw, monkeypatch):
     """Round 6: an image of 4 Mpixels and more takes the adaptive pair by default -- the skip kernel first, the tiles
     whose sampled row is mostly outside the LUT's flat centre left on a device-side list for the all-in-LDS kernel.
     A 2 304 x 2 100 image that is smooth on the left, noise on the right and striped (a hard edge every 8 rows: tiles
     whose SAMPLED row says little about the rest) at the bottom: both kernels make tiles of one image, some 64 x 64
-    tiles half by one and half by the other; against the compiled reference / the port, whole image."""
+    tiles half by one and half by the other; against the compiled reference / the port, whole image.  The first
+    judge of a tile: sharpen_survey_kernel on the raw bytes of its middle row (the default) / the skip kernel itself
+    on L of three rows ($VIPS_HIP_SHARPEN_DEFER_RAW=0); the skip kernel's second rule -- a list longer than 640 pixels
+    -- stands behind both (the striped tiles: horizontal neighbours equal, a third of the pixels on the list)."""
+    if raw is not None:
+        monkeypatch.setenv("VIPS_HIP_SHARPEN_DEFER_RAW", str(raw))
     w, h = 2304, 2100
     noise = helpers.lcg_image(w, h, 3, np.uint8, 97)
     small = helpers.lcg_image(w // 8 + 1, h // 8 + 1, 3, np.uint8, 98).astype(np.float32)
@@ -653,7 +664,7 @@ def test_sharpen_adaptive_large_mixed(params):
     finally:
         lib.vips_hip_gate_enable(0)
         lib.vips_hip_gate_reset()
-    assert sorted(report) == ["sharpen_quad_u8", "sharpen_skip_u8"], report
+    assert sorted(report) == ["sharpen_quad_u8", "sharpen_skip_u8"] + (["sharpen_survey"] if raw is None else []), report
     if helpers.have_ref():
         args = ",".join("%s=%s" % kv for kv in params.items())
         want = Ref.run("sharpen", src, args, cases.INTERP["srgb"])
